@@ -1,0 +1,616 @@
+"""
+CPU restatement (numpy/scipy) of the three kernels on the hot path and of the
+thin slice of kernel algebra the GP evaluates them through -- test
+infrastructure only, see ``oracle/__init__.py``.  parity unpinned vs JAX-CPU.
+
+Follows (reference paths):
+``src/lsqfitgp/_Kernel/_crosskernel.py:152-200`` (call contract, ctor xtransf chain),
+``_Kernel/_ops.py:292-326`` (loc, scale), ``_Kernel/_alg.py:32-82`` (scalar add/mul),
+``_Kernel/_isotropic.py:61-81`` + ``_Kernel/_util.py:74-99`` (r^2 over fields),
+``_kernels/_basic.py:61-75`` (ExpQuad), ``_kernels/_matern.py:29-49`` +
+``_special/_bessel.py:101-110`` (Maternp), ``_kernels/_bart.py`` (BART),
+``_jaxext/_fasthash.py:56-102`` (fasthash64/32).
+"""
+
+import numbers
+
+import numpy
+from numpy.lib import recfunctions
+from scipy import special
+
+
+# --------------------------------------------------------------------------
+# structured-array helpers (``_Kernel/_util.py:74-117``)
+
+def _leaf_apply(fun, x):
+    """ ``_util.py:104-117`` ufunc_recurse_dtype: apply to every leaf field """
+    if x.dtype.names is None:
+        return fun(x)
+    out = numpy.empty(x.shape, x.dtype)
+    for name in x.dtype.names:
+        out[name] = _leaf_apply(fun, x[name])
+    return out
+
+
+def _to_float_struct(x):
+    """ promote integer leaves to float so that (x - loc)/scale is a true division """
+    if x.dtype.names is None:
+        return x if numpy.issubdtype(x.dtype, numpy.floating) else x.astype(float)
+    return x
+
+
+def sum_recurse_dtype(fun, x, y):
+    """ ``_util.py:74-99``: sum over fields, left to right, of fun(x_f, y_f);
+    sub-array fields are summed over their trailing axes first """
+    if x.dtype.names is None:
+        return fun(x, y)
+    acc = None
+    for name in x.dtype.names:
+        result = sum_recurse_dtype(fun, x[name], y[name])
+        dtype = x.dtype[name]
+        if dtype.ndim:
+            result = numpy.sum(result, axis=tuple(range(-dtype.ndim, 0)))
+        acc = result if acc is None else acc + result
+    return acc
+
+
+# --------------------------------------------------------------------------
+# kernel objects
+
+class Kernel:
+    """
+    Minimal stand-in for ``CrossKernel`` (``_crosskernel.py:54-200``): wraps a
+    ``core(x, y)`` and applies ``(x - loc) / scale`` to both arguments
+    (``:172-185``; see ``_transf_inputs`` for the order).
+    """
+
+    def __init__(self, core, *, scale=None, loc=None, outops=()):
+        self._core = core
+        self._scale = scale
+        self._loc = loc
+        # output algops applied in order: ('mul', c) is kernel * c
+        # (``_alg.py:58-82``), ('add', c) is kernel + c (``_alg.py:32-56``)
+        self._outops = tuple(outops)
+
+    def _transf_inputs(self, x):
+        # ``_crosskernel.py:172-185`` applies linop('scale') FIRST, then
+        # linop('loc') (dict order); each linop wraps the core as
+        # core'(x) = core(T(x)): k1(x) = k0(x / scale), then
+        # k2(x) = k1(x - loc) = k0((x - loc) / scale).
+        if self._loc is not None:
+            l = self._loc
+            x = _leaf_apply(lambda v: v - l, x)
+        if self._scale is not None:
+            s = self._scale
+            x = _leaf_apply(lambda v: v / s, _to_float_struct(x))
+        return x
+
+    def __call__(self, x, y):
+        """ ``_crosskernel.py:192-200`` """
+        x = numpy.asarray(x)
+        y = numpy.asarray(y)
+        shape = numpy.broadcast_shapes(x.shape, y.shape)
+        x = self._transf_inputs(x)
+        y = self._transf_inputs(y)
+        result = numpy.asarray(self._core(x, y))
+        for op, c in self._outops:
+            result = result * c if op == 'mul' else result + c
+        assert result.shape == shape, (result.shape, shape)
+        return result
+
+    def _with(self, op, c):
+        if not isinstance(c, numbers.Number) and numpy.ndim(c) != 0:
+            return NotImplemented
+        return Kernel(self._core, scale=self._scale, loc=self._loc, outops=self._outops + ((op, c),))
+
+    def __mul__(self, c):
+        return self._with('mul', c)
+
+    __rmul__ = __mul__
+
+    def __add__(self, c):
+        return self._with('add', c)
+
+    __radd__ = __add__
+
+
+def _isotropic(core):
+    """ ``_isotropic.py:61-81`` with input='squared' """
+    def newcore(x, y):
+        r2 = sum_recurse_dtype(lambda a, b: numpy.square(a - b), x, y)
+        return core(r2)
+    return newcore
+
+
+def expquad_core(r2):
+    """ ``_kernels/_basic.py:75`` """
+    return numpy.exp(-1/2 * r2)
+
+
+def kvmodx2_hi(x2, p):
+    """ ``_special/_bessel.py:103-110`` """
+    x = numpy.sqrt(x2)
+    poly = 1
+    for k in reversed(range(p)):
+        c_kp1_over_ck = (p - k) / ((2 * p - k) * (k + 1))
+        poly = 1 + poly * c_kp1_over_ck * 2 * x
+    return numpy.exp(-x) * poly
+
+
+def maternp_core(r2, p):
+    """ ``_kernels/_matern.py:46-49`` """
+    assert int(p) == p and p >= 0, p
+    r2 = (2 * p + 1) * r2
+    return kvmodx2_hi(r2 + 1e-30, p)
+
+
+def ExpQuad(*, scale=None, loc=None):
+    return Kernel(_isotropic(expquad_core), scale=scale, loc=loc)
+
+
+def Maternp(*, p=None, scale=None, loc=None):
+    p = int(p)
+    return Kernel(_isotropic(lambda r2: maternp_core(r2, p)), scale=scale, loc=loc)
+
+
+# --------------------------------------------------------------------------
+# fasthash (``_jaxext/_fasthash.py:56-102``; original C ``tests/fast-hash/fasthash.c:30-75``)
+
+_M64 = numpy.uint64(0x880355f21e6d1965)
+_MIXC = numpy.uint64(0x2127599bf4325c37)
+
+
+def _mix(h):
+    with numpy.errstate(over='ignore'):
+        h = h ^ (h >> numpy.uint64(23))
+        h = h * _MIXC
+        h = h ^ (h >> numpy.uint64(47))
+    return h
+
+
+def fasthash64(buf, seed):
+    buf = numpy.ascontiguousarray(buf).view(numpy.uint8).reshape(-1)
+    seed = numpy.uint64(seed)
+    nfull = buf.size - buf.size % 8
+    pos = buf[:nfull].view(numpy.uint64)
+    with numpy.errstate(over='ignore'):
+        h = seed ^ (numpy.uint64(buf.size) * _M64)
+        for v in pos:
+            h = h ^ _mix(v)
+            h = h * _M64
+        pos2 = buf[nfull:]
+        v = numpy.uint64(0)
+        for i in reversed(range(pos2.size)):
+            v = v ^ (numpy.uint64(pos2[i]) << numpy.uint64(8 * i))
+        if pos2.size:
+            h = h ^ _mix(v)
+            h = h * _M64
+    return _mix(h)
+
+
+def fasthash32(buf, seed):
+    h = fasthash64(buf, numpy.uint32(seed))
+    with numpy.errstate(over='ignore'):
+        return numpy.uint32((h - (h >> numpy.uint64(32))) & numpy.uint64(0xffffffff))
+
+
+# --------------------------------------------------------------------------
+# BART (``_kernels/_bart.py``)
+
+def _float_type(*args):
+    """ ``_jaxext/__init__.py:140-144`` """
+    t = numpy.result_type(*[numpy.asarray(a).dtype for a in args])
+    if numpy.issubdtype(t, numpy.floating):
+        return t
+    return numpy.dtype(numpy.float64)
+
+
+class BART:
+    """ namespace mirroring the reference classmethods; ``BART(...)`` builds the kernel object """
+
+    def __new__(cls, **kw):
+        return _make_bart_kernel(**kw)
+
+    # -- input munging ----------------------------------------------------
+
+    @staticmethod
+    def _check_x(x):
+        """ ``_bart.py:478-483`` """
+        x = numpy.asarray(x)
+        if x.dtype.names:
+            x = recfunctions.structured_to_unstructured(x)
+        return x
+
+    @staticmethod
+    def _check_splits(splits, indices):
+        """ ``_bart.py:485-501`` """
+        l, s = splits
+        l = numpy.asarray(l)
+        assert l.ndim == 1
+        if not indices:
+            s = numpy.asarray(s)
+            assert 1 <= s.ndim <= 2
+            if s.ndim == 1:
+                s = s[:, None]
+            assert l.size == s.shape[1]
+            assert numpy.all((0 <= l) & (l <= s.shape[0])), 'length out of bounds'
+            assert numpy.all(numpy.sort(s, axis=0) == s), 'unsorted splitting points'
+        return l, s
+
+    @classmethod
+    def splits_from_coord(cls, x):
+        """ ``_bart.py:209-259`` """
+        x = cls._check_x(x)
+        x = x.reshape(-1, x.shape[-1]) if x.size else x.reshape(1, x.shape[-1])
+        if numpy.issubdtype(x.dtype, numpy.inexact):
+            fill = numpy.finfo(x.dtype).max
+        else:
+            fill = numpy.iinfo(x.dtype).max
+        lengths = []
+        mids = []
+        for xi in x.T:
+            u = numpy.unique(xi)
+            u = numpy.concatenate([u, numpy.full(xi.size - u.size, fill, u.dtype)])   # unique(size=, fill_value=)
+            with numpy.errstate(over='ignore'):
+                m = numpy.where(u[1:] < fill, (u[1:] + u[:-1]) / 2, fill)
+            l = numpy.searchsorted(m, fill)
+            lengths.append(l)
+            mids.append(m)
+        return numpy.array(lengths), numpy.stack(mids, axis=1) if mids else numpy.empty((max(len(x) - 1, 0), 0))
+
+    @classmethod
+    def indices_from_coord(cls, x, splits):
+        """ ``_bart.py:261-299,503-514`` """
+        splits = cls._check_splits(splits, False)
+        return cls._indices_from_coord(x, splits)
+
+    @classmethod
+    def _indices_from_coord(cls, x, checked_splits):
+        x = cls._check_x(x)
+        if x.shape[-1] != checked_splits[0].size:
+            raise ValueError(f'splitting grid is for {checked_splits[0].size} dimensions, found {x.shape[-1]}')
+        A = checked_splits[1]
+        out = numpy.empty(x.shape, numpy.int64)
+        for j in range(A.shape[1]):
+            out[..., j] = numpy.searchsorted(A[:, j], x[..., j], side='left')
+        return out
+
+    # -- correlation ------------------------------------------------------
+
+    @classmethod
+    def correlation(cls, splitsbefore_or_totalsplits, splitsbetween_or_index1, splitsafter_or_index2, *,
+        alpha=0.95, beta=2, gamma=1, maxd=2, debug=False, pnt=None, intercept=True,
+        weights=None, reset=None, altinput=False):
+        """ ``_bart.py:301-455`` """
+        a0 = numpy.asarray(splitsbefore_or_totalsplits)
+        a1 = numpy.asarray(splitsbetween_or_index1)
+        a2 = numpy.asarray(splitsafter_or_index2)
+        assert numpy.issubdtype(a0.dtype, numpy.integer)
+        assert numpy.issubdtype(a1.dtype, numpy.integer)
+        assert numpy.issubdtype(a2.dtype, numpy.integer)
+        assert numpy.all(a0 >= 0), 'splitting counts must be nonnegative'
+        if altinput:
+            assert numpy.all((0 <= a1) & (a1 <= a0)), 'splitting index must be in [0, n]'
+            assert numpy.all((0 <= a2) & (a2 <= a0)), 'splitting index must be in [0, n]'
+        else:
+            assert numpy.all(a1 >= 0) and numpy.all(a2 >= 0), 'splitting counts must be nonnegative'
+
+        if pnt is None:                                           # :373-384
+            assert maxd == int(maxd) and maxd >= 0, maxd
+            alpha = numpy.asarray(alpha)
+            beta = numpy.asarray(beta)
+            assert numpy.all((0 <= alpha) & (alpha <= 1)), 'alpha must be in [0, 1]'
+            assert numpy.all(beta >= 0), 'beta must be in [0, inf)'
+            d = numpy.arange(maxd + 1)
+            pnt = alpha[..., None] / (1 + d) ** beta[..., None]
+        else:
+            pnt = numpy.asarray(pnt)
+
+        if weights is None:                                       # :387-390
+            weights = numpy.ones(a0.shape[-1], pnt.dtype)
+        else:
+            weights = numpy.asarray(weights)
+
+        if isinstance(gamma, str):                                # :393-401
+            if gamma == 'auto':
+                assert reset is None and 1 <= pnt.shape[-1] - 1 <= 3
+                gamma = cls._gamma(weights.shape[-1], pnt)
+            else:
+                raise KeyError(gamma)
+        else:
+            gamma = numpy.asarray(gamma)
+
+        assert numpy.all((0 <= gamma) & (gamma <= 1)), 'gamma must be in [0, 1]'
+        assert numpy.all((0 <= pnt) & (pnt <= 1)), 'pnt must be in [0, 1]'
+        assert numpy.all(weights >= 0), 'weights must be in [0, inf)'
+
+        if not intercept:                                         # :411-412
+            pnt = pnt.copy()
+            pnt[..., 0] = 1
+
+        if reset is None:                                         # :415-421
+            reset = []
+        if not hasattr(reset, '__len__'):
+            reset = [reset]
+        reset = [0] + list(reset) + [pnt.shape[-1] - 1]
+        for i, j in zip(reset, reset[1:]):
+            assert int(j) == j and i <= j, (i, j)
+
+        brackets_norep = list(zip(reset, reset[1:]))              # :424-431
+        brackets = [brackets_norep[0] + (1,)]
+        for t, b in brackets_norep[1:]:
+            lt, lb, lr = brackets[-1]
+            if altinput and not debug and lr * (b - t) == lb - lt and b - t <= 2:
+                brackets[-1] = lt, b, lr + 1
+            else:
+                brackets.append((t, b, 1))
+
+        corr = gamma                                              # :434-455
+        for t, b, repeat in reversed(brackets):
+            probs = pnt[..., t:b + 1]
+            if t > 0:
+                probs = probs.copy()
+                probs[..., 0] = 1
+            if repeat > 1:
+                head = probs[..., 0:1]
+                one = numpy.ones_like(head)
+                pieces = [
+                    [head if i == 0 else one, p]
+                    for i, p in enumerate(numpy.split(probs[..., 1:], repeat, axis=-1))
+                ]
+                probs = numpy.concatenate(sum(reversed(pieces), start=[]), axis=-1)
+            else:
+                repeat = None
+            corr = cls._correlation_vectorized(a0, a1, a2, probs, corr, weights, debug, altinput, repeat)
+        return corr
+
+    @staticmethod
+    def _gamma(p, pnt):
+        """ ``_bart.py:458-476`` """
+        gamma_0 = 0.611 + 0.021 * numpy.exp(-1.3 * (p - 1))
+        gamma_d = -0.0034 + 0.084 * numpy.exp(-2.02 * (p - 1))
+        s = 2.03 - 0.69 * numpy.exp(-0.72 * (p - 1))
+        t = 4.01 - 1.49 * numpy.exp(-0.77 * (p - 1))
+        maxd = pnt.shape[-1] - 1
+        floor = numpy.clip(gamma_0 - gamma_d * maxd, 0, 1)
+        P0 = pnt[..., 0]
+        P1 = numpy.minimum(P0, pnt[..., 1])
+        with numpy.errstate(divide='ignore', invalid='ignore'):
+            corner = numpy.where(P0, 1 - P0 ** (s - t) * P1 ** t, 1)
+        return floor * corner
+
+    @classmethod
+    def _correlation_vectorized(cls, a0, a1, a2, pnt, gamma, w, debug, altinput, repeat):
+        """ ``_bart.py:808-815``: jnp.vectorize with signature '(p),(p),(p),(d),(),(p)->()' """
+        a0, a1, a2 = numpy.broadcast_arrays(a0, a1, a2)
+        pnt = numpy.asarray(pnt)
+        gamma = numpy.asarray(gamma)
+        w = numpy.asarray(w)
+        bshape = numpy.broadcast_shapes(a0.shape[:-1], pnt.shape[:-1], gamma.shape, w.shape[:-1])
+        flt = _float_type(pnt, gamma, w)
+        fast = (altinput and not debug and pnt.ndim == 1 and w.ndim == 1
+                and pnt.size // (repeat or 1) <= 3)
+        if fast:
+            return cls._correlation_fast(a0, a1, a2, pnt, numpy.broadcast_to(gamma, bshape), w, repeat or 1, flt)
+        a0b = numpy.broadcast_to(a0, bshape + a0.shape[-1:])
+        a1b = numpy.broadcast_to(a1, bshape + a1.shape[-1:])
+        a2b = numpy.broadcast_to(a2, bshape + a2.shape[-1:])
+        pntb = numpy.broadcast_to(pnt, bshape + pnt.shape[-1:])
+        gb = numpy.broadcast_to(gamma, bshape)
+        wb = numpy.broadcast_to(w, bshape + w.shape[-1:])
+        out = numpy.empty(bshape, flt)
+        for idx in numpy.ndindex(*bshape):
+            if altinput:
+                out[idx] = cls._correlation(a0b[idx], a1b[idx], a2b[idx], pntb[idx], gb[idx], wb[idx], bool(debug), repeat)
+            else:
+                out[idx] = cls._correlation_old(a0b[idx], a1b[idx], a2b[idx], pntb[idx], gb[idx], wb[idx], bool(debug))
+        return out
+
+    # The vectorised fast path restates ``_bart.py:628-757`` (depth <= 3
+    # closed forms) with the pair axes kept as leading numpy axes.
+    @classmethod
+    def _correlation_fast(cls, n, ix, iy, pnt, gamma, w, repeat, flt):
+        if n.shape[-1] == 0:
+            return numpy.ones(gamma.shape, flt)
+        pnt = pnt.astype(flt)
+        gamma = gamma.astype(flt)
+        w = w.astype(flt)
+        n = numpy.where(w, n, 0)
+        ix = numpy.where(w, ix, 0)
+        iy = numpy.where(w, iy, 0)
+        anyn0 = numpy.any(ix != iy, axis=-1)    # reference: 64-bit hash inequality (:674-681)
+        one = flt.type(1)
+        size = pnt.size // repeat
+        rows = pnt.reshape(repeat, -1)
+
+        if size == 1:                                             # :685-691
+            for row in rows:
+                gamma = numpy.where(anyn0, one - (one - gamma) * row[0], one)
+            return gamma.astype(flt)
+
+        with numpy.errstate(divide='ignore', invalid='ignore'):
+            Wn = numpy.sum(numpy.where(n, w, 0), axis=-1, dtype=flt)          # :694
+            if size == 2:                                         # :697-708
+                n0 = numpy.abs(ix - iy)
+                wn = numpy.where(n, w / n, 0).astype(flt)
+                sum_term = numpy.sum(wn * n0, axis=-1, dtype=flt)
+                for row in rows:
+                    Q = one - row[1] + gamma * row[1]
+                    P0 = row[0]
+                    result = one - P0 + Q * (P0 - P0 / Wn * sum_term)
+                    gamma = numpy.where(anyn0, result, one)
+                return gamma.astype(flt)
+
+            xlty = ix < iy                                        # :711-714
+            minxy = numpy.where(xlty, ix, iy)
+            maxxy = numpy.where(xlty, iy, ix)
+            n0 = maxxy - minxy
+
+            assert size == 3                                      # :716-757
+            nminus0 = maxxy
+            nplus0 = n - minxy
+            nout = n - n0
+            inv_Wn = (one / Wn)[..., None]
+            inv_Wnmod = one / (Wn[..., None] - numpy.where(n, w, 0))
+            inv_Wnminus = numpy.where(nplus0, inv_Wn, inv_Wnmod)
+            inv_Wnplus = numpy.where(nminus0, inv_Wn, inv_Wnmod)
+            wn = numpy.where(n, w / n, 0).astype(flt)
+            S = numpy.sum(wn * nout, axis=-1, dtype=flt)
+            t = wn * n0
+            terms1 = (S[..., None] + t) * (inv_Wnminus + inv_Wnplus + inv_Wn * (nout - 2))
+            terms2 = numpy.where(nplus0, w * inv_Wn * n0 / nplus0, w * inv_Wnmod)
+            terms2 = terms2 + numpy.where(nminus0, w * inv_Wn * n0 / nminus0, w * inv_Wnmod)
+            psin = special.digamma(numpy.where(n, n, 1).astype(flt))
+            psiminus = numpy.where(xlty, special.digamma((1 + iy).astype(flt)), special.digamma((1 + ix).astype(flt)))
+            psiplus = numpy.where(xlty, special.digamma((1 + n - ix).astype(flt)), special.digamma((1 + n - iy).astype(flt)))
+            terms3 = w * inv_Wn * n0 * (2 * psin - psiminus - psiplus)
+            terms = terms1 - terms2 - terms3
+            sumi = numpy.sum(wn * terms, axis=-1, dtype=flt)
+            inv_Wn = inv_Wn[..., 0]
+            for row in rows:
+                Q = one + row[2] * (gamma - one)
+                sump = S + row[1] * (Q * sumi - S)
+                result = one + row[0] * (inv_Wn * sump - one)
+                gamma = numpy.where(anyn0, result, one)
+            return gamma.astype(flt)
+
+    @classmethod
+    def _correlation(cls, n, ix, iy, pnt, gamma, w, debug, repeat):
+        """ ``_bart.py:628-806`` for one pair (scalar loops for the deep recursion) """
+        assert n.ndim == 1
+        assert n.shape == ix.shape == iy.shape == w.shape
+        assert pnt.ndim == 1 and pnt.size > 0
+        gamma = numpy.asarray(gamma)
+        assert gamma.ndim == 0
+        if repeat is not None:
+            assert not debug and repeat > 0 and pnt.size % repeat == 0 and pnt.size // repeat <= 3
+        else:
+            repeat = 1
+        flt = _float_type(pnt, gamma, w)
+        if n.size == 0:
+            return flt.type(1)
+        if not debug and pnt.size // repeat <= 3:
+            return cls._correlation_fast(n, ix, iy, pnt, gamma, w, repeat, flt)[()]
+        pnt = pnt.astype(flt)
+        gamma = gamma.astype(flt)
+        w = w.astype(flt)
+        n = numpy.where(w, n, 0)
+        ix = numpy.where(w, ix, 0)
+        iy = numpy.where(w, iy, 0)
+        anyn0 = bool(numpy.any(ix != iy))
+        if pnt.size == 1:
+            return (1 - (1 - gamma) * pnt[0]) if anyn0 else flt.type(1)
+        Wn = numpy.sum(numpy.where(n, w, 0))
+        minxy = numpy.minimum(ix, iy)
+        maxxy = numpy.maximum(ix, iy)
+        n0 = maxxy - minxy
+        nminus = minxy.copy()                                     # :759-806
+        nplus = n - maxxy
+        p = len(nminus)
+        sump = flt.type(0)
+        if anyn0:
+            for i in range(p):
+                nminusi, n0i, nplusi = nminus[i], n0[i], nplus[i]
+                ni = nminusi + n0i + nplusi
+                if not ni:
+                    continue
+                sumn = flt.type(0)
+                for k in range(nminusi + nplusi):
+                    nm = nminus.copy()
+                    npl = nplus.copy()
+                    if k < nminusi:
+                        nm[i] = k
+                    else:
+                        npl[i] = k - nminusi
+                    nn = nm + n0 + npl
+                    sumn += cls._correlation(nn, nm, nm + n0, pnt[1:], gamma, w, debug, None)
+                sump += w[i] * sumn / ni
+            return 1 - pnt[0] * (1 - sump / Wn)
+        return flt.type(1)
+
+    @classmethod
+    def _correlation_old(cls, nminus, n0, nplus, pnt, gamma, w, debug):
+        """ ``_bart.py:516-610``: the reference's older, independent implementation """
+        assert nminus.shape == n0.shape == nplus.shape == w.shape
+        assert nminus.ndim == 1 and pnt.ndim == 1 and pnt.size > 0
+        nminus = numpy.where(w, nminus, 0)
+        n0 = numpy.where(w, n0, 0)
+        nplus = numpy.where(w, nplus, 0)
+        flt = _float_type(pnt, gamma, w)
+        if nminus.size == 0:
+            return flt.type(1)
+        anyn0 = bool(numpy.any(numpy.logical_and(n0, w)))
+        if pnt.size == 1:
+            return flt.type(1 - (1 - gamma) * pnt[0]) if anyn0 else flt.type(1)
+        nout = nminus + nplus
+        n = nout + n0
+        Wn = numpy.sum(numpy.where(n, w, 0))
+        with numpy.errstate(divide='ignore', invalid='ignore'):
+            if pnt.size == 2 and not debug:
+                Q = 1 - (1 - gamma) * pnt[1]
+                sump = Q * numpy.sum(numpy.where(n, w * nout / n, 0))
+                return flt.type(1 - pnt[0] * (1 - sump / Wn)) if anyn0 else flt.type(1)
+            if pnt.size == 3 and not debug:
+                Q = 1 - (1 - gamma) * pnt[2]
+                s = w * nout / n
+                S = numpy.sum(numpy.where(n, s, 0))
+                t = w * n0 / n
+                psin = special.digamma(n.astype(flt))
+                def terms(nminus, nplus):
+                    nminus0 = nminus + n0
+                    Wnmod = Wn - numpy.where(nminus0, 0, w)
+                    frac = numpy.where(nminus0, w * nminus / nminus0, 0)
+                    terms1 = (S - s + frac) / Wnmod
+                    psi1nminus0 = special.digamma((1 + nminus0).astype(flt))
+                    terms2 = ((nplus - 1) * (S + t) - w * n0 * (psin - psi1nminus0)) / Wn
+                    return numpy.where(nplus, terms1 + terms2, 0)
+                tplus = terms(nminus, nplus)
+                tminus = terms(nplus, nminus)
+                tall = numpy.where(n, w * (tplus + tminus) / n, 0)
+                sump = (1 - pnt[1]) * S + pnt[1] * Q * numpy.sum(tall)
+                return flt.type(1 - pnt[0] * (1 - sump / Wn)) if anyn0 else flt.type(1)
+        p = len(nminus)
+        sump = 0.
+        if anyn0:
+            for i in range(p):
+                nminusi, n0i, nplusi = nminus[i], n0[i], nplus[i]
+                ni = nminusi + n0i + nplusi
+                if not ni:
+                    continue
+                sumn = 0.
+                for k in range(nminusi + nplusi):
+                    nm = nminus.copy()
+                    npl = nplus.copy()
+                    if k < nminusi:
+                        nm[i] = k
+                    else:
+                        npl[i] = k - nminusi
+                    sumn += cls._correlation_old(nm, n0, npl, pnt[1:], gamma, w, debug)
+                sump += w[i] * sumn / ni
+            return flt.type(1 - pnt[0] * (1 - sump / Wn))
+        return flt.type(1)
+
+
+def _make_bart_kernel(*, alpha=0.95, beta=2, maxd=2, gamma=1, splits=None, pnt=None,
+    intercept=True, weights=None, reset=None, indices=False, scale=None, loc=None):
+    """ ``_bart.py:32-202`` wrapper: kernel(x, y) -> BART.correlation(splits[0], ix, iy, altinput=True) """
+    checked = BART._check_splits(splits, indices)
+
+    def core(x, y):
+        if not x.dtype.names:
+            x = x[..., None]
+        if not y.dtype.names:
+            y = y[..., None]
+        if indices:
+            ix = BART._check_x(x)
+            iy = BART._check_x(y)
+        else:
+            ix = BART._indices_from_coord(x, checked)
+            iy = BART._indices_from_coord(y, checked)
+        return BART.correlation(
+            checked[0], ix, iy,
+            pnt=pnt, alpha=alpha, beta=beta, gamma=gamma, maxd=maxd,
+            intercept=intercept, weights=weights, reset=reset, altinput=True,
+        )
+
+    return Kernel(core, scale=scale, loc=loc)
