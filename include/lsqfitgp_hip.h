@@ -1,0 +1,265 @@
+/*
+ * lsqfitgp_hip.h -- C-ABI of the MI355X (gfx950) dense-GP hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or framework
+ * types.  Every entry point names the reference interface it replaces
+ * (paths relative to the lsqfitgp checkout, v0.22.dev0).  The reference has no
+ * FFI of its own (it is pure Python over jax); the binding a maintainer would
+ * add is a ctypes stub, shown in INTEGRATION.md and implemented in
+ * lsqfitgp_amd/_lib.py.
+ *
+ * Conventions
+ *  - all matrices are dense ROW-MAJOR (C order, like the numpy/jax arrays of the
+ *    reference) with an explicit leading dimension in ELEMENTS (ld >= cols);
+ *  - `*_f64` entry points compute in IEEE double, `*_f32` in IEEE float;
+ *  - pointers named d* / "device" are HIP device pointers obtained from
+ *    lgp_malloc (or any hipMalloc allocation of the same device); pointers
+ *    named h* are host pointers;
+ *  - every function returns an int status: 0 = ok; >0 = LAPACK-style info
+ *    (1-based index of the first non-positive / non-finite pivot);
+ *    <0 = error (LGP_E*), message in lgp_last_error();
+ *  - all work is enqueued on the context's stream; functions that return
+ *    scalars to the host synchronise that stream, the others do not (call
+ *    lgp_sync);
+ *  - ownership: the caller owns every buffer and handle it allocates and frees
+ *    it explicitly; the library never frees caller memory.  Re-entrant per
+ *    context; no global mutable state except the thread-local error string.
+ */
+#ifndef LSQFITGP_HIP_H
+#define LSQFITGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGP_OK 0
+#define LGP_EINVAL (-1)   /* bad argument */
+#define LGP_EHIP (-2)     /* HIP runtime error */
+#define LGP_ECOMM (-3)    /* RCCL error */
+#define LGP_ENOMEM (-4)   /* device allocation failed */
+
+typedef struct lgp_ctx lgp_ctx;
+
+/* ---- context, memory, timing ------------------------------------------------ */
+
+int lgp_version(void);                                  /* ABI version */
+const char *lgp_last_error(void);                       /* thread-local message */
+int lgp_device_count(int *count);
+int lgp_ctx_create(int device, lgp_ctx **ctx);          /* one stream + workspace on `device` */
+int lgp_ctx_destroy(lgp_ctx *ctx);
+int lgp_sync(lgp_ctx *ctx);                             /* wait for the context's stream(s) */
+int lgp_device_info(lgp_ctx *ctx, char *name, int namelen, int *cus, int *clock_khz, size_t *mem_bytes);
+
+int lgp_malloc(lgp_ctx *ctx, size_t bytes, void **dptr);
+int lgp_free(lgp_ctx *ctx, void *dptr);
+int lgp_memset(lgp_ctx *ctx, void *dptr, int byte, size_t bytes);
+int lgp_upload(lgp_ctx *ctx, void *ddst, const void *hsrc, size_t bytes);     /* synchronous */
+int lgp_download(lgp_ctx *ctx, void *hdst, const void *dsrc, size_t bytes);   /* synchronous */
+/* strided device-to-device copy of a rows x cols block (elemsize 4 or 8); used to assemble
+ * block matrices like jnp.block in _GP/_elements.py:642-649 */
+int lgp_copy2d(lgp_ctx *ctx, void *ddst, size_t ldd, const void *dsrc, size_t lds,
+               size_t rows, size_t cols, size_t elemsize);
+/* dst (cols x rows) = src^T; the transposed block stored "for free" by _elements.py:637 */
+int lgp_transpose_f64(lgp_ctx *ctx, double *ddst, size_t ldd, const double *dsrc, size_t lds, size_t rows, size_t cols);
+int lgp_transpose_f32(lgp_ctx *ctx, float *ddst, size_t ldd, const float *dsrc, size_t lds, size_t rows, size_t cols);
+
+/* HIP-event timing on the context's stream (bench.py measures kernels with these) */
+int lgp_event_create(lgp_ctx *ctx, void **event);
+int lgp_event_destroy(lgp_ctx *ctx, void *event);
+int lgp_event_record(lgp_ctx *ctx, void *event);
+int lgp_event_elapsed_ms(lgp_ctx *ctx, void *start, void *stop, float *ms);   /* synchronises on stop */
+
+/* ---- Gram build: _GP/_elements.py:554-579 -> _Kernel/_crosskernel.py:192-200 ------- */
+
+#define LGP_KERNEL_EXPQUAD 0   /* _kernels/_basic.py:61-75   exp(-1/2 r2)                        */
+#define LGP_KERNEL_MATERNP 1   /* _kernels/_matern.py:29-49 + _special/_bessel.py:101-110 (p)  */
+#define LGP_OP_MUL 0           /* kernel * c  (_Kernel/_alg.py:58-82)  */
+#define LGP_OP_ADD 1           /* kernel + c  (_Kernel/_alg.py:32-56)  */
+
+/* out[i,j] = ops(core(r2_ij)), r2_ij = sum_f (u_if - v_jf)^2 accumulated in field order
+ * (_Kernel/_isotropic.py:61-81, _Kernel/_util.py:74-99), u = (x - loc)/scale, v = (y - loc)/scale
+ * (_Kernel/_ops.py:292-326; has_loc/has_scale = 0 skips the operation like loc=None/scale=None).
+ * dx: d field arrays of n values, SoA: field f at dx + f*ldx  (columnar StructuredArray, _array.py:104-105)
+ * dy: same for the m column points.  out: n x m, ld ldo.
+ * nops output algops (hops_code/hops_val are HOST arrays, nops <= 8) applied in order.
+ * symmetric != 0 (requires dx == dy, n == m): evaluate tiles on/below the diagonal and mirror them
+ * (the `halfmatrix` option of _elements.py:567-573). */
+int lgp_gram_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int d,
+                           const double *dx, size_t ldx, size_t n,
+                           const double *dy, size_t ldy, size_t m,
+                           int has_loc, double loc, int has_scale, double scale,
+                           int nops, const int *hops_code, const double *hops_val,
+                           int symmetric, double *dout, size_t ldo);
+int lgp_gram_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int d,
+                           const float *dx, size_t ldx, size_t n,
+                           const float *dy, size_t ldy, size_t m,
+                           int has_loc, float loc, int has_scale, float scale,
+                           int nops, const int *hops_code, const float *hops_val,
+                           int symmetric, float *dout, size_t ldo);
+
+/* BART correlation Gram matrix, the `altinput=True` path of _kernels/_bart.py:301-455,628-757 for one
+ * recursion slice ("bracket") of `size` = 1, 2 or 3 probabilities, iterated `repeat` times (the folding of
+ * `reset` depths, :424-447; e.g. maxd=10, reset=[2,4,6,8] is ONE slice with size 3, repeat 5).
+ * dix: n x p int32 row-major bin indices (one row per point), diy: m x p; hnsplits: HOST p totals
+ * (splits[0]); hweights: HOST p weights; hprobs: HOST repeat*size probabilities laid out as _bart.py:436-447
+ * does (rows evaluated first to last); gamma: scalar interpolation coefficient, or dgamma_mat (n x m, ld ldo,
+ * may alias dout) = per-pair result of the previous, deeper slice (:434-455).
+ * dpsi: device table psi[k] = digamma(k), k = 1..npsi-1, npsi >= max(nsplits)+2 (needed for size 3, :735-744).
+ * The reference tests point equality by a 64-bit hash (:674-681); here the index vectors are compared exactly. */
+int lgp_gram_bart_f32(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const int32_t *diy, size_t m,
+                      const int32_t *hnsplits, const float *hweights,
+                      int size, int repeat, const float *hprobs, float gamma, const float *dgamma_mat,
+                      const float *dpsi, size_t npsi,
+                      int nops, const int *hops_code, const float *hops_val,
+                      float *dout, size_t ldo);
+int lgp_gram_bart_f64(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const int32_t *diy, size_t m,
+                      const int32_t *hnsplits, const double *hweights,
+                      int size, int repeat, const double *hprobs, double gamma, const double *dgamma_mat,
+                      const double *dpsi, size_t npsi,
+                      int nops, const int *hops_code, const double *hops_val,
+                      double *dout, size_t ldo);
+
+/* Elementwise ("pairs") forms of the same kernels: out[i] = k(x_i, y_i), i < npairs -- the broadcasting
+ * call contract of CrossKernel.__call__ for equally shaped inputs (_Kernel/_crosskernel.py:192-200) and the
+ * flat upper-triangle evaluation of `halfmatrix` (_GP/_elements.py:567-573).  Arguments as the Gram forms.
+ * BART: dnpair (npairs x p int32, or NULL to use hnsplits for every pair) gives per-pair split totals, which
+ * makes it the fully vectorised BART.correlation(..., altinput=True) of _kernels/_bart.py:301-455;
+ * dgamma_vec (npairs, may alias dout) chains recursion slices. */
+int lgp_pairs_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int d, const double *dx, size_t ldx,
+                            const double *dy, size_t ldy, size_t npairs,
+                            int has_loc, double loc, int has_scale, double scale,
+                            int nops, const int *hops_code, const double *hops_val, double *dout);
+int lgp_pairs_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int d, const float *dx, size_t ldx,
+                            const float *dy, size_t ldy, size_t npairs,
+                            int has_loc, float loc, int has_scale, float scale,
+                            int nops, const int *hops_code, const float *hops_val, float *dout);
+int lgp_pairs_bart_f32(lgp_ctx *ctx, int p, const int32_t *dix, const int32_t *diy, size_t npairs,
+                       const int32_t *hnsplits, const int32_t *dnpair, const float *hweights,
+                       int size, int repeat, const float *hprobs, float gamma, const float *dgamma_vec,
+                       const float *dpsi, size_t npsi,
+                       int nops, const int *hops_code, const float *hops_val, float *dout);
+int lgp_pairs_bart_f64(lgp_ctx *ctx, int p, const int32_t *dix, const int32_t *diy, size_t npairs,
+                       const int32_t *hnsplits, const int32_t *dnpair, const double *hweights,
+                       int size, int repeat, const double *hprobs, double gamma, const double *dgamma_vec,
+                       const double *dpsi, size_t npsi,
+                       int nops, const int *hops_code, const double *hops_val, double *dout);
+
+/* ---- elementwise helpers used by the GP facade ---------------------------------- */
+
+/* C = alpha*A + beta*B elementwise (rows x cols); `Kxsxs - Q` of _GP/_compute.py:260, `Kxx + ycov` :85 */
+int lgp_axpby_f64(lgp_ctx *ctx, size_t rows, size_t cols, double alpha, const double *dA, size_t lda,
+                  double beta, const double *dB, size_t ldb, double *dC, size_t ldc);
+int lgp_axpby_f32(lgp_ctx *ctx, size_t rows, size_t cols, float alpha, const float *dA, size_t lda,
+                  float beta, const float *dB, size_t ldb, float *dC, size_t ldc);
+/* A[i,i] += dvec[i]*alpha (dvec may be NULL: += alpha); diag noise of bayestree/_bart.py:196 */
+int lgp_add_diag_f64(lgp_ctx *ctx, size_t n, double *dA, size_t lda, const double *dvec, double alpha);
+int lgp_add_diag_f32(lgp_ctx *ctx, size_t n, float *dA, size_t lda, const float *dvec, float alpha);
+/* A += c elementwise (`k_sigma_mu^2 * 11^T`) */
+int lgp_add_scalar_f64(lgp_ctx *ctx, size_t rows, size_t cols, double *dA, size_t lda, double c);
+int lgp_add_scalar_f32(lgp_ctx *ctx, size_t rows, size_t cols, float *dA, size_t lda, float c);
+/* flags[0] = any non-finite entry, flags[1] = max |A - A^T| > atol + rtol*|A^T| anywhere (jnp.allclose),
+ * checks of _GP/_elements.py:618-622 and _GP/_compute.py:369-381.  Synchronises. */
+int lgp_check_matrix_f64(lgp_ctx *ctx, size_t rows, size_t cols, const double *dA, size_t lda,
+                         int check_sym, double rtol, double atol, int *hflags);
+int lgp_check_matrix_f32(lgp_ctx *ctx, size_t rows, size_t cols, const float *dA, size_t lda,
+                         int check_sym, float rtol, float atol, int *hflags);
+
+/* *hclose = 1 iff |A - B| <= atol + rtol*|B| everywhere (jnp.allclose(A, B), the off-diagonal symmetry
+ * check `allclose(block.T, blockT)` of _GP/_elements.py:631-636).  Synchronises. */
+int lgp_allclose_f64(lgp_ctx *ctx, size_t rows, size_t cols, const double *dA, size_t lda,
+                     const double *dB, size_t ldb, double rtol, double atol, int *hclose);
+int lgp_allclose_f32(lgp_ctx *ctx, size_t rows, size_t cols, const float *dA, size_t lda,
+                     const float *dB, size_t ldb, float rtol, float atol, int *hclose);
+
+/* ---- decomposition: _linalg/_decomp.py:376-393 ----------------------------------- */
+
+#define LGP_EPS_AUTO_REL 1   /* epsrel='auto' -> n * finfo.eps   (_decomp.py:248-249) */
+#define LGP_EPS_AUTO_ABS 2   /* epsabs='auto' -> finfo.eps       (_decomp.py:250-251) */
+
+/* Chol.__init__: s = diag_scale_pow2(K) (:356-361); Kt = K/s/s[:,None]; eps = epsrel*max_i sum_j|Kt_ij| + epsabs
+ * (:245-255,349-354); Kt_ii += eps; Lt = cholesky(Kt) lower; L = Lt*s[:,None]; eps_out = eps*min(s^2).
+ * dK: n x n symmetric (only read).  dL: n x n output, strict upper triangle zeroed.
+ * dinvd: workspace/output, lgp_chol_invd_size(n) elements: inverses of the 128x128 diagonal blocks of L,
+ * consumed by lgp_trsm_*.  Returns 0, or info > 0 = 1-based index of the first non-positive or non-finite
+ * pivot (the reference's "cholesky decomposition not finite" LinAlgError, :389-391).  Synchronises. */
+size_t lgp_chol_invd_size(size_t n);
+int lgp_chol_factor_f64(lgp_ctx *ctx, size_t n, const double *dK, size_t ldk,
+                        double epsrel, double epsabs, int eps_flags,
+                        double *dL, size_t ldl, double *dinvd, double *heps_out);
+int lgp_chol_factor_f32(lgp_ctx *ctx, size_t n, const float *dK, size_t ldk,
+                        float epsrel, float epsabs, int eps_flags,
+                        float *dL, size_t ldl, float *dinvd, float *heps_out);
+/* the bare blocked factorisation (jlinalg.cholesky, _decomp.py:388) of the lower triangle of dL in place */
+int lgp_potrf_f64(lgp_ctx *ctx, size_t n, double *dL, size_t ldl, double *dinvd);
+int lgp_potrf_f32(lgp_ctx *ctx, size_t n, float *dL, size_t ldl, float *dinvd);
+
+/* ---- solves and products with L: _linalg/_decomp.py:398-439 ---------------------- */
+
+/* B <- L^-1 B (trans=0) or L^-T B (trans=1), B n x nrhs in place: jlinalg.solve_triangular(L, B, lower=True)
+ * (_decomp.py:402,407,408,414,419,426,439,467) and solve_triangular(L.T, ., lower=False) (:403,469) */
+int lgp_trsm_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *dinvd,
+                 int trans, double *dB, size_t ldb, size_t nrhs);
+int lgp_trsm_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, const float *dinvd,
+                 int trans, float *dB, size_t ldb, size_t nrhs);
+/* C (m x n) = alpha * op(A) op(B) + beta * C;  ta/tb = 0: as stored, 1: transposed.
+ * op(A) is m x k, op(B) is k x n.  `invLA.T @ invLr` (:409), `invLA.T @ invLA` (:420),
+ * `L @ x` (:431), `L.T @ X` (:435), `A.T @ ycov @ A` (_compute.py:269) */
+int lgp_gemm_f64(lgp_ctx *ctx, int ta, int tb, size_t m, size_t n, size_t k, double alpha,
+                 const double *dA, size_t lda, const double *dB, size_t ldb, double beta, double *dC, size_t ldc);
+int lgp_gemm_f32(lgp_ctx *ctx, int ta, int tb, size_t m, size_t n, size_t k, float alpha,
+                 const float *dA, size_t lda, const float *dB, size_t ldb, float beta, float *dC, size_t ldc);
+/* out[j] = sum_i A[i,j]^2 : einsum('ji,ji->i') of _decomp.py:427 */
+int lgp_colsumsq_f64(lgp_ctx *ctx, size_t rows, size_t cols, const double *dA, size_t lda, double *dout);
+int lgp_colsumsq_f32(lgp_ctx *ctx, size_t rows, size_t cols, const float *dA, size_t lda, float *dout);
+/* sum_i log L_ii (_decomp.py:486) and x.y (:487); results to host, synchronise */
+int lgp_logdet_diag_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, double *hout);
+int lgp_logdet_diag_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, float *hout);
+int lgp_dot_f64(lgp_ctx *ctx, size_t n, const double *dx, const double *dy, double *hout);
+int lgp_dot_f32(lgp_ctx *ctx, size_t n, const float *dx, const float *dy, float *hout);
+
+/* ---- fused conveniences for GP.pred / GP.marginal_likelihood --------------------- */
+
+/* _GP/_compute.py:259-260 with L^-1 Kxxs computed once:
+ * dW: n x (m+1) workspace, on entry [Kxxs | y] (column m = y), overwritten with L^-1 [Kxxs | y];
+ * mean (m) = (L^-1 Kxxs)^T (L^-1 y); cov (m x m, ld ldc) = Kxsxs - (L^-1 Kxxs)^T (L^-1 Kxxs).
+ * dKxsxs may alias dcov.  dmean/dcov are device pointers. */
+int lgp_posterior_f64(lgp_ctx *ctx, size_t n, size_t m, const double *dL, size_t ldl, const double *dinvd,
+                      double *dW, size_t ldw, const double *dKxsxs, size_t ldk,
+                      double *dmean, double *dcov, size_t ldc);
+int lgp_posterior_f32(lgp_ctx *ctx, size_t n, size_t m, const float *dL, size_t ldl, const float *dinvd,
+                      float *dW, size_t ldw, const float *dKxsxs, size_t ldk,
+                      float *dmean, float *dcov, size_t ldc);
+/* minus_log_normal_density(r, value=True) (_decomp.py:466-488): 1/2 (n log 2pi + 2 sum log L_ii + |L^-1 r|^2).
+ * dr (n) is overwritten with L^-1 r.  Synchronises. */
+int lgp_mlnd_value_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *dinvd,
+                       double *dr, double *hvalue);
+int lgp_mlnd_value_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, const float *dinvd,
+                       float *dr, float *hvalue);
+
+/* ---- multi-GPU: 1-D block-column-cyclic Cholesky over RCCL (no reference counterpart) -- */
+
+#define LGP_COMM_ID_BYTES 128
+int lgp_comm_unique_id(void *hid128);                                   /* ncclGetUniqueId on rank 0 */
+int lgp_comm_init(lgp_ctx *ctx, int rank, int nranks, const void *hid128);  /* ncclCommInitRank */
+int lgp_comm_destroy(lgp_ctx *ctx);
+int lgp_bcast(lgp_ctx *ctx, void *dbuf, size_t bytes, int root);        /* ncclBroadcast on the ctx stream */
+int lgp_allreduce_sum_f64(lgp_ctx *ctx, double *dbuf, size_t count);
+int lgp_allreduce_max_f64(lgp_ctx *ctx, double *dbuf, size_t count);
+
+/* building blocks of the distributed factorisation (the single-GPU driver is built from the same ones):
+ * factor one block-column panel held locally: dP is rows x nb (ld ldp), its top nb x nb block is the
+ * diagonal block; on exit dP holds the L panel and dinvd_blk (128x128 blocks) its diagonal-block inverses.
+ * info offset `row0` is added to pivot indices. */
+int lgp_panel_factor_f64(lgp_ctx *ctx, size_t rows, size_t nb, double *dP, size_t ldp, double *dinvd_blk, size_t row0);
+/* C (rows x cols, ldc) -= A (rows x k) * B (cols x k)^T, `lower` != 0 restricts to row >= col + diag_offset */
+int lgp_update_nt_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dA, size_t lda,
+                      const double *dB, size_t ldb, double *dC, size_t ldc, int lower);
+int lgp_get_info(lgp_ctx *ctx, int *hinfo);    /* read & reset the pivot info word; synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSQFITGP_HIP_H */

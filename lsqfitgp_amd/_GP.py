@@ -1,0 +1,668 @@
+"""
+Host-side mirror of the raw-output subset of ``lsqfitgp.GP``
+(``src/lsqfitgp/_GP/_gp.py:22-129``): the thin part of the façade needed to
+drive the device hot path -- ``addx``, ``addcov``, ``addtransf`` (scalar or
+tensor coefficients), ``prior(raw=True)``, ``pred/predfromdata/predfromfit(...,
+raw=True)``, ``marginal_likelihood``, ``decompose``.  Same names, keyword
+arguments, immutability (every ``add*`` returns a new object,
+``_GP/_base.py:86-104``), caches (``_covblocks`` ``_elements.py:43,626-640``,
+``_decompcache`` ``_compute.py:35,55-58``) and exceptions as the reference.
+Covariance blocks, decompositions and all intermediate matrices stay in HBM;
+only the requested outputs are downloaded.  Outputs that would be ``gvar``
+objects (``raw=False``) are out of scope and raise ``NotImplementedError``.
+"""
+
+import copy
+import ctypes
+import math
+
+import numpy
+
+from . import _lib
+from ._device import Context, DeviceArray
+from ._linalg import Decomposition, Chol
+from . import _kernels
+
+
+class _Element:
+    @property
+    def size(self):
+        return math.prod(self.shape)
+
+
+class _Points(_Element):
+    """ Points where the process is evaluated (``_elements.py:104-117``) """
+    def __init__(self, x):
+        self.x = x
+    @property
+    def shape(self):
+        return self.x.shape
+
+
+class _LinTransf(_Element):
+    """ Linear transformation of other elements with fixed coefficient tensors
+    (``_elements.py:119-147`` restricted to what `addtransf` builds, ``:332-344``) """
+    def __init__(self, tensors, keys, shape, axes):
+        self.tensors = tensors
+        self.keys = keys
+        self.shape = shape
+        self.axes = axes
+
+
+class _Cov(_Element):
+    """ User-provided covariance matrix block(s) (``_elements.py:149-156``) """
+    def __init__(self, blocks, shape):
+        self.blocks = blocks
+        self.shape = shape
+
+
+def _allclose_dev(A, B):
+    """ ``jnp.allclose(A, B)`` on device matrices """
+    f, F = _lib.fn('lgp_allclose', A.dtype)
+    flag = ctypes.c_int()
+    _lib.check(f(A.ctx.handle, A.shape[0], A.shape[1], A.ptr, A.ld, B.ptr, B.ld, F(1e-5), F(1e-8), ctypes.byref(flag)), 'lgp_allclose')
+    return bool(flag.value)
+
+
+def _check_dev(A, sym):
+    """ (nonfinite, asymmetric) flags of a device matrix """
+    f, F = _lib.fn('lgp_check_matrix', A.dtype)
+    flags = (ctypes.c_int * 2)()
+    _lib.check(f(A.ctx.handle, A.shape[0], A.shape[1], A.ptr, A.ld, int(bool(sym)), F(1e-5), F(1e-8), flags), 'lgp_check_matrix')
+    return bool(flags[0]), bool(flags[1])
+
+
+def _axpby(alpha, A, beta, B, out=None):
+    """ out = alpha*A + beta*B on device (B may be None) """
+    ref = A if A is not None else B
+    if out is None:
+        out = DeviceArray.empty(ref.shape, ref.dtype, ref.ctx)
+    f, F = _lib.fn('lgp_axpby', ref.dtype)
+    _lib.check(f(ref.ctx.handle, ref.shape[0], ref.shape[1], F(alpha), None if A is None else A.ptr, 0 if A is None else A.ld,
+                 F(beta), None if B is None else B.ptr, 0 if B is None else B.ld, out.ptr, out.ld), 'lgp_axpby')
+    return out
+
+
+def _gemm(ta, tb, A, B, alpha=1., beta=0., C=None):
+    f, F = _lib.fn('lgp_gemm', A.dtype)
+    m = A.shape[1] if ta else A.shape[0]
+    k = A.shape[0] if ta else A.shape[1]
+    n = B.shape[0] if tb else B.shape[1]
+    if C is None:
+        C = DeviceArray.empty((m, n), A.dtype, A.ctx)
+    _lib.check(f(A.ctx.handle, int(ta), int(tb), m, n, k, F(alpha), A.ptr, A.ld, B.ptr, B.ld, F(beta), C.ptr, C.ld), 'lgp_gemm')
+    return C
+
+
+def _astype_dev(A, dtype):
+    """ dtype conversion through the host: only on the rare mixed-precision assembly path """
+    if A.dtype == dtype:
+        return A
+    return DeviceArray.from_host(A.to_host().astype(dtype), ctx=A.ctx)
+
+
+class GP:
+    """
+    Object that represents a Gaussian process (device-resident subset).
+
+    Parameters mirror ``lsqfitgp.GP`` (``_gp.py:114-129``): ``covfun`` is a
+    kernel object of this package, ``solver`` must be ``'chol'``, the
+    ``check*`` flags and ``posepsfac``/``halfmatrix`` keep their meaning, and
+    extra keyword arguments (``epsrel``, ``epsabs``) go to the decomposition.
+    """
+
+    DefaultProcess = 'default'
+
+    def __init__(self, covfun=None, *, solver='chol', checkpos=True, checksym=True,
+        checkfinite=True, checklin=True, posepsfac=1, halfmatrix=False, ctx=None, **kw):
+        if covfun is not None and not isinstance(covfun, _kernels.Kernel):
+            raise TypeError('covariance function must be a lsqfitgp_amd kernel object')
+        self._covfun = covfun
+        self._ctx = ctx
+        self._elements = {}        # key -> _Element
+        self._covblocks = {}       # (key, key) -> DeviceArray (2d flattened)
+        self._decompcache = {}     # tuple of keys -> Decomposition
+        self._checkpositive = bool(checkpos)
+        self._posepsfac = float(posepsfac)
+        self._checksym = bool(checksym)
+        self._checkfinite = bool(checkfinite)
+        self._checklin = bool(checklin)
+        self._halfmatrix = bool(halfmatrix)
+        assert not (halfmatrix and checksym)
+        self._dtype = None
+        decomp = self._getdecomp(solver)
+        self._decompclass = lambda K, **kwargs: decomp(K, **kwargs, **kw)
+        self._checkpos_cache = []
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = Context.default()
+        return self._ctx
+
+    def _clone(self):
+        """ ``_GP/_base.py:86-104`` clone-on-write """
+        new = copy.copy(self)
+        new._elements = self._elements.copy()
+        new._covblocks = self._covblocks.copy()
+        new._decompcache = self._decompcache.copy()
+        new._checkpos_cache = list(self._checkpos_cache)
+        return new
+
+    # ---- elements (``_GP/_elements.py``) -------------------------------------
+
+    def addx(self, x, key=None, *, deriv=0, proc=DefaultProcess):
+        """ Add points where the Gaussian process is evaluated (``_elements.py:158-242``) """
+        if deriv not in (0, None) and deriv != ():
+            raise NotImplementedError('derivative observations are out of scope of the device path')
+        if proc != self.DefaultProcess:
+            raise KeyError(f'process named {proc!r} not found')
+        self = self._clone()
+        if hasattr(x, 'keys'):
+            if key is not None:
+                raise ValueError('can not specify key if x is a dictionary')
+            if None in x:
+                raise ValueError('None key in x not allowed')
+        else:
+            if key is None:
+                raise ValueError('x is not dictionary but key is None')
+            x = {key: x}
+        for key in x:
+            if key in self._elements:
+                raise KeyError('key {!r} already in GP'.format(key))
+            gx = numpy.asarray(x[key])
+            if self._dtype is not None:
+                try:
+                    self._dtype = numpy.result_type(self._dtype, gx.dtype)
+                except TypeError:
+                    raise TypeError('x[{!r}].dtype = {!r} not compatible with {!r}'.format(key, gx.dtype, self._dtype))
+            else:
+                self._dtype = gx.dtype
+            self._elements[key] = _Points(gx)
+        return self
+
+    def addtransf(self, tensors, key, *, axes=1):
+        """ Apply a linear transformation with fixed coefficients to already
+        specified process values (``_elements.py:248-346``) """
+        self = self._clone()
+        if key is None:
+            raise ValueError('key can not be None')
+        if key in self._elements:
+            raise KeyError(f'key {key!r} already in GP')
+        for k in tensors:
+            if k not in self._elements:
+                raise KeyError(k)
+        if len(tensors) == 0:
+            raise ValueError('empty tensors, undetermined output shape')
+        tens = {}
+        for k, t in tensors.items():
+            t = numpy.asarray(t)
+            if self._checkfinite and not numpy.all(numpy.isfinite(t)):
+                raise ValueError(f'tensors[{k!r}] contains infs/nans')
+            rshape = self._elements[k].shape
+            if t.shape and t.shape[t.ndim - axes:] != rshape[:axes]:
+                raise ValueError(f'tensors[{k!r}].shape = {t.shape!r} can not be multiplied with shape {rshape!r} with {axes}-axes contraction')
+            tens[k] = t
+        shapes = [
+            t.shape[:t.ndim - axes] + self._elements[k].shape[axes:] if t.shape else self._elements[k].shape
+            for k, t in tens.items()
+        ]
+        try:
+            shape = numpy.broadcast_shapes(*shapes)
+        except ValueError:
+            msg = 'can not broadcast tensors with shapes ['
+            msg += ', '.join(repr(t.shape) for t in tens.values())
+            msg += '] contracted with arrays with shapes ['
+            msg += ', '.join(repr(self._elements[k].shape) for k in tens) + ']'
+            raise ValueError(msg)
+        self._elements[key] = _LinTransf(tens, list(tens.keys()), tuple(shape), axes)
+        return self
+
+    def addcov(self, covblocks, key=None, *, decomps=None):
+        """ Add user-defined prior covariance matrix blocks (``_elements.py:408-552``) """
+        self = self._clone()
+        if hasattr(covblocks, 'keys'):
+            if key is not None:
+                raise ValueError('can not specify key if covblocks is a dictionary')
+            if None in covblocks:
+                raise ValueError('None key in covblocks not allowed')
+            if decomps is not None and not hasattr(decomps, 'keys'):
+                raise TypeError('covblocks is dictionary but decomps is not')
+        else:
+            if key is None:
+                raise ValueError('covblocks is not dictionary but key is None')
+            covblocks = {(key, key): covblocks}
+            if decomps is not None:
+                decomps = {key: decomps}
+        if decomps is None:
+            decomps = {}
+        shapes = {}
+        preblocks = {}
+        for keys, block in covblocks.items():
+            for key in keys:
+                if key in self._elements:
+                    raise KeyError(f'key {key!r} already in GP')
+            xkey, ykey = keys
+            if block is None:
+                raise TypeError(f'block {keys!r} is None')
+            block = numpy.asarray(block)
+            if xkey == ykey:
+                if block.ndim % 2 == 1:
+                    raise ValueError(f'diagonal block {key!r} has odd number of axes')
+                half = block.ndim // 2
+                head = block.shape[:half]
+                tail = block.shape[half:]
+                if head != tail:
+                    raise ValueError(f'shape {block.shape!r} of diagonal block {key!r} is not symmetric')
+                shapes[xkey] = head
+                if self._checksym and not numpy.allclose(block, block.T):
+                    raise ValueError(f'diagonal block {key!r} is not symmetric')
+            preblocks[keys] = block
+        for key, dec in decomps.items():
+            if key not in shapes:
+                raise KeyError(f'key {key!r} in decomps not found in diagonal blocks')
+            if not isinstance(dec, Decomposition):
+                raise TypeError(f'decomps[{key!r}] = {dec!r} is not a decomposition')
+            n = math.prod(shapes[key])
+            if dec.n != n:
+                raise ValueError(f'decomposition matrix size {dec.n} != diagonal block size {n} for key {key!r}')
+        blocks = {}
+        for keys, block in preblocks.items():
+            if self._checkfinite and not numpy.all(numpy.isfinite(block)):
+                raise ValueError(f'block {keys!r} not finite')
+            xkey, ykey = keys
+            if xkey == ykey:
+                size = math.prod(shapes[xkey])
+                blocks[keys] = block.reshape((size, size))
+            else:
+                for key in keys:
+                    if key not in shapes:
+                        raise KeyError(f'key {key!r} from off-diagonal block {keys!r} not found in diagonal blocks')
+                eshape = shapes[xkey] + shapes[ykey]
+                if block.shape != eshape:
+                    raise ValueError(f'shape {block.shape!r} of block {keys!r} is not {eshape!r} as expected from diagonal blocks')
+                xsize = math.prod(shapes[xkey])
+                ysize = math.prod(shapes[ykey])
+                block = block.reshape((xsize, ysize))
+                blocks[keys] = block
+                revkeys = keys[::-1]
+                if preblocks.get(revkeys) is None:
+                    blocks[revkeys] = block.T
+        if self._checksym:
+            for keys, block in blocks.items():
+                xkey, ykey = keys
+                if xkey != ykey:
+                    blockT = blocks[ykey, xkey]
+                    if not numpy.allclose(block.T, blockT):
+                        raise ValueError(f'block {keys!r} is not the transpose of block {keys[::-1]!r}')
+        for key, shape in shapes.items():
+            self._elements[key] = _Cov(blocks, shape)
+            decomp = decomps.get(key)
+            if decomp is not None:
+                self._decompcache[key,] = decomp
+        return self
+
+    # ---- covariance blocks -----------------------------------------------------
+
+    def _upload_block(self, block):
+        block = numpy.asarray(block)
+        dtype = numpy.float32 if block.dtype == numpy.float32 else numpy.float64
+        return DeviceArray.from_host(block, dtype=dtype, ctx=self.ctx)
+
+    def _makecovblock_points(self, xkey, ykey):
+        """ ``_elements.py:554-579``: HOT LOOP 1, one Gram-kernel launch """
+        x = self._elements[xkey]
+        y = self._elements[ykey]
+        kernel = self._covfun
+        if kernel is None:
+            raise ValueError('no covariance function: GP(covfun) is required to add points')
+        xf = x.x.reshape(-1)
+        if x is y and not self._checksym and self._halfmatrix:
+            # the reference evaluates the upper triangle as a flat vector and gathers (:567-573);
+            # the device Gram kernels are exactly symmetric, so the full tile evaluation gives the same matrix
+            return kernel.gram(xf, xf, ctx=self.ctx)
+        yf = xf if y is x else y.x.reshape(-1)
+        return kernel.gram(xf, yf, ctx=self.ctx)
+
+    def _makecovblock_lintransf_any(self, xkey, ykey):
+        """ ``_elements.py:581-601`` for the tensordot transformation of `addtransf` (``:332-344``) """
+        x = self._elements[xkey]
+        y = self._elements[ykey]
+        out = None
+        for k in x.keys:
+            elem = self._elements[k]
+            cov = self._covblock(k, ykey)
+            assert cov.shape == (elem.size, y.size)
+            t = x.tensors[k]
+            if out is not None and cov.dtype != out.dtype:
+                dt = numpy.result_type(cov.dtype, out.dtype)
+                cov, out = _astype_dev(cov, dt), _astype_dev(out, dt)
+            if t.shape:
+                # tensordot(t, cov.reshape(elem.shape + (ysize,)), axes): (out.., contracted..) x (contracted.., rest.., ysize)
+                axes = x.axes
+                csize = math.prod(elem.shape[:axes])
+                rest = math.prod(elem.shape[axes:])
+                osize = math.prod(t.shape[:t.ndim - axes])
+                if (osize * rest) != x.size:
+                    raise NotImplementedError('broadcasting between transformed elements of different shapes')
+                td = DeviceArray.from_host(t.reshape(osize, csize), dtype=cov.dtype, ctx=self.ctx)
+                covr = cov if cov.contiguous else cov.copy()
+                covr = covr.reshape_contiguous((csize, rest * y.size))
+                if out is None:
+                    out = _gemm(False, False, td, covr).reshape_contiguous((x.size, y.size))
+                else:
+                    _gemm(False, False, td, covr, 1., 1., out.reshape_contiguous((osize, rest * y.size)))
+            else:
+                if elem.size != x.size:
+                    raise NotImplementedError('broadcasting between transformed elements of different shapes')
+                if out is None:
+                    out = _axpby(float(t), cov, 0., None)
+                else:
+                    _axpby(float(t), cov, 1., out, out)
+        return out
+
+    def _makecovblock(self, xkey, ykey):
+        """ ``_elements.py:603-624`` """
+        x = self._elements[xkey]
+        y = self._elements[ykey]
+        if isinstance(x, _Points) and isinstance(y, _Points):
+            cov = self._makecovblock_points(xkey, ykey)
+        elif isinstance(x, _LinTransf):
+            cov = self._makecovblock_lintransf_any(xkey, ykey)
+        elif isinstance(y, _LinTransf):
+            cov = self._makecovblock_lintransf_any(ykey, xkey).transpose()
+        elif isinstance(x, _Cov) and isinstance(y, _Cov) and x.blocks is y.blocks and (xkey, ykey) in x.blocks:
+            cov = self._upload_block(x.blocks[xkey, ykey])
+        else:
+            cov = DeviceArray.zeros((x.size, y.size), numpy.float64, self.ctx)
+        if (self._checkfinite or (self._checksym and xkey == ykey)) and cov.size:
+            nonfinite, asym = _check_dev(cov, self._checksym and xkey == ykey)
+            if self._checkfinite and nonfinite:
+                raise RuntimeError(f'covariance block {(xkey, ykey)!r} is not finite')
+            if self._checksym and xkey == ykey and asym:
+                raise RuntimeError(f'covariance block {(xkey, ykey)!r} is not symmetric')
+        return cov
+
+    def _covblock(self, row, col):
+        """ ``_elements.py:626-640``: block cache, transposed block stored too """
+        if (row, col) not in self._covblocks:
+            block = self._makecovblock(row, col)
+            if row != col:
+                blockT = None
+                if self._checksym:
+                    blockT = self._makecovblock(col, row)
+                    bt = block.transpose()
+                    if bt.dtype != blockT.dtype or not _allclose_dev(bt, blockT):
+                        if bt.dtype == blockT.dtype:
+                            raise RuntimeError('covariance block {!r} is not symmetric'.format((row, col)))
+                    blockT = bt
+                self._covblocks[col, row] = blockT if blockT is not None else block.transpose()
+            self._covblocks[row, col] = block
+        return self._covblocks[row, col]
+
+    def _assemblecovblocks(self, rowkeys, colkeys=None):
+        """ ``_elements.py:642-649`` (jnp.block): strided device copies into one matrix """
+        if colkeys is None:
+            colkeys = rowkeys
+        blocks = [[self._covblock(row, col) for col in colkeys] for row in rowkeys]
+        if len(blocks) == 1 and len(blocks[0]) == 1:
+            return blocks[0][0]
+        dtype = numpy.result_type(*[b.dtype for r in blocks for b in r])
+        nr = sum(r[0].shape[0] for r in blocks)
+        nc = sum(b.shape[1] for b in blocks[0])
+        out = DeviceArray.empty((nr, nc), dtype, self.ctx)
+        r0 = 0
+        for r in blocks:
+            c0 = 0
+            for b in r:
+                out.block(r0, r0 + b.shape[0], c0, c0 + b.shape[1]).assign(_astype_dev(b, dtype))
+                c0 += b.shape[1]
+            r0 += r[0].shape[0]
+        return out
+
+    def _checkpos(self, cov):
+        """
+        ``_elements.py:651-668``.  The reference estimates the extreme
+        eigenvalues with two host lobpcg runs and rejects
+        ``mineigv < -n eps maxeigv posepsfac``; here the same threshold is
+        applied by a device factorisation: the matrix shifted by
+        ``n eps posepsfac`` times the Gershgorin bound of its largest
+        eigenvalue must be numerically positive definite.
+        """
+        try:
+            Chol(cov, epsrel=len(cov) * numpy.finfo(cov.dtype).eps * self._posepsfac, epsabs=0)
+        except numpy.linalg.LinAlgError:
+            raise numpy.linalg.LinAlgError('covariance matrix is not positive definite: mineigv < -n * eps * maxeigv * posepsfac')
+
+    def _checkpos_keys(self, keys):
+        """ ``_elements.py:672-680`` """
+        if not self._checkpositive:
+            return
+        keys = set(keys)
+        for prev_keys in self._checkpos_cache:
+            if keys.issubset(prev_keys):
+                return
+        cov = self._assemblecovblocks(list(keys))
+        self._checkpos(cov)
+        self._checkpos_cache.append(keys)
+
+    def prior(self, key=None, *, raw=False):
+        """ Prior covariance (``_elements.py:758-817``); ``raw=True`` only """
+        raw = bool(raw)
+        if not raw:
+            raise NotImplementedError('gvar outputs are out of scope of the device path: use raw=True')
+        if key is None:
+            outkeys = list(self._elements)
+        elif isinstance(key, list):
+            outkeys = key
+        else:
+            outkeys = None
+        self._checkpos_keys([key] if outkeys is None else outkeys)
+        if outkeys is not None:
+            return {
+                (row, col): self._covblock(row, col).to_host().reshape(self._elements[row].shape + self._elements[col].shape)
+                for row in outkeys for col in outkeys
+            }
+        return self._covblock(key, key).to_host().reshape(2 * self._elements[key].shape)
+
+    def _slices(self, keylist):
+        """ ``_elements.py:819-826`` """
+        sizes = [self._elements[key].size for key in keylist]
+        stops = numpy.pad(numpy.cumsum(sizes), (1, 0))
+        return [slice(stops[i - 1], stops[i]) for i in range(1, len(stops))]
+
+    # ---- compute (``_GP/_compute.py``) ---------------------------------------------
+
+    @staticmethod
+    def _getdecomp(solver):
+        """ ``_compute.py:424-428`` """
+        return {'chol': Chol}[solver]
+
+    def _solver(self, keys, ycov=None, **kw):
+        """ Decomposition of the covariance of ``keys`` plus ``ycov``
+        (``_compute.py:45-94``): HOT LOOP 2 """
+        keys = tuple(keys)
+        if ycov is None:
+            cache = self._decompcache.get(keys)
+            if cache is not None:
+                return cache
+        Kxx = self._assemblecovblocks(keys)
+        if ycov is not None:
+            if ycov.dtype != Kxx.dtype:
+                dt = numpy.result_type(ycov.dtype, Kxx.dtype)
+                ycov, Kxx = _astype_dev(ycov, dt), _astype_dev(Kxx, dt)
+            Kxx = _axpby(1., Kxx, 1., ycov)                               # Kxx + ycov, :85
+        decomp = self._decompclass(Kxx, **kw)                              # :88
+        if ycov is None:
+            self._decompcache[keys] = decomp
+        return decomp
+
+    def _flatgiven(self, given, givencov):
+        """ ``_compute.py:96-136`` """
+        if not hasattr(given, 'keys'):
+            raise TypeError('`given` must be dict')
+        gcblack = givencov is None or isinstance(givencov, Decomposition)
+        if not gcblack and not hasattr(givencov, 'keys'):
+            raise TypeError('`givenconv` must be None, dict or Decomposition')
+        ylist = []
+        keylist = []
+        for key, l in given.items():
+            if key not in self._elements:
+                raise KeyError(key)
+            l = numpy.asarray(l)
+            shape = self._elements[key].shape
+            if l.shape != shape:
+                raise ValueError('given[{!r}] has shape {!r} different from shape {!r}'.format(key, l.shape, shape))
+            if l.dtype == object:
+                raise NotImplementedError('gvar inputs are out of scope of the device path')
+            if not numpy.issubdtype(l.dtype, numpy.number):
+                raise TypeError('given[{!r}] has non-numerical dtype {!r}'.format(key, l.dtype))
+            ylist.append(l.reshape(-1))
+            keylist.append(key)
+        if gcblack:
+            if givencov is not None:
+                raise NotImplementedError('Decomposition as givencov (Woodbury) is un-implemented in the reference too')
+            covblocks = givencov
+        else:
+            covblocks = [
+                [
+                    numpy.asarray(givencov[keylist[i], keylist[j]]).reshape(ylist[i].shape + ylist[j].shape)
+                    for j in range(len(keylist))
+                ]
+                for i in range(len(keylist))
+            ]
+        return ylist, keylist, covblocks
+
+    def _check_ymean(self, ymean):
+        """ ``_compute.py:369-372`` """
+        if self._checkfinite and not numpy.all(numpy.isfinite(ymean)):
+            raise ValueError('mean of `given` is not finite')
+
+    def _check_ycov(self, ycov):
+        """ ``_compute.py:374-381`` (ycov is a host array here: it comes from the caller) """
+        if ycov is None:
+            return
+        if self._checkfinite and not numpy.all(numpy.isfinite(ycov)):
+            raise ValueError('covariance matrix of `given` is not finite')
+        if self._checksym and not numpy.allclose(ycov, ycov.T):
+            raise ValueError('covariance matrix of `given` is not symmetric')
+
+    def pred(self, given, key=None, givencov=None, *, fromdata=None, raw=False, keepcorr=None):
+        """ Compute the posterior (``_compute.py:138-305``), raw outputs """
+        if fromdata is None:
+            raise ValueError('you must specify if `given` is data or fit result')
+        fromdata = bool(fromdata)
+        raw = bool(raw)
+        if keepcorr is None:
+            keepcorr = not raw
+        if keepcorr and raw:
+            raise ValueError('both keepcorr=True and raw=True')
+        if not raw:
+            raise NotImplementedError('gvar outputs are out of scope of the device path: use raw=True')
+
+        strip = False
+        if key is None:
+            outkeys = list(self._elements)
+        elif isinstance(key, list):
+            outkeys = key
+        else:
+            outkeys = [key]
+            strip = True
+        outslices = self._slices(outkeys)
+
+        ylist, inkeys, ycovblocks = self._flatgiven(given, givencov)
+        y = numpy.concatenate(ylist)
+
+        self._checkpos_keys(inkeys + outkeys)
+
+        Kxxs = self._assemblecovblocks(inkeys, outkeys)                   # :230
+
+        ycov = numpy.block(ycovblocks) if ycovblocks is not None else None
+        self._check_ycov(ycov)
+        ymean = y
+        self._check_ymean(ymean)
+
+        Kxsxs = self._assemblecovblocks(outkeys)                          # :252
+        ycov_dev = None if ycov is None else self._upload_block(ycov)
+        if fromdata:
+            solver = self._solver(inkeys, ycov_dev)                       # :255
+        else:
+            solver = self._solver(inkeys)
+
+        dtype = solver._dtype
+        n, m = Kxxs.shape
+        # W = [Kxxs | y]; one forward solve serves mean and covariance (:259-260)
+        W = DeviceArray.empty((n, m + 1), dtype, self.ctx)
+        W.block(0, n, 0, m).assign(_astype_dev(Kxxs, dtype))
+        W.block(0, n, m, m + 1).assign(DeviceArray.from_host(ymean.reshape(n, 1), dtype=dtype, ctx=self.ctx))
+        mean_d = DeviceArray.empty((m,), dtype, self.ctx)
+        cov_d = DeviceArray.empty((m, m), dtype, self.ctx)
+        Kss = _astype_dev(Kxsxs, dtype)
+        f, _ = _lib.fn('lgp_posterior', dtype)
+        _lib.check(f(self.ctx.handle, n, m, solver._L.ptr, solver._L.ld, solver._invd.ptr, W.ptr, W.ld,
+                     Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld), 'lgp_posterior')
+        if not fromdata and ycov_dev is not None:
+            # cov += A' ycov A, A = K^-1 Kxxs = L^-T (L^-1 Kxxs)             (:262-269)
+            A = W.block(0, n, 0, m).copy()
+            solver._trsm(A, 1)
+            yA = _gemm(False, False, _astype_dev(ycov_dev, dtype), A)
+            _gemm(True, False, A, yA, 1., 1., cov_d)
+        mean = mean_d.to_host()
+        cov = cov_d.to_host()
+
+        if not strip:                                                     # :286-300
+            meandict = {
+                key: mean[slic].reshape(self._elements[key].shape)
+                for key, slic in zip(outkeys, outslices)
+            }
+            covdict = {
+                (row, col): cov[rowslice, colslice].reshape(self._elements[row].shape + self._elements[col].shape)
+                for row, rowslice in zip(outkeys, outslices)
+                for col, colslice in zip(outkeys, outslices)
+            }
+            return meandict, covdict
+        outkey, = outkeys                                                 # :301-305
+        return mean.reshape(self._elements[outkey].shape), cov.reshape(2 * self._elements[outkey].shape)
+
+    def predfromfit(self, *args, **kw):
+        """ Like `pred` with ``fromdata=False`` """
+        return self.pred(*args, fromdata=False, **kw)
+
+    def predfromdata(self, *args, **kw):
+        """ Like `pred` with ``fromdata=True`` """
+        return self.pred(*args, fromdata=True, **kw)
+
+    def _prior_decomp(self, given, givencov=None, **kw):
+        """ ``_compute.py:336-367`` """
+        ylist, inkeys, ycovblocks = self._flatgiven(given, givencov)
+        y = numpy.concatenate(ylist)
+        self._checkpos_keys(inkeys)
+        ymean = y
+        self._check_ymean(ymean)
+        ycov = numpy.block(ycovblocks) if ycovblocks is not None else None
+        self._check_ycov(ycov)
+        ycov_dev = None if ycov is None else self._upload_block(ycov)
+        decomp = self._solver(inkeys, ycov_dev, **kw)
+        return decomp, ymean
+
+    def marginal_likelihood(self, given, givencov=None, **kw):
+        """ Logarithm of the probability of the data (``_compute.py:383-422``) """
+        decomp, ymean = self._prior_decomp(given, givencov, **kw)
+        mll, _, _, _, _ = decomp.minus_log_normal_density(ymean, value=True)
+        return -mll
+
+    @classmethod
+    def decompose(cls, posdefmatrix, solver='chol', **kw):
+        """ Decompose a nonnegative definite matrix (``_compute.py:430-516``) """
+        m = posdefmatrix if isinstance(posdefmatrix, DeviceArray) else numpy.asarray(posdefmatrix)
+        assert m.size > 0
+        assert m.ndim % 2 == 0
+        half = m.ndim // 2
+        head = m.shape[:half]
+        tail = m.shape[half:]
+        assert head == tail
+        n = math.prod(head)
+        if not isinstance(m, DeviceArray):
+            m = m.reshape(n, n)
+        decompcls = cls._getdecomp(solver)
+        return decompcls(m, **kw)

@@ -1,0 +1,17 @@
+"""
+lsqfitgp_amd -- MI355X (gfx950) native implementation of the dense-GP fit/predict
+hot path of lsqfitgp: kernel Gram-matrix build (ExpQuad, Maternp, BART),
+regularised blocked Cholesky, triangular solves, posterior mean/covariance and
+log marginal likelihood, behind lsqfitgp's own ``GP`` / ``Decomposition`` API
+surface (raw outputs).  Python host code -> ctypes -> ``liblsqfitgp_hip.so``
+(hand-written HIP kernels, ``include/lsqfitgp_hip.h``).  No CPU fallback.
+"""
+
+from ._lib import LibraryError
+from ._device import Context, DeviceArray, asdevice
+from ._linalg import Decomposition, Chol
+from ._kernels import Kernel, ExpQuad, Maternp, BART
+from ._GP import GP
+from . import _linalg
+
+__version__ = '0.1.0'

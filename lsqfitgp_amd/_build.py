@@ -1,0 +1,78 @@
+"""
+Build recipe of liblsqfitgp_hip.so: every HIP translation unit under
+``lsqfitgp_amd/csrc`` is compiled for gfx950 with hipcc and linked into one
+shared library that lives next to this file (in-tree, so that it travels to the
+GPU box with the snapshot).  No PyTorch, no cmake: plain ``hipcc`` commands.
+"""
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBNAME = 'liblsqfitgp_hip.so'
+LIBPATH = os.path.join(HERE, LIBNAME)
+
+# (source, extra flags)
+UNITS = [
+    ('api.hip', []),
+    ('gemm.hip', []),
+    ('potrf.hip', []),
+    ('elementwise.hip', []),
+    # the Gram kernels follow the reference's unfused square-then-add evaluation
+    ('gram.hip', ['-ffp-contract=off']),
+]
+
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found: the HIP toolchain (ROCm) is required to build ' + LIBNAME)
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """ compile and link; returns the library path """
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'lsqfitgp_hip.h')]
+    objdir = os.path.join(CSRC, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for src, extra in UNITS:
+        srcpath = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, [srcpath] + headers):
+            cmd = [hipcc] + COMMON + extra + ['-c', srcpath, '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, proc in procs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            raise RuntimeError('compilation failed: ' + ' '.join(cmd) + '\n' + out)
+        if verbose and out.strip():
+            print(out)
+    if force or _stale(LIBPATH, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIBPATH] + objs + ['-ldl']
+        if verbose:
+            print(' '.join(cmd))
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode != 0:
+            raise RuntimeError('link failed: ' + ' '.join(cmd) + '\n' + res.stdout)
+    return LIBPATH
+
+
+if __name__ == '__main__':
+    print(build_library(verbose=True))

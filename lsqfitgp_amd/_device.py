@@ -1,0 +1,259 @@
+"""
+Device context and device-resident arrays (HBM) for the host-side mirror of
+lsqfitgp's hot path.  Everything here is plumbing over the C-ABI
+(``lgp_ctx_*``, ``lgp_malloc``, ``lgp_upload`` ...); there is no compute.
+"""
+
+import ctypes
+import math
+import os
+import threading
+import weakref
+
+import numpy
+
+from . import _lib
+
+
+class Context:
+    """ one GPU: a ``lgp_ctx`` (stream + workspace).  ``Context.default()`` is
+    the process-wide context on ``LGP_DEVICE`` / ``LOCAL_RANK`` / device 0. """
+
+    _default = None
+    _lock = threading.Lock()
+
+    def __init__(self, device=0):
+        lib = _lib.load()
+        count = ctypes.c_int(0)
+        st = lib.lgp_device_count(ctypes.byref(count))
+        if st != 0 or count.value == 0:
+            raise _lib.LibraryError(
+                'no HIP device visible: lsqfitgp_amd computes on an MI355X (gfx950) GPU '
+                'and has no CPU fallback (' + _lib.last_error() + ')')
+        handle = ctypes.c_void_p()
+        _lib.check(lib.lgp_ctx_create(int(device), ctypes.byref(handle)), 'lgp_ctx_create')
+        self._lib = lib
+        self._handle = handle
+        self.device = int(device)
+        self.rank = 0
+        self.nranks = 1
+        self._finalizer = weakref.finalize(self, lib.lgp_ctx_destroy, handle)
+
+    @property
+    def handle(self):
+        return self._handle
+
+    @classmethod
+    def default(cls):
+        with cls._lock:
+            if cls._default is None:
+                dev = os.environ.get('LGP_DEVICE')
+                if dev is None:
+                    dev = os.environ.get('LOCAL_RANK', '0')
+                    count = ctypes.c_int(0)
+                    _lib.load().lgp_device_count(ctypes.byref(count))
+                    dev = int(dev) % max(count.value, 1)
+                cls._default = cls(int(dev))
+            return cls._default
+
+    def sync(self):
+        _lib.check(self._lib.lgp_sync(self._handle), 'lgp_sync')
+
+    def info(self):
+        name = ctypes.create_string_buffer(256)
+        cus = ctypes.c_int()
+        clock = ctypes.c_int()
+        mem = ctypes.c_size_t()
+        _lib.check(self._lib.lgp_device_info(self._handle, name, 256, ctypes.byref(cus), ctypes.byref(clock), ctypes.byref(mem)))
+        return dict(name=name.value.decode(), cus=cus.value, clock_khz=clock.value, mem_bytes=mem.value)
+
+    # ---- events (HIP-event timing on the context's stream)
+    def event(self):
+        ev = ctypes.c_void_p()
+        _lib.check(self._lib.lgp_event_create(self._handle, ctypes.byref(ev)))
+        return ev
+
+    def record(self, ev):
+        _lib.check(self._lib.lgp_event_record(self._handle, ev))
+
+    def elapsed_ms(self, start, stop):
+        ms = ctypes.c_float()
+        _lib.check(self._lib.lgp_event_elapsed_ms(self._handle, start, stop, ctypes.byref(ms)))
+        return ms.value
+
+    def event_destroy(self, ev):
+        self._lib.lgp_event_destroy(self._handle, ev)
+
+    # ---- RCCL
+    def comm_init(self, rank, nranks, unique_id):
+        buf = ctypes.create_string_buffer(bytes(unique_id), _lib.LGP_COMM_ID_BYTES)
+        _lib.check(self._lib.lgp_comm_init(self._handle, int(rank), int(nranks), buf), 'lgp_comm_init')
+        self.rank, self.nranks = int(rank), int(nranks)
+
+    @staticmethod
+    def comm_unique_id():
+        buf = ctypes.create_string_buffer(_lib.LGP_COMM_ID_BYTES)
+        _lib.check(_lib.load().lgp_comm_unique_id(buf), 'lgp_comm_unique_id')
+        return buf.raw
+
+
+class _Buffer:
+    """ owns one lgp_malloc allocation """
+
+    def __init__(self, ctx, nbytes):
+        ptr = ctypes.c_void_p()
+        _lib.check(ctx._lib.lgp_malloc(ctx.handle, int(nbytes), ctypes.byref(ptr)), f'lgp_malloc({nbytes})')
+        self.ctx = ctx
+        self.ptr = ptr.value
+        self.nbytes = int(nbytes)
+        self._finalizer = weakref.finalize(self, ctx._lib.lgp_free, ctx.handle, ctypes.c_void_p(ptr.value))
+
+
+_ALLOWED = (numpy.dtype(numpy.float64), numpy.dtype(numpy.float32), numpy.dtype(numpy.int32))
+
+
+class DeviceArray:
+    """
+    A 1-D or 2-D row-major array resident in HBM: pointer + shape + leading
+    dimension.  Views (``block``/``rows``/``col``) share the buffer.
+    ``numpy.asarray(a)`` / ``a.to_host()`` download it.
+    """
+
+    __array_priority__ = 1000
+
+    def __init__(self, buffer, ptr, shape, dtype, ld):
+        self._buffer = buffer
+        self.ptr = int(ptr)
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = numpy.dtype(dtype)
+        self.ld = int(ld)       # elements between rows (2-D) ; 1 for 1-D
+
+    # ---- construction
+    @classmethod
+    def empty(cls, shape, dtype=numpy.float64, ctx=None):
+        ctx = ctx or Context.default()
+        dtype = numpy.dtype(dtype)
+        assert dtype in _ALLOWED, dtype
+        if isinstance(shape, (int, numpy.integer)):
+            shape = (int(shape),)
+        shape = tuple(int(s) for s in shape)
+        assert 1 <= len(shape) <= 2, shape
+        n = math.prod(shape)
+        buf = _Buffer(ctx, max(n, 1) * dtype.itemsize)
+        return cls(buf, buf.ptr, shape, dtype, shape[-1] if len(shape) == 2 else 1)
+
+    @classmethod
+    def zeros(cls, shape, dtype=numpy.float64, ctx=None):
+        out = cls.empty(shape, dtype, ctx)
+        out.fill_zero()
+        return out
+
+    @classmethod
+    def from_host(cls, a, dtype=None, ctx=None):
+        a = numpy.ascontiguousarray(a, dtype=dtype)
+        out = cls.empty(a.shape if a.ndim else (1,), a.dtype, ctx)
+        if a.size:
+            _lib.check(out.ctx._lib.lgp_upload(out.ctx.handle, out.ptr, a.ctypes.data, a.nbytes), 'lgp_upload')
+        return out
+
+    # ---- properties
+    @property
+    def ctx(self):
+        return self._buffer.ctx
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return math.prod(self.shape)
+
+    @property
+    def itemsize(self):
+        return self.dtype.itemsize
+
+    @property
+    def contiguous(self):
+        return self.ndim == 1 or self.ld == self.shape[1] or self.shape[0] <= 1
+
+    def __len__(self):
+        return self.shape[0]
+
+    # ---- views
+    def block(self, r0, r1, c0, c1):
+        assert self.ndim == 2 and 0 <= r0 <= r1 <= self.shape[0] and 0 <= c0 <= c1 <= self.shape[1]
+        return DeviceArray(self._buffer, self.ptr + (r0 * self.ld + c0) * self.itemsize, (r1 - r0, c1 - c0), self.dtype, self.ld)
+
+    def rows(self, r0, r1):
+        if self.ndim == 1:
+            assert 0 <= r0 <= r1 <= self.shape[0]
+            return DeviceArray(self._buffer, self.ptr + r0 * self.itemsize, (r1 - r0,), self.dtype, 1)
+        return self.block(r0, r1, 0, self.shape[1])
+
+    def as2d(self):
+        """ a vector as an (n, 1) column """
+        if self.ndim == 2:
+            return self
+        return DeviceArray(self._buffer, self.ptr, (self.shape[0], 1), self.dtype, 1)
+
+    def reshape_contiguous(self, shape):
+        assert self.contiguous and math.prod(shape) == self.size
+        shape = tuple(shape)
+        return DeviceArray(self._buffer, self.ptr, shape, self.dtype, shape[-1] if len(shape) == 2 else 1)
+
+    # ---- data movement
+    def fill_zero(self):
+        if self.contiguous:
+            _lib.check(self.ctx._lib.lgp_memset(self.ctx.handle, self.ptr, 0, self.size * self.itemsize))
+        else:
+            for i in range(self.shape[0]):
+                _lib.check(self.ctx._lib.lgp_memset(self.ctx.handle, self.ptr + i * self.ld * self.itemsize, 0, self.shape[1] * self.itemsize))
+
+    def to_host(self):
+        out = numpy.empty(self.shape, self.dtype)
+        if self.size == 0:
+            return out
+        if self.contiguous:
+            _lib.check(self.ctx._lib.lgp_download(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes), 'lgp_download')
+        else:
+            tmp = self.copy()
+            _lib.check(self.ctx._lib.lgp_download(self.ctx.handle, out.ctypes.data, tmp.ptr, out.nbytes), 'lgp_download')
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.to_host()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def copy(self):
+        out = DeviceArray.empty(self.shape, self.dtype, self.ctx)
+        out.assign(self)
+        return out
+
+    def assign(self, src):
+        """ self[...] = src (device array of the same shape and dtype) """
+        assert src.shape == self.shape and src.dtype == self.dtype, (src.shape, self.shape, src.dtype, self.dtype)
+        if self.size == 0:
+            return
+        rows, cols = (self.shape if self.ndim == 2 else (1, self.shape[0]))
+        _lib.check(self.ctx._lib.lgp_copy2d(self.ctx.handle, self.ptr, max(self.ld, cols), src.ptr, max(src.ld, cols), rows, cols, self.itemsize), 'lgp_copy2d')
+
+    def transpose(self):
+        assert self.ndim == 2 and self.dtype.kind == 'f'
+        out = DeviceArray.empty((self.shape[1], self.shape[0]), self.dtype, self.ctx)
+        if self.size:
+            f, _ = _lib.fn('lgp_transpose', self.dtype)
+            _lib.check(f(self.ctx.handle, out.ptr, out.ld, self.ptr, self.ld, self.shape[0], self.shape[1]), 'lgp_transpose')
+        return out
+
+    def __repr__(self):
+        return f'DeviceArray(shape={self.shape}, dtype={self.dtype}, ld={self.ld}, device={self.ctx.device})'
+
+
+def asdevice(a, dtype=None, ctx=None):
+    """ DeviceArray as is (dtype must match), host array uploaded """
+    if isinstance(a, DeviceArray):
+        if dtype is not None and numpy.dtype(dtype) != a.dtype:
+            raise TypeError(f'device array has dtype {a.dtype}, expected {numpy.dtype(dtype)}')
+        return a
+    return DeviceArray.from_host(numpy.asarray(a), dtype=dtype, ctx=ctx)

@@ -1,0 +1,531 @@
+"""
+Host-side kernel objects for the three kernels of the hot path, mirroring the
+call contract of ``lsqfitgp.CrossKernel`` (``src/lsqfitgp/_Kernel/_crosskernel.py:152-200``):
+
+* ``kernel(x, y)`` -- broadcasting elementwise evaluation on host arrays
+  (plain or structured), result shape ``broadcast(x, y).shape``;
+* constructor arguments ``scale`` and ``loc`` (``_Kernel/_ops.py:292-326``):
+  inputs are transformed as ``(x - loc) / scale``;
+* ``kernel * c`` and ``kernel + c`` with scalar ``c`` (``_Kernel/_alg.py:32-82``);
+* plus the fast path the GP uses: ``kernel.gram(xs, ys)`` -> ``DeviceArray``
+  (the ``kernel(x[:, None], y[None, :])`` of ``_GP/_elements.py:575-577``).
+
+All evaluation happens in ``csrc/gram.hip``.
+"""
+
+import ctypes
+import numbers
+
+import numpy
+from numpy.lib import recfunctions
+from scipy import special as _special   # digamma table for BART (scipy is a dependency of the reference too)
+
+from . import _lib
+from ._device import Context, DeviceArray
+
+
+def _leaf_columns(x):
+    """
+    Flat (1-D) host array -> list of 1-D leaf columns in field order
+    (``_Kernel/_util.py:74-99`` recursion order; a sub-array field contributes
+    its elements consecutively).  Columnar like ``StructuredArray``
+    (``src/lsqfitgp/_array.py:104-105``).
+    """
+    x = numpy.asarray(x)
+    assert x.ndim == 1
+    if x.dtype.names is None:
+        return [x]
+    cols = []
+    for name in x.dtype.names:
+        f = x[name]
+        if f.dtype.names is not None:
+            if f.ndim > 1:
+                for idx in numpy.ndindex(*f.shape[1:]):
+                    cols.extend(_leaf_columns(numpy.ascontiguousarray(f[(slice(None),) + idx])))
+            else:
+                cols.extend(_leaf_columns(f))
+        elif f.ndim > 1:
+            f2 = f.reshape(len(f), -1)
+            cols.extend(f2[:, k] for k in range(f2.shape[1]))
+        else:
+            cols.append(f)
+    return cols
+
+
+def _float_dtype_of(cols, *scalars):
+    """ float32 only if every input is float32 (x64 mode, ``_patch_jax.py:27``) """
+    dts = [c.dtype for c in cols] + [numpy.asarray(s).dtype for s in scalars if s is not None and isinstance(s, numpy.generic)]
+    if dts and all(d == numpy.float32 for d in dts):
+        return numpy.dtype(numpy.float32)
+    return numpy.dtype(numpy.float64)
+
+
+def _ops_arrays(outops, F):
+    n = len(outops)
+    codes = (ctypes.c_int * max(n, 1))(*[_lib.LGP_OP_MUL if op == 'mul' else _lib.LGP_OP_ADD for op, _ in outops])
+    vals = (F * max(n, 1))(*[float(c) for _, c in outops])
+    return n, codes, vals
+
+
+def _is_outer(xshape, yshape):
+    """ x of shape (..., n, 1) and y (..., 1, m) with only those axes non trivial? """
+    nd = max(len(xshape), len(yshape))
+    xs = (1,) * (nd - len(xshape)) + tuple(xshape)
+    ys = (1,) * (nd - len(yshape)) + tuple(yshape)
+    xa = [i for i, s in enumerate(xs) if s != 1]
+    ya = [i for i, s in enumerate(ys) if s != 1]
+    if len(xa) > 1 or len(ya) > 1:
+        return None
+    if xa and ya and xa[0] == ya[0]:
+        return None
+    return (xa[0] if xa else None), (ya[0] if ya else None), nd
+
+
+class Kernel:
+    """ base class: input transformation, output algops, call contract """
+
+    def __init__(self, *, scale=None, loc=None, outops=()):
+        if scale is not None:
+            if not (0 < scale < numpy.inf):                       # _ops.py:324-325
+                raise AssertionError(scale)
+        if loc is not None:
+            if not (-numpy.inf < loc < numpy.inf):                # _ops.py:306-307
+                raise AssertionError(loc)
+        self._scale = scale
+        self._loc = loc
+        self._outops = tuple(outops)
+
+    def _copy(self, **kw):
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__.update(self.__dict__)
+        new.__dict__.update(kw)
+        return new
+
+    # -- algops (``_Kernel/_alg.py:32-82``), scalars only
+    def _algop(self, op, c):
+        if isinstance(c, Kernel):
+            raise NotImplementedError('kernel-kernel algebra is out of scope of the device path; only scalars')
+        if not (isinstance(c, numbers.Number) or (isinstance(c, numpy.ndarray) and c.ndim == 0) or isinstance(c, numpy.generic)):
+            return NotImplemented
+        if len(self._outops) >= 8:
+            raise NotImplementedError('at most 8 chained scalar operations')
+        return self._copy(_outops=self._outops + ((op, c),))
+
+    def __mul__(self, c):
+        return self._algop('mul', c)
+
+    __rmul__ = __mul__
+
+    def __add__(self, c):
+        return self._algop('add', c)
+
+    __radd__ = __add__
+
+    # -- evaluation
+    def __call__(self, x, y):
+        """ ``_crosskernel.py:192-200`` """
+        x = numpy.asarray(x)
+        y = numpy.asarray(y)
+        shape = numpy.broadcast_shapes(x.shape, y.shape)
+        outer = _is_outer(x.shape, y.shape)
+        if outer is not None and x.size and y.size:
+            res = self.gram(x.reshape(-1), y.reshape(-1)).to_host()     # (n, m)
+            xa, ya, nd = outer
+            if xa is not None and ya is not None and xa > ya:
+                res = res.T
+            return res.reshape(shape)
+        if 0 in shape:
+            return numpy.empty(shape, self._result_dtype(x, y))
+        xb = numpy.broadcast_to(x, shape).reshape(-1)
+        yb = numpy.broadcast_to(y, shape).reshape(-1)
+        return self.pairs(xb, yb).to_host().reshape(shape)
+
+    def gram(self, xs, ys, *, ctx=None):  # pragma: no cover
+        raise NotImplementedError
+
+    def pairs(self, xs, ys, *, ctx=None):  # pragma: no cover
+        raise NotImplementedError
+
+
+class _Isotropic(Kernel):
+    """ ``_Kernel/_isotropic.py:61-81`` with input='squared' """
+
+    _kind = None
+    _p = 0
+
+    def _result_dtype(self, x, y):
+        return _float_dtype_of(_leaf_columns(x.reshape(-1)[:0]) + _leaf_columns(y.reshape(-1)[:0]), self._scale, self._loc)
+
+    def _prepare(self, xs, ys, ctx):
+        xc = _leaf_columns(numpy.asarray(xs))
+        yc = _leaf_columns(numpy.asarray(ys))
+        if len(xc) != len(yc):
+            raise ValueError(f'x has {len(xc)} leaf fields, y has {len(yc)}')
+        dtype = _float_dtype_of(xc + yc, self._scale, self._loc)
+        ctx = ctx or Context.default()
+        xd = DeviceArray.from_host(numpy.stack([numpy.asarray(c, dtype) for c in xc]), ctx=ctx)   # SoA d x n
+        same = xs is ys
+        yd = xd if same else DeviceArray.from_host(numpy.stack([numpy.asarray(c, dtype) for c in yc]), ctx=ctx)
+        return xd, yd, dtype, ctx, len(xc)
+
+    def gram(self, xs, ys, *, ctx=None, out=None):
+        """ device Gram matrix of two flat point sets """
+        xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
+        n, m = xd.shape[1], yd.shape[1]
+        if out is None:
+            out = DeviceArray.empty((n, m), dtype, ctx)
+        assert out.shape == (n, m) and out.dtype == dtype
+        if n == 0 or m == 0:
+            return out
+        f, F = _lib.fn('lgp_gram_isotropic', dtype)
+        nops, codes, vals = _ops_arrays(self._outops, F)
+        _lib.check(f(ctx.handle, self._kind, int(self._p), d, xd.ptr, xd.ld, n, yd.ptr, yd.ld, m,
+                     int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
+                     nops, codes, vals, int(xd is yd), out.ptr, out.ld), 'lgp_gram_isotropic')
+        return out
+
+    def pairs(self, xs, ys, *, ctx=None):
+        xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
+        n = xd.shape[1]
+        assert yd.shape[1] == n
+        out = DeviceArray.empty((n,), dtype, ctx)
+        if n == 0:
+            return out
+        f, F = _lib.fn('lgp_pairs_isotropic', dtype)
+        nops, codes, vals = _ops_arrays(self._outops, F)
+        _lib.check(f(ctx.handle, self._kind, int(self._p), d, xd.ptr, xd.ld, yd.ptr, yd.ld, n,
+                     int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
+                     nops, codes, vals, out.ptr), 'lgp_pairs_isotropic')
+        return out
+
+
+class ExpQuad(_Isotropic):
+    """ Exponential quadratic kernel, k(r) = exp(-r²/2) (``_kernels/_basic.py:61-75``) """
+    _kind = _lib.LGP_KERNEL_EXPQUAD
+
+    def __init__(self, *, scale=None, loc=None):
+        super().__init__(scale=scale, loc=loc)
+
+
+class Maternp(_Isotropic):
+    """ Matérn kernel of half-integer order ν = p + 1/2 (``_kernels/_matern.py:29-49``) """
+    _kind = _lib.LGP_KERNEL_MATERNP
+
+    def __init__(self, *, p=None, scale=None, loc=None):
+        if p is None or int(p) != p or p < 0:                      # _matern.py:46-47
+            raise AssertionError(p)
+        if p > 16:
+            raise NotImplementedError('Maternp order above 16')
+        super().__init__(scale=scale, loc=loc)
+        self._p = int(p)
+
+
+# ------------------------------------------------------------------------------
+# BART
+
+def _bart_brackets(npnt, reset, altinput=True, debug=False):
+    """ ``_kernels/_bart.py:415-431``: recursion slices (top, bottom, repeat) """
+    if reset is None:
+        reset = []
+    if not hasattr(reset, '__len__'):
+        reset = [reset]
+    reset = [0] + list(reset) + [npnt - 1]
+    for i, j in zip(reset, reset[1:]):
+        assert int(j) == j and i <= j, (i, j)
+    brackets_norep = list(zip(reset, reset[1:]))
+    brackets = [brackets_norep[0] + (1,)]
+    for t, b in brackets_norep[1:]:
+        lt, lb, lr = brackets[-1]
+        if altinput and not debug and lr * (b - t) == lb - lt and b - t <= 2:
+            brackets[-1] = lt, b, lr + 1
+        else:
+            brackets.append((t, b, 1))
+    return brackets
+
+
+def _bart_probs(pnt, t, b, repeat):
+    """ ``_kernels/_bart.py:436-447``: probabilities of one slice, laid out for iteration """
+    probs = numpy.array(pnt[t:b + 1])
+    if t > 0:
+        probs[0] = 1
+    if repeat > 1:
+        head = probs[0:1]
+        one = numpy.ones_like(head)
+        pieces = [[head if i == 0 else one, p] for i, p in enumerate(numpy.split(probs[1:], repeat))]
+        probs = numpy.concatenate(sum(reversed(pieces), start=[]))
+    return probs
+
+
+class BART(Kernel):
+    """
+    BART kernel (``_kernels/_bart.py:32-202``): prior correlation of the
+    infinite-trees limit of BART, depth-truncated, with the `reset` slicing.
+    The device path covers every slice of at most 3 probabilities (depth <= 2
+    per slice), i.e. ``maxd <= 2`` or ``maxd`` with ``reset`` depths at most 2
+    apart -- which includes the configurations the reference recommends
+    (``maxd=4, reset=2`` and ``maxd=10, reset=[2,4,6,8]``, ``_bart.py:47-49``).
+    """
+
+    def __init__(self, *, alpha=0.95, beta=2, maxd=2, gamma=1, splits=None, pnt=None,
+                 intercept=True, weights=None, reset=None, indices=False, scale=None, loc=None):
+        super().__init__(scale=scale, loc=loc)
+        if scale is not None or loc is not None:
+            if indices:
+                raise ValueError('scale/loc make no sense with indices=True')
+        self._splits = self._check_splits(splits, indices)
+        self._indices = bool(indices)
+        # splitting probabilities, _bart.py:373-384
+        if pnt is None:
+            assert maxd == int(maxd) and maxd >= 0, maxd
+            alpha_a = numpy.asarray(alpha)
+            beta_a = numpy.asarray(beta)
+            if alpha_a.ndim or beta_a.ndim:
+                raise NotImplementedError('vectorised alpha/beta')
+            assert 0 <= alpha_a <= 1, 'alpha must be in [0, 1]'
+            assert beta_a >= 0, 'beta must be in [0, inf)'
+            d = numpy.arange(int(maxd) + 1)
+            pnt = alpha_a / (1 + d) ** beta_a
+        else:
+            pnt = numpy.asarray(pnt)
+            if pnt.ndim != 1:
+                raise NotImplementedError('vectorised pnt')
+        p = len(self._splits[0])
+        if weights is None:
+            weights = numpy.ones(p, pnt.dtype)                      # :387-390
+        else:
+            weights = numpy.asarray(weights)
+            if weights.shape != (p,):
+                raise ValueError(f'weights must have shape ({p},)')
+        if isinstance(gamma, str):                                   # :393-401
+            if gamma != 'auto':
+                raise KeyError(gamma)
+            assert reset is None and 1 <= pnt.shape[-1] - 1 <= 3
+            gamma = self._gamma(p, pnt)
+        gamma = numpy.asarray(gamma)
+        if gamma.ndim:
+            raise NotImplementedError('vectorised gamma')
+        assert 0 <= gamma <= 1, 'gamma must be in [0, 1]'
+        assert numpy.all((0 <= pnt) & (pnt <= 1)), 'pnt must be in [0, 1]'
+        assert numpy.all(weights >= 0), 'weights must be in [0, inf)'
+        if not intercept:                                            # :411-412
+            pnt = pnt.copy()
+            pnt[0] = 1
+        # float type of (pnt, gamma, w): fp32 iff all three are fp32 (:657, tests/kernels/test_bart.py:313-330)
+        t = numpy.result_type(pnt.dtype, gamma.dtype, weights.dtype)
+        self._flt = numpy.dtype(numpy.float32) if t == numpy.float32 else numpy.dtype(numpy.float64)
+        self._pnt = pnt.astype(self._flt)
+        self._gamma0 = self._flt.type(gamma)
+        self._weights = weights.astype(self._flt)
+        self._brackets = _bart_brackets(len(pnt), reset)
+        for t_, b_, rep in self._brackets:
+            if (b_ - t_ + 1) > 3 and rep == 1 or (rep > 1 and (b_ - t_) // rep + 1 > 3):
+                raise NotImplementedError(
+                    f'recursion slice of depth {b_ - t_} > 2: only the closed-form slices '
+                    '(_bart.py:685-757) run on the device; use `reset` depths at most 2 apart')
+
+    # ---- classmethods kept from the reference API ------------------------------
+
+    @staticmethod
+    def _check_x(x):
+        """ ``_bart.py:478-483`` """
+        x = numpy.asarray(x)
+        if x.dtype.names:
+            x = recfunctions.structured_to_unstructured(x)
+        return x
+
+    @staticmethod
+    def _check_splits(splits, indices):
+        """ ``_bart.py:485-501`` """
+        if splits is None:
+            raise ValueError('splits is required')
+        l, s = splits
+        l = numpy.asarray(l)
+        assert l.ndim == 1
+        if not indices:
+            s = numpy.asarray(s)
+            assert 1 <= s.ndim <= 2
+            if s.ndim == 1:
+                s = s[:, None]
+            assert l.size == s.shape[1]
+            assert numpy.all((0 <= l) & (l <= s.shape[0])), 'length out of bounds'
+            assert numpy.all(numpy.sort(s, axis=0) == s), 'unsorted splitting points'
+        return l, s
+
+    @classmethod
+    def splits_from_coord(cls, x):
+        """ Generate splitting points from data (``_bart.py:209-259``): per
+        dimension, midpoints between consecutive distinct values; host
+        sort/unique (O(N log N), not on the O(N^2) path). """
+        x = cls._check_x(x)
+        x = x.reshape(-1, x.shape[-1]) if x.size else x.reshape(1, x.shape[-1])
+        if numpy.issubdtype(x.dtype, numpy.inexact):
+            fill = numpy.finfo(x.dtype).max
+        else:
+            fill = numpy.iinfo(x.dtype).max
+        nrow = x.shape[0]
+        length = numpy.empty(x.shape[1], numpy.int64)
+        midpoints = numpy.empty((max(nrow - 1, 0), x.shape[1]), numpy.result_type(x.dtype, numpy.float32) if not numpy.issubdtype(x.dtype, numpy.inexact) else x.dtype)
+        for j in range(x.shape[1]):
+            u = numpy.unique(x[:, j])
+            u = numpy.concatenate([u, numpy.full(nrow - u.size, fill, u.dtype)])
+            with numpy.errstate(over='ignore'):
+                m = numpy.where(u[1:] < fill, (u[1:] + u[:-1]) / 2, fill)
+            length[j] = numpy.searchsorted(m, fill)
+            midpoints[:, j] = m
+        return length, midpoints
+
+    @classmethod
+    def indices_from_coord(cls, x, splits):
+        """ Convert coordinates to bin indices w.r.t. splitting points (``_bart.py:261-299``) """
+        splits = cls._check_splits(splits, False)
+        return cls._indices_from_coord(x, splits)
+
+    @classmethod
+    def _indices_from_coord(cls, x, checked_splits):
+        x = cls._check_x(x)
+        if x.shape[-1] != checked_splits[0].size:
+            raise ValueError(f'splitting grid is for {checked_splits[0].size} dimensions, found {x.shape[-1]}')
+        A = checked_splits[1]
+        out = numpy.empty(x.shape, numpy.int32)
+        for j in range(A.shape[1]):
+            out[..., j] = numpy.searchsorted(A[:, j], x[..., j], side='left')     # _bart.py:511-514
+        return out
+
+    @staticmethod
+    def _gamma(p, pnt):
+        """ ``_bart.py:458-476`` """
+        gamma_0 = 0.611 + 0.021 * numpy.exp(-1.3 * (p - 1))
+        gamma_d = -0.0034 + 0.084 * numpy.exp(-2.02 * (p - 1))
+        s = 2.03 - 0.69 * numpy.exp(-0.72 * (p - 1))
+        t = 4.01 - 1.49 * numpy.exp(-0.77 * (p - 1))
+        maxd = pnt.shape[-1] - 1
+        floor = numpy.clip(gamma_0 - gamma_d * maxd, 0, 1)
+        P0 = pnt[..., 0]
+        P1 = numpy.minimum(P0, pnt[..., 1])
+        with numpy.errstate(divide='ignore', invalid='ignore'):
+            corner = numpy.where(P0, 1 - P0 ** (s - t) * P1 ** t, 1)
+        return floor * corner
+
+    @classmethod
+    def correlation(cls, splitsbefore_or_totalsplits, splitsbetween_or_index1, splitsafter_or_index2, *,
+        alpha=0.95, beta=2, gamma=1, maxd=2, debug=False, pnt=None, intercept=True,
+        weights=None, reset=None, altinput=False):
+        """
+        Compute the BART prior correlation between two points
+        (``_bart.py:301-455``), vectorised over leading axes of the three
+        integer inputs.  With ``altinput=False`` the counts
+        (before, between, after) are converted to (total, index1, index2).
+        """
+        a0 = numpy.asarray(splitsbefore_or_totalsplits)
+        a1 = numpy.asarray(splitsbetween_or_index1)
+        a2 = numpy.asarray(splitsafter_or_index2)
+        for a in (a0, a1, a2):
+            assert numpy.issubdtype(a.dtype, numpy.integer)
+        assert numpy.all(a0 >= 0), 'splitting counts must be nonnegative'
+        if altinput:
+            assert numpy.all((0 <= a1) & (a1 <= a0)), 'splitting index must be in [0, n]'
+            assert numpy.all((0 <= a2) & (a2 <= a0)), 'splitting index must be in [0, n]'
+            n, ix, iy = a0, a1, a2
+        else:
+            assert numpy.all(a1 >= 0) and numpy.all(a2 >= 0), 'splitting counts must be nonnegative'
+            if debug:
+                raise NotImplementedError('debug=True (full recursion) is not available on the device')
+            # nminus, n0, nplus -> totals and bin indices: ix = nminus, iy = nminus + n0
+            n, ix, iy = a0 + a1 + a2, a0, a0 + a1
+        if debug:
+            raise NotImplementedError('debug=True (full recursion) is not available on the device')
+        n, ix, iy = numpy.broadcast_arrays(n, ix, iy)
+        p = n.shape[-1]
+        kern = cls(alpha=alpha, beta=beta, maxd=maxd, gamma=gamma, splits=(numpy.zeros(p, numpy.int64), None),
+                   pnt=pnt, intercept=intercept, weights=weights, reset=reset, indices=True)
+        shape = n.shape[:-1]
+        npairs = int(numpy.prod(shape, dtype=int))
+        out = kern._pairs_indices(ix.reshape(npairs, p), iy.reshape(npairs, p), npair=n.reshape(npairs, p))
+        return out.to_host().reshape(shape)
+
+    # ---- evaluation ---------------------------------------------------------
+
+    def _result_dtype(self, x, y):
+        return self._flt
+
+    def _to_indices(self, xs):
+        xs = numpy.asarray(xs)
+        if not xs.dtype.names:
+            xs = xs[..., None]
+        if self._indices:
+            ix = self._check_x(xs)
+            if not numpy.issubdtype(ix.dtype, numpy.integer):
+                raise TypeError('indices=True requires integer inputs')
+        else:
+            ix = self._check_x(xs)
+            if self._loc is not None:
+                ix = ix - self._loc
+            if self._scale is not None:
+                ix = ix / self._scale
+            ix = self._indices_from_coord(ix, self._splits)
+        ix = numpy.ascontiguousarray(ix.reshape(-1, ix.shape[-1]), numpy.int32)
+        if ix.shape[1] != len(self._splits[0]):
+            raise ValueError(f'splitting grid is for {len(self._splits[0])} dimensions, found {ix.shape[1]}')
+        return ix
+
+    def _psi_table(self, maxn, ctx):
+        k = numpy.arange(maxn + 2, dtype=float)
+        k[0] = 1
+        return DeviceArray.from_host(_special.digamma(k).astype(self._flt), ctx=ctx)
+
+    def _run(self, name, ctx, p, ixd, iyd, n, m, nsplits, npair, out, ld):
+        f, F = _lib.fn(name, self._flt)
+        pairs = name.startswith('lgp_pairs')
+        nsp = None if nsplits is None else (ctypes.c_int32 * max(p, 1))(*[int(v) for v in nsplits])
+        w = (F * max(p, 1))(*[float(v) for v in self._weights])
+        maxn = int(numpy.max(nsplits)) if nsplits is not None and p else 0
+        if npair is not None and npair.size:
+            maxn = max(maxn, int(npair.max()))
+        psi = self._psi_table(maxn, ctx)
+        npd = None
+        if npair is not None:
+            npd = DeviceArray.from_host(numpy.ascontiguousarray(npair, numpy.int32), ctx=ctx)
+        gamma_ptr = None
+        first = True
+        for t, b, repeat in reversed(self._brackets):                # :434-455
+            probs = _bart_probs(self._pnt, t, b, repeat)
+            size = len(probs) // repeat
+            pr = (F * len(probs))(*[float(v) for v in probs])
+            last = (t, b, repeat) == self._brackets[0]
+            nops, codes, vals = _ops_arrays(self._outops if last else (), F)
+            gptr = None if first else out.ptr
+            if pairs:
+                _lib.check(f(ctx.handle, p, ixd.ptr, iyd.ptr, n, nsp, None if npd is None else npd.ptr, w, size, repeat, pr,
+                             F(float(self._gamma0)), gptr, psi.ptr, psi.shape[0], nops, codes, vals, out.ptr), name)
+            else:
+                _lib.check(f(ctx.handle, p, ixd.ptr, n, iyd.ptr, m, nsp, w, size, repeat, pr,
+                             F(float(self._gamma0)), gptr, psi.ptr, psi.shape[0], nops, codes, vals, out.ptr, ld), name)
+            first = False
+        return out
+
+    def gram(self, xs, ys, *, ctx=None, out=None):
+        ctx = ctx or Context.default()
+        ix = self._to_indices(xs)
+        iy = ix if ys is xs else self._to_indices(ys)
+        n, m, p = ix.shape[0], iy.shape[0], ix.shape[1]
+        if out is None:
+            out = DeviceArray.empty((n, m), self._flt, ctx)
+        assert out.shape == (n, m) and out.dtype == self._flt
+        if n == 0 or m == 0:
+            return out
+        ixd = DeviceArray.from_host(ix, ctx=ctx)
+        iyd = ixd if iy is ix else DeviceArray.from_host(iy, ctx=ctx)
+        return self._run('lgp_gram_bart', ctx, p, ixd, iyd, n, m, self._splits[0], None, out, out.ld)
+
+    def _pairs_indices(self, ix, iy, npair=None, ctx=None):
+        ctx = ctx or Context.default()
+        n, p = ix.shape
+        out = DeviceArray.empty((n,), self._flt, ctx)
+        if n == 0:
+            return out
+        ixd = DeviceArray.from_host(numpy.ascontiguousarray(ix, numpy.int32), ctx=ctx)
+        iyd = DeviceArray.from_host(numpy.ascontiguousarray(iy, numpy.int32), ctx=ctx)
+        return self._run('lgp_pairs_bart', ctx, p, ixd, iyd, n, n, None if npair is not None else self._splits[0], npair, out, n)
+
+    def pairs(self, xs, ys, *, ctx=None):
+        return self._pairs_indices(self._to_indices(xs), self._to_indices(ys), ctx=ctx)

@@ -1,0 +1,381 @@
+// api.hip -- context, memory, timing, the fused posterior / log-density conveniences and the RCCL
+// plumbing of liblsqfitgp_hip.so.  See include/lsqfitgp_hip.h for the contract of every entry point.
+#include "common.h"
+#include <dlfcn.h>
+#include <cmath>
+#include <rccl/rccl.h>
+
+// ---- error string ----------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void lgp_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+template <typename T>
+int lgp_dot_strided_device(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *x, size_t incx, const T *y, size_t incy, T *dout);
+template <typename T>
+int lgp_logdet_device(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t ldl, T *dout);
+
+extern "C" {
+
+int lgp_version(void) { return 1; }
+const char *lgp_last_error(void) { return g_err; }
+
+int lgp_device_count(int *count) {
+  LGP_REQUIRE(count != nullptr, "null pointer");
+  *count = 0;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    lgp_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return LGP_EHIP;
+  }
+  return LGP_OK;
+}
+
+int lgp_ctx_create(int device, lgp_ctx **out) {
+  LGP_REQUIRE(out != nullptr, "null pointer");
+  *out = nullptr;
+  int count = 0;
+  LGP_HIP(hipGetDeviceCount(&count));
+  LGP_REQUIRE(device >= 0 && device < count, "no such HIP device (is a GPU visible?)");
+  LGP_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  LGP_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    lgp_set_error("device %d is %s: this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    return LGP_EINVAL;
+  }
+  lgp_ctx *c = new lgp_ctx();
+  c->device = device;
+  c->cus = prop.multiProcessorCount;
+  LGP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  LGP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  LGP_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
+  LGP_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+  LGP_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_info), sizeof(int)));
+  LGP_HIP(hipMemset(c->d_info, 0, sizeof(int)));
+  c->scratch_bytes = 1 << 20;
+  LGP_HIP(hipMalloc(&c->d_scratch, c->scratch_bytes));
+  LGP_HIP(hipHostMalloc(&c->h_pinned, 4096, hipHostMallocDefault));
+  // keep stream-ordered allocations cached instead of returning them to the OS at every sync
+  hipMemPool_t pool;
+  if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+    uint64_t thr = ~0ull;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+  }
+  *out = c;
+  return LGP_OK;
+}
+
+int lgp_ctx_destroy(lgp_ctx *c) {
+  if (!c) return LGP_OK;
+  DeviceGuard dg(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream2);
+  lgp_comm_destroy(c);
+  (void)hipFree(c->d_info);
+  (void)hipFree(c->d_scratch);
+  (void)hipHostFree(c->h_pinned);
+  (void)hipEventDestroy(c->ev_a);
+  (void)hipEventDestroy(c->ev_b);
+  (void)hipStreamDestroy(c->stream);
+  (void)hipStreamDestroy(c->stream2);
+  delete c;
+  return LGP_OK;
+}
+
+int lgp_sync(lgp_ctx *c) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  DeviceGuard dg(c->device);
+  LGP_HIP(hipStreamSynchronize(c->stream));
+  LGP_HIP(hipStreamSynchronize(c->stream2));
+  return LGP_OK;
+}
+
+int lgp_device_info(lgp_ctx *c, char *name, int namelen, int *cus, int *clock_khz, size_t *mem_bytes) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  hipDeviceProp_t prop;
+  LGP_HIP(hipGetDeviceProperties(&prop, c->device));
+  if (name && namelen > 0) snprintf(name, (size_t)namelen, "%s (%s)", prop.name, prop.gcnArchName);
+  if (cus) *cus = prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = prop.clockRate;
+  if (mem_bytes) *mem_bytes = prop.totalGlobalMem;
+  return LGP_OK;
+}
+
+int lgp_malloc(lgp_ctx *c, size_t bytes, void **dptr) {
+  LGP_REQUIRE(c != nullptr && dptr != nullptr, "null pointer");
+  *dptr = nullptr;
+  if (bytes == 0) bytes = 16;
+  DeviceGuard dg(c->device);
+  hipError_t e = hipMalloc(dptr, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    lgp_set_error("hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    return LGP_ENOMEM;
+  }
+  return LGP_OK;
+}
+
+int lgp_free(lgp_ctx *c, void *dptr) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  if (!dptr) return LGP_OK;
+  DeviceGuard dg(c->device);
+  LGP_HIP(hipStreamSynchronize(c->stream));
+  LGP_HIP(hipStreamSynchronize(c->stream2));
+  LGP_HIP(hipFree(dptr));
+  return LGP_OK;
+}
+
+int lgp_memset(lgp_ctx *c, void *dptr, int byte, size_t bytes) {
+  LGP_REQUIRE(c != nullptr && (dptr != nullptr || bytes == 0), "null pointer");
+  DeviceGuard dg(c->device);
+  if (bytes) LGP_HIP(hipMemsetAsync(dptr, byte, bytes, c->stream));
+  return LGP_OK;
+}
+
+int lgp_upload(lgp_ctx *c, void *ddst, const void *hsrc, size_t bytes) {
+  LGP_REQUIRE(c != nullptr && ((ddst != nullptr && hsrc != nullptr) || bytes == 0), "null pointer");
+  DeviceGuard dg(c->device);
+  if (bytes) {
+    LGP_HIP(hipMemcpyAsync(ddst, hsrc, bytes, hipMemcpyHostToDevice, c->stream));
+    LGP_HIP(hipStreamSynchronize(c->stream));
+  }
+  return LGP_OK;
+}
+
+int lgp_download(lgp_ctx *c, void *hdst, const void *dsrc, size_t bytes) {
+  LGP_REQUIRE(c != nullptr && ((hdst != nullptr && dsrc != nullptr) || bytes == 0), "null pointer");
+  DeviceGuard dg(c->device);
+  if (bytes) {
+    LGP_HIP(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, c->stream));
+    LGP_HIP(hipStreamSynchronize(c->stream));
+  }
+  return LGP_OK;
+}
+
+int lgp_copy2d(lgp_ctx *c, void *ddst, size_t ldd, const void *dsrc, size_t lds, size_t rows, size_t cols, size_t elemsize) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  if (rows == 0 || cols == 0) return LGP_OK;
+  LGP_REQUIRE(ddst != nullptr && dsrc != nullptr, "null pointer");
+  LGP_REQUIRE(elemsize == 4 || elemsize == 8, "element size must be 4 or 8");
+  LGP_REQUIRE(ldd >= cols && lds >= cols, "leading dimension too small");
+  DeviceGuard dg(c->device);
+  LGP_HIP(hipMemcpy2DAsync(ddst, ldd * elemsize, dsrc, lds * elemsize, cols * elemsize, rows, hipMemcpyDeviceToDevice, c->stream));
+  return LGP_OK;
+}
+
+int lgp_event_create(lgp_ctx *c, void **event) {
+  LGP_REQUIRE(c != nullptr && event != nullptr, "null pointer");
+  DeviceGuard dg(c->device);
+  hipEvent_t e;
+  LGP_HIP(hipEventCreate(&e));
+  *event = e;
+  return LGP_OK;
+}
+int lgp_event_destroy(lgp_ctx *c, void *event) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  if (event) LGP_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return LGP_OK;
+}
+int lgp_event_record(lgp_ctx *c, void *event) {
+  LGP_REQUIRE(c != nullptr && event != nullptr, "null pointer");
+  DeviceGuard dg(c->device);
+  LGP_HIP(hipEventRecord(static_cast<hipEvent_t>(event), c->stream));
+  return LGP_OK;
+}
+int lgp_event_elapsed_ms(lgp_ctx *c, void *start, void *stop, float *ms) {
+  LGP_REQUIRE(c != nullptr && start != nullptr && stop != nullptr && ms != nullptr, "null pointer");
+  DeviceGuard dg(c->device);
+  LGP_HIP(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+  LGP_HIP(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+  return LGP_OK;
+}
+
+}  // extern "C"
+
+// ---- fused posterior / log density --------------------------------------------------------------
+
+template <typename T>
+static int posterior_impl(lgp_ctx *c, size_t n, size_t m, const T *L, size_t ldl, const T *invd, T *W, size_t ldw, const T *Kxsxs,
+                          size_t ldk, T *mean, T *cov, size_t ldc) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  LGP_REQUIRE(n >= 1, "empty training set");
+  LGP_REQUIRE(L != nullptr && invd != nullptr && W != nullptr, "null pointer");
+  LGP_REQUIRE(ldw >= m + 1, "W must have m+1 columns");
+  DeviceGuard dg(c->device);
+  hipStream_t st = c->stream;
+  // W <- L^-1 [Kxxs | y]   (the reference solves L^-1 Kxxs twice, _decomp.py:408 and :419; once is enough)
+  LGP_CHECK(lgp_trsm_impl<T>(c, st, n, L, ldl, invd, 0, W, ldw, m + 1));
+  if (m == 0) return LGP_OK;
+  // mean = (L^-1 Kxxs)^T (L^-1 y)                      _decomp.py:409
+  if (mean) LGP_CHECK(lgp_gemm_launch<T>(c, st, true, false, m, 1, n, T(1), W, ldw, W + m, ldw, T(0), mean, 1, false));
+  // cov = Kxsxs - (L^-1 Kxxs)^T (L^-1 Kxxs)            _decomp.py:420, _compute.py:260
+  if (cov) {
+    LGP_REQUIRE(Kxsxs != nullptr && ldk >= m && ldc >= m, "bad covariance arguments");
+    if (Kxsxs != cov) LGP_HIP(hipMemcpy2DAsync(cov, ldc * sizeof(T), Kxsxs, ldk * sizeof(T), m * sizeof(T), m, hipMemcpyDeviceToDevice, st));
+    LGP_CHECK(lgp_gemm_launch<T>(c, st, true, false, m, m, n, T(-1), W, ldw, W, ldw, T(1), cov, ldc, false));
+  }
+  return LGP_OK;
+}
+
+template <typename T>
+static int mlnd_impl(lgp_ctx *c, size_t n, const T *L, size_t ldl, const T *invd, T *r, T *hvalue) {
+  LGP_REQUIRE(c != nullptr && L != nullptr && invd != nullptr && r != nullptr && hvalue != nullptr, "null pointer");
+  LGP_REQUIRE(n >= 1, "empty matrix");
+  DeviceGuard dg(c->device);
+  hipStream_t st = c->stream;
+  LGP_CHECK(lgp_trsm_impl<T>(c, st, n, L, ldl, invd, 0, r, 1, 1));          // invLr, _decomp.py:467
+  T *d = reinterpret_cast<T *>(c->d_scratch);
+  LGP_CHECK(lgp_logdet_device<T>(c, st, n, L, ldl, d));                        // sum(log(diag(L))), :486
+  LGP_CHECK(lgp_dot_strided_device<T>(c, st, n, r, 1, r, 1, d + 1));          // invLr @ invLr, :487
+  T h[2];
+  LGP_HIP(hipMemcpyAsync(h, d, 2 * sizeof(T), hipMemcpyDeviceToHost, st));
+  LGP_HIP(hipStreamSynchronize(st));
+  // :484-488   1/2 * (len(L) * log(2 pi) + 2 * sum(log(diag(L))) + invLr @ invLr)
+  *hvalue = T(0.5) * (T(n) * T(std::log(2 * M_PI)) + T(2) * h[0] + h[1]);
+  return LGP_OK;
+}
+
+extern "C" {
+int lgp_posterior_f64(lgp_ctx *c, size_t n, size_t m, const double *L, size_t ldl, const double *invd, double *W, size_t ldw,
+                      const double *K, size_t ldk, double *mean, double *cov, size_t ldc) {
+  return posterior_impl<double>(c, n, m, L, ldl, invd, W, ldw, K, ldk, mean, cov, ldc);
+}
+int lgp_posterior_f32(lgp_ctx *c, size_t n, size_t m, const float *L, size_t ldl, const float *invd, float *W, size_t ldw,
+                      const float *K, size_t ldk, float *mean, float *cov, size_t ldc) {
+  return posterior_impl<float>(c, n, m, L, ldl, invd, W, ldw, K, ldk, mean, cov, ldc);
+}
+int lgp_mlnd_value_f64(lgp_ctx *c, size_t n, const double *L, size_t ldl, const double *invd, double *r, double *h) {
+  return mlnd_impl<double>(c, n, L, ldl, invd, r, h);
+}
+int lgp_mlnd_value_f32(lgp_ctx *c, size_t n, const float *L, size_t ldl, const float *invd, float *r, float *h) {
+  return mlnd_impl<float>(c, n, L, ldl, invd, r, h);
+}
+}
+
+// ---- RCCL (loaded lazily: single-GPU use never touches librccl) -----------------------------------
+namespace {
+struct RcclApi {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+  if (g_rccl.handle) return LGP_OK;
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) {
+    lgp_set_error("cannot load librccl.so: %s", dlerror());
+    return LGP_ECOMM;
+  }
+#define LGP_SYM(field, name)                                              \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); \
+  if (!g_rccl.field) {                                                    \
+    lgp_set_error("librccl.so lacks %s", name);                          \
+    dlclose(h);                                                           \
+    return LGP_ECOMM;                                                     \
+  }
+  LGP_SYM(GetUniqueId, "ncclGetUniqueId")
+  LGP_SYM(CommInitRank, "ncclCommInitRank")
+  LGP_SYM(CommDestroy, "ncclCommDestroy")
+  LGP_SYM(Broadcast, "ncclBroadcast")
+  LGP_SYM(AllReduce, "ncclAllReduce")
+  LGP_SYM(GetErrorString, "ncclGetErrorString")
+#undef LGP_SYM
+  g_rccl.handle = h;
+  return LGP_OK;
+}
+
+#define LGP_NCCL(expr)                                                                       \
+  do {                                                                                       \
+    ncclResult_t _r = (expr);                                                                \
+    if (_r != ncclSuccess) {                                                                 \
+      lgp_set_error("%s failed: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?"); \
+      return LGP_ECOMM;                                                                      \
+    }                                                                                        \
+  } while (0)
+}  // namespace
+
+extern "C" {
+
+int lgp_comm_unique_id(void *hid128) {
+  LGP_REQUIRE(hid128 != nullptr, "null pointer");
+  static_assert(sizeof(ncclUniqueId) <= LGP_COMM_ID_BYTES, "unique id does not fit");
+  LGP_CHECK(rccl_load());
+  ncclUniqueId id;
+  LGP_NCCL(g_rccl.GetUniqueId(&id));
+  memset(hid128, 0, LGP_COMM_ID_BYTES);
+  memcpy(hid128, &id, sizeof(id));
+  return LGP_OK;
+}
+
+int lgp_comm_init(lgp_ctx *c, int rank, int nranks, const void *hid128) {
+  LGP_REQUIRE(c != nullptr && hid128 != nullptr, "null pointer");
+  LGP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank");
+  LGP_REQUIRE(c->comm == nullptr, "communicator already initialised");
+  LGP_CHECK(rccl_load());
+  DeviceGuard dg(c->device);
+  ncclUniqueId id;
+  memcpy(&id, hid128, sizeof(id));
+  ncclComm_t comm;
+  LGP_NCCL(g_rccl.CommInitRank(&comm, nranks, id, rank));
+  c->comm = comm;
+  c->rank = rank;
+  c->nranks = nranks;
+  return LGP_OK;
+}
+
+int lgp_comm_destroy(lgp_ctx *c) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  if (c->comm && g_rccl.handle) {
+    DeviceGuard dg(c->device);
+    (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(c->comm));
+  }
+  c->comm = nullptr;
+  c->rank = 0;
+  c->nranks = 1;
+  return LGP_OK;
+}
+
+int lgp_bcast(lgp_ctx *c, void *dbuf, size_t bytes, int root) {
+  LGP_REQUIRE(c != nullptr && (dbuf != nullptr || bytes == 0), "null pointer");
+  LGP_REQUIRE(root >= 0 && root < c->nranks, "bad root");
+  if (c->nranks == 1 || bytes == 0) return LGP_OK;
+  LGP_REQUIRE(c->comm != nullptr, "communicator not initialised");
+  DeviceGuard dg(c->device);
+  LGP_NCCL(g_rccl.Broadcast(dbuf, dbuf, bytes, ncclUint8, root, static_cast<ncclComm_t>(c->comm), c->stream));
+  return LGP_OK;
+}
+
+int lgp_allreduce_sum_f64(lgp_ctx *c, double *dbuf, size_t count) {
+  LGP_REQUIRE(c != nullptr && (dbuf != nullptr || count == 0), "null pointer");
+  if (c->nranks == 1 || count == 0) return LGP_OK;
+  LGP_REQUIRE(c->comm != nullptr, "communicator not initialised");
+  DeviceGuard dg(c->device);
+  LGP_NCCL(g_rccl.AllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(c->comm), c->stream));
+  return LGP_OK;
+}
+
+int lgp_allreduce_max_f64(lgp_ctx *c, double *dbuf, size_t count) {
+  LGP_REQUIRE(c != nullptr && (dbuf != nullptr || count == 0), "null pointer");
+  if (c->nranks == 1 || count == 0) return LGP_OK;
+  LGP_REQUIRE(c->comm != nullptr, "communicator not initialised");
+  DeviceGuard dg(c->device);
+  LGP_NCCL(g_rccl.AllReduce(dbuf, dbuf, count, ncclDouble, ncclMax, static_cast<ncclComm_t>(c->comm), c->stream));
+  return LGP_OK;
+}
+
+}  // extern "C"

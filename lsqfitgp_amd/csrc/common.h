@@ -1,0 +1,90 @@
+// Internal definitions shared by the HIP translation units of liblsqfitgp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+#include "../../include/lsqfitgp_hip.h"
+
+struct lgp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;       // main stream: all public entry points enqueue here
+  hipStream_t stream2 = nullptr;      // look-ahead stream of the blocked factorisation
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  int *d_info = nullptr;              // pivot info word (0 = ok, else 1-based index), device
+  void *d_scratch = nullptr;          // small reductions (>= 64 KiB)
+  size_t scratch_bytes = 0;
+  void *h_pinned = nullptr;           // pinned host staging for scalar results (4 KiB)
+  void *comm = nullptr;               // ncclComm_t
+  int rank = 0, nranks = 1;
+  int cus = 256;
+};
+
+void lgp_set_error(const char *fmt, ...);
+
+#define LGP_HIP(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      lgp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return LGP_EHIP;                                                                      \
+    }                                                                                       \
+  } while (0)
+
+#define LGP_REQUIRE(cond, msg)                                        \
+  do {                                                                \
+    if (!(cond)) {                                                    \
+      lgp_set_error("invalid argument: %s (%s)", msg, #cond);         \
+      return LGP_EINVAL;                                              \
+    }                                                                 \
+  } while (0)
+
+#define LGP_CHECK(expr)          \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != 0) return _s;      \
+  } while (0)
+
+#define LGP_LAUNCH_CHECK() LGP_HIP(hipGetLastError())
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    (void)hipGetDevice(&prev);
+    if (prev != dev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// ---- blocked-algorithm geometry -------------------------------------------------------
+constexpr int LGP_DB = 128;    // diagonal block factored (and inverted) by one workgroup
+constexpr int LGP_NB = 512;    // outer panel width of the right-looking factorisation
+
+// ---- GEMM (gemm.hip) ---------------------------------------------------------------------
+// C (m x n) = alpha * op(A) op(B) + beta * C, row-major; ta/tb: operand stored transposed.
+// lower != 0: only entries with row >= col are produced (C(0,0) is a diagonal element); tiles
+// entirely above the diagonal are skipped.  C may alias A only when n <= 128 (one tile column),
+// and may alias B only when m <= 128 (one tile row) and the aliased operand is read completely
+// (k covers it) before the epilogue -- used by the in-place triangular kernels.
+template <typename T>
+int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
+                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower);
+
+// ---- factorisation pieces (potrf.hip) ------------------------------------------------------
+template <typename T>
+int lgp_potf2_trtri_launch(lgp_ctx *ctx, hipStream_t stream, T *A, size_t lda, int nb, T *invd, size_t row0);
+template <typename T>
+int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t nb, T *P, size_t ldp, T *invd, size_t row0);
+template <typename T>
+int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *invd);
+template <typename T>
+int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t ldl, const T *invd, int trans, T *B, size_t ldb, size_t nrhs);
+
+// ---- reductions (elementwise.hip) -------------------------------------------------------------
+template <typename T>
+int lgp_colsumsq_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t cols, const T *A, size_t lda, T *out);

@@ -1,0 +1,328 @@
+// elementwise.hip -- HBM-bound helpers of the hot path: block assembly (jnp.block,
+// src/lsqfitgp/_GP/_elements.py:642-649), `Kxx + ycov` (_GP/_compute.py:85), `Kxsxs - Q` (:260), finite /
+// symmetry checks (_elements.py:618-622, _compute.py:369-381), column sums of squares (einsum 'ji,ji->i',
+// _linalg/_decomp.py:427), sum log diag and dot (:486-487).
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) axpby_kernel(size_t rows, size_t cols, T alpha, const T *A, size_t lda, T beta, const T *B,
+                                                    size_t ldb, T *C, size_t ldc) {
+  const size_t nbx = (cols + 255) / 256;
+  for (size_t blk = blockIdx.x; blk < rows * nbx; blk += gridDim.x) {
+    const size_t i = blk / nbx, j = (blk % nbx) * 256 + threadIdx.x;
+    if (j < cols) {
+      T v = T(0);
+      if (A) v = alpha * A[i * lda + j];
+      if (B) v += beta * B[i * ldb + j];
+      C[i * ldc + j] = v;
+    }
+  }
+}
+
+template <typename T>
+__global__ void add_diag_kernel(size_t n, T *A, size_t lda, const T *vec, T alpha) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[i * lda + i] += vec ? vec[i] * alpha : alpha;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) add_scalar_kernel(size_t rows, size_t cols, T *A, size_t lda, T c) {
+  const size_t nbx = (cols + 255) / 256;
+  for (size_t blk = blockIdx.x; blk < rows * nbx; blk += gridDim.x) {
+    const size_t i = blk / nbx, j = (blk % nbx) * 256 + threadIdx.x;
+    if (j < cols) A[i * lda + j] += c;
+  }
+}
+
+// 32x32 LDS-tiled transpose: dst (cols x rows) = src^T
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_kernel(T *dst, size_t ldd, const T *src, size_t lds, size_t rows, size_t cols) {
+  __shared__ T tile[32][33];
+  const size_t ntc = (cols + 31) / 32;
+  const size_t tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int k = 0; k < 32; k += 8) {
+    const size_t r = tr * 32 + ty + k, c = tc * 32 + tx;
+    if (r < rows && c < cols) tile[ty + k][tx] = src[r * lds + c];
+  }
+  __syncthreads();
+  for (int k = 0; k < 32; k += 8) {
+    const size_t c = tc * 32 + ty + k, r = tr * 32 + tx;
+    if (r < rows && c < cols) dst[c * ldd + r] = tile[tx][ty + k];
+  }
+}
+
+// flags[0] |= any non-finite; flags[1] |= any |a_ij - a_ji| > atol + rtol*|a_ji|  (jnp.allclose(A, A.T))
+template <typename T>
+__global__ void __launch_bounds__(256) check_kernel(size_t rows, size_t cols, const T *A, size_t lda, int check_sym, T rtol, T atol,
+                                                    int *flags) {
+  const size_t nbx = (cols + 255) / 256;
+  int nonfinite = 0, asym = 0;
+  for (size_t blk = blockIdx.x; blk < rows * nbx; blk += gridDim.x) {
+    const size_t i = blk / nbx, j = (blk % nbx) * 256 + threadIdx.x;
+    if (j < cols) {
+      const T v = A[i * lda + j];
+      if (!(fabs(v) <= (sizeof(T) == 8 ? T(1.7976931348623157e308) : T(3.4028234663852886e38)))) nonfinite = 1;
+      if (check_sym && j < i) {
+        const T u = A[j * lda + i];
+        if (!(fabs(v - u) <= atol + rtol * fabs(u))) asym = 1;
+      }
+    }
+  }
+  if (__any(nonfinite) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
+  if (__any(asym) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+}
+
+// flag |= any |a_ij - b_ij| > atol + rtol*|b_ij|  (not jnp.allclose(A, B))
+template <typename T>
+__global__ void __launch_bounds__(256) allclose_kernel(size_t rows, size_t cols, const T *A, size_t lda, const T *B, size_t ldb, T rtol,
+                                                       T atol, int *flag) {
+  const size_t nbx = (cols + 255) / 256;
+  int bad = 0;
+  for (size_t blk = blockIdx.x; blk < rows * nbx; blk += gridDim.x) {
+    const size_t i = blk / nbx, j = (blk % nbx) * 256 + threadIdx.x;
+    if (j < cols) {
+      const T a = A[i * lda + j], b = B[i * ldb + j];
+      if (!(fabs(a - b) <= atol + rtol * fabs(b)) && !(a == b)) bad = 1;
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// out[j] = sum_i A[i][j]^2.  One workgroup per (256-column strip, row chunk); partial sums by atomicAdd.
+template <typename T>
+__global__ void __launch_bounds__(256) colsumsq_kernel(size_t rows, size_t cols, const T *A, size_t lda, T *out, size_t rows_per_blk) {
+  const size_t nbx = (cols + 255) / 256;
+  const size_t strip = blockIdx.x % nbx, chunk = blockIdx.x / nbx;
+  const size_t j = strip * 256 + threadIdx.x;
+  if (j >= cols) return;
+  const size_t r0 = chunk * rows_per_blk;
+  const size_t r1 = (r0 + rows_per_blk) < rows ? (r0 + rows_per_blk) : rows;
+  T acc = T(0);
+  for (size_t i = r0; i < r1; ++i) {
+    const T v = A[i * lda + j];
+    acc += v * v;
+  }
+  atomicAdd(&out[j], acc);
+}
+
+// single-workgroup reductions (n up to ~1e5: negligible), deterministic order
+template <typename T>
+__global__ void __launch_bounds__(1024) logdet_kernel(size_t n, const T *L, size_t ldl, T *out) {
+  __shared__ T sh[16];
+  T acc = T(0);
+  for (size_t i = threadIdx.x; i < n; i += 1024) acc += log(L[i * ldl + i]);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T t = T(0);
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    out[0] = t;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) dot_kernel(size_t n, const T *x, size_t incx, const T *y, size_t incy, T *out) {
+  __shared__ T sh[16];
+  T acc = T(0);
+  for (size_t i = threadIdx.x; i < n; i += 1024) acc += x[i * incx] * y[i * incy];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T t = T(0);
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    out[0] = t;
+  }
+}
+
+inline unsigned grid_for(size_t rows, size_t cols) {
+  const size_t nb = rows * ((cols + 255) / 256);
+  return (unsigned)(nb < 1048576 ? (nb ? nb : 1) : 1048576);
+}
+
+template <typename T>
+int axpby_impl(lgp_ctx *ctx, size_t rows, size_t cols, T alpha, const T *A, size_t lda, T beta, const T *B, size_t ldb, T *C, size_t ldc) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  if (rows == 0 || cols == 0) return LGP_OK;
+  LGP_REQUIRE(C != nullptr && ldc >= cols, "bad output");
+  LGP_REQUIRE((A == nullptr || lda >= cols) && (B == nullptr || ldb >= cols), "leading dimension too small");
+  DeviceGuard dg(ctx->device);
+  hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid_for(rows, cols)), dim3(256), 0, ctx->stream, rows, cols, alpha, A, lda, beta, B, ldb, C, ldc);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
+template <typename T>
+int add_diag_impl(lgp_ctx *ctx, size_t n, T *A, size_t lda, const T *vec, T alpha) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  if (n == 0) return LGP_OK;
+  LGP_REQUIRE(A != nullptr && lda >= n, "bad matrix");
+  DeviceGuard dg(ctx->device);
+  hipLaunchKernelGGL((add_diag_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, A, lda, vec, alpha);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
+template <typename T>
+int add_scalar_impl(lgp_ctx *ctx, size_t rows, size_t cols, T *A, size_t lda, T c) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  if (rows == 0 || cols == 0) return LGP_OK;
+  LGP_REQUIRE(A != nullptr && lda >= cols, "bad matrix");
+  DeviceGuard dg(ctx->device);
+  hipLaunchKernelGGL((add_scalar_kernel<T>), dim3(grid_for(rows, cols)), dim3(256), 0, ctx->stream, rows, cols, A, lda, c);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
+template <typename T>
+int transpose_impl(lgp_ctx *ctx, T *dst, size_t ldd, const T *src, size_t lds, size_t rows, size_t cols) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  if (rows == 0 || cols == 0) return LGP_OK;
+  LGP_REQUIRE(dst != nullptr && src != nullptr && ldd >= rows && lds >= cols, "bad matrix");
+  const size_t nt = ((rows + 31) / 32) * ((cols + 31) / 32);
+  LGP_REQUIRE(nt < (1ull << 31), "matrix too large");
+  DeviceGuard dg(ctx->device);
+  hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)nt), dim3(256), 0, ctx->stream, dst, ldd, src, lds, rows, cols);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
+template <typename T>
+int check_impl(lgp_ctx *ctx, size_t rows, size_t cols, const T *A, size_t lda, int check_sym, T rtol, T atol, int *hflags) {
+  LGP_REQUIRE(ctx != nullptr && hflags != nullptr, "null pointer");
+  hflags[0] = hflags[1] = 0;
+  if (rows == 0 || cols == 0) return LGP_OK;
+  LGP_REQUIRE(A != nullptr && lda >= cols, "bad matrix");
+  LGP_REQUIRE(!check_sym || rows == cols, "symmetry check needs a square matrix");
+  DeviceGuard dg(ctx->device);
+  int *dflags = reinterpret_cast<int *>(ctx->d_scratch);
+  LGP_HIP(hipMemsetAsync(dflags, 0, 2 * sizeof(int), ctx->stream));
+  hipLaunchKernelGGL((check_kernel<T>), dim3(grid_for(rows, cols)), dim3(256), 0, ctx->stream, rows, cols, A, lda, check_sym, rtol, atol, dflags);
+  LGP_LAUNCH_CHECK();
+  LGP_HIP(hipMemcpyAsync(hflags, dflags, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  LGP_HIP(hipStreamSynchronize(ctx->stream));
+  return LGP_OK;
+}
+
+template <typename T>
+int allclose_impl(lgp_ctx *ctx, size_t rows, size_t cols, const T *A, size_t lda, const T *B, size_t ldb, T rtol, T atol, int *hflag) {
+  LGP_REQUIRE(ctx != nullptr && hflag != nullptr, "null pointer");
+  *hflag = 1;
+  if (rows == 0 || cols == 0) return LGP_OK;
+  LGP_REQUIRE(A != nullptr && B != nullptr && lda >= cols && ldb >= cols, "bad matrix");
+  DeviceGuard dg(ctx->device);
+  int *dflag = reinterpret_cast<int *>(ctx->d_scratch);
+  LGP_HIP(hipMemsetAsync(dflag, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL((allclose_kernel<T>), dim3(grid_for(rows, cols)), dim3(256), 0, ctx->stream, rows, cols, A, lda, B, ldb, rtol, atol, dflag);
+  LGP_LAUNCH_CHECK();
+  int bad = 0;
+  LGP_HIP(hipMemcpyAsync(&bad, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  LGP_HIP(hipStreamSynchronize(ctx->stream));
+  *hflag = bad ? 0 : 1;
+  return LGP_OK;
+}
+
+template <typename T>
+int logdet_impl(lgp_ctx *ctx, size_t n, const T *L, size_t ldl, T *hout) {
+  LGP_REQUIRE(ctx != nullptr && hout != nullptr && L != nullptr && ldl >= n, "bad argument");
+  DeviceGuard dg(ctx->device);
+  T *d = reinterpret_cast<T *>(ctx->d_scratch);
+  hipLaunchKernelGGL((logdet_kernel<T>), dim3(1), dim3(1024), 0, ctx->stream, n, L, ldl, d);
+  LGP_LAUNCH_CHECK();
+  LGP_HIP(hipMemcpyAsync(hout, d, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+  LGP_HIP(hipStreamSynchronize(ctx->stream));
+  return LGP_OK;
+}
+
+template <typename T>
+int dot_impl(lgp_ctx *ctx, size_t n, const T *x, const T *y, T *hout) {
+  LGP_REQUIRE(ctx != nullptr && hout != nullptr && (n == 0 || (x != nullptr && y != nullptr)), "bad argument");
+  DeviceGuard dg(ctx->device);
+  T *d = reinterpret_cast<T *>(ctx->d_scratch);
+  hipLaunchKernelGGL((dot_kernel<T>), dim3(1), dim3(1024), 0, ctx->stream, n, x, (size_t)1, y, (size_t)1, d);
+  LGP_LAUNCH_CHECK();
+  LGP_HIP(hipMemcpyAsync(hout, d, sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+  LGP_HIP(hipStreamSynchronize(ctx->stream));
+  return LGP_OK;
+}
+
+}  // namespace
+
+template <typename T>
+int lgp_colsumsq_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t cols, const T *A, size_t lda, T *out) {
+  if (cols == 0) return LGP_OK;
+  LGP_REQUIRE(out != nullptr && (rows == 0 || (A != nullptr && lda >= cols)), "bad argument");
+  LGP_HIP(hipMemsetAsync(out, 0, cols * sizeof(T), stream));
+  if (rows == 0) return LGP_OK;
+  const size_t nbx = (cols + 255) / 256;
+  size_t chunks = (size_t)ctx->cus * 8 / nbx;
+  if (chunks < 1) chunks = 1;
+  if (chunks > rows) chunks = rows;
+  const size_t rpb = (rows + chunks - 1) / chunks;
+  chunks = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL((colsumsq_kernel<T>), dim3((unsigned)(nbx * chunks)), dim3(256), 0, stream, rows, cols, A, lda, out, rpb);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+template int lgp_colsumsq_impl<double>(lgp_ctx *, hipStream_t, size_t, size_t, const double *, size_t, double *);
+template int lgp_colsumsq_impl<float>(lgp_ctx *, hipStream_t, size_t, size_t, const float *, size_t, float *);
+
+template <typename T>
+int lgp_dot_strided_device(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *x, size_t incx, const T *y, size_t incy, T *dout) {
+  hipLaunchKernelGGL((dot_kernel<T>), dim3(1), dim3(1024), 0, stream, n, x, incx, y, incy, dout);
+  LGP_LAUNCH_CHECK();
+  (void)ctx;
+  return LGP_OK;
+}
+template int lgp_dot_strided_device<double>(lgp_ctx *, hipStream_t, size_t, const double *, size_t, const double *, size_t, double *);
+template int lgp_dot_strided_device<float>(lgp_ctx *, hipStream_t, size_t, const float *, size_t, const float *, size_t, float *);
+
+template <typename T>
+int lgp_logdet_device(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t ldl, T *dout) {
+  hipLaunchKernelGGL((logdet_kernel<T>), dim3(1), dim3(1024), 0, stream, n, L, ldl, dout);
+  LGP_LAUNCH_CHECK();
+  (void)ctx;
+  return LGP_OK;
+}
+template int lgp_logdet_device<double>(lgp_ctx *, hipStream_t, size_t, const double *, size_t, double *);
+template int lgp_logdet_device<float>(lgp_ctx *, hipStream_t, size_t, const float *, size_t, float *);
+
+extern "C" {
+int lgp_axpby_f64(lgp_ctx *c, size_t r, size_t n, double a, const double *A, size_t lda, double b, const double *B, size_t ldb, double *C, size_t ldc) { return axpby_impl<double>(c, r, n, a, A, lda, b, B, ldb, C, ldc); }
+int lgp_axpby_f32(lgp_ctx *c, size_t r, size_t n, float a, const float *A, size_t lda, float b, const float *B, size_t ldb, float *C, size_t ldc) { return axpby_impl<float>(c, r, n, a, A, lda, b, B, ldb, C, ldc); }
+int lgp_add_diag_f64(lgp_ctx *c, size_t n, double *A, size_t lda, const double *v, double a) { return add_diag_impl<double>(c, n, A, lda, v, a); }
+int lgp_add_diag_f32(lgp_ctx *c, size_t n, float *A, size_t lda, const float *v, float a) { return add_diag_impl<float>(c, n, A, lda, v, a); }
+int lgp_add_scalar_f64(lgp_ctx *c, size_t r, size_t n, double *A, size_t lda, double v) { return add_scalar_impl<double>(c, r, n, A, lda, v); }
+int lgp_add_scalar_f32(lgp_ctx *c, size_t r, size_t n, float *A, size_t lda, float v) { return add_scalar_impl<float>(c, r, n, A, lda, v); }
+int lgp_transpose_f64(lgp_ctx *c, double *d, size_t ldd, const double *s, size_t lds, size_t r, size_t n) { return transpose_impl<double>(c, d, ldd, s, lds, r, n); }
+int lgp_transpose_f32(lgp_ctx *c, float *d, size_t ldd, const float *s, size_t lds, size_t r, size_t n) { return transpose_impl<float>(c, d, ldd, s, lds, r, n); }
+int lgp_check_matrix_f64(lgp_ctx *c, size_t r, size_t n, const double *A, size_t lda, int sym, double rtol, double atol, int *f) { return check_impl<double>(c, r, n, A, lda, sym, rtol, atol, f); }
+int lgp_check_matrix_f32(lgp_ctx *c, size_t r, size_t n, const float *A, size_t lda, int sym, float rtol, float atol, int *f) { return check_impl<float>(c, r, n, A, lda, sym, rtol, atol, f); }
+int lgp_allclose_f64(lgp_ctx *c, size_t r, size_t n, const double *A, size_t lda, const double *B, size_t ldb, double rtol, double atol, int *f) { return allclose_impl<double>(c, r, n, A, lda, B, ldb, rtol, atol, f); }
+int lgp_allclose_f32(lgp_ctx *c, size_t r, size_t n, const float *A, size_t lda, const float *B, size_t ldb, float rtol, float atol, int *f) { return allclose_impl<float>(c, r, n, A, lda, B, ldb, rtol, atol, f); }
+int lgp_colsumsq_f64(lgp_ctx *c, size_t r, size_t n, const double *A, size_t lda, double *o) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  DeviceGuard dg(c->device);
+  return lgp_colsumsq_impl<double>(c, c->stream, r, n, A, lda, o);
+}
+int lgp_colsumsq_f32(lgp_ctx *c, size_t r, size_t n, const float *A, size_t lda, float *o) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  DeviceGuard dg(c->device);
+  return lgp_colsumsq_impl<float>(c, c->stream, r, n, A, lda, o);
+}
+int lgp_logdet_diag_f64(lgp_ctx *c, size_t n, const double *L, size_t ldl, double *h) { return logdet_impl<double>(c, n, L, ldl, h); }
+int lgp_logdet_diag_f32(lgp_ctx *c, size_t n, const float *L, size_t ldl, float *h) { return logdet_impl<float>(c, n, L, ldl, h); }
+int lgp_dot_f64(lgp_ctx *c, size_t n, const double *x, const double *y, double *h) { return dot_impl<double>(c, n, x, y, h); }
+int lgp_dot_f32(lgp_ctx *c, size_t n, const float *x, const float *y, float *h) { return dot_impl<float>(c, n, x, y, h); }
+}

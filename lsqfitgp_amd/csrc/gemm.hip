@@ -1,0 +1,376 @@
+// gemm.hip -- LDS-tiled MFMA GEMM for gfx950 (CDNA4), fp64 (v_mfma_f64_16x16x4_f64) and fp32
+// (v_mfma_f32_16x16x4_f32).  This one kernel family is the dense-contraction workhorse of the hot path:
+//   * syrk/gemm trailing update of the blocked Cholesky (replaces the LAPACK potrf that
+//     jlinalg.cholesky lowers to, src/lsqfitgp/_linalg/_decomp.py:388),
+//   * the gemm updates of the blocked triangular solves (solve_triangular, _decomp.py:402-439),
+//   * `invLA.T @ invLr`, `invLA.T @ invLA`, `L @ x`, `L.T @ X` (_decomp.py:409,420,431,435).
+//
+// Geometry: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA
+// tiles, 16 accumulators x 4 values), K-step 16, double-buffered LDS (73.7 KB -> 2 workgroups per CU),
+// register-staged global->LDS prefetch one K-step ahead, one barrier per K-step.  An fp64 MFMA occupies
+// the SIMD for 64 cycles (measured, tools/f64_rate_probe.hip), so per K-step each wave has 4096 cycles
+// of matrix work against 32 ds_read_b64 and 8 global loads: the kernel is MFMA-bound by design.
+//
+// LDS images are chosen per operand so that the staging store is a straight 16-byte copy and the
+// fragment read (one element per lane: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]) is
+// bank-conflict free for ds_read_b64:
+//   * operand stored k-contiguous in memory  -> image [row][BK + 2]   (stride 18 doubles = 36 dwords)
+//   * operand stored row-contiguous in memory -> image [k][128 + 16]  (stride 144 doubles, 288 = 32 mod 64)
+//
+// Workgroup -> tile map: tiles are grouped in 8x8 super-tiles; super-tile s goes to the XCD that the
+// dispatcher's round-robin gives to blockIdx % 8 == s % 8, so the 64 co-resident workgroups of an XCD
+// share 8 A-panels and 8 B-panels through that XCD's L2 while they walk K together.  Placement only
+// affects speed, never results.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int NTHREADS = 256;
+
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg (verified on device)
+  static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+  static constexpr int SMK = BK + 2;   // [row][k] image stride (elements)
+};
+template <> struct Mfma<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D map of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
+  static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+  static constexpr int SMK = BK + 4;
+};
+constexpr int SKM = 128 + 16;          // [k][row] image stride (elements)
+
+template <typename T>
+struct GemmArgs {
+  const T *A;
+  const T *B;
+  T *C;
+  long lda, ldb, ldc;
+  int m, n, k;
+  T alpha, beta;
+  int lower;
+  int tm, tn;          // tile counts
+  int nsm, nsn;        // super-tile counts (0: direct mapping)
+  int alignedA, alignedB;
+  int nsplit, kchunk;  // split-K: blockIdx.y = K slice, partial tiles go to Cpart[slice] (dense m x n), reduced afterwards
+  T *Cpart;
+};
+
+// One operand tile: 128 "rows" (m or n index) x BK k-values.
+// TR = false: memory is [row][k] (k contiguous);  TR = true: memory is [k][row] (row contiguous).
+template <typename T, bool TR>
+struct Tile {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int NV = 128 * BK / VEC / NTHREADS;
+  static constexpr int IMG = TR ? BK * SKM : 128 * Mfma<T>::SMK;   // elements per LDS image
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+
+  vec_t reg[NV];
+
+  __device__ __forceinline__ void load(const T *base, long ld, int row0, int k0, int R, int K, bool aligned) {
+    const int t = threadIdx.x;
+    if (!TR) {
+      constexpr int VPR = BK / VEC;   // vectors per row
+      const bool fast = aligned && (row0 + 128 <= R) && (k0 + BK <= K);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = t + NTHREADS * i;
+        const int row = v / VPR, kv = (v % VPR) * VEC;
+        const T *p = base + (long)(row0 + row) * ld + (k0 + kv);
+        if (fast) {
+          reg[i] = *reinterpret_cast<const vec_t *>(p);
+        } else {
+          const bool rok = (row0 + row) < R;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) reg[i][e] = (rok && (k0 + kv + e) < K) ? p[e] : T(0);
+        }
+      }
+    } else {
+      constexpr int VPR = 128 / VEC;  // vectors per k-row
+      const bool fast = aligned && (row0 + 128 <= R) && (k0 + BK <= K);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = t + NTHREADS * i;
+        const int kr = v / VPR, rv = (v % VPR) * VEC;
+        const T *p = base + (long)(k0 + kr) * ld + (row0 + rv);
+        if (fast) {
+          reg[i] = *reinterpret_cast<const vec_t *>(p);
+        } else {
+          const bool kok = (k0 + kr) < K;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) reg[i][e] = (kok && (row0 + rv + e) < R) ? p[e] : T(0);
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(T *lds) const {
+    const int t = threadIdx.x;
+    if (!TR) {
+      constexpr int VPR = BK / VEC;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = t + NTHREADS * i;
+        const int row = v / VPR, kv = (v % VPR) * VEC;
+        *reinterpret_cast<vec_t *>(lds + row * Mfma<T>::SMK + kv) = reg[i];
+      }
+    } else {
+      constexpr int VPR = 128 / VEC;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = t + NTHREADS * i;
+        const int kr = v / VPR, rv = (v % VPR) * VEC;
+        *reinterpret_cast<vec_t *>(lds + kr * SKM + rv) = reg[i];
+      }
+    }
+  }
+
+  // fragment element for MFMA: row index r (0..127), k index kk (0..BK-1)
+  static __device__ __forceinline__ T frag(const T *lds, int r, int kk) {
+    return TR ? lds[kk * SKM + r] : lds[r * Mfma<T>::SMK + kk];
+  }
+};
+
+__device__ __forceinline__ bool map_tile(int tm, int tn, int nsm, int nsn, int lower, int &ti, int &tj) {
+  const int bid = blockIdx.x;
+  if (nsm == 0) {   // direct map, small grids
+    ti = bid / tn;
+    tj = bid % tn;
+    return !(lower && ti < tj);
+  }
+  const int xcd = bid & 7, local = bid >> 3;
+  const int sidx = (local >> 6) * 8 + xcd, slot = local & 63;
+  int I, J;
+  if (!lower) {
+    if (sidx >= nsm * nsn) return false;
+    I = sidx / nsn;
+    J = sidx % nsn;
+  } else {
+    // column-major over J of super-tiles with I >= J
+    int rem = sidx;
+    J = 0;
+    const int jmax = nsn < nsm ? nsn : nsm;
+    while (J < jmax && rem >= nsm - J) {
+      rem -= nsm - J;
+      ++J;
+    }
+    if (J >= jmax) return false;
+    I = J + rem;
+  }
+  ti = I * 8 + (slot >> 3);
+  tj = J * 8 + (slot & 7);
+  if (ti >= tm || tj >= tn) return false;
+  return !(lower && ti < tj);
+}
+
+template <typename T, bool TA, bool TB>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) {
+  // A operand: op(A) is m x k.  TA=false: A stored [m][k] -> Tile<T,false>; TA=true: A stored [k][m] -> Tile<T,true>
+  // B operand: op(B) is k x n.  TB=false: B stored [k][n] -> Tile<T,true>;  TB=true: B stored [n][k] -> Tile<T,false>
+  typedef Tile<T, TA> TileA;
+  typedef Tile<T, !TB> TileB;
+  typedef typename Mfma<T>::acc_t acc_t;
+  constexpr int IMG_A = TileA::IMG, IMG_B = TileB::IMG;
+  __shared__ __attribute__((aligned(16))) T lds[2 * IMG_A + 2 * IMG_B];
+
+  int ti, tj;
+  if (!map_tile(g.tm, g.tn, g.nsm, g.nsn, g.lower, ti, tj)) return;
+  const int row0 = ti * BM, col0 = tj * BN;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int fr = lane & 15, fk = lane >> 4;
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+  TileA ta;
+  TileB tb;
+  // K range of this workgroup (split-K slices are multiples of BK, so vector loads stay aligned)
+  const int kbeg = g.nsplit > 1 ? (int)blockIdx.y * g.kchunk : 0;
+  const int kend = g.nsplit > 1 ? ((kbeg + g.kchunk) < g.k ? (kbeg + g.kchunk) : g.k) : g.k;
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  T *ldsA = lds, *ldsB = lds + 2 * IMG_A;
+
+  if (nk > 0) {
+    ta.load(g.A, g.lda, row0, kbeg, g.m, kend, g.alignedA);
+    tb.load(g.B, g.ldb, col0, kbeg, g.n, kend, g.alignedB);
+    ta.store(ldsA);
+    tb.store(ldsB);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    const bool more = (t + 1) < nk;
+    if (more) {
+      ta.load(g.A, g.lda, row0, kbeg + (t + 1) * BK, g.m, kend, g.alignedA);
+      tb.load(g.B, g.ldb, col0, kbeg + (t + 1) * BK, g.n, kend, g.alignedB);
+    }
+    const T *la = ldsA + cur * IMG_A;
+    const T *lb = ldsB + cur * IMG_B;
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 4) {
+      T af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = TileA::frag(la, wm + i * 16 + fr, ks + fk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = TileB::frag(lb, wn + j * 16 + fr, ks + fk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+    }
+    if (more) {
+      ta.store(ldsA + (cur ^ 1) * IMG_A);
+      tb.store(ldsB + (cur ^ 1) * IMG_B);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C = alpha * acc + beta * C   (split-K: raw partial sums into this slice's slab)
+  const bool interior = (row0 + BM <= g.m) && (col0 + BN <= g.n) && !(g.lower && ti == tj);
+  const bool split = g.nsplit > 1;
+  const T alpha = split ? T(1) : g.alpha, beta = split ? T(0) : g.beta;
+  T *Cbase = split ? g.Cpart + (long)blockIdx.y * g.m * g.n : g.C;
+  const long ldc = split ? (long)g.n : g.ldc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + wm + i * 16 + Mfma<T>::crow(lane, r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = col0 + wn + j * 16 + fr;
+        if (interior || (row < g.m && col < g.n && !(g.lower && col > row))) {
+          T *p = Cbase + row * ldc + col;
+          T v = alpha * acc[i][j][r];
+          if (beta != T(0)) v += beta * (*p);
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+// C = alpha * sum_s part[s] + beta * C
+template <typename T>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const T *part, int nsplit, long mn, int n, T alpha, T beta, T *C, long ldc) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= mn) return;
+  T acc = T(0);
+  for (int s = 0; s < nsplit; ++s) acc += part[(long)s * mn + idx];
+  T *p = C + (idx / n) * ldc + (idx % n);
+  T v = alpha * acc;
+  if (beta != T(0)) v += beta * (*p);
+  *p = v;
+}
+
+}  // namespace
+
+template <typename T>
+int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
+                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower) {
+  if (m == 0 || n == 0) return LGP_OK;
+  LGP_REQUIRE(m < (1u << 30) && n < (1u << 30) && k < (1u << 30), "gemm dimension too large");
+  LGP_REQUIRE(C != nullptr && (k == 0 || (A != nullptr && B != nullptr)), "null matrix pointer");
+  LGP_REQUIRE(ldc >= n, "ldc < n");
+  LGP_REQUIRE(k == 0 || lda >= (ta ? m : k), "lda too small");
+  LGP_REQUIRE(k == 0 || ldb >= (tb ? k : n), "ldb too small");
+  constexpr size_t VEC = 16 / sizeof(T);
+  GemmArgs<T> g;
+  g.A = A; g.B = B; g.C = C;
+  g.lda = (long)lda; g.ldb = (long)ldb; g.ldc = (long)ldc;
+  g.m = (int)m; g.n = (int)n; g.k = (int)k;
+  g.alpha = alpha; g.beta = beta;
+  g.lower = lower ? 1 : 0;
+  g.tm = (int)((m + BM - 1) / BM);
+  g.tn = (int)((n + BN - 1) / BN);
+  g.alignedA = ((reinterpret_cast<uintptr_t>(A) % 16) == 0 && (lda % VEC) == 0) ? 1 : 0;
+  g.alignedB = ((reinterpret_cast<uintptr_t>(B) % 16) == 0 && (ldb % VEC) == 0) ? 1 : 0;
+  size_t grid;
+  if ((size_t)g.tm * g.tn <= 64) {
+    g.nsm = g.nsn = 0;
+    grid = (size_t)g.tm * g.tn;
+  } else {
+    g.nsm = (g.tm + 7) / 8;
+    g.nsn = (g.tn + 7) / 8;
+    size_t nsuper;
+    if (!lower) {
+      nsuper = (size_t)g.nsm * g.nsn;
+    } else {
+      const int jmax = g.nsn < g.nsm ? g.nsn : g.nsm;
+      nsuper = 0;
+      for (int J = 0; J < jmax; ++J) nsuper += (size_t)(g.nsm - J);
+    }
+    grid = ((nsuper + 7) / 8) * 8 * 64;
+  }
+  LGP_REQUIRE(grid < (1ull << 31), "gemm grid too large");
+  // split-K for few-tile, deep-K products (X^T X, X^T y over N rows): deterministic slab reduction
+  g.nsplit = 1; g.kchunk = 0; g.Cpart = nullptr;
+  const size_t tiles = (size_t)g.tm * g.tn;
+  if (!lower && tiles * 4 <= (size_t)ctx->cus && k >= 2048) {
+    size_t ns = (2 * (size_t)ctx->cus) / tiles;
+    const size_t maxs = (k + 511) / 512;
+    if (ns > maxs) ns = maxs;
+    if (ns > 1) {
+      size_t kc = (k + ns - 1) / ns;
+      kc = ((kc + BK - 1) / BK) * BK;
+      ns = (k + kc - 1) / kc;
+      g.nsplit = (int)ns; g.kchunk = (int)kc;
+      LGP_HIP(hipMallocAsync(reinterpret_cast<void **>(&g.Cpart), ns * m * n * sizeof(T), stream));
+    }
+  }
+  dim3 gd((unsigned)grid, (unsigned)g.nsplit), bd(NTHREADS);
+  if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true>), gd, bd, 0, stream, g);
+  else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false>), gd, bd, 0, stream, g);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false>), gd, bd, 0, stream, g);
+  else hipLaunchKernelGGL((gemm_kernel<T, true, true>), gd, bd, 0, stream, g);
+  LGP_LAUNCH_CHECK();
+  if (g.nsplit > 1) {
+    const long mn = (long)m * (long)n;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, g.Cpart, g.nsplit, mn, (int)n,
+                       alpha, beta, C, (long)ldc);
+    LGP_LAUNCH_CHECK();
+    LGP_HIP(hipFreeAsync(g.Cpart, stream));
+  }
+  return LGP_OK;
+}
+
+template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t,
+                                     const double *, size_t, double, double *, size_t, bool);
+template int lgp_gemm_launch<float>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, float, const float *, size_t,
+                                    const float *, size_t, float, float *, size_t, bool);
+
+extern "C" int lgp_gemm_f64(lgp_ctx *ctx, int ta, int tb, size_t m, size_t n, size_t k, double alpha, const double *dA,
+                            size_t lda, const double *dB, size_t ldb, double beta, double *dC, size_t ldc) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  DeviceGuard dg(ctx->device);
+  return lgp_gemm_launch<double>(ctx, ctx->stream, ta != 0, tb != 0, m, n, k, alpha, dA, lda, dB, ldb, beta, dC, ldc, false);
+}
+
+extern "C" int lgp_gemm_f32(lgp_ctx *ctx, int ta, int tb, size_t m, size_t n, size_t k, float alpha, const float *dA,
+                            size_t lda, const float *dB, size_t ldb, float beta, float *dC, size_t ldc) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  DeviceGuard dg(ctx->device);
+  return lgp_gemm_launch<float>(ctx, ctx->stream, ta != 0, tb != 0, m, n, k, alpha, dA, lda, dB, ldb, beta, dC, ldc, false);
+}
+
+extern "C" int lgp_update_nt_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dA, size_t lda,
+                                 const double *dB, size_t ldb, double *dC, size_t ldc, int lower) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  DeviceGuard dg(ctx->device);
+  return lgp_gemm_launch<double>(ctx, ctx->stream, false, true, rows, cols, k, -1.0, dA, lda, dB, ldb, 1.0, dC, ldc, lower != 0);
+}
