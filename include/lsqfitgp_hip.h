@@ -182,27 +182,27 @@ int lgp_allclose_f32(lgp_ctx *ctx, size_t rows, size_t cols, const float *dA, si
 /* Chol.__init__: s = diag_scale_pow2(K) (:356-361); Kt = K/s/s[:,None]; eps = epsrel*max_i sum_j|Kt_ij| + epsabs
  * (:245-255,349-354); Kt_ii += eps; Lt = cholesky(Kt) lower; L = Lt*s[:,None]; eps_out = eps*min(s^2).
  * dK: n x n symmetric (only read).  dL: n x n output, strict upper triangle zeroed.
- * dinvd: workspace/output, lgp_chol_invd_size(n) elements: inverses of the 128x128 diagonal blocks of L,
- * consumed by lgp_trsm_*.  Returns 0, or info > 0 = 1-based index of the first non-positive or non-finite
+ * ddblk: workspace/output, lgp_chol_dblk_size(n) elements: packed copies (block, transposed block, reciprocal
+ * diagonal) of the 128x128 diagonal blocks of L, read by the substitution kernels of lgp_trsm_*.  Returns 0, or info > 0 = 1-based index of the first non-positive or non-finite
  * pivot (the reference's "cholesky decomposition not finite" LinAlgError, :389-391).  Synchronises. */
-size_t lgp_chol_invd_size(size_t n);
+size_t lgp_chol_dblk_size(size_t n);
 int lgp_chol_factor_f64(lgp_ctx *ctx, size_t n, const double *dK, size_t ldk,
                         double epsrel, double epsabs, int eps_flags,
-                        double *dL, size_t ldl, double *dinvd, double *heps_out);
+                        double *dL, size_t ldl, double *ddblk, double *heps_out);
 int lgp_chol_factor_f32(lgp_ctx *ctx, size_t n, const float *dK, size_t ldk,
                         float epsrel, float epsabs, int eps_flags,
-                        float *dL, size_t ldl, float *dinvd, float *heps_out);
+                        float *dL, size_t ldl, float *ddblk, float *heps_out);
 /* the bare blocked factorisation (jlinalg.cholesky, _decomp.py:388) of the lower triangle of dL in place */
-int lgp_potrf_f64(lgp_ctx *ctx, size_t n, double *dL, size_t ldl, double *dinvd);
-int lgp_potrf_f32(lgp_ctx *ctx, size_t n, float *dL, size_t ldl, float *dinvd);
+int lgp_potrf_f64(lgp_ctx *ctx, size_t n, double *dL, size_t ldl, double *ddblk);
+int lgp_potrf_f32(lgp_ctx *ctx, size_t n, float *dL, size_t ldl, float *ddblk);
 
 /* ---- solves and products with L: _linalg/_decomp.py:398-439 ---------------------- */
 
 /* B <- L^-1 B (trans=0) or L^-T B (trans=1), B n x nrhs in place: jlinalg.solve_triangular(L, B, lower=True)
  * (_decomp.py:402,407,408,414,419,426,439,467) and solve_triangular(L.T, ., lower=False) (:403,469) */
-int lgp_trsm_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *dinvd,
+int lgp_trsm_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *ddblk,
                  int trans, double *dB, size_t ldb, size_t nrhs);
-int lgp_trsm_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, const float *dinvd,
+int lgp_trsm_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, const float *ddblk,
                  int trans, float *dB, size_t ldb, size_t nrhs);
 /* C (m x n) = alpha * op(A) op(B) + beta * C;  ta/tb = 0: as stored, 1: transposed.
  * op(A) is m x k, op(B) is k x n.  `invLA.T @ invLr` (:409), `invLA.T @ invLA` (:420),
@@ -226,17 +226,17 @@ int lgp_dot_f32(lgp_ctx *ctx, size_t n, const float *dx, const float *dy, float 
  * dW: n x (m+1) workspace, on entry [Kxxs | y] (column m = y), overwritten with L^-1 [Kxxs | y];
  * mean (m) = (L^-1 Kxxs)^T (L^-1 y); cov (m x m, ld ldc) = Kxsxs - (L^-1 Kxxs)^T (L^-1 Kxxs).
  * dKxsxs may alias dcov.  dmean/dcov are device pointers. */
-int lgp_posterior_f64(lgp_ctx *ctx, size_t n, size_t m, const double *dL, size_t ldl, const double *dinvd,
+int lgp_posterior_f64(lgp_ctx *ctx, size_t n, size_t m, const double *dL, size_t ldl, const double *ddblk,
                       double *dW, size_t ldw, const double *dKxsxs, size_t ldk,
                       double *dmean, double *dcov, size_t ldc);
-int lgp_posterior_f32(lgp_ctx *ctx, size_t n, size_t m, const float *dL, size_t ldl, const float *dinvd,
+int lgp_posterior_f32(lgp_ctx *ctx, size_t n, size_t m, const float *dL, size_t ldl, const float *ddblk,
                       float *dW, size_t ldw, const float *dKxsxs, size_t ldk,
                       float *dmean, float *dcov, size_t ldc);
 /* minus_log_normal_density(r, value=True) (_decomp.py:466-488): 1/2 (n log 2pi + 2 sum log L_ii + |L^-1 r|^2).
  * dr (n) is overwritten with L^-1 r.  Synchronises. */
-int lgp_mlnd_value_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *dinvd,
+int lgp_mlnd_value_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *ddblk,
                        double *dr, double *hvalue);
-int lgp_mlnd_value_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, const float *dinvd,
+int lgp_mlnd_value_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, const float *ddblk,
                        float *dr, float *hvalue);
 
 /* ---- multi-GPU: 1-D block-column-cyclic Cholesky over RCCL (no reference counterpart) -- */
@@ -251,9 +251,9 @@ int lgp_allreduce_max_f64(lgp_ctx *ctx, double *dbuf, size_t count);
 
 /* building blocks of the distributed factorisation (the single-GPU driver is built from the same ones):
  * factor one block-column panel held locally: dP is rows x nb (ld ldp), its top nb x nb block is the
- * diagonal block; on exit dP holds the L panel and dinvd_blk (128x128 blocks) its diagonal-block inverses.
+ * diagonal block; on exit dP holds the L panel and ddblk its packed diagonal blocks (lgp_chol_dblk_size(nb)).
  * info offset `row0` is added to pivot indices. */
-int lgp_panel_factor_f64(lgp_ctx *ctx, size_t rows, size_t nb, double *dP, size_t ldp, double *dinvd_blk, size_t row0);
+int lgp_panel_factor_f64(lgp_ctx *ctx, size_t rows, size_t nb, double *dP, size_t ldp, double *ddblk, size_t row0);
 /* C (rows x cols, ldc) -= A (rows x k) * B (cols x k)^T, `lower` != 0 restricts to row >= col + diag_offset */
 int lgp_update_nt_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dA, size_t lda,
                       const double *dB, size_t ldb, double *dC, size_t ldc, int lower);

@@ -54,7 +54,7 @@ def _signatures():
         'lgp_event_destroy': (c_int, [c_void_p, c_void_p]),
         'lgp_event_record': (c_int, [c_void_p, c_void_p]),
         'lgp_event_elapsed_ms': (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float)]),
-        'lgp_chol_invd_size': (c_size_t, [_S]),
+        'lgp_chol_dblk_size': (c_size_t, [_S]),
         'lgp_comm_unique_id': (c_int, [c_void_p]),
         'lgp_comm_init': (c_int, [c_void_p, c_int, c_int, c_void_p]),
         'lgp_comm_destroy': (c_int, [c_void_p]),

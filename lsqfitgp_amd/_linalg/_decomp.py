@@ -158,13 +158,13 @@ class Chol(Decomposition):
             epsabs = 0.
         f, F = _lib.fn('lgp_chol_factor', self._dtype)
         L = DeviceArray.empty((n, n), self._dtype, self._ctx)
-        invd = DeviceArray.empty((_lib.load().lgp_chol_invd_size(n),), self._dtype, self._ctx)
+        dblk = DeviceArray.empty((_lib.load().lgp_chol_dblk_size(n),), self._dtype, self._ctx)
         eps = F()
-        info = _lib.check(f(self._ctx.handle, n, K.ptr, K.ld, F(epsrel), F(epsabs), flags, L.ptr, L.ld, invd.ptr, ctypes.byref(eps)), 'lgp_chol_factor')
+        info = _lib.check(f(self._ctx.handle, n, K.ptr, K.ld, F(epsrel), F(epsabs), flags, L.ptr, L.ld, dblk.ptr, ctypes.byref(eps)), 'lgp_chol_factor')
         if info != 0:                                                  # :389-391
             raise numpy.linalg.LinAlgError('cholesky decomposition not finite, probably matrix not pos def numerically')
         self._L = L
-        self._invd = invd
+        self._dblk = dblk
         self._eps = self._dtype.type(eps.value)                        # :393
 
     # ---- helpers ---------------------------------------------------------
@@ -199,7 +199,7 @@ class Chol(Decomposition):
     def _trsm(self, B, trans):
         """ B <- L^-1 B (trans=0) or L^-T B (trans=1) in place """
         f, _ = _lib.fn('lgp_trsm', self._dtype)
-        _lib.check(f(self._ctx.handle, self.n, self._L.ptr, self._L.ld, self._invd.ptr, int(trans), B.ptr, B.ld, B.shape[1]), 'lgp_trsm')
+        _lib.check(f(self._ctx.handle, self.n, self._L.ptr, self._L.ld, self._dblk.ptr, int(trans), B.ptr, B.ld, B.shape[1]), 'lgp_trsm')
         return B
 
     def _gemm(self, ta, tb, A, B, alpha=1., beta=0., C=None):
@@ -319,7 +319,7 @@ class Chol(Decomposition):
                 raise ValueError('r must be a vector')
             f, F = _lib.fn('lgp_mlnd_value', self._dtype)
             val = F()
-            _lib.check(f(self._ctx.handle, self.n, self._L.ptr, self._L.ld, self._invd.ptr, rd.ptr, ctypes.byref(val)), 'lgp_mlnd_value')
+            _lib.check(f(self._ctx.handle, self.n, self._L.ptr, self._L.ld, self._dblk.ptr, rd.ptr, ctypes.byref(val)), 'lgp_mlnd_value')
             out['value'] = self._dtype.type(val.value)
         else:
             out['value'] = None

@@ -53,8 +53,12 @@ int lgp_ctx_create(int device, lgp_ctx **out) {
   lgp_ctx *c = new lgp_ctx();
   c->device = device;
   c->cus = prop.multiProcessorCount;
-  LGP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  LGP_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  // stream2 carries the latency-bound panel factorisation of the look-ahead: highest priority, so that its
+  // few workgroups are dispatched ahead of the queued trailing-update workgroups of the main stream
+  int prio_lo = 0, prio_hi = 0;
+  LGP_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  LGP_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo));
+  LGP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi));
   LGP_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
   LGP_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
   LGP_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_info), sizeof(int)));
@@ -202,16 +206,16 @@ int lgp_event_elapsed_ms(lgp_ctx *c, void *start, void *stop, float *ms) {
 // ---- fused posterior / log density --------------------------------------------------------------
 
 template <typename T>
-static int posterior_impl(lgp_ctx *c, size_t n, size_t m, const T *L, size_t ldl, const T *invd, T *W, size_t ldw, const T *Kxsxs,
+static int posterior_impl(lgp_ctx *c, size_t n, size_t m, const T *L, size_t ldl, const T *dblk, T *W, size_t ldw, const T *Kxsxs,
                           size_t ldk, T *mean, T *cov, size_t ldc) {
   LGP_REQUIRE(c != nullptr, "null context");
   LGP_REQUIRE(n >= 1, "empty training set");
-  LGP_REQUIRE(L != nullptr && invd != nullptr && W != nullptr, "null pointer");
+  LGP_REQUIRE(L != nullptr && dblk != nullptr && W != nullptr, "null pointer");
   LGP_REQUIRE(ldw >= m + 1, "W must have m+1 columns");
   DeviceGuard dg(c->device);
   hipStream_t st = c->stream;
   // W <- L^-1 [Kxxs | y]   (the reference solves L^-1 Kxxs twice, _decomp.py:408 and :419; once is enough)
-  LGP_CHECK(lgp_trsm_impl<T>(c, st, n, L, ldl, invd, 0, W, ldw, m + 1));
+  LGP_CHECK(lgp_trsm_impl<T>(c, st, n, L, ldl, dblk, 0, W, ldw, m + 1));
   if (m == 0) return LGP_OK;
   // mean = (L^-1 Kxxs)^T (L^-1 y)                      _decomp.py:409
   if (mean) LGP_CHECK(lgp_gemm_launch<T>(c, st, true, false, m, 1, n, T(1), W, ldw, W + m, ldw, T(0), mean, 1, false));
@@ -225,12 +229,12 @@ static int posterior_impl(lgp_ctx *c, size_t n, size_t m, const T *L, size_t ldl
 }
 
 template <typename T>
-static int mlnd_impl(lgp_ctx *c, size_t n, const T *L, size_t ldl, const T *invd, T *r, T *hvalue) {
-  LGP_REQUIRE(c != nullptr && L != nullptr && invd != nullptr && r != nullptr && hvalue != nullptr, "null pointer");
+static int mlnd_impl(lgp_ctx *c, size_t n, const T *L, size_t ldl, const T *dblk, T *r, T *hvalue) {
+  LGP_REQUIRE(c != nullptr && L != nullptr && dblk != nullptr && r != nullptr && hvalue != nullptr, "null pointer");
   LGP_REQUIRE(n >= 1, "empty matrix");
   DeviceGuard dg(c->device);
   hipStream_t st = c->stream;
-  LGP_CHECK(lgp_trsm_impl<T>(c, st, n, L, ldl, invd, 0, r, 1, 1));          // invLr, _decomp.py:467
+  LGP_CHECK(lgp_trsm_impl<T>(c, st, n, L, ldl, dblk, 0, r, 1, 1));          // invLr, _decomp.py:467
   T *d = reinterpret_cast<T *>(c->d_scratch);
   LGP_CHECK(lgp_logdet_device<T>(c, st, n, L, ldl, d));                        // sum(log(diag(L))), :486
   LGP_CHECK(lgp_dot_strided_device<T>(c, st, n, r, 1, r, 1, d + 1));          // invLr @ invLr, :487
@@ -243,19 +247,19 @@ static int mlnd_impl(lgp_ctx *c, size_t n, const T *L, size_t ldl, const T *invd
 }
 
 extern "C" {
-int lgp_posterior_f64(lgp_ctx *c, size_t n, size_t m, const double *L, size_t ldl, const double *invd, double *W, size_t ldw,
+int lgp_posterior_f64(lgp_ctx *c, size_t n, size_t m, const double *L, size_t ldl, const double *dblk, double *W, size_t ldw,
                       const double *K, size_t ldk, double *mean, double *cov, size_t ldc) {
-  return posterior_impl<double>(c, n, m, L, ldl, invd, W, ldw, K, ldk, mean, cov, ldc);
+  return posterior_impl<double>(c, n, m, L, ldl, dblk, W, ldw, K, ldk, mean, cov, ldc);
 }
-int lgp_posterior_f32(lgp_ctx *c, size_t n, size_t m, const float *L, size_t ldl, const float *invd, float *W, size_t ldw,
+int lgp_posterior_f32(lgp_ctx *c, size_t n, size_t m, const float *L, size_t ldl, const float *dblk, float *W, size_t ldw,
                       const float *K, size_t ldk, float *mean, float *cov, size_t ldc) {
-  return posterior_impl<float>(c, n, m, L, ldl, invd, W, ldw, K, ldk, mean, cov, ldc);
+  return posterior_impl<float>(c, n, m, L, ldl, dblk, W, ldw, K, ldk, mean, cov, ldc);
 }
-int lgp_mlnd_value_f64(lgp_ctx *c, size_t n, const double *L, size_t ldl, const double *invd, double *r, double *h) {
-  return mlnd_impl<double>(c, n, L, ldl, invd, r, h);
+int lgp_mlnd_value_f64(lgp_ctx *c, size_t n, const double *L, size_t ldl, const double *dblk, double *r, double *h) {
+  return mlnd_impl<double>(c, n, L, ldl, dblk, r, h);
 }
-int lgp_mlnd_value_f32(lgp_ctx *c, size_t n, const float *L, size_t ldl, const float *invd, float *r, float *h) {
-  return mlnd_impl<float>(c, n, L, ldl, invd, r, h);
+int lgp_mlnd_value_f32(lgp_ctx *c, size_t n, const float *L, size_t ldl, const float *dblk, float *r, float *h) {
+  return mlnd_impl<float>(c, n, L, ldl, dblk, r, h);
 }
 }
 

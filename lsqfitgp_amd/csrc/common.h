@@ -64,6 +64,7 @@ struct DeviceGuard {
 // ---- blocked-algorithm geometry -------------------------------------------------------
 constexpr int LGP_DB = 128;    // diagonal block factored (and inverted) by one workgroup
 constexpr int LGP_NB = 512;    // outer panel width of the right-looking factorisation
+constexpr int LGP_DBLK = 2 * LGP_DB * LGP_DB + LGP_DB;   // per-diagonal-block workspace: D, D^T, 1/diag
 
 // ---- GEMM (gemm.hip) ---------------------------------------------------------------------
 // C (m x n) = alpha * op(A) op(B) + beta * C, row-major; ta/tb: operand stored transposed.
@@ -77,13 +78,13 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
 
 // ---- factorisation pieces (potrf.hip) ------------------------------------------------------
 template <typename T>
-int lgp_potf2_trtri_launch(lgp_ctx *ctx, hipStream_t stream, T *A, size_t lda, int nb, T *invd, size_t row0);
+int lgp_potf2_launch(lgp_ctx *ctx, hipStream_t stream, T *A, size_t lda, int nb, T *dblk, size_t row0);
 template <typename T>
-int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t nb, T *P, size_t ldp, T *invd, size_t row0);
+int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t nb, T *P, size_t ldp, T *dblk, size_t row0);
 template <typename T>
-int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *invd);
+int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk);
 template <typename T>
-int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t ldl, const T *invd, int trans, T *B, size_t ldb, size_t nrhs);
+int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t ldl, const T *dblk, int trans, T *B, size_t ldb, size_t nrhs);
 
 // ---- reductions (elementwise.hip) -------------------------------------------------------------
 template <typename T>

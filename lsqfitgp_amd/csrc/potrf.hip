@@ -6,14 +6,14 @@
 //   prep      : s = diag_scale_pow2(K) (:356-361); Gershgorin bound of K/s/s' (:349-354); eps (:245-255);
 //               L <- tril(K/s/s') + eps*I with the strict upper triangle zeroed      [HBM-bound passes]
 //   potrf     : right-looking, outer panel LGP_NB = 512, inner diagonal blocks LGP_DB = 128:
-//                 potf2_trtri : one workgroup factors a 128x128 diagonal block held in REGISTERS
-//                               (8x8 cyclic tile per thread) and forms its inverse alongside;
-//                 panel trsm  : X = B * inv(L_jj)^T as an MFMA gemm (in place);
+//                 potf2       : one workgroup factors a 128x128 diagonal block held in REGISTERS
+//                               (8x8 cyclic tile per thread);
+//                 panel trsm  : X = B * L_jj^-T by substitution, one thread per row, L_jj through scalar loads;
 //                 panel update: gemm NT, K = 128;
 //                 trailing    : syrk (gemm NT, lower tiles only), K = 512 -- the N^3/3 flops, MFMA-bound;
 //               the next panel is factored on a second stream while the rest of the trailing update
 //               runs (look-ahead).
-//   finish    : L <- L * s[:,None], inv(D) <- inv(D) / s', eps_out = eps * min(s^2).
+//   finish    : L <- L * s[:,None], diagonal-block workspace re-extracted, eps_out = eps * min(s^2).
 // A non-positive or non-finite pivot is recorded in ctx->d_info (first one wins) and the factor goes
 // NaN from there on, like LAPACK-in-jax; the host turns info != 0 into the reference's LinAlgError.
 #include "common.h"
@@ -21,141 +21,334 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// potf2 + trtri of one diagonal block (nb <= 128) by one 256-thread workgroup.
-// Thread (ti, tj), tid = tj*16 + ti, owns A[ti+16a][tj+16b] and Y[ti+16a][tj+16b], a,b in 0..7.
-// Step j: the 16 owners of column j (one 16-lane group of one wave) get the pivot by a wave shuffle,
-// publish l_i = a_ij/piv and l_i/piv in LDS; the owners of row j publish the unscaled row j of Y;
-// ONE barrier; everybody applies the rank-1 updates  A_ic -= l_i l_c (c > j),  Y_ic -= (l_i/piv) y~_jc (c <= j).
-// LDS vectors are double-buffered on j&1 so that the next step's publish does not wait for stragglers.
+// Diagonal-block workspace ("dblk"): for every 128x128 diagonal block of L, LGP_DBLK elements:
+//   [0, 128*128)          D   = the block, row-major, zeros above the diagonal, identity padding past n
+//   [128*128, 2*128*128)  Dt  = its transpose, row-major
+//   [2*128*128, +128)     rd  = 1 / diag
+// The triangular solves read D / Dt rows with wave-uniform (scalar) loads.
+
+// potf2 of one diagonal block (nb <= 128) by one 256-thread workgroup, matrix held in REGISTERS.
+// Thread (ti, tj), tid = tj*16 + ti, owns A[ti+16a][tj+16b], a,b in 0..7 (cyclic, so the shrinking
+// trailing matrix stays balanced).  Step j: the 16 owners of column j (one 16-lane row of one wave)
+// read the pivot with v_readlane, scale their column by an accurate reciprocal square root (fp64
+// latency on gfx950 is ~32 cycles per dependent op, so the 128-pivot chain is what bounds this kernel:
+// rsqrt + multiply is ~9 dependent ops, sqrt + divide ~20) and publish l_i in LDS; ONE barrier;
+// everybody applies the rank-1 update A_ic -= l_i l_c (i, c > j) branch-free.  The 16-column group
+// index JA is a template parameter so that every register index is static.  The LDS column is
+// double-buffered on j&1 so that the next step's publish does not wait for stragglers.
 template <typename T>
-__global__ void __launch_bounds__(256, 1) potf2_trtri_kernel(T *A, long lda, int nb, T *invd, int *info, long row0) {
+__device__ __forceinline__ T rsqrt_accurate(T d) {
+  if (sizeof(T) == 8) {
+    double y = __builtin_amdgcn_rsq((double)d);
+    // two Newton steps: y <- y * (1.5 - 0.5 d y^2)
+    double h = 0.5 * (double)d;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return (T)y;
+  } else {
+    float y = __builtin_amdgcn_rsqf((float)d);
+    float h = 0.5f * (float)d;
+    y = y * (1.5f - h * y * y);
+    return (T)y;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T readlane_t(T v, int lane) {
+  if (sizeof(T) == 8) {
+    long long bits = __builtin_bit_cast(long long, (double)v);
+    int lo = __builtin_amdgcn_readlane((int)bits, lane);
+    int hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
+    long long r = ((long long)hi << 32) | (unsigned int)lo;
+    return (T)__builtin_bit_cast(double, r);
+  } else {
+    int bits = __builtin_bit_cast(int, (float)v);
+    return (T)__builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, lane));
+  }
+}
+
+template <typename T, int JA>
+__device__ __forceinline__ void potf2_group(T (&a)[8][8], T (*scol)[LGP_DB], int ti, int tj, int nb, int *info, long row0) {
+#pragma unroll 1
+  for (int jm = 0; jm < 16; ++jm) {
+    const int j = JA * 16 + jm, buf = jm & 1;
+    if (tj == jm) {   // column owners: lanes (jm&3)*16 .. +15 of wave jm>>2; the diagonal owner has ti == jm
+      const T d = readlane_t<T>(a[JA][JA], (jm & 3) * 16 + jm);
+      const bool bad = !(d > T(0)) || (d + d == d);   // <= 0, NaN, or +inf
+      if (bad && ti == jm && j < nb) atomicCAS(info, 0, (int)(row0 + j + 1));
+      const T rinv = bad ? T(NAN) : rsqrt_accurate<T>(d);
+#pragma unroll
+      for (int p = JA; p < 8; ++p) {
+        const int i = ti + 16 * p;
+        T l = a[p][JA] * rinv;
+        if (i == j) l = d * rinv;
+        if (i >= j) {
+          scol[buf][i] = l;
+          a[p][JA] = l;
+        }
+      }
+    }
+    __syncthreads();
+    T lc[8], lr[8];
+#pragma unroll
+    for (int q = JA; q < 8; ++q) {
+      const int c = tj + 16 * q, i = ti + 16 * q;
+      lc[q] = (c > j) ? scol[buf][c] : T(0);
+      lr[q] = (i > j) ? scol[buf][i] : T(0);
+    }
+#pragma unroll
+    for (int p = JA; p < 8; ++p)
+#pragma unroll
+      for (int q = JA; q < 8; ++q) a[p][q] -= lr[p] * lc[q];   // zero factors where i <= j or c <= j
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 1) potf2_kernel(T *A, long lda, int nb, T *dblk, int *info, long row0) {
+  // LDS: only the 2 KB double-buffered column, so that this single workgroup can always be placed next
+  // to the 73 KB workgroups of the trailing update running on the other stream (look-ahead).
   constexpr int D = LGP_DB;        // 128
-  constexpr int LS = D + 1;        // padded LDS stride
-  __shared__ T sA[D * LS];
-  __shared__ T scol[2][D], scol2[2][D], syrow[2][D];
-  __shared__ T spiv[2];
+  __shared__ T scol[2][D];
 
   const int tid = threadIdx.x;
   const int ti = tid & 15, tj = tid >> 4;
-  const int lane = tid & 63;
 
-  // coalesced load of the lower triangle (identity padding beyond nb)
-  for (int idx = tid; idx < D * D; idx += 256) {
-    const int i = idx / D, c = idx % D;
-    T v = (i == c) ? T(1) : T(0);
-    if (i < nb && c <= i) v = A[(long)i * lda + c];
-    sA[i * LS + c] = v;
-  }
-  __syncthreads();
-
-  T a[8][8], y[8][8];
+  // lower triangle straight into registers (identity padding beyond nb); the block was just written by
+  // the previous update, so these 64 strided loads per thread come out of L2
+  T a[8][8];
 #pragma unroll
   for (int p = 0; p < 8; ++p)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int i = ti + 16 * p, c = tj + 16 * q;
-      a[p][q] = sA[i * LS + c];
-      y[p][q] = (i == c) ? T(1) : T(0);
+      T v = (i == c) ? T(1) : T(0);
+      if (i < nb && c <= i) v = A[(long)i * lda + c];
+      a[p][q] = v;
     }
-  __syncthreads();
 
-  for (int j = 0; j < D; ++j) {
-    const int ja = j >> 4, jm = j & 15, buf = j & 1;
-    // ---- publish phase
-    if (tj == jm) {   // column owners: lanes (tj&3)*16 .. +15 of wave tj>>2
-      T d = T(0), colv[8];
+  potf2_group<T, 0>(a, scol, ti, tj, nb, info, row0);
+  potf2_group<T, 1>(a, scol, ti, tj, nb, info, row0);
+  potf2_group<T, 2>(a, scol, ti, tj, nb, info, row0);
+  potf2_group<T, 3>(a, scol, ti, tj, nb, info, row0);
+  potf2_group<T, 4>(a, scol, ti, tj, nb, info, row0);
+  potf2_group<T, 5>(a, scol, ti, tj, nb, info, row0);
+  potf2_group<T, 6>(a, scol, ti, tj, nb, info, row0);
+  potf2_group<T, 7>(a, scol, ti, tj, nb, info, row0);
+
+  // write-back: L block (lower part only) and the workspace copies D, D^T, 1/diag
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        T v = T(0);
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (q == ja) v = a[p][q];     // ja is uniform: static register index after unrolling
-        colv[p] = v;
-        if (p == ja) d = v;             // meaningful only on the lane with ti == jm
-      }
-      d = __shfl(d, (lane & 48) | jm, 64);
-      const bool bad = !(d > T(0)) || (d + d == d);   // <= 0, NaN, or +inf
-      if (bad && ti == jm && j < nb) atomicCAS(info, 0, (int)(row0 + j + 1));
-      const T piv = sqrt(d);
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int i = ti + 16 * p;
-        if (p >= ja) {
-          T l = colv[p] / piv;
-          if (i == j) l = piv;
-          if (i >= j) {
-            scol[buf][i] = l;
-            scol2[buf][i] = l / piv;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-              if (q == ja) a[p][q] = l;
-          }
-        }
-      }
-      if (ti == jm) spiv[buf] = piv;
-    }
-    if (ti == jm) {   // row owners of Y: unscaled row j, columns <= j
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int c = tj + 16 * q;
-        T v = T(0);
-#pragma unroll
-        for (int p = 0; p < 8; ++p)
-          if (p == ja) v = y[p][q];
-        if (q <= ja && c <= j) syrow[buf][c] = v;
-      }
-    }
-    __syncthreads();
-    // ---- update phase
-    T lc[8], yr[8];
+  for (int p = 0; p < 8; ++p)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int c = tj + 16 * q;
-      lc[q] = (q >= ja && c > j) ? scol[buf][c] : T(0);
-      yr[q] = (q <= ja && c <= j) ? syrow[buf][c] : T(0);
+      const int i = ti + 16 * p, c = tj + 16 * q;
+      const T v = (c <= i) ? a[p][q] : T(0);
+      if (i < nb && c <= i) A[(long)i * lda + c] = v;
+      dblk[i * D + c] = v;
+      dblk[D * D + c * D + i] = v;
+      if (i == c) dblk[2 * D * D + i] = T(1) / v;
     }
-    const T piv = spiv[buf];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      if (p >= ja) {
-        const int i = ti + 16 * p;
-        if (i > j) {
-          const T li = scol[buf][i], li2 = scol2[buf][i];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            if (q >= ja) a[p][q] -= li * lc[q];    // lc = 0 where c <= j
-            if (q <= ja) y[p][q] -= li2 * yr[q];   // yr = 0 where c > j
-          }
-        } else if (i == j) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (q <= ja) y[p][q] = yr[q] / piv;    // final row j of the inverse (zero right of the diagonal)
-        }
-      }
-    }
-  }
-  __syncthreads();
+}
 
-  // ---- coalesced write-back: L block (lower part only), then the inverse
-#pragma unroll
-  for (int p = 0; p < 8; ++p)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) sA[(ti + 16 * p) * LS + tj + 16 * q] = a[p][q];
-  __syncthreads();
-  for (int idx = tid; idx < D * D; idx += 256) {
+// Re-extract the workspace copies of every diagonal block from the finished factor (after row scaling)
+template <typename T>
+__global__ void __launch_bounds__(256) extract_dblk_kernel(const T *L, long ldl, int n, T *dblk) {
+  constexpr int D = LGP_DB;
+  const int b = blockIdx.x;
+  T *w = dblk + (long)b * LGP_DBLK;
+  const long j0 = (long)b * D;
+  for (int idx = threadIdx.x; idx < D * D; idx += 256) {
     const int i = idx / D, c = idx % D;
-    if (i < nb && c <= i) A[(long)i * lda + c] = sA[i * LS + c];
+    // lower element (i, c), c <= i
+    T v = (i == c) ? T(1) : T(0);
+    if (c <= i && j0 + i < n) v = L[(j0 + i) * ldl + j0 + c];
+    if (c > i) v = T(0);
+    w[idx] = v;
+    // transposed image: Dt[i][c] = D[c][i], nonzero for i <= c
+    T u = (i == c) ? T(1) : T(0);
+    if (i <= c && j0 + c < n) u = L[(j0 + c) * ldl + j0 + i];
+    if (i > c) u = T(0);
+    w[D * D + idx] = u;
   }
-  __syncthreads();
-#pragma unroll
-  for (int p = 0; p < 8; ++p)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) sA[(ti + 16 * p) * LS + tj + 16 * q] = y[p][q];
-  __syncthreads();
-  for (int idx = tid; idx < D * D; idx += 256) {
-    const int i = idx / D, c = idx % D;
-    invd[idx] = (c <= i) ? sA[i * LS + c] : T(0);
+  if (threadIdx.x < D) {
+    const long g = j0 + threadIdx.x;
+    w[2 * D * D + threadIdx.x] = (g < n) ? T(1) / L[g * ldl + g] : T(1);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triangular solves with one diagonal block by SUBSTITUTION (backward stable, like LAPACK trsm/trsv; an
+// explicit inverse of the block loses cond(L_jj) * eps, which is fatal for the near-singular ExpQuad
+// Gram matrices the reference's jitter rule is tuned for).  One thread solves one right-hand side of
+// 128 unknowns held in registers; the matrix entries are wave-uniform and come through scalar loads.
+// Right-looking (axpy) form in 8 steps of 16 unknowns: the current 16 always sit in x[0..15]
+// (x[112..127] for the transposed solve), are solved against the 16x16 diagonal sub-block, applied to the
+// remaining unknowns (independent FMAs: the DP pipe stays full with one wave per SIMD), handed to
+// `emit`, and the register array is rotated by 16 -- so the step loop is a RUNTIME loop whose body is
+// ~2000 FMAs instead of an 8128-FMA straight line.
+constexpr int SUBST_NT = 128;   // threads (right-hand sides) per workgroup: 2 waves share one LDS image of the block
+constexpr int SUBST_HALF = LGP_DB / 2;
+
+// stage 64 rows (row0 .. row0+63) of the 128x128 image `src` into LDS (64 KB for fp64: the kernel must fit
+// beside a 73 KB trailing-update workgroup so that the look-ahead stream is never starved of a CU)
+template <typename T>
+__device__ __forceinline__ void subst_stage(const T *__restrict__ src, int row0, T *sM) {
+  constexpr int D = LGP_DB;
+  constexpr int VEC = 16 / sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+  const vec_t *s = reinterpret_cast<const vec_t *>(src + (long)row0 * D);
+  vec_t *d = reinterpret_cast<vec_t *>(sM);
+  for (int idx = threadIdx.x; idx < SUBST_HALF * D / VEC; idx += SUBST_NT) d[idx] = s[idx];
+}
+
+// 16 consecutive matrix entries from LDS into registers (ds_read_b128: all lanes read the same address)
+template <typename T>
+__device__ __forceinline__ void load16(const T *p, T (&m)[16]) {
+  constexpr int VEC = 16 / sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(VEC)));
+#pragma unroll
+  for (int i = 0; i < 16 / VEC; ++i) {
+    const vec_t v = reinterpret_cast<const vec_t *>(p)[i];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m[i * VEC + e] = v[e];
+  }
+}
+
+// x[xo .. xo+15] -= sum_t M[t][0..15] * piv[t], t = 0..15 (REV: 15..0), M rows `stride` apart in LDS.
+// Software-pipelined by hand: the rows of steps t+1 and t+2 are already in flight while step t's 16
+// independent FMAs issue (an LDS read takes ~130 cycles, 16 fp64 FMAs 64: two rows ahead covers it).
+template <typename T, bool REV, int XO, int PO>
+__device__ __forceinline__ void rank16_update(const T *M, int stride, T (&x)[LGP_DB]) {
+  T m[3][16];
+  load16<T>(M + (REV ? 15 : 0) * stride, m[0]);
+  load16<T>(M + (REV ? 14 : 1) * stride, m[1]);
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    if (s + 2 < 16) load16<T>(M + (REV ? 15 - (s + 2) : s + 2) * stride, m[(s + 2) % 3]);
+    const int t = REV ? 15 - s : s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[XO + e] -= m[s % 3][e] * x[PO + t];
+  }
+}
+
+template <typename T, bool TRANS, typename Emit>
+__device__ __forceinline__ void subst128(const T *__restrict__ w, T *sM, T (&x)[LGP_DB], Emit emit) {
+  // w: diagonal-block workspace (D, Dt, 1/diag); sM: LDS, SUBST_HALF*128 + 128 elements
+  constexpr int D = LGP_DB, S = 16, NS = D / S;
+  T *rd = sM + SUBST_HALF * D;
+  for (int idx = threadIdx.x; idx < D; idx += SUBST_NT) rd[idx] = w[2 * D * D + idx];
+  if (!TRANS) {
+    // L x = b, forward.  Row t of Dt holds column t of L.
+    const T *__restrict__ Dt = w + D * D;
+    subst_stage<T>(Dt, 0, sM);
+    __syncthreads();
+#pragma unroll 1
+    for (int tb = 0; tb < NS; ++tb) {
+      if (tb == NS / 2) {
+        __syncthreads();
+        subst_stage<T>(Dt, SUBST_HALF, sM);
+        __syncthreads();
+      }
+      const T *Mb = sM + ((tb * S) & (SUBST_HALF - 1)) * D + tb * S;   // Mb[t*D + c] = L[tb*16 + c][tb*16 + t]
+      const T *rdb = rd + tb * S;
+#pragma unroll
+      for (int t = 0; t < S; ++t) {
+        const T xt = x[t] * rdb[t];
+        x[t] = xt;
+#pragma unroll
+        for (int c = t + 1; c < S; ++c) x[c] -= Mb[t * D + c] * xt;
+      }
+      // remaining unknowns, 16 at a time (wave-uniform guards: group q exists while q < NS - tb)
+      if (1 < NS - tb) rank16_update<T, false, 1 * S, 0>(Mb + 1 * S, D, x);
+      if (2 < NS - tb) rank16_update<T, false, 2 * S, 0>(Mb + 2 * S, D, x);
+      if (3 < NS - tb) rank16_update<T, false, 3 * S, 0>(Mb + 3 * S, D, x);
+      if (4 < NS - tb) rank16_update<T, false, 4 * S, 0>(Mb + 4 * S, D, x);
+      if (5 < NS - tb) rank16_update<T, false, 5 * S, 0>(Mb + 5 * S, D, x);
+      if (6 < NS - tb) rank16_update<T, false, 6 * S, 0>(Mb + 6 * S, D, x);
+      if (7 < NS - tb) rank16_update<T, false, 7 * S, 0>(Mb + 7 * S, D, x);
+      emit(tb * S, x);   // x[0..15] are unknowns tb*16 .. tb*16+15
+#pragma unroll
+      for (int i = 0; i < D - S; ++i) x[i] = x[i + S];
+    }
+  } else {
+    // L^T x = b, backward.  Row t of D holds row t of L = column t of L^T.
+    const T *__restrict__ Dm = w;
+    subst_stage<T>(Dm, SUBST_HALF, sM);
+    __syncthreads();
+#pragma unroll 1
+    for (int tb = 0; tb < NS; ++tb) {
+      if (tb == NS / 2) {
+        __syncthreads();
+        subst_stage<T>(Dm, 0, sM);
+        __syncthreads();
+      }
+      const int bt = NS - 1 - tb;                                   // block being solved
+      const T *Mr = sM + ((bt * S) & (SUBST_HALF - 1)) * D;          // Mr[t*D + g] = L[bt*16 + t][g]
+      const T *rdb = rd + bt * S;
+#pragma unroll
+      for (int t = S - 1; t >= 0; --t) {
+        const T xt = x[D - S + t] * rdb[t];
+        x[D - S + t] = xt;
+#pragma unroll
+        for (int c = 0; c < t; ++c) x[D - S + c] -= Mr[t * D + bt * S + c] * xt;
+      }
+      // register group q (< 7) currently holds unknowns 16*(q - tb) ..; it exists while q >= tb
+      const T *Mq = Mr - tb * S;
+      if (0 >= tb) rank16_update<T, true, 0 * S, D - S>(Mq + 0 * S, D, x);
+      if (1 >= tb) rank16_update<T, true, 1 * S, D - S>(Mq + 1 * S, D, x);
+      if (2 >= tb) rank16_update<T, true, 2 * S, D - S>(Mq + 2 * S, D, x);
+      if (3 >= tb) rank16_update<T, true, 3 * S, D - S>(Mq + 3 * S, D, x);
+      if (4 >= tb) rank16_update<T, true, 4 * S, D - S>(Mq + 4 * S, D, x);
+      if (5 >= tb) rank16_update<T, true, 5 * S, D - S>(Mq + 5 * S, D, x);
+      if (6 >= tb) rank16_update<T, true, 6 * S, D - S>(Mq + 6 * S, D, x);
+      emit(bt * S, x);   // x[112..127] are unknowns bt*16 .. bt*16+15
+#pragma unroll
+      for (int i = D - 1; i >= S; --i) x[i] = x[i - S];
+    }
+  }
+}
+
+// left side: B (jb x nrhs, ld ldb) <- L_jj^-1 B or L_jj^-T B; thread per column (coalesced across lanes)
+template <typename T, bool TRANS>
+__global__ void __launch_bounds__(SUBST_NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
+subst_left_kernel(const T *__restrict__ w, int jb, T *B, long ldb, int nrhs) {
+  __shared__ __attribute__((aligned(16))) T sM[SUBST_HALF * LGP_DB + LGP_DB];
+  int c = blockIdx.x * SUBST_NT + threadIdx.x;
+  const bool live = c < nrhs;
+  if (!live) c = nrhs - 1;   // dead lanes compute a duplicate and do not store
+  T x[LGP_DB];
+#pragma unroll
+  for (int i = 0; i < LGP_DB; ++i) x[i] = (i < jb) ? B[(long)i * ldb + c] : T(0);
+  subst128<T, TRANS>(w, sM, x, [&](int g0, const T(&xx)[LGP_DB]) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (live && g0 + t < jb) B[(long)(g0 + t) * ldb + c] = xx[(TRANS ? LGP_DB - 16 : 0) + t];
+  });
+}
+
+// right side: X (rows x jb, ld ldx) <- X L_jj^-T, i.e. every row solves L_jj x = b; thread per row
+// (each lane streams its own contiguous row: 16-byte loads, whole 128-byte lines consumed through L1)
+template <typename T>
+__global__ void __launch_bounds__(SUBST_NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
+subst_right_kernel(const T *__restrict__ w, int jb, T *X, long ldx, long rows) {
+  constexpr int D = LGP_DB;
+  __shared__ __attribute__((aligned(16))) T sM[SUBST_HALF * D + D];
+  long r = (long)blockIdx.x * SUBST_NT + threadIdx.x;
+  const bool live = r < rows;
+  if (!live) r = rows - 1;
+  T *row = X + r * ldx;
+  T x[D];
+  if (jb == D) {
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = row[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[c] = (c < jb) ? row[c] : T(0);
+  }
+  subst128<T, false>(w, sM, x, [&](int g0, const T(&xx)[D]) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (live && g0 + t < jb) row[g0 + t] = xx[t];
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -275,45 +468,35 @@ __global__ void __launch_bounds__(256) scale_rows_kernel(T *L, long ldl, int n, 
   L[(long)i * ldl + j] *= s[i];
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) scale_invd_kernel(T *invd, int n, const T *s) {
-  // invd block b: [128][128], column c corresponds to global index b*128 + c : inv(S L~) = inv(L~) inv(S)
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)((n + LGP_DB - 1) / LGP_DB) * LGP_DB * LGP_DB;
-  if (idx >= total) return;
-  const int b = (int)(idx / (LGP_DB * LGP_DB));
-  const int c = (int)(idx % LGP_DB);
-  const int g = b * LGP_DB + c;
-  if (g < n) invd[idx] /= s[g];
-}
-
 }  // namespace
 
 // ================================================================================================
 // host drivers
 
 template <typename T>
-int lgp_potf2_trtri_launch(lgp_ctx *ctx, hipStream_t stream, T *A, size_t lda, int nb, T *invd, size_t row0) {
+int lgp_potf2_launch(lgp_ctx *ctx, hipStream_t stream, T *A, size_t lda, int nb, T *dblk, size_t row0) {
   LGP_REQUIRE(nb >= 1 && nb <= LGP_DB, "diagonal block size must be in [1,128]");
-  hipLaunchKernelGGL((potf2_trtri_kernel<T>), dim3(1), dim3(256), 0, stream, A, (long)lda, nb, invd, ctx->d_info, (long)row0);
+  hipLaunchKernelGGL((potf2_kernel<T>), dim3(1), dim3(256), 0, stream, A, (long)lda, nb, dblk, ctx->d_info, (long)row0);
   LGP_LAUNCH_CHECK();
   return LGP_OK;
 }
 
 // Factor a block-column panel: P is rows x nb (ld ldp), top nb x nb block is the diagonal block.
-// invd receives ceil(nb/128) inverse diagonal blocks.
+// dblk receives ceil(nb/128) diagonal-block workspaces.
 template <typename T>
-int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t nb, T *P, size_t ldp, T *invd, size_t row0) {
+int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t nb, T *P, size_t ldp, T *dblk, size_t row0) {
   LGP_REQUIRE(rows >= nb, "panel must have at least nb rows");
   for (size_t j0 = 0; j0 < nb; j0 += LGP_DB) {
     const size_t jb = (nb - j0) < (size_t)LGP_DB ? (nb - j0) : (size_t)LGP_DB;
-    T *D = P + j0 * ldp + j0;
-    T *Y = invd + (j0 / LGP_DB) * (size_t)LGP_DB * LGP_DB;
-    LGP_CHECK(lgp_potf2_trtri_launch<T>(ctx, stream, D, ldp, (int)jb, Y, row0 + j0));
+    T *Dg = P + j0 * ldp + j0;
+    T *w = dblk + (j0 / LGP_DB) * (size_t)LGP_DBLK;
+    LGP_CHECK(lgp_potf2_launch<T>(ctx, stream, Dg, ldp, (int)jb, w, row0 + j0));
     const size_t below = rows - (j0 + jb);
     if (below > 0) {
-      T *X = P + (j0 + jb) * ldp + j0;   // below x jb, solved in place: X <- X * Y^T
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, false, true, below, jb, jb, T(1), X, ldp, Y, LGP_DB, T(0), X, ldp, false));
+      T *X = P + (j0 + jb) * ldp + j0;   // below x jb, solved in place: X <- X * L_jj^-T
+      hipLaunchKernelGGL((subst_right_kernel<T>), dim3((unsigned)((below + SUBST_NT - 1) / SUBST_NT)), dim3(SUBST_NT), 0, stream, w,
+                         (int)jb, X, (long)ldp, (long)below);
+      LGP_LAUNCH_CHECK();
       const size_t wc = nb - (j0 + jb);
       if (wc > 0) {
         // remaining panel columns: C (below x wc, C(0,0) on the diagonal) -= X * X[0:wc]^T, lower part
@@ -326,7 +509,7 @@ int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t 
 }
 
 template <typename T>
-int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *invd) {
+int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk) {
   LGP_REQUIRE(ldl >= n, "ldl < n");
   hipStream_t s0 = ctx->stream, s1 = ctx->stream2;
   const size_t NB = LGP_NB;
@@ -334,7 +517,7 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *invd) {
   for (size_t k0 = 0; k0 < n; k0 += NB) {
     const size_t kb = (n - k0) < NB ? (n - k0) : NB;
     T *P = L + k0 * ldl + k0;
-    T *Yk = invd + (k0 / LGP_DB) * (size_t)LGP_DB * LGP_DB;
+    T *Yk = dblk + (k0 / LGP_DB) * (size_t)LGP_DBLK;
     if (k0 == 0) {
       LGP_CHECK(lgp_panel_factor_impl<T>(ctx, s0, n - k0, kb, P, ldl, Yk, k0));
     }
@@ -349,7 +532,7 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *invd) {
     LGP_HIP(hipStreamWaitEvent(s1, ctx->ev_a, 0));
     T *C1 = L + t0 * ldl + t0;                  // rows_t x nb1 block column (lower part)
     LGP_CHECK(lgp_gemm_launch<T>(ctx, s1, false, true, rows_t, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
-    LGP_CHECK(lgp_panel_factor_impl<T>(ctx, s1, rows_t, nb1, C1, ldl, invd + (t0 / LGP_DB) * (size_t)LGP_DB * LGP_DB, t0));
+    LGP_CHECK(lgp_panel_factor_impl<T>(ctx, s1, rows_t, nb1, C1, ldl, dblk + (t0 / LGP_DB) * (size_t)LGP_DBLK, t0));
     LGP_HIP(hipEventRecord(ctx->ev_b, s1));
     // s0: rest of the trailing update (columns beyond the next panel)
     if (rows_t > nb1) {
@@ -364,27 +547,31 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *invd) {
 }
 
 template <typename T>
-int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t ldl, const T *invd, int trans, T *B, size_t ldb, size_t nrhs) {
+int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t ldl, const T *dblk, int trans, T *B, size_t ldb, size_t nrhs) {
   if (n == 0 || nrhs == 0) return LGP_OK;
   LGP_REQUIRE(ldl >= n && ldb >= nrhs, "leading dimension too small");
+  LGP_REQUIRE(nrhs < (1u << 30), "too many right-hand sides");
   const size_t nblk = (n + LGP_DB - 1) / LGP_DB;
+  const dim3 gs((unsigned)((nrhs + SUBST_NT - 1) / SUBST_NT)), bs(SUBST_NT);
   if (!trans) {
+    // forward: B_j <- L_jj^-1 B_j (substitution), then B_below -= L[below, j] B_j (MFMA gemm)
     for (size_t b = 0; b < nblk; ++b) {
       const size_t j0 = b * LGP_DB, jb = (n - j0) < (size_t)LGP_DB ? (n - j0) : (size_t)LGP_DB;
-      const T *Y = invd + b * (size_t)LGP_DB * LGP_DB;
       T *Bj = B + j0 * ldb;
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, false, false, jb, nrhs, jb, T(1), Y, LGP_DB, Bj, ldb, T(0), Bj, ldb, false));
+      hipLaunchKernelGGL((subst_left_kernel<T, false>), gs, bs, 0, stream, dblk + b * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
+      LGP_LAUNCH_CHECK();
       const size_t below = n - (j0 + jb);
       if (below > 0)
         LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, false, false, below, nrhs, jb, T(-1), L + (j0 + jb) * ldl + j0, ldl, Bj, ldb, T(1),
                                      B + (j0 + jb) * ldb, ldb, false));
     }
   } else {
+    // backward: B_j <- L_jj^-T B_j, then B_above -= L[j, above]^T B_j
     for (size_t bb = nblk; bb-- > 0;) {
       const size_t j0 = bb * LGP_DB, jb = (n - j0) < (size_t)LGP_DB ? (n - j0) : (size_t)LGP_DB;
-      const T *Y = invd + bb * (size_t)LGP_DB * LGP_DB;
       T *Bj = B + j0 * ldb;
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, true, false, jb, nrhs, jb, T(1), Y, LGP_DB, Bj, ldb, T(0), Bj, ldb, false));
+      hipLaunchKernelGGL((subst_left_kernel<T, true>), gs, bs, 0, stream, dblk + bb * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
+      LGP_LAUNCH_CHECK();
       if (j0 > 0)
         LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, true, false, j0, nrhs, jb, T(-1), L + j0 * ldl, ldl, Bj, ldb, T(1), B, ldb, false));
     }
@@ -394,10 +581,10 @@ int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t
 
 template <typename T>
 static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T epsrel, T epsabs, int flags, T *L, size_t ldl,
-                            T *invd, T *heps_out) {
+                            T *dblk, T *heps_out) {
   LGP_REQUIRE(ctx != nullptr, "null context");
   LGP_REQUIRE(n >= 1 && n < (1u << 30), "matrix size out of range");
-  LGP_REQUIRE(K != nullptr && L != nullptr && invd != nullptr, "null pointer");
+  LGP_REQUIRE(K != nullptr && L != nullptr && dblk != nullptr, "null pointer");
   LGP_REQUIRE(ldk >= n && ldl >= n, "leading dimension too small");
   DeviceGuard dg(ctx->device);
   hipStream_t st = ctx->stream;
@@ -423,12 +610,11 @@ static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T ep
   hipLaunchKernelGGL((prep_lower_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, st, K, (long)ldk, ni, nbx, s, unit,
                      stats, L, (long)ldl);
   LGP_LAUNCH_CHECK();
-  LGP_CHECK(lgp_potrf_impl<T>(ctx, n, L, ldl, invd));
+  LGP_CHECK(lgp_potrf_impl<T>(ctx, n, L, ldl, dblk));
   if (!unit) {
     hipLaunchKernelGGL((scale_rows_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, st, L, (long)ldl, ni, nbx, s);
     LGP_LAUNCH_CHECK();
-    const size_t total = ((n + LGP_DB - 1) / LGP_DB) * (size_t)LGP_DB * LGP_DB;
-    hipLaunchKernelGGL((scale_invd_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, invd, ni, s);
+    hipLaunchKernelGGL((extract_dblk_kernel<T>), dim3((unsigned)((n + LGP_DB - 1) / LGP_DB)), dim3(256), 0, st, L, (long)ldl, ni, dblk);
     LGP_LAUNCH_CHECK();
   }
   T hstats[3];
@@ -441,49 +627,49 @@ static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T ep
   return info;
 }
 
-extern "C" size_t lgp_chol_invd_size(size_t n) { return ((n + LGP_DB - 1) / LGP_DB) * (size_t)LGP_DB * LGP_DB; }
+extern "C" size_t lgp_chol_dblk_size(size_t n) { return ((n + LGP_DB - 1) / LGP_DB) * (size_t)LGP_DBLK; }
 
 extern "C" int lgp_chol_factor_f64(lgp_ctx *ctx, size_t n, const double *dK, size_t ldk, double epsrel, double epsabs, int eps_flags,
-                                   double *dL, size_t ldl, double *dinvd, double *heps_out) {
-  return chol_factor_impl<double>(ctx, n, dK, ldk, epsrel, epsabs, eps_flags, dL, ldl, dinvd, heps_out);
+                                   double *dL, size_t ldl, double *ddblk, double *heps_out) {
+  return chol_factor_impl<double>(ctx, n, dK, ldk, epsrel, epsabs, eps_flags, dL, ldl, ddblk, heps_out);
 }
 extern "C" int lgp_chol_factor_f32(lgp_ctx *ctx, size_t n, const float *dK, size_t ldk, float epsrel, float epsabs, int eps_flags,
-                                   float *dL, size_t ldl, float *dinvd, float *heps_out) {
-  return chol_factor_impl<float>(ctx, n, dK, ldk, epsrel, epsabs, eps_flags, dL, ldl, dinvd, heps_out);
+                                   float *dL, size_t ldl, float *ddblk, float *heps_out) {
+  return chol_factor_impl<float>(ctx, n, dK, ldk, epsrel, epsabs, eps_flags, dL, ldl, ddblk, heps_out);
 }
 
 template <typename T>
-static int potrf_entry(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *invd) {
-  LGP_REQUIRE(ctx != nullptr && L != nullptr && invd != nullptr, "null pointer");
+static int potrf_entry(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk) {
+  LGP_REQUIRE(ctx != nullptr && L != nullptr && dblk != nullptr, "null pointer");
   LGP_REQUIRE(n >= 1 && n < (1u << 30), "matrix size out of range");
   DeviceGuard dg(ctx->device);
   LGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
-  LGP_CHECK(lgp_potrf_impl<T>(ctx, n, L, ldl, invd));
+  LGP_CHECK(lgp_potrf_impl<T>(ctx, n, L, ldl, dblk));
   int info = 0;
   LGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   LGP_HIP(hipStreamSynchronize(ctx->stream));
   return info;
 }
-extern "C" int lgp_potrf_f64(lgp_ctx *ctx, size_t n, double *dL, size_t ldl, double *dinvd) { return potrf_entry<double>(ctx, n, dL, ldl, dinvd); }
-extern "C" int lgp_potrf_f32(lgp_ctx *ctx, size_t n, float *dL, size_t ldl, float *dinvd) { return potrf_entry<float>(ctx, n, dL, ldl, dinvd); }
+extern "C" int lgp_potrf_f64(lgp_ctx *ctx, size_t n, double *dL, size_t ldl, double *ddblk) { return potrf_entry<double>(ctx, n, dL, ldl, ddblk); }
+extern "C" int lgp_potrf_f32(lgp_ctx *ctx, size_t n, float *dL, size_t ldl, float *ddblk) { return potrf_entry<float>(ctx, n, dL, ldl, ddblk); }
 
-extern "C" int lgp_trsm_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *dinvd, int trans, double *dB, size_t ldb,
+extern "C" int lgp_trsm_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *ddblk, int trans, double *dB, size_t ldb,
                             size_t nrhs) {
-  LGP_REQUIRE(ctx != nullptr && dL != nullptr && dinvd != nullptr && (dB != nullptr || nrhs == 0), "null pointer");
+  LGP_REQUIRE(ctx != nullptr && dL != nullptr && ddblk != nullptr && (dB != nullptr || nrhs == 0), "null pointer");
   DeviceGuard dg(ctx->device);
-  return lgp_trsm_impl<double>(ctx, ctx->stream, n, dL, ldl, dinvd, trans, dB, ldb, nrhs);
+  return lgp_trsm_impl<double>(ctx, ctx->stream, n, dL, ldl, ddblk, trans, dB, ldb, nrhs);
 }
-extern "C" int lgp_trsm_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, const float *dinvd, int trans, float *dB, size_t ldb,
+extern "C" int lgp_trsm_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, const float *ddblk, int trans, float *dB, size_t ldb,
                             size_t nrhs) {
-  LGP_REQUIRE(ctx != nullptr && dL != nullptr && dinvd != nullptr && (dB != nullptr || nrhs == 0), "null pointer");
+  LGP_REQUIRE(ctx != nullptr && dL != nullptr && ddblk != nullptr && (dB != nullptr || nrhs == 0), "null pointer");
   DeviceGuard dg(ctx->device);
-  return lgp_trsm_impl<float>(ctx, ctx->stream, n, dL, ldl, dinvd, trans, dB, ldb, nrhs);
+  return lgp_trsm_impl<float>(ctx, ctx->stream, n, dL, ldl, ddblk, trans, dB, ldb, nrhs);
 }
 
-extern "C" int lgp_panel_factor_f64(lgp_ctx *ctx, size_t rows, size_t nb, double *dP, size_t ldp, double *dinvd_blk, size_t row0) {
-  LGP_REQUIRE(ctx != nullptr && dP != nullptr && dinvd_blk != nullptr, "null pointer");
+extern "C" int lgp_panel_factor_f64(lgp_ctx *ctx, size_t rows, size_t nb, double *dP, size_t ldp, double *ddblk, size_t row0) {
+  LGP_REQUIRE(ctx != nullptr && dP != nullptr && ddblk != nullptr, "null pointer");
   DeviceGuard dg(ctx->device);
-  return lgp_panel_factor_impl<double>(ctx, ctx->stream, rows, nb, dP, ldp, dinvd_blk, row0);
+  return lgp_panel_factor_impl<double>(ctx, ctx->stream, rows, nb, dP, ldp, ddblk, row0);
 }
 
 extern "C" int lgp_get_info(lgp_ctx *ctx, int *hinfo) {

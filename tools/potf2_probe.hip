@@ -1,0 +1,59 @@
+// Probe: time potf2_kernel / subst kernels alone (1 workgroup) and back-to-back, and read the shader clock.
+#include "../lsqfitgp_amd/csrc/potrf.hip"
+#include <vector>
+#include <cmath>
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} }while(0)
+void lgp_set_error(const char *fmt, ...) {}
+template <typename T> int lgp_gemm_launch(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, T, const T *, size_t, const T *, size_t, T, T *, size_t, bool) { return 0; }
+template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t, const double *, size_t, double, double *, size_t, bool);
+template int lgp_gemm_launch<float>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, float, const float *, size_t, const float *, size_t, float, float *, size_t, bool);
+
+__global__ void clock_probe(unsigned long long *out, int iters) {
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  double a = threadIdx.x, b = 1e-9;
+  for (int i = 0; i < iters; ++i) a = __builtin_fma(a, 1.0000001, b);
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; out[2] = (unsigned long long)a; }
+}
+
+int main() {
+  const int n = 128;
+  std::vector<double> A(n * n);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[i * n + j] = std::exp(-0.5 * (i - j) * (i - j) / 400.0) + (i == j ? 1e-3 : 0);
+  double *dA, *dW; int *dinfo; unsigned long long *dclk;
+  CK(hipMalloc(&dA, n * n * 8)); CK(hipMalloc(&dW, LGP_DBLK * 8)); CK(hipMalloc(&dinfo, 4)); CK(hipMemset(dinfo, 0, 4)); CK(hipMalloc(&dclk, 64));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  // clock when a single wave is running
+  for (int rep = 0; rep < 3; ++rep) {
+    clock_probe<<<1, 64>>>(dclk, 200000); CK(hipDeviceSynchronize());
+    unsigned long long h[3]; CK(hipMemcpy(h, dclk, 24, hipMemcpyDeviceToHost));
+    printf("single-wave clock: %.0f MHz (%llu cycles)\n", (double)h[0] / h[1] * 100.0, h[0]);
+  }
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice));
+    CK(hipEventRecord(e0));
+    potf2_kernel<double><<<1, 256>>>(dA, n, n, dW, dinfo, 0);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("potf2 alone: %.1f us\n", ms * 1e3);
+  }
+  // 50 back-to-back
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < 50; ++i) potf2_kernel<double><<<1, 256>>>(dA, n, n, dW, dinfo, 0);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("potf2 x50 back-to-back: %.1f us each\n", ms * 1e3 / 50);
+  // subst right on 64, 4096, 16384 rows
+  for (long rows : {64L, 4096L, 16384L}) {
+    double *dX; CK(hipMalloc(&dX, rows * 128 * 8)); CK(hipMemset(dX, 0, rows * 128 * 8));
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipEventRecord(e0));
+      subst_right_kernel<double><<<(rows + SUBST_NT - 1) / SUBST_NT, SUBST_NT>>>(dW, 128, dX, 128, rows);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("subst_right rows=%ld: %.1f us\n", rows, ms * 1e3);
+    }
+    CK(hipFree(dX));
+  }
+  return 0;
+}

@@ -1,0 +1,20 @@
+"""profile helper: python tools/prof_chol.py N [reps] -- Cholesky with preallocated buffers, HIP-event timing"""
+import sys, time, ctypes
+sys.path.insert(0, '.')
+import numpy as np
+import lsqfitgp_amd as lgp
+from lsqfitgp_amd import _lib
+n = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+ctx = lgp.Context.default(); lib = _lib.load()
+rng = np.random.default_rng(0)
+x = rng.uniform(0, n / 16, n)
+K = lgp.ExpQuad().gram(x, x)
+_lib.check(lib.lgp_add_diag_f64(ctx.handle, n, K.ptr, K.ld, None, 0.01))
+L = lgp.DeviceArray.empty((n, n)); W = lgp.DeviceArray.empty((lib.lgp_chol_dblk_size(n),))
+eps = ctypes.c_double()
+e0, e1 = ctx.event(), ctx.event()
+for r in range(reps):
+    ctx.sync(); t0 = time.time(); ctx.record(e0)
+    info = lib.lgp_chol_factor_f64(ctx.handle, n, K.ptr, K.ld, 0., 0., 1, L.ptr, L.ld, W.ptr, ctypes.byref(eps))
+    ctx.record(e1); ms = ctx.elapsed_ms(e0, e1); t1 = time.time()
+    print('n', n, 'info', info, 'chol %.2f ms (wall %.2f) -> %.1f TFLOP/s' % (ms, (t1 - t0) * 1e3, n**3 / 3 / ms / 1e9), flush=True)
