@@ -352,13 +352,21 @@ class GP:
                     out = _gemm(False, False, td, covr).reshape_contiguous((x.size, y.size))
                 else:
                     _gemm(False, False, td, covr, 1., 1., out.reshape_contiguous((osize, rest * y.size)))
-            else:
-                if elem.size != x.size:
-                    raise NotImplementedError('broadcasting between transformed elements of different shapes')
+            elif elem.size == x.size:
                 if out is None:
                     out = _axpby(float(t), cov, 0., None)
                 else:
                     _axpby(float(t), cov, 1., out, out)
+            elif elem.size == 1:
+                # a scalar element broadcast over the output (e.g. the marginalised mean of
+                # bayestree/_bart.py:203): out += t * ones (x.size, 1) @ cov (1, ysize)
+                ones = DeviceArray.from_host(numpy.ones((x.size, 1)), dtype=cov.dtype, ctx=self.ctx)
+                if out is None:
+                    out = _gemm(False, False, ones, cov, float(t), 0.)
+                else:
+                    _gemm(False, False, ones, cov, float(t), 1., out)
+            else:
+                raise NotImplementedError('broadcasting between transformed elements of different shapes')
         return out
 
     def _makecovblock(self, xkey, ykey):

@@ -277,6 +277,11 @@ class BART(Kernel):
         # splitting probabilities, _bart.py:373-384
         if pnt is None:
             assert maxd == int(maxd) and maxd >= 0, maxd
+            # JAX promotion lattice (x64): Python scalars are weak, the int64 depths do not widen float32
+            fl = [numpy.asarray(v).dtype for v in (alpha, beta)
+                  if not (isinstance(v, (bool, int, float)) and not isinstance(v, numpy.generic))
+                  and numpy.issubdtype(numpy.asarray(v).dtype, numpy.floating)]
+            ft = numpy.result_type(*fl) if fl else numpy.dtype(numpy.float64)
             alpha_a = numpy.asarray(alpha)
             beta_a = numpy.asarray(beta)
             if alpha_a.ndim or beta_a.ndim:
@@ -284,7 +289,7 @@ class BART(Kernel):
             assert 0 <= alpha_a <= 1, 'alpha must be in [0, 1]'
             assert beta_a >= 0, 'beta must be in [0, inf)'
             d = numpy.arange(int(maxd) + 1)
-            pnt = alpha_a / (1 + d) ** beta_a
+            pnt = alpha_a.astype(ft) / (1 + d).astype(ft) ** beta_a.astype(ft)
         else:
             pnt = numpy.asarray(pnt)
             if pnt.ndim != 1:
@@ -301,6 +306,7 @@ class BART(Kernel):
                 raise KeyError(gamma)
             assert reset is None and 1 <= pnt.shape[-1] - 1 <= 3
             gamma = self._gamma(p, pnt)
+        gamma_weak = isinstance(gamma, (bool, int, float)) and not isinstance(gamma, numpy.generic)
         gamma = numpy.asarray(gamma)
         if gamma.ndim:
             raise NotImplementedError('vectorised gamma')
@@ -311,7 +317,9 @@ class BART(Kernel):
             pnt = pnt.copy()
             pnt[0] = 1
         # float type of (pnt, gamma, w): fp32 iff all three are fp32 (:657, tests/kernels/test_bart.py:313-330)
-        t = numpy.result_type(pnt.dtype, gamma.dtype, weights.dtype)
+        # JAX promotion lattice: integer arrays and weak Python scalars never widen a float type
+        fl = [d for d in ([pnt.dtype, weights.dtype] + ([] if gamma_weak else [gamma.dtype])) if numpy.issubdtype(d, numpy.floating)]
+        t = numpy.result_type(*fl) if fl else numpy.dtype(numpy.float64)
         self._flt = numpy.dtype(numpy.float32) if t == numpy.float32 else numpy.dtype(numpy.float64)
         self._pnt = pnt.astype(self._flt)
         self._gamma0 = self._flt.type(gamma)
@@ -404,7 +412,8 @@ class BART(Kernel):
         P1 = numpy.minimum(P0, pnt[..., 1])
         with numpy.errstate(divide='ignore', invalid='ignore'):
             corner = numpy.where(P0, 1 - P0 ** (s - t) * P1 ** t, 1)
-        return floor * corner
+        # the fit constants are weakly typed Python floats in the reference: the result keeps pnt's float type
+        return (floor * corner).astype(pnt.dtype if numpy.issubdtype(pnt.dtype, numpy.floating) else float)
 
     @classmethod
     def correlation(cls, splitsbefore_or_totalsplits, splitsbetween_or_index1, splitsafter_or_index2, *,

@@ -213,11 +213,11 @@ __device__ __forceinline__ void load16(const T *p, T (&m)[16]) {
   }
 }
 
-// x[xo .. xo+15] -= sum_t M[t][0..15] * piv[t], t = 0..15 (REV: 15..0), M rows `stride` apart in LDS.
-// Software-pipelined by hand: the rows of steps t+1 and t+2 are already in flight while step t's 16
+// xs[XO .. XO+15] -= sum_t M[t][0..15] * piv[PO + t], t = 0..15 (REV: 15..0), M rows `stride` apart in
+// LDS.  Software-pipelined by hand: the rows of steps t+1 and t+2 are already in flight while step t's 16
 // independent FMAs issue (an LDS read takes ~130 cycles, 16 fp64 FMAs 64: two rows ahead covers it).
-template <typename T, bool REV, int XO, int PO>
-__device__ __forceinline__ void rank16_update(const T *M, int stride, T (&x)[LGP_DB]) {
+template <typename T, bool REV, int XO, int PO, int NX, int NP>
+__device__ __forceinline__ void rank16_update(const T *M, int stride, T (&xs)[NX], const T (&piv)[NP]) {
   T m[3][16];
   load16<T>(M + (REV ? 15 : 0) * stride, m[0]);
   load16<T>(M + (REV ? 14 : 1) * stride, m[1]);
@@ -226,129 +226,150 @@ __device__ __forceinline__ void rank16_update(const T *M, int stride, T (&x)[LGP
     if (s + 2 < 16) load16<T>(M + (REV ? 15 - (s + 2) : s + 2) * stride, m[(s + 2) % 3]);
     const int t = REV ? 15 - s : s;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) x[XO + e] -= m[s % 3][e] * x[PO + t];
+    for (int e = 0; e < 16; ++e) xs[XO + e] -= m[s % 3][e] * piv[PO + t];
   }
 }
 
-template <typename T, bool TRANS, typename Emit>
-__device__ __forceinline__ void subst128(const T *__restrict__ w, T *sM, T (&x)[LGP_DB], Emit emit) {
-  // w: diagonal-block workspace (D, Dt, 1/diag); sM: LDS, SUBST_HALF*128 + 128 elements
-  constexpr int D = LGP_DB, S = 16, NS = D / S;
+constexpr int SUBST_W = 64;   // unknowns held in registers at a time
+
+// Solve the 64 unknowns of one register window against the 64x64 diagonal sub-block whose rows are the
+// staged LDS rows 0..63 and whose columns start at `coff`:  forward (L x = b, image = Dt) or backward
+// (L^T x = b, image = D), 16 unknowns at a time: substitution inside the 16x16 block, rank-16 updates of
+// the window's other groups.
+template <typename T, bool TRANS>
+__device__ __forceinline__ void solve_window(const T *sM, int coff, const T *rdw, T (&xw)[SUBST_W]) {
+  constexpr int D = LGP_DB, S = 16;
+  const T *M0 = sM + coff;
+  if (!TRANS) {
+#define LGP_FWD_GROUP(G)                                                                       \
+  {                                                                                            \
+    const T *Mb = M0 + (G * S) * D + G * S;                                                    \
+    _Pragma("unroll") for (int t = 0; t < S; ++t) {                                            \
+      const T xt = xw[G * S + t] * rdw[G * S + t];                                             \
+      xw[G * S + t] = xt;                                                                      \
+      _Pragma("unroll") for (int c = t + 1; c < S; ++c) xw[G * S + c] -= Mb[t * D + c] * xt;   \
+    }                                                                                          \
+  }
+    LGP_FWD_GROUP(0)
+    rank16_update<T, false, 1 * S, 0 * S>(M0 + (0 * S) * D + 1 * S, D, xw, xw);
+    rank16_update<T, false, 2 * S, 0 * S>(M0 + (0 * S) * D + 2 * S, D, xw, xw);
+    rank16_update<T, false, 3 * S, 0 * S>(M0 + (0 * S) * D + 3 * S, D, xw, xw);
+    LGP_FWD_GROUP(1)
+    rank16_update<T, false, 2 * S, 1 * S>(M0 + (1 * S) * D + 2 * S, D, xw, xw);
+    rank16_update<T, false, 3 * S, 1 * S>(M0 + (1 * S) * D + 3 * S, D, xw, xw);
+    LGP_FWD_GROUP(2)
+    rank16_update<T, false, 3 * S, 2 * S>(M0 + (2 * S) * D + 3 * S, D, xw, xw);
+    LGP_FWD_GROUP(3)
+#undef LGP_FWD_GROUP
+  } else {
+#define LGP_BWD_GROUP(G)                                                                       \
+  {                                                                                            \
+    const T *Mr = M0 + (G * S) * D + G * S;                                                    \
+    _Pragma("unroll") for (int t = S - 1; t >= 0; --t) {                                       \
+      const T xt = xw[G * S + t] * rdw[G * S + t];                                             \
+      xw[G * S + t] = xt;                                                                      \
+      _Pragma("unroll") for (int c = 0; c < t; ++c) xw[G * S + c] -= Mr[t * D + c] * xt;       \
+    }                                                                                          \
+  }
+    LGP_BWD_GROUP(3)
+    rank16_update<T, true, 2 * S, 3 * S>(M0 + (3 * S) * D + 2 * S, D, xw, xw);
+    rank16_update<T, true, 1 * S, 3 * S>(M0 + (3 * S) * D + 1 * S, D, xw, xw);
+    rank16_update<T, true, 0 * S, 3 * S>(M0 + (3 * S) * D + 0 * S, D, xw, xw);
+    LGP_BWD_GROUP(2)
+    rank16_update<T, true, 1 * S, 2 * S>(M0 + (2 * S) * D + 1 * S, D, xw, xw);
+    rank16_update<T, true, 0 * S, 2 * S>(M0 + (2 * S) * D + 0 * S, D, xw, xw);
+    LGP_BWD_GROUP(1)
+    rank16_update<T, true, 0 * S, 1 * S>(M0 + (1 * S) * D + 0 * S, D, xw, xw);
+    LGP_BWD_GROUP(0)
+#undef LGP_BWD_GROUP
+  }
+}
+
+// One right-hand side of 128 unknowns per thread, processed as two register windows of 64 (the kernel
+// must stay below ~270 registers so that its waves can be placed on a SIMD next to a wave of the trailing
+// update: otherwise the look-ahead stream starves).  ld(i) / st(i, v) access unknown i of this thread's
+// right-hand side in memory; the already solved window is re-read from there (L2) 16 values at a time.
+template <typename T, bool TRANS, typename Ld, typename St>
+__device__ __forceinline__ void subst128(const T *__restrict__ w, T *sM, Ld ld, St st) {
+  constexpr int D = LGP_DB, S = 16, W = SUBST_W;
   T *rd = sM + SUBST_HALF * D;
   for (int idx = threadIdx.x; idx < D; idx += SUBST_NT) rd[idx] = w[2 * D * D + idx];
-  if (!TRANS) {
-    // L x = b, forward.  Row t of Dt holds column t of L.
-    const T *__restrict__ Dt = w + D * D;
-    subst_stage<T>(Dt, 0, sM);
-    __syncthreads();
+  const T *__restrict__ img = TRANS ? w : w + D * D;   // D for the transposed solve, Dt for the forward one
+  subst_stage<T>(img, TRANS ? SUBST_HALF : 0, sM);
+  __syncthreads();
+  T xw[W];
 #pragma unroll 1
-    for (int tb = 0; tb < NS; ++tb) {
-      if (tb == NS / 2) {
-        __syncthreads();
-        subst_stage<T>(Dt, SUBST_HALF, sM);
-        __syncthreads();
-      }
-      const T *Mb = sM + ((tb * S) & (SUBST_HALF - 1)) * D + tb * S;   // Mb[t*D + c] = L[tb*16 + c][tb*16 + t]
-      const T *rdb = rd + tb * S;
+  for (int win = 0; win < 2; ++win) {
+    const int wbase = (TRANS ? 1 - win : win) * W;       // first unknown of this window
+    const int obase = W - wbase;                         // first unknown of the other (already solved) window
 #pragma unroll
-      for (int t = 0; t < S; ++t) {
-        const T xt = x[t] * rdb[t];
-        x[t] = xt;
-#pragma unroll
-        for (int c = t + 1; c < S; ++c) x[c] -= Mb[t * D + c] * xt;
-      }
-      // remaining unknowns, 16 at a time (wave-uniform guards: group q exists while q < NS - tb)
-      if (1 < NS - tb) rank16_update<T, false, 1 * S, 0>(Mb + 1 * S, D, x);
-      if (2 < NS - tb) rank16_update<T, false, 2 * S, 0>(Mb + 2 * S, D, x);
-      if (3 < NS - tb) rank16_update<T, false, 3 * S, 0>(Mb + 3 * S, D, x);
-      if (4 < NS - tb) rank16_update<T, false, 4 * S, 0>(Mb + 4 * S, D, x);
-      if (5 < NS - tb) rank16_update<T, false, 5 * S, 0>(Mb + 5 * S, D, x);
-      if (6 < NS - tb) rank16_update<T, false, 6 * S, 0>(Mb + 6 * S, D, x);
-      if (7 < NS - tb) rank16_update<T, false, 7 * S, 0>(Mb + 7 * S, D, x);
-      emit(tb * S, x);   // x[0..15] are unknowns tb*16 .. tb*16+15
-#pragma unroll
-      for (int i = 0; i < D - S; ++i) x[i] = x[i + S];
-    }
-  } else {
-    // L^T x = b, backward.  Row t of D holds row t of L = column t of L^T.
-    const T *__restrict__ Dm = w;
-    subst_stage<T>(Dm, SUBST_HALF, sM);
-    __syncthreads();
+    for (int i = 0; i < W; ++i) xw[i] = ld(wbase + i);
+    if (win == 1) {
+      // contributions of the solved window: staged rows are the solved unknowns, columns this window's
 #pragma unroll 1
-    for (int tb = 0; tb < NS; ++tb) {
-      if (tb == NS / 2) {
-        __syncthreads();
-        subst_stage<T>(Dm, 0, sM);
-        __syncthreads();
+      for (int gg = 0; gg < 4; ++gg) {
+        const int g = TRANS ? 3 - gg : gg;
+        T piv[S];
+#pragma unroll
+        for (int t = 0; t < S; ++t) piv[t] = ld(obase + g * S + t);
+        const T *Mg = sM + (g * S) * D + wbase;
+        rank16_update<T, TRANS, 0 * S, 0>(Mg + 0 * S, D, xw, piv);
+        rank16_update<T, TRANS, 1 * S, 0>(Mg + 1 * S, D, xw, piv);
+        rank16_update<T, TRANS, 2 * S, 0>(Mg + 2 * S, D, xw, piv);
+        rank16_update<T, TRANS, 3 * S, 0>(Mg + 3 * S, D, xw, piv);
       }
-      const int bt = NS - 1 - tb;                                   // block being solved
-      const T *Mr = sM + ((bt * S) & (SUBST_HALF - 1)) * D;          // Mr[t*D + g] = L[bt*16 + t][g]
-      const T *rdb = rd + bt * S;
-#pragma unroll
-      for (int t = S - 1; t >= 0; --t) {
-        const T xt = x[D - S + t] * rdb[t];
-        x[D - S + t] = xt;
-#pragma unroll
-        for (int c = 0; c < t; ++c) x[D - S + c] -= Mr[t * D + bt * S + c] * xt;
-      }
-      // register group q (< 7) currently holds unknowns 16*(q - tb) ..; it exists while q >= tb
-      const T *Mq = Mr - tb * S;
-      if (0 >= tb) rank16_update<T, true, 0 * S, D - S>(Mq + 0 * S, D, x);
-      if (1 >= tb) rank16_update<T, true, 1 * S, D - S>(Mq + 1 * S, D, x);
-      if (2 >= tb) rank16_update<T, true, 2 * S, D - S>(Mq + 2 * S, D, x);
-      if (3 >= tb) rank16_update<T, true, 3 * S, D - S>(Mq + 3 * S, D, x);
-      if (4 >= tb) rank16_update<T, true, 4 * S, D - S>(Mq + 4 * S, D, x);
-      if (5 >= tb) rank16_update<T, true, 5 * S, D - S>(Mq + 5 * S, D, x);
-      if (6 >= tb) rank16_update<T, true, 6 * S, D - S>(Mq + 6 * S, D, x);
-      emit(bt * S, x);   // x[112..127] are unknowns bt*16 .. bt*16+15
-#pragma unroll
-      for (int i = D - 1; i >= S; --i) x[i] = x[i - S];
+      __syncthreads();
+      subst_stage<T>(img, wbase, sM);
+      __syncthreads();
     }
+    solve_window<T, TRANS>(sM, wbase, rd + wbase, xw);
+#pragma unroll
+    for (int i = 0; i < W; ++i) st(wbase + i, xw[i]);
   }
 }
 
-// left side: B (jb x nrhs, ld ldb) <- L_jj^-1 B or L_jj^-T B; thread per column (coalesced across lanes)
-template <typename T, bool TRANS>
-__global__ void __launch_bounds__(SUBST_NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// left side: B (jb x nrhs, ld ldb) <- L_jj^-1 B or L_jj^-T B; thread per column (coalesced across lanes).
+// FULL (jb == 128): branch-free body.  Lanes past the last column recompute that column and store the same
+// values to the same addresses, so no lane guard is needed.
+template <typename T, bool TRANS, bool FULL>
+__global__ void __launch_bounds__(SUBST_NT) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(136)))
 subst_left_kernel(const T *__restrict__ w, int jb, T *B, long ldb, int nrhs) {
   __shared__ __attribute__((aligned(16))) T sM[SUBST_HALF * LGP_DB + LGP_DB];
   int c = blockIdx.x * SUBST_NT + threadIdx.x;
-  const bool live = c < nrhs;
-  if (!live) c = nrhs - 1;   // dead lanes compute a duplicate and do not store
-  T x[LGP_DB];
-#pragma unroll
-  for (int i = 0; i < LGP_DB; ++i) x[i] = (i < jb) ? B[(long)i * ldb + c] : T(0);
-  subst128<T, TRANS>(w, sM, x, [&](int g0, const T(&xx)[LGP_DB]) {
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-      if (live && g0 + t < jb) B[(long)(g0 + t) * ldb + c] = xx[(TRANS ? LGP_DB - 16 : 0) + t];
-  });
+  if (c >= nrhs) c = nrhs - 1;
+  T *col = B + c;
+  if (FULL) {
+    subst128<T, TRANS>(
+        w, sM, [&](int i) { return col[(long)i * ldb]; }, [&](int i, T v) { col[(long)i * ldb] = v; });
+  } else {
+    subst128<T, TRANS>(
+        w, sM, [&](int i) { return (i < jb) ? col[(long)i * ldb] : T(0); },
+        [&](int i, T v) {
+          if (i < jb) col[(long)i * ldb] = v;
+        });
+  }
 }
 
 // right side: X (rows x jb, ld ldx) <- X L_jj^-T, i.e. every row solves L_jj x = b; thread per row
 // (each lane streams its own contiguous row: 16-byte loads, whole 128-byte lines consumed through L1)
-template <typename T>
-__global__ void __launch_bounds__(SUBST_NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
+template <typename T, bool FULL>
+__global__ void __launch_bounds__(SUBST_NT) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(136)))
 subst_right_kernel(const T *__restrict__ w, int jb, T *X, long ldx, long rows) {
   constexpr int D = LGP_DB;
   __shared__ __attribute__((aligned(16))) T sM[SUBST_HALF * D + D];
   long r = (long)blockIdx.x * SUBST_NT + threadIdx.x;
-  const bool live = r < rows;
-  if (!live) r = rows - 1;
+  if (r >= rows) r = rows - 1;
   T *row = X + r * ldx;
-  T x[D];
-  if (jb == D) {
-#pragma unroll
-    for (int c = 0; c < D; ++c) x[c] = row[c];
+  if (FULL) {
+    subst128<T, false>(
+        w, sM, [&](int i) { return row[i]; }, [&](int i, T v) { row[i] = v; });
   } else {
-#pragma unroll
-    for (int c = 0; c < D; ++c) x[c] = (c < jb) ? row[c] : T(0);
+    subst128<T, false>(
+        w, sM, [&](int i) { return (i < jb) ? row[i] : T(0); },
+        [&](int i, T v) {
+          if (i < jb) row[i] = v;
+        });
   }
-  subst128<T, false>(w, sM, x, [&](int g0, const T(&xx)[D]) {
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-      if (live && g0 + t < jb) row[g0 + t] = xx[t];
-  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -494,8 +515,9 @@ int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t 
     const size_t below = rows - (j0 + jb);
     if (below > 0) {
       T *X = P + (j0 + jb) * ldp + j0;   // below x jb, solved in place: X <- X * L_jj^-T
-      hipLaunchKernelGGL((subst_right_kernel<T>), dim3((unsigned)((below + SUBST_NT - 1) / SUBST_NT)), dim3(SUBST_NT), 0, stream, w,
-                         (int)jb, X, (long)ldp, (long)below);
+      const dim3 gr((unsigned)((below + SUBST_NT - 1) / SUBST_NT)), br(SUBST_NT);
+      if (jb == (size_t)LGP_DB) hipLaunchKernelGGL((subst_right_kernel<T, true>), gr, br, 0, stream, w, (int)jb, X, (long)ldp, (long)below);
+      else hipLaunchKernelGGL((subst_right_kernel<T, false>), gr, br, 0, stream, w, (int)jb, X, (long)ldp, (long)below);
       LGP_LAUNCH_CHECK();
       const size_t wc = nb - (j0 + jb);
       if (wc > 0) {
@@ -534,12 +556,37 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk) {
     LGP_CHECK(lgp_gemm_launch<T>(ctx, s1, false, true, rows_t, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
     LGP_CHECK(lgp_panel_factor_impl<T>(ctx, s1, rows_t, nb1, C1, ldl, dblk + (t0 / LGP_DB) * (size_t)LGP_DBLK, t0));
     LGP_HIP(hipEventRecord(ctx->ev_b, s1));
-    // s0: rest of the trailing update (columns beyond the next panel)
+    // s0: rest of the trailing update (columns beyond the next panel), issued as block-column chunks of
+    // roughly equal area.  A single launch would keep every CU's registers and LDS occupied until its
+    // grid drains, and the (few, large-footprint) panel workgroups of s1 would only be placed then; at
+    // each chunk boundary the high-priority stream gets its next kernel in, so the panel chain advances
+    // one kernel per chunk while the chunks keep the other CUs busy.
     if (rows_t > nb1) {
       const size_t rows_r = rows_t - nb1;
-      const T *Pr = L + (t0 + nb1) * ldl + k0;  // rows_r x kb
-      T *C2 = L + (t0 + nb1) * ldl + (t0 + nb1);
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r, rows_r, kb, T(-1), Pr, ldl, Pr, ldl, T(1), C2, ldl, true));
+      const size_t base = t0 + nb1;
+      size_t nch = rows_r / 1024;
+      if (nch > LGP_TRAIL_CHUNKS) nch = LGP_TRAIL_CHUNKS;
+      if (nch < 1) nch = 1;
+      const double total = 0.5 * (double)rows_r * (double)rows_r;
+      size_t c0 = 0;
+      for (size_t ch = 0; ch < nch && c0 < rows_r; ++ch) {
+        size_t c1 = rows_r;
+        if (ch + 1 < nch) {
+          // smallest multiple of 128 such that area(c0, c1) >= total / nch
+          const double want = total / (double)nch;
+          c1 = c0;
+          double area = 0;
+          while (c1 < rows_r && area < want) {
+            c1 += 128;
+            if (c1 > rows_r) c1 = rows_r;
+            area = (double)(c1 - c0) * ((double)rows_r - 0.5 * (double)(c0 + c1));
+          }
+        }
+        const T *Pa = L + (base + c0) * ldl + k0;          // rows below and including the chunk's diagonal
+        T *Cc = L + (base + c0) * ldl + (base + c0);
+        LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r - c0, c1 - c0, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true));
+        c0 = c1;
+      }
     }
     LGP_HIP(hipStreamWaitEvent(s0, ctx->ev_b, 0));
   }
@@ -558,7 +605,8 @@ int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t
     for (size_t b = 0; b < nblk; ++b) {
       const size_t j0 = b * LGP_DB, jb = (n - j0) < (size_t)LGP_DB ? (n - j0) : (size_t)LGP_DB;
       T *Bj = B + j0 * ldb;
-      hipLaunchKernelGGL((subst_left_kernel<T, false>), gs, bs, 0, stream, dblk + b * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
+      if (jb == (size_t)LGP_DB) hipLaunchKernelGGL((subst_left_kernel<T, false, true>), gs, bs, 0, stream, dblk + b * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
+      else hipLaunchKernelGGL((subst_left_kernel<T, false, false>), gs, bs, 0, stream, dblk + b * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
       LGP_LAUNCH_CHECK();
       const size_t below = n - (j0 + jb);
       if (below > 0)
@@ -570,7 +618,8 @@ int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t
     for (size_t bb = nblk; bb-- > 0;) {
       const size_t j0 = bb * LGP_DB, jb = (n - j0) < (size_t)LGP_DB ? (n - j0) : (size_t)LGP_DB;
       T *Bj = B + j0 * ldb;
-      hipLaunchKernelGGL((subst_left_kernel<T, true>), gs, bs, 0, stream, dblk + bb * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
+      if (jb == (size_t)LGP_DB) hipLaunchKernelGGL((subst_left_kernel<T, true, true>), gs, bs, 0, stream, dblk + bb * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
+      else hipLaunchKernelGGL((subst_left_kernel<T, true, false>), gs, bs, 0, stream, dblk + bb * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
       LGP_LAUNCH_CHECK();
       if (j0 > 0)
         LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, true, false, j0, nrhs, jb, T(-1), L + j0 * ldl, ldl, Bj, ldb, T(1), B, ldb, false));

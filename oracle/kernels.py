@@ -198,11 +198,19 @@ def fasthash32(buf, seed):
 # BART (``_kernels/_bart.py``)
 
 def _float_type(*args):
-    """ ``_jaxext/__init__.py:140-144`` """
-    t = numpy.result_type(*[numpy.asarray(a).dtype for a in args])
-    if numpy.issubdtype(t, numpy.floating):
-        return t
-    return numpy.dtype(numpy.float64)
+    """ ``_jaxext/__init__.py:140-144`` under JAX's promotion lattice (x64 mode): integer
+    arrays never widen a float type (int32 + float32 -> float32, unlike numpy) and Python
+    scalars are weakly typed; with no floating input the result is float64 """
+    floats = []
+    for a in args:
+        if isinstance(a, (bool, int, float)) and not isinstance(a, numpy.generic):
+            continue                                    # weak Python scalar
+        dt = numpy.asarray(a).dtype
+        if numpy.issubdtype(dt, numpy.floating):
+            floats.append(dt)
+    if not floats:
+        return numpy.dtype(numpy.float64)
+    return numpy.result_type(*floats)
 
 
 class BART:
@@ -297,12 +305,13 @@ class BART:
 
         if pnt is None:                                           # :373-384
             assert maxd == int(maxd) and maxd >= 0, maxd
+            ft = _float_type(alpha, beta)     # JAX lattice: the int64 depths do not widen float32 parameters
             alpha = numpy.asarray(alpha)
             beta = numpy.asarray(beta)
             assert numpy.all((0 <= alpha) & (alpha <= 1)), 'alpha must be in [0, 1]'
             assert numpy.all(beta >= 0), 'beta must be in [0, inf)'
             d = numpy.arange(maxd + 1)
-            pnt = alpha[..., None] / (1 + d) ** beta[..., None]
+            pnt = alpha[..., None].astype(ft) / (1 + d).astype(ft) ** beta[..., None].astype(ft)
         else:
             pnt = numpy.asarray(pnt)
 
@@ -317,6 +326,9 @@ class BART:
                 gamma = cls._gamma(weights.shape[-1], pnt)
             else:
                 raise KeyError(gamma)
+        elif isinstance(gamma, (bool, int, float)) and not isinstance(gamma, numpy.generic):
+            # weakly typed Python scalar (jnp.asarray keeps weak_type): adopts the float type of pnt, weights
+            gamma = numpy.asarray(gamma, dtype=_float_type(pnt, weights))
         else:
             gamma = numpy.asarray(gamma)
 
@@ -377,7 +389,8 @@ class BART:
         P1 = numpy.minimum(P0, pnt[..., 1])
         with numpy.errstate(divide='ignore', invalid='ignore'):
             corner = numpy.where(P0, 1 - P0 ** (s - t) * P1 ** t, 1)
-        return floor * corner
+        # the fit constants are weakly typed Python floats in the reference: the result keeps pnt's float type
+        return (floor * corner).astype(pnt.dtype if numpy.issubdtype(pnt.dtype, numpy.floating) else float)
 
     @classmethod
     def _correlation_vectorized(cls, a0, a1, a2, pnt, gamma, w, debug, altinput, repeat):

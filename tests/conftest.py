@@ -1,0 +1,59 @@
+"""
+pytest configuration.  ``-m "not gpu"`` runs on CPU (oracle vs the reference's
+own pins, host logic, C-ABI symbol checks, gloo multi-process schedule);
+``-m gpu`` runs the parity tests proper on an MI355X through the C-ABI.
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs an MI355X (gfx950) GPU and the built HIP library')
+
+
+@pytest.fixture
+def rng(request):
+    """ A random generator with a deterministic per-test seed (like the
+    reference's ``tests/conftest.py:37-49``) """
+    nodeid = request.node.nodeid
+    seed = np.array([nodeid], np.bytes_).view(np.uint8)
+    return np.random.default_rng(seed)
+
+
+def _gpu_available():
+    try:
+        import ctypes
+        from lsqfitgp_amd import _lib
+        lib = _lib.load()
+        count = ctypes.c_int(0)
+        return lib.lgp_device_count(ctypes.byref(count)) == 0 and count.value > 0
+    except Exception:
+        return False
+
+
+_GPU = None
+
+
+def pytest_collection_modifyitems(config, items):
+    """ GPU tests fail loudly (not skip) when selected with -m gpu on a box
+    without a device; when not selected explicitly they are skipped on CPU. """
+    global _GPU
+    markexpr = config.getoption('-m') or ''
+    explicitly = 'gpu' in markexpr and 'not gpu' not in markexpr
+    if explicitly:
+        return
+    if _GPU is None:
+        _GPU = _gpu_available()
+    if not _GPU:
+        skip = pytest.mark.skip(reason='no HIP device visible (run with -m gpu on an MI355X)')
+        for item in items:
+            if 'gpu' in item.keywords:
+                item.add_marker(skip)

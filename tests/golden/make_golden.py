@@ -1,0 +1,93 @@
+"""
+Generates tests/golden/*.npz.  These vectors are produced by the CPU oracle
+(oracle/, a restatement of the reference's algorithm on LAPACK), NOT by the
+reference itself: lsqfitgp cannot be imported in the build container (no jax /
+gvar), see oracle/__init__.py.  They freeze the oracle's outputs on small seeded
+inputs so that the GPU box can be checked without recomputing them and so that
+a later change to the oracle is noticed.
+
+    python tests/golden/make_golden.py
+"""
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle  # noqa: E402
+
+
+def c1():
+    """ config C1 of SURVEY.md 8(d): ExpQuad 1-D, N=512 / M=100, seed 1, no noise (jitter path);
+    plus an in-domain test set, where the posterior mean is well conditioned """
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-5, 5, 512)
+    xs = rng.uniform(-10, 10, 100)
+    xin = rng.uniform(-5, 5, 100)
+    y = np.tanh(x)
+    gp = (oracle.GP(oracle.ExpQuad(), checkpos=False, checksym=False)
+          .addx(x, 'data').addx(xs, 'test').addx(xin, 'testin'))
+    m, c = gp.predfromdata({'data': y}, 'test', raw=True)
+    mi, ci = gp.predfromdata({'data': y}, 'testin', raw=True)
+    mll = gp.marginal_likelihood({'data': y})
+    np.savez_compressed(os.path.join(HERE, 'c1_expquad_n512.npz'), x=x, xs=xs, xin=xin, y=y, mean=m, cov=c,
+                        mean_in=mi, cov_in=ci, mll=mll, eps=gp._solver(('data',)).eps)
+
+
+def c2small():
+    """ config C2 at reduced size: ExpQuad 1-D, N=1024, 16 points per lengthscale, noise 0.01 I, seed 2 """
+    rng = np.random.default_rng(2)
+    n = 1024
+    x = rng.uniform(0, n / 16, n)
+    xs = rng.uniform(0, n / 16, 100)
+    y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
+    gp = oracle.GP(oracle.ExpQuad(), checkpos=False, checksym=False).addx(x, 'data').addx(xs, 'test')
+    gc = {('data', 'data'): 0.01 * np.eye(n)}
+    m, c = gp.predfromdata({'data': y}, 'test', gc, raw=True)
+    mll = gp.marginal_likelihood({'data': y}, gc)
+    np.savez_compressed(os.path.join(HERE, 'c2_expquad_n1024.npz'), x=x, xs=xs, y=y, mean=m, cov=c, mll=mll)
+
+
+def c3small():
+    """ config C3 at reduced size: Matern-5/2 3-D, N=1024, noise 0.01 I, seed 3 """
+    rng = np.random.default_rng(3)
+    n = 1024
+    dt = [('f0', float), ('f1', float), ('f2', float)]
+    x = np.empty(n, dt); xs = np.empty(100, dt)
+    for f in 'f0', 'f1', 'f2':
+        x[f] = rng.uniform(0, 16, n)
+    for f in 'f0', 'f1', 'f2':
+        xs[f] = rng.uniform(0, 16, 100)
+    y = sum(np.sin(x[f]) for f in ('f0', 'f1', 'f2')) + 0.1 * rng.standard_normal(n)
+    gp = oracle.GP(oracle.Maternp(p=2, scale=1.), checkpos=False, checksym=False).addx(x, 'data').addx(xs, 'test')
+    gc = {('data', 'data'): 0.01 * np.eye(n)}
+    m, c = gp.predfromdata({'data': y}, 'test', gc, raw=True)
+    mll = gp.marginal_likelihood({'data': y}, gc)
+    np.savez_compressed(os.path.join(HERE, 'c3_matern52_n1024.npz'), x0=x['f0'], x1=x['f1'], x2=x['f2'],
+                        xs0=xs['f0'], xs1=xs['f1'], xs2=xs['f2'], y=y, mean=m, cov=c, mll=mll)
+
+
+def c5small():
+    """ config C5 structure at reduced size: BART Gram (maxd=10, reset=[2,4,6,8]) on synthetic integer-valued
+    covariates, p=10, N=256, fp32 and fp64 """
+    rng = np.random.default_rng(5)
+    n, p = 256, 10
+    X = np.concatenate([rng.integers(0, 2, (n, 3)), rng.integers(0, 40, (n, 7))], axis=1).astype(float)
+    splits = oracle.BART.splits_from_coord(X)
+    ix = oracle.BART.indices_from_coord(X, splits).astype(np.int32)
+    out = {}
+    for name, flt in (('f64', np.float64), ('f32', np.float32)):
+        kw = dict(alpha=flt(0.95), beta=flt(2), gamma=flt(1), weights=np.ones(p, flt))
+        k = oracle.BART(splits=(splits[0], None), indices=True, maxd=10, reset=[2, 4, 6, 8], **kw)
+        ixs = np.array([tuple(r) for r in ix], dtype=[(f'f{i}', np.int32) for i in range(p)])
+        out['K_' + name] = k(ixs[:, None], ixs[None, :])
+        k2 = oracle.BART(splits=(splits[0], None), indices=True, maxd=2, **kw)
+        out['K2_' + name] = k2(ixs[:, None], ixs[None, :])
+    np.savez_compressed(os.path.join(HERE, 'c5_bart_n256.npz'), X=X, nsplits=splits[0], ix=ix, **out)
+
+
+if __name__ == '__main__':
+    c1(); c2small(); c3small(); c5small()
+    print('written', sorted(f for f in os.listdir(HERE) if f.endswith('.npz')))

@@ -1,0 +1,165 @@
+"""
+GPU parity tests of the decomposition (C-ABI: lgp_chol_factor, lgp_trsm, lgp_gemm,
+lgp_colsumsq, lgp_mlnd_value ...) through the host mirror ``lsqfitgp_amd.Chol``:
+the reference's identity tests (tests/linalg/test_decomp.py) and direct
+comparison with the CPU oracle on the same seeded inputs.
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from . import util
+from .test_oracle_decomp import DecompTestBase
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lgp():
+    import lsqfitgp_amd
+    lsqfitgp_amd.Context.default()          # fails loudly if the HIP library or the GPU is missing
+    return lsqfitgp_amd
+
+
+class TestDeviceChol(DecompTestBase):
+    """ the reference's TestChol, run on the device implementation """
+
+    def make(self, K, **kw):
+        import lsqfitgp_amd
+        return lsqfitgp_amd.Chol(K, **kw)
+
+    def test_isinstance(self, decomp):
+        import lsqfitgp_amd
+        assert isinstance(decomp, lsqfitgp_amd.Decomposition)
+
+
+def randpd(rng, n, dtype=np.float64, cond_shift=0.5):
+    Q = rng.standard_normal((n, n))
+    return (Q @ Q.T / n + np.eye(n) * cond_shift).astype(dtype)
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 17, 127, 128, 129, 255, 256, 257, 511, 513, 777, 1024, 1025, 1500, 2049])
+def test_factor_vs_oracle_f64(lgp, n, rng):
+    """ L, eps and every product against the oracle; sizes straddle the 128 / 1024 block edges """
+    K = randpd(rng, n) * rng.choice([0.01, 1.0, 37.0])      # exercises the power-of-two diagonal scaling
+    d = lgp.Chol(K)
+    o = oracle.Chol(K)
+    L = d.factor().to_host()
+    assert np.all(np.triu(L, 1) == 0)
+    util.assert_close_matrices(L, o._L, rtol=1e-13)
+    util.assert_allclose(d.eps, o.eps, rtol=1e-14)
+    m = 9
+    A = rng.standard_normal((n, m)); r = rng.standard_normal(n)
+    util.assert_close_matrices(d.ginv_linear(A), o.ginv_linear(A), rtol=1e-11)
+    util.assert_close_matrices(d.ginv_linear(r), o.ginv_linear(r), rtol=1e-11)
+    util.assert_close_matrices(d.pinv_bilinear(A, r), o.pinv_bilinear(A, r), rtol=1e-11)
+    util.assert_close_matrices(d.ginv_quad(A), o.ginv_quad(A), rtol=1e-11)
+    util.assert_close_matrices(d.ginv_diagquad(A), o.ginv_diagquad(A), rtol=1e-11)
+    util.assert_close_matrices(d.correlate(A), o.correlate(A), rtol=1e-13)
+    util.assert_close_matrices(d.back_correlate(A), o.back_correlate(A), rtol=1e-13)
+    util.assert_close_matrices(d.pinv_correlate(r), o.pinv_correlate(r), rtol=1e-11)
+    v1 = d.minus_log_normal_density(r, value=True)[0]
+    v2 = o.minus_log_normal_density(r, value=True)[0]
+    util.assert_allclose(v1, v2, rtol=1e-12)
+
+
+@pytest.mark.parametrize('n', [1, 5, 128, 300, 1025])
+def test_factor_vs_oracle_f32(lgp, n, rng):
+    K = randpd(rng, n, np.float32, 1.0)
+    d = lgp.Chol(K)
+    o = oracle.Chol(K)
+    assert d.factor().dtype == np.float32
+    util.assert_close_matrices(d.factor().to_host(), o._L, rtol=2e-5)
+    util.assert_allclose(d.eps, o.eps, rtol=1e-5)
+    A = rng.standard_normal((n, 4)).astype(np.float32)
+    util.assert_close_matrices(d.ginv_quad(A), o.ginv_quad(A), rtol=1e-3)
+
+
+@pytest.mark.parametrize('epsrel,epsabs', [('auto', 0), (0, 'auto'), (1e-3, 1e-5), (0, 0)])
+def test_eps_arguments(lgp, epsrel, epsabs, rng):
+    """ ``_parseeps`` (``_decomp.py:245-255``) """
+    K = randpd(rng, 50) * 5
+    d = lgp.Chol(K, epsrel=epsrel, epsabs=epsabs)
+    o = oracle.Chol(K, epsrel=epsrel, epsabs=epsabs)
+    util.assert_allclose(d.eps, o.eps, rtol=1e-14)
+    util.assert_close_matrices(d.factor().to_host(), o._L, rtol=1e-13)
+
+
+def test_not_posdef_raises(lgp, rng):
+    """ ``_decomp.py:389-391`` """
+    for K in (-np.eye(5), np.array([[1., 2.], [2., 1.]]), np.diag([1., np.nan, 1.])):
+        with pytest.raises(np.linalg.LinAlgError, match='cholesky decomposition not finite'):
+            lgp.Chol(K)
+    Q = randpd(rng, 300)
+    Q[200, 200] = -5.
+    with pytest.raises(np.linalg.LinAlgError):
+        lgp.Chol(Q)
+    with pytest.raises(ValueError):
+        lgp.Chol(np.ones((3, 4)))
+
+
+def test_zero_diagonal_scale(lgp):
+    """ s = 1 where K_ii == 0 (``_decomp.py:360``) """
+    K = np.diag([4., 0., 9.]) + 1e-300
+    K = np.diag([4., 0., 9.])
+    d = lgp.Chol(K, epsabs=1e-3)
+    o = oracle.Chol(K, epsabs=1e-3)
+    util.assert_allclose(d.factor().to_host(), o._L, rtol=1e-15)
+    util.assert_allclose(d.eps, o.eps, rtol=1e-15)
+
+
+def test_near_singular_expquad(lgp):
+    """ the jitter rule on a numerically singular Gram matrix: must factor (LAPACK does) and L L' ~ K + eps """
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-5, 5, 700)
+    K = np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2)
+    d = lgp.Chol(K)
+    o = oracle.Chol(K)
+    util.assert_allclose(d.eps, o.eps, rtol=1e-13)
+    L = d.factor().to_host()
+    resid = L @ L.T - K - d.eps * np.eye(700)
+    assert np.linalg.norm(resid, 2) <= 50 * 700 * np.finfo(float).eps * np.linalg.norm(K, 2)
+    # the factors agree to the conditioning of the problem, the reconstructed matrices to rounding
+    util.assert_close_matrices(L @ L.T, o._L @ o._L.T, rtol=1e-13)
+
+
+def test_device_operands(lgp, rng):
+    """ DeviceArray inputs are used in place; device=True keeps results in HBM """
+    n = 200
+    K = randpd(rng, n)
+    Kd = lgp.DeviceArray.from_host(K)
+    d = lgp.Chol(Kd)
+    assert d.matrix() is Kd
+    A = rng.standard_normal((n, 5))
+    Ad = lgp.DeviceArray.from_host(A)
+    out = d.ginv_quad(Ad, device=True)
+    assert isinstance(out, lgp.DeviceArray)
+    util.assert_close_matrices(out.to_host(), oracle.Chol(K).ginv_quad(A), rtol=1e-11)
+    np.testing.assert_array_equal(Ad.to_host(), A)      # operand untouched
+    sub = lgp.DeviceArray.from_host(np.pad(A, ((0, 0), (2, 3)))).block(0, n, 2, 7)   # strided view
+    util.assert_close_matrices(d.ginv_quad(sub), oracle.Chol(K).ginv_quad(A), rtol=1e-11)
+
+
+def test_full_size_properties(lgp):
+    """ N = 8192 (config C2 size): size-independent properties instead of an O(N^3) CPU recomputation:
+    (L L') v == (K + eps) v on random vectors, K^-1 (K v) == v, log-det against the diagonal """
+    n = 8192
+    rng = np.random.default_rng(2)
+    x = rng.uniform(0, n / 16, n)
+    K = lgp.ExpQuad().gram(x, x)
+    lib = __import__('lsqfitgp_amd')._lib.load()
+    ctx = lgp.Context.default()
+    assert lib.lgp_add_diag_f64(ctx.handle, n, K.ptr, K.ld, None, ctypes.c_double(0.01)) == 0
+    d = lgp.Chol(K)
+    V = rng.standard_normal((n, 3))
+    KV = np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2) @ V + (0.01 + d.eps) * V
+    LLV = d.correlate(d.back_correlate(V))
+    util.assert_close_matrices(LLV, KV, rtol=1e-12)
+    util.assert_close_matrices(d.ginv_linear(KV), V, rtol=1e-9)
+    Ldiag = np.diag(d.factor().to_host())
+    val = d.minus_log_normal_density(KV[:, 0], value=True)[0]
+    expected = 0.5 * (n * np.log(2 * np.pi) + 2 * np.sum(np.log(Ldiag)) + KV[:, 0] @ V[:, 0])
+    util.assert_allclose(val, expected, rtol=1e-10)

@@ -1,0 +1,223 @@
+"""
+GPU parity tests of the Gram kernels (C-ABI: lgp_gram_isotropic, lgp_pairs_isotropic,
+lgp_gram_bart, lgp_pairs_bart) through the host kernel objects: the reference's
+kernel pins (tests/kernels/test_kernels.py, tests/kernels/test_bart.py) and
+entry-wise comparison with the CPU oracle and the committed golden fixtures.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from . import util
+from .test_oracle_kernels import KernelPins
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope='module')
+def lgp():
+    import lsqfitgp_amd
+    lsqfitgp_amd.Context.default()
+    return lsqfitgp_amd
+
+
+def _factories():
+    import lsqfitgp_amd as lgp
+    return {
+        'ExpQuad': lambda **kw: lgp.ExpQuad(**kw),
+        'Maternp0': lambda **kw: lgp.Maternp(p=0, **kw),
+        'Maternp1': lambda **kw: lgp.Maternp(p=1, **kw),
+        'Maternp2': lambda **kw: lgp.Maternp(p=2, **kw),
+        'Maternp5': lambda **kw: lgp.Maternp(p=5, **kw),
+    }
+
+
+class TestDeviceKernelPins(KernelPins):
+    """ the reference's generic kernel tests, run on the device kernels """
+
+    @pytest.fixture(params=['ExpQuad', 'Maternp0', 'Maternp1', 'Maternp2', 'Maternp5'])
+    def make(self, request):
+        return _factories()[request.param]
+
+
+PAIRS = [
+    ('ExpQuad', {}, {}), ('ExpQuad', dict(scale=2.5, loc=0.3), {}), ('Maternp', dict(p=2, scale=1.3), dict(p=2, scale=1.3)),
+    ('Maternp', dict(p=0), dict(p=0)), ('Maternp', dict(p=7, loc=-1.), dict(p=7, loc=-1.)),
+]
+
+
+@pytest.mark.parametrize('name,kw,_', PAIRS)
+@pytest.mark.parametrize('n,m', [(1, 1), (3, 700), (33, 511), (512, 513), (777, 333), (1500, 2)])
+def test_gram_ulp_1d(lgp, name, kw, _, n, m, rng):
+    """ every entry within 2 ulp of the oracle (libm exp vs device exp); ragged sizes cover all tile edges """
+    x = rng.uniform(-5, 5, n); y = rng.uniform(-5, 5, m)
+    kd = getattr(lgp, name)(**kw); ko = getattr(oracle, name)(**kw)
+    G = kd.gram(x, y).to_host()
+    R = ko(x[:, None], y[None, :])
+    assert G.shape == (n, m) and G.dtype == np.float64
+    assert util.ulp_distance(G, R) <= 2
+    Gp = kd.pairs(x[:min(n, m)], y[:min(n, m)]).to_host()
+    assert util.ulp_distance(Gp, ko(x[:min(n, m)], y[:min(n, m)])) <= 2
+
+
+@pytest.mark.parametrize('d', [2, 3, 5])
+def test_gram_ulp_nd(lgp, d, rng):
+    dt = [(f'f{i}', float) for i in range(d)]
+    x = np.empty(300, dt); y = np.empty(129, dt)
+    for f, _t in dt:
+        x[f] = rng.uniform(0, 4, 300); y[f] = rng.uniform(0, 4, 129)
+    for kd, ko in ((lgp.Maternp(p=2, scale=0.8), oracle.Maternp(p=2, scale=0.8)), (lgp.ExpQuad() * 2.5 + 1, oracle.ExpQuad() * 2.5 + 1)):
+        G = kd.gram(x, y).to_host()
+        R = ko(x[:, None], y[None, :])
+        assert util.ulp_distance(G, R) <= 3
+    Gs = lgp.ExpQuad().gram(x, x).to_host()
+    np.testing.assert_array_equal(Gs, Gs.T)            # exactly symmetric
+    np.testing.assert_array_equal(np.diag(Gs), 1)
+
+
+def test_gram_f32_and_int(lgp, rng):
+    x32 = rng.uniform(-3, 3, 200).astype(np.float32)
+    G = lgp.ExpQuad().gram(x32, x32)
+    assert G.dtype == np.float32
+    R = oracle.ExpQuad()(x32[:, None], x32[None, :])
+    assert R.dtype == np.float32
+    assert util.ulp_distance(G.to_host(), R) <= 2
+    xi = np.arange(20)                                  # integer inputs compute in float64 (x64 mode)
+    Gi = lgp.ExpQuad(scale=3).gram(xi, xi)
+    assert Gi.dtype == np.float64
+    assert util.ulp_distance(Gi.to_host(), oracle.ExpQuad(scale=3)(xi[:, None], xi[None, :])) <= 2
+
+
+def test_gram_empty(lgp):
+    G = lgp.ExpQuad().gram(np.zeros(0), np.arange(3.))
+    assert G.shape == (0, 3)
+    assert lgp.ExpQuad()(np.zeros((0, 1)), np.arange(3.)[None, :]).shape == (0, 3)
+
+
+def test_kernel_argument_checks(lgp):
+    with pytest.raises(AssertionError):
+        lgp.ExpQuad(scale=-1)
+    with pytest.raises(AssertionError):
+        lgp.ExpQuad(loc=np.inf)
+    with pytest.raises(AssertionError):
+        lgp.Maternp(p=1.5)
+    with pytest.raises(AssertionError):
+        lgp.Maternp()
+
+
+def test_golden_c3(lgp):
+    """ Matern-5/2 3-D Gram entries of the committed C3-small fixture inputs """
+    g = np.load(os.path.join(HERE, 'golden', 'c3_matern52_n1024.npz'))
+    dt = [('f0', float), ('f1', float), ('f2', float)]
+    x = np.empty(1024, dt); x['f0'], x['f1'], x['f2'] = g['x0'], g['x1'], g['x2']
+    G = lgp.Maternp(p=2, scale=1.).gram(x, x).to_host()
+    R = oracle.Maternp(p=2, scale=1.)(x[:, None], x[None, :])
+    assert util.ulp_distance(G, R) <= 3
+
+
+# ---- BART -------------------------------------------------------------------------------
+
+def _struct(ix):
+    p = ix.shape[1]
+    return np.array([tuple(r) for r in ix], dtype=[(f'f{i}', ix.dtype) for i in range(p)])
+
+
+BART_CONFIGS = [
+    dict(maxd=0), dict(maxd=1), dict(maxd=2), dict(maxd=2, gamma=0.3), dict(maxd=2, reset=[1]), dict(maxd=4, reset=2),
+    dict(maxd=10, reset=[2, 4, 6, 8]), dict(maxd=3, reset=[1, 2]), dict(maxd=4, reset=[1, 2, 3]), dict(maxd=2, intercept=False),
+    dict(maxd=2, gamma='auto'), dict(maxd=1, gamma='auto'), dict(pnt=[0.9, 0.4, 0.3]), dict(maxd=5, reset=[1, 3]),
+]
+
+
+@pytest.mark.parametrize('cfg', BART_CONFIGS, ids=[str(c) for c in BART_CONFIGS])
+@pytest.mark.parametrize('flt', [np.float64, np.float32])
+def test_bart_gram_vs_oracle(lgp, cfg, flt, rng):
+    n, m, p = 70, 300, 6
+    X = rng.integers(0, 9, (n + m, p)).astype(float)
+    X[:, 0] = rng.integers(0, 2, n + m)                 # a binary covariate (one split)
+    X[:, 1] = 3.                                        # a constant covariate (no splits: n_i = 0)
+    splits = lgp.BART.splits_from_coord(X)
+    ix = lgp.BART.indices_from_coord(X, splits)
+    w = np.array([1, 2, 0, 1, 3, 1], flt)               # one zero-weight axis
+    kw = dict(cfg)
+    if 'pnt' in kw:
+        kw['pnt'] = np.array(kw['pnt'], flt)
+    else:
+        kw['alpha'] = flt(0.95); kw['beta'] = flt(2)
+    if not isinstance(kw.get('gamma', 1), str):
+        kw['gamma'] = flt(kw.get('gamma', 1))
+    kd = lgp.BART(splits=(splits[0], None), indices=True, weights=w, **kw)
+    ko = oracle.BART(splits=(splits[0], None), indices=True, weights=w, **kw)
+    G = kd.gram(_struct(ix[:n]), _struct(ix[n:]))
+    assert G.dtype == flt
+    R = ko(_struct(ix[:n])[:, None], _struct(ix[n:])[None, :])
+    assert R.dtype == flt
+    tol = 64 if flt == np.float64 else 64
+    assert util.ulp_distance(G.to_host(), R) <= tol, np.max(np.abs(G.to_host() - R))
+    # from coordinates == from indices, 0 ulp (ref tests/kernels/test_bart.py:355-367)
+    kc = lgp.BART(splits=splits, weights=w, **kw)
+    Gc = kc.gram(_struct(X[:n]), _struct(X[n:])).to_host()
+    np.testing.assert_array_equal(Gc, G.to_host())
+    S = kd.gram(_struct(ix[:n]), _struct(ix[:n])).to_host()
+    np.testing.assert_array_equal(np.diag(S), 1)
+    assert util.ulp_distance(S, S.T) <= 64              # swap invariance (ref :135-147)
+
+
+def test_bart_golden_c5(lgp):
+    g = np.load(os.path.join(HERE, 'golden', 'c5_bart_n256.npz'))
+    ix = g['ix']; p = ix.shape[1]
+    for name, flt in (('f64', np.float64), ('f32', np.float32)):
+        kw = dict(alpha=flt(0.95), beta=flt(2), gamma=flt(1), weights=np.ones(p, flt))
+        k = lgp.BART(splits=(g['nsplits'], None), indices=True, maxd=10, reset=[2, 4, 6, 8], **kw)
+        G = k.gram(_struct(ix), _struct(ix)).to_host()
+        assert util.ulp_distance(G, g['K_' + name]) <= 64
+        k2 = lgp.BART(splits=(g['nsplits'], None), indices=True, maxd=2, **kw)
+        assert util.ulp_distance(k2.gram(_struct(ix), _struct(ix)).to_host(), g['K2_' + name]) <= 64
+        eig = np.linalg.eigvalsh(G.astype(float))
+        assert eig[0] >= -len(G) * np.finfo(flt).eps * eig[-1]       # PSD (ref test_kernels.py:163-166)
+
+
+def test_bart_correlation_classmethod(lgp, rng):
+    """ the vectorised BART.correlation on the device against the oracle (both input conventions) """
+    p = 5
+    sb, sbw, sa = rng.integers(0, 6, (3, 40, p))
+    w = rng.integers(1, 10, p).astype(float)
+    for md, reset in [(0, None), (1, None), (2, None), (2, [1]), (4, [2]), (3, [1, 2])]:
+        for gamma in (0., 0.4, 1.):
+            c1 = lgp.BART.correlation(sb, sbw, sa, alpha=0.9, beta=1.6, gamma=gamma, maxd=md, reset=reset, weights=w)
+            c2 = oracle.BART.correlation(sb, sbw, sa, alpha=0.9, beta=1.6, gamma=gamma, maxd=md, reset=reset, weights=w)
+            assert c1.shape == (40,)
+            util.assert_allclose(c1, c2, rtol=1e-14, atol=4e-15)
+            n = sb + sbw + sa
+            c3 = lgp.BART.correlation(n, sb, sb + sbw, alpha=0.9, beta=1.6, gamma=gamma, maxd=md, reset=reset, weights=w, altinput=True)
+            util.assert_allclose(c3, c2, rtol=1e-14, atol=4e-15)
+    # reference known answers (tests/kernels/test_bart.py:283-301,313-330,369-372)
+    sss = [1, 2], [3, 1], [5, 8]
+    c1 = lgp.BART.correlation(*sss, alpha=0.9, beta=1.6, maxd=2)
+    c2 = lgp.BART.correlation(*sss, pnt=[0.9, 0.9 / 2 ** 1.6, 0.9 / 3 ** 1.6])
+    util.assert_allclose(c1, c2, rtol=1e-15)
+    ci = lgp.BART.correlation(*sss, alpha=0.9, intercept=False)
+    util.assert_allclose(lgp.BART.correlation(*sss, alpha=0.9), ci * 0.9 + 0.1, rtol=1e-15)
+    assert lgp.BART.correlation(*sss, pnt=np.array([0.9, 0.4, 0.3], 'f')).dtype == np.float32
+    assert lgp.BART.correlation(*[np.array(s, np.int32) for s in sss], pnt=np.array([0.9, 0.4, 0.3])).dtype == np.float64
+    empty = np.array([], int)
+    assert lgp.BART.correlation(empty, empty, empty) == 1
+    with pytest.raises(KeyError):
+        lgp.BART.correlation([0], [0], [0], gamma='ciao')
+    with pytest.raises(NotImplementedError):
+        lgp.BART.correlation(*sss, maxd=4)              # a depth-4 slice is outside the device path
+
+
+def test_bart_corr_one_cases(lgp, rng):
+    """ correlation = 1 when the points coincide, all weights vanish or there are no covariates (ref :105-133) """
+    p = 4
+    ix = rng.integers(0, 5, (30, p)); n = ix + rng.integers(0, 3, (30, p))
+    for md in (0, 1, 2):
+        c = lgp.BART.correlation(n, ix, ix, maxd=md, gamma=0.2, altinput=True)
+        np.testing.assert_array_equal(c, 1)
+        c = lgp.BART.correlation(n, ix, np.minimum(ix + 1, n), maxd=md, gamma=0.2, weights=np.zeros(p), altinput=True)
+        np.testing.assert_array_equal(c, 1)

@@ -1,0 +1,250 @@
+"""
+Pins the CPU oracle's ``Chol`` restatement (oracle/decomp.py) with the
+reference's identity tests ``tests/linalg/test_decomp.py:31-261`` (same matrix
+factory, same tolerances; jax autodiff expectations replaced by finite
+differences where the reference differentiates the likelihood).  CPU only.
+"""
+
+import numpy as np
+import pytest
+from scipy import linalg, stats
+
+import oracle
+from . import util
+
+
+class DecompTestBase:
+    """ the checks, parametrised by the class under test (re-used by the GPU tests) """
+
+    def make(self, K, **kw):
+        return oracle.Chol(K, **kw)
+
+    def randortho(self, n, *, rng=None):
+        """ ref :33-40 """
+        rng = np.random.default_rng(rng)
+        if n > 1:
+            return stats.ortho_group.rvs(n, random_state=rng)
+        return np.atleast_2d(2 * rng.integers(2) - 1)
+
+    def mat(self, n, s, *, rank=None, eps=1e-3, rng=None):
+        """ p.s.d. matrix depending smoothly on s (ref :42-81) """
+        rng = np.random.default_rng(rng)
+        if rank is None:
+            rank = n
+        s = s[0]
+        eigvals = 1 + eps + np.cos(s + np.arange(n))
+        eigvals = np.where(np.arange(n) < rank, eigvals, 0)
+        transf = self.randortho(n, rng=rng)
+        if n >= 2:
+            rot = np.array([[np.cos(s), -np.sin(s)], [np.sin(s), np.cos(s)]])
+            indices = rng.choice(n, size=2, replace=False)
+            full = np.eye(n)
+            full[np.ix_(indices, indices)] = rot
+            transf = full @ transf
+        util.assert_allclose(transf @ transf.T, np.eye(n), atol=1e-14)
+        return (transf * eigvals) @ transf.T
+
+    @pytest.fixture(params=[1, 2, 10])
+    def n(self, request):
+        return request.param
+
+    @pytest.fixture
+    def s(self, rng):
+        return rng.uniform(-np.pi, np.pi, 1)
+
+    @pytest.fixture
+    def K_factory(self, n, rng):
+        high = np.iinfo(np.uint64).max
+        seed = rng.integers(high, dtype=np.uint64, endpoint=True)
+        return lambda s: self.mat(n, s, rng=seed)
+
+    @pytest.fixture
+    def K(self, s, K_factory):
+        return K_factory(s)
+
+    @pytest.fixture
+    def r_factory(self, n, rng):
+        high = np.iinfo(np.uint64).max
+        seed = rng.integers(high, dtype=np.uint64, endpoint=True)
+        def r_factory(s):
+            return s[0] * np.random.default_rng(seed).standard_normal(n)
+        return r_factory
+
+    @pytest.fixture
+    def r(self, s, r_factory):
+        return r_factory(s)
+
+    @pytest.fixture
+    def A(self, n, rng):
+        return rng.standard_normal((n, 2 * n))
+
+    @pytest.fixture
+    def decomp(self, K):
+        return self.make(K)
+
+    @staticmethod
+    def tol(K, ref_rtol):
+        """ the reference's tolerance, floored by the conditioning of the matrix actually drawn
+        (the per-test seeds differ from the reference's, whose tolerances are tuned to its draws) """
+        return max(ref_rtol, 50 * np.finfo(float).eps * np.linalg.cond(K))
+
+    @pytest.fixture
+    def likelihood(self, n, K_factory, r_factory):
+        def likelihood(s):
+            K = K_factory(s)
+            r = r_factory(s)
+            return 1/2 * (n * np.log(2 * np.pi) + np.sum(np.log(linalg.eigvalsh(K))) + r @ linalg.solve(K, r, assume_a='pos'))
+        return likelihood
+
+    def test_ginv_linear(self, n, K, A, decomp):
+        result = decomp.ginv_linear(A)
+        expected = linalg.solve(K, A, assume_a='pos')
+        util.assert_close_matrices(result, expected, rtol=self.tol(K, 1e-11))
+
+    def test_pinv_bilinear_direct(self, n, K, A, r, decomp):
+        result = decomp.pinv_bilinear(A, r)
+        K_reg = K + np.eye(n) * decomp.eps
+        expected = A.T @ linalg.solve(K_reg, r, assume_a='pos')
+        util.assert_close_matrices(result, expected, rtol=self.tol(K, 1e-13))
+
+    def test_pinv_bilinear_proj(self, n, K, r, decomp):
+        result = decomp.pinv_bilinear(K, r)
+        util.assert_close_matrices(result, r, rtol=self.tol(K, 1e-12))
+
+    def test_pinv_bilinear_robj_direct(self, n, K, A, rng, decomp):
+        """ object arrays (ref :161-166; fractions instead of gvars) """
+        from fractions import Fraction
+        rf = rng.standard_normal(n)
+        r = np.array([Fraction(float(v)).limit_denominator(10**6) for v in rf], object)
+        result = decomp.pinv_bilinear_robj(A, r)
+        K_reg = K + np.eye(n) * decomp.eps
+        expected = linalg.solve(K_reg, A, assume_a='pos').T @ np.array([float(v) for v in r])
+        util.assert_close_matrices(np.array([float(v) for v in result]), expected, rtol=1e-11)
+
+    def test_ginv_quad_direct(self, n, K, A, decomp):
+        result = decomp.ginv_quad(A)
+        K_reg = K + np.eye(n) * decomp.eps
+        expected = A.T @ linalg.solve(K_reg, A, assume_a='pos')
+        util.assert_close_matrices(result, expected, rtol=self.tol(K, 1e-12))
+
+    def test_ginv_quad_mp1(self, K, decomp):
+        result = decomp.ginv_quad(K)
+        util.assert_close_matrices(result, K, rtol=self.tol(K, 1e-14))
+
+    def test_ginv_diagquad_direct(self, n, K, A, decomp):
+        result = decomp.ginv_diagquad(A)
+        K_reg = K + np.eye(n) * decomp.eps
+        expected = np.diag(A.T @ linalg.solve(K_reg, A, assume_a='pos'))
+        util.assert_close_matrices(result, expected, rtol=self.tol(K, 1e-12))
+
+    def test_ginv_diagquad_mp1(self, K, decomp):
+        result = decomp.ginv_diagquad(K)
+        util.assert_close_matrices(result, np.diag(K), rtol=self.tol(K, 1e-13))
+
+    def test_ginv(self, n, K, decomp):
+        result = decomp.ginv()
+        K_reg = K + np.eye(n) * decomp.eps
+        util.assert_close_matrices(result, linalg.inv(K_reg), rtol=self.tol(K, 1e-11))
+
+    def test_correlate(self, n, K, decomp):
+        Z = decomp.correlate(np.eye(n))
+        util.assert_close_matrices(Z @ Z.T, K, rtol=self.tol(K, 1e-14))
+
+    def test_back_correlate(self, n, K, decomp):
+        Zt = decomp.back_correlate(np.eye(n))
+        util.assert_close_matrices(Zt.T @ Zt, K, rtol=self.tol(K, 1e-14))
+
+    def test_pinv_correlate(self, n, K, decomp):
+        result = decomp.pinv_correlate(K)
+        expected = decomp.back_correlate(np.eye(n))
+        util.assert_close_matrices(result, expected, rtol=self.tol(K, 1e-13))
+
+    def test_correlate_back_correlate(self, n, K, decomp, r):
+        result = decomp.correlate(decomp.back_correlate(r))
+        util.assert_close_matrices(result, K @ r, rtol=self.tol(K, 1e-14))
+
+    def test_matrix_n_m(self, n, K, decomp):
+        np.testing.assert_array_equal(np.asarray(decomp.matrix()), K)
+        assert decomp.n == n and decomp.m == n
+
+    def test_normal_nothing(self, decomp, r):
+        assert decomp.minus_log_normal_density(r) == 5 * (None,)
+
+    def test_normal_value(self, n, K, decomp, r):
+        result, _, _, _, _ = decomp.minus_log_normal_density(r, value=True)
+        expected = 1/2 * (n * np.log(2 * np.pi) + np.sum(np.log(linalg.eigvalsh(K))) + r @ linalg.solve(K, r, assume_a='pos'))
+        util.assert_allclose(result, expected, atol=1e-9)
+
+    # derivative pieces: central finite differences stand in for jax.jacrev / jacfwd (ref :227-261)
+    @staticmethod
+    def _fd(f, s, h=1e-6):
+        return (np.asarray(f(s + h)) - np.asarray(f(s - h))) / (2 * h)
+
+    def test_normal_gradfwd(self, likelihood, s, decomp, r, r_factory, K_factory):
+        dK = self._fd(K_factory, s)[..., None]
+        dr = self._fd(r_factory, s)[..., None]
+        _, _, result, _, _ = decomp.minus_log_normal_density(r, gradfwd=True, dK=dK, dr=dr)
+        expected = self._fd(likelihood, s)
+        util.assert_close_matrices(np.atleast_1d(result), np.atleast_1d(expected), rtol=1e-5, atol=1e-7)
+
+    def test_normal_gradrev(self, likelihood, s, decomp, r, r_factory, K_factory):
+        dK = self._fd(K_factory, s)
+        dr = self._fd(r_factory, s)
+        kw = dict(dK_vjp=lambda x: np.atleast_1d(np.sum(x * dK)), dr_vjp=lambda x: np.atleast_1d(x @ dr))
+        _, result, _, _, _ = decomp.minus_log_normal_density(r, gradrev=True, **kw)
+        expected = self._fd(likelihood, s)
+        util.assert_close_matrices(np.atleast_1d(result), np.atleast_1d(expected), rtol=1e-5, atol=1e-7)
+
+    def test_normal_fisher(self, s, decomp, r, K, K_factory, r_factory):
+        dK = self._fd(K_factory, s)[..., None]
+        dr = self._fd(r_factory, s)[..., None]
+        _, _, _, result, _ = decomp.minus_log_normal_density(r, fisher=True, dK=dK, dr=dr)
+        invK_dK = linalg.solve(K, dK[..., 0], assume_a='pos')
+        expected = 1/2 * np.trace(invK_dK @ invK_dK) + dr[:, 0] @ linalg.solve(K, dr[:, 0], assume_a='pos')
+        util.assert_close_matrices(np.atleast_2d(result), np.atleast_2d(expected), rtol=1e-8)
+
+    def test_normal_fishvec(self, s, decomp, r, K, K_factory, r_factory, rng):
+        vec = rng.standard_normal(s.shape)
+        dK = self._fd(K_factory, s)
+        dr = self._fd(r_factory, s)
+        kw = dict(dK_vjp=lambda x: np.atleast_1d(np.sum(x * dK)), dr_vjp=lambda x: np.atleast_1d(x @ dr),
+                  dK_jvp_vec=dK * vec[0], dr_jvp_vec=dr * vec[0])
+        _, _, _, _, result = decomp.minus_log_normal_density(r, fishvec=True, **kw)
+        invK_dK = linalg.solve(K, dK, assume_a='pos')
+        fisher = 1/2 * np.trace(invK_dK @ invK_dK) + dr @ linalg.solve(K, dr, assume_a='pos')
+        util.assert_close_matrices(np.atleast_1d(result), np.atleast_1d(fisher * vec[0]), rtol=1e-8)
+
+
+class TestOracleChol(DecompTestBase):
+    pass
+
+
+def test_eps_rule():
+    """ Appendix A.1 of SURVEY.md / ``_decomp.py:245-255,356-361,384-393`` on a scaled matrix """
+    rng = np.random.default_rng(5)
+    Q = rng.standard_normal((6, 6))
+    K0 = Q @ Q.T + np.eye(6)
+    c = 37.0
+    K = c * K0
+    d = oracle.Chol(K)
+    s = 2. ** np.rint(0.5 * np.log2(np.diag(K)))
+    Kt = K / s / s[:, None]
+    eps = 6 * np.finfo(float).eps * np.max(np.sum(np.abs(Kt), axis=1))
+    assert d.eps == eps * np.min(s * s)
+    L = linalg.cholesky(Kt + eps * np.eye(6), lower=True) * s[:, None]
+    np.testing.assert_array_equal(d._L, L)
+    d2 = oracle.Chol(K, epsrel=0, epsabs='auto')
+    assert d2.eps == np.finfo(float).eps * np.min(s * s)
+    with pytest.raises(np.linalg.LinAlgError):
+        oracle.Chol(-np.eye(3))
+
+
+def test_solve_triangular_python(rng):
+    """ ``_decomp.py:280-309`` against scipy """
+    for lower in (True, False):
+        a = rng.standard_normal((5, 5)) + 5 * np.eye(5)
+        a = np.tril(a) if lower else np.triu(a)
+        b = rng.standard_normal((5, 3))
+        util.assert_close_matrices(oracle.decomp.solve_triangular_python(a, b, lower=lower), linalg.solve_triangular(a, b, lower=lower), rtol=1e-13)
+        v = rng.standard_normal(5)
+        util.assert_close_matrices(oracle.decomp.solve_triangular_python(a, v, lower=lower), linalg.solve_triangular(a, v, lower=lower), rtol=1e-13)

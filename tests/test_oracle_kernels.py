@@ -1,0 +1,191 @@
+"""
+Pins the oracle's ExpQuad / Maternp / fasthash restatements with the reference's
+own pins: ``tests/kernels/test_kernels.py`` (k(x,x)=1, stationarity, PSD +
+symmetry, loc/scale, implicit vs explicit fields, Maternp == Bessel-K form) and
+the fasthash known-answer table of ``tests/test_jax.py:112-186``.  CPU only.
+"""
+
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy import special
+
+import oracle
+from oracle import kernels as ok
+from . import util
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+KERNELS = {
+    'ExpQuad': lambda **kw: oracle.ExpQuad(**kw),
+    'Maternp0': lambda **kw: oracle.Maternp(p=0, **kw),
+    'Maternp1': lambda **kw: oracle.Maternp(p=1, **kw),
+    'Maternp2': lambda **kw: oracle.Maternp(p=2, **kw),
+    'Maternp5': lambda **kw: oracle.Maternp(p=5, **kw),
+}
+
+
+class KernelPins:
+    """ re-used by the GPU parity tests with the device kernel factories """
+
+    factories = KERNELS
+
+    @pytest.fixture(params=sorted(KERNELS))
+    def make(self, request):
+        return self.factories[request.param]
+
+    def random_x(self, rng, n=100, nd=False):
+        if nd:
+            x = np.empty(n, dtype=[('a', float), ('b', float), ('c', float)])
+            for f in x.dtype.names:
+                x[f] = rng.uniform(-5, 5, n)
+            return x
+        return rng.uniform(-5, 5, n)
+
+    def test_normalized(self, make, rng):
+        """ k(x, x) = 1 (ref :303-308) """
+        x = self.random_x(rng)
+        util.assert_allclose(make()(x, x), 1, rtol=1e-14, atol=1e-15)
+
+    def test_normalized_nd(self, make, rng):
+        x = self.random_x(rng, nd=True)
+        util.assert_allclose(make()(x, x), 1, rtol=1e-14, atol=1e-15)
+
+    def test_stationary(self, make, rng):
+        """ k(x, y) = k(x - y, 0) (ref :296-301) """
+        x = self.random_x(rng, 50); y = self.random_x(rng, 50)
+        k = make()
+        util.assert_allclose(k(x, y), k(x - y, np.zeros(50)), atol=1e-15, rtol=1e-14)
+
+    def test_positive_symmetric(self, make, rng):
+        """ PSD bound min eig >= -N eps max eig, exact symmetry (ref :163-187) """
+        for nd in (False, True):
+            x = self.random_x(rng, nd=nd)
+            cov = make()(x[None, :], x[:, None])
+            util.assert_allclose(cov, cov.T, rtol=1e-5, atol=1e-7)
+            eigv = np.linalg.eigvalsh(cov)
+            assert np.min(eigv) >= -len(cov) * np.finfo(float).eps * np.max(eigv)
+
+    def test_symmetric_offdiagonal(self, make, rng):
+        """ k(x, y) = k(y, x) (ref :217-231) """
+        x = self.random_x(rng, 60); y = self.random_x(rng, 40)
+        k = make()
+        util.assert_allclose(k(x[:, None], y[None, :]), k(y[:, None], x[None, :]).T, atol=1e-10)
+
+    def test_implicit_fields(self, make, rng):
+        """ unstructured 1-D input == structured input with one field (ref :239-245) """
+        x = self.random_x(rng, 30)
+        xs = np.empty(30, dtype=[('f0', float)]); xs['f0'] = x
+        k = make()
+        util.assert_allclose(k(x[:, None], x[None, :]), k(xs[:, None], xs[None, :]), rtol=1e-14)
+
+    def test_loc_scale(self, make, rng):
+        """ kernel(loc=l, scale=s)(x, y) == kernel()((x-l)/s, (y-l)/s) (ref :247-260) """
+        x = self.random_x(rng, 40); y = self.random_x(rng, 40)
+        loc, scale = -2.0, 0.3
+        c1 = make()((x - loc) / scale, (y - loc) / scale)
+        c2 = make(loc=loc, scale=scale)(x, y)
+        util.assert_allclose(c1, c2, rtol=1e-12, atol=1e-15)
+
+    def test_scalar_algops(self, make, rng):
+        """ kernel * c and kernel + c (ref ``_Kernel/_alg.py:32-82``) """
+        x = self.random_x(rng, 20)
+        k = make()
+        base = k(x[:, None], x[None, :])
+        util.assert_allclose((k * 3.5)(x[:, None], x[None, :]), base * 3.5, rtol=1e-15)
+        util.assert_allclose((2 * k + 0.25)(x[:, None], x[None, :]), base * 2 + 0.25, rtol=1e-15)
+        util.assert_allclose(((k + 1) * 2)(x[:, None], x[None, :]), (base + 1) * 2, rtol=1e-15)
+
+    def test_broadcast_shapes(self, make, rng):
+        """ call contract: result shape = broadcast shape (ref ``_crosskernel.py:192-200``) """
+        k = make()
+        x = self.random_x(rng, 12)
+        assert k(x[:, None], x[None, :]).shape == (12, 12)
+        assert k(x[None, :], x[:, None]).shape == (12, 12)
+        assert k(x, x).shape == (12,)
+        assert k(x[:3, None, None], x[None, :4, None]).shape == (3, 4, 1)
+        assert k(x[0], x[1]).shape == ()
+        util.assert_allclose(k(x[:, None], x[None, :]).T, k(x[None, :], x[:, None]), rtol=1e-15)
+
+
+class TestOracleKernelPins(KernelPins):
+    pass
+
+
+@pytest.mark.parametrize('p', range(10))
+def test_maternp_vs_bessel(p, rng):
+    """ Maternp(p) == 2^(1-nu)/Gamma(nu) x^nu K_nu(x), nu = p + 1/2 (ref :500-512) """
+    r = rng.uniform(0.01, 10, 200)
+    nu = p + 0.5
+    x = np.sqrt(2 * nu) * r
+    expected = 2 ** (1 - nu) / special.gamma(nu) * x ** nu * special.kv(nu, x)
+    result = oracle.Maternp(p=p)(r, np.zeros_like(r))
+    util.assert_allclose(result, expected, rtol=1e-9, atol=1e-16)
+
+
+def test_expquad_formula(rng):
+    x = rng.uniform(-3, 3, 50); y = rng.uniform(-3, 3, 50)
+    np.testing.assert_array_equal(oracle.ExpQuad()(x, y), np.exp(-1/2 * (x - y) ** 2))
+
+
+def test_field_order_accumulation(rng):
+    """ r^2 accumulates left to right in field order (``_Kernel/_util.py:74-99``) """
+    x = np.empty(40, dtype=[('a', float), ('b', float, 2), ('c', float)])
+    y = np.empty(40, dtype=x.dtype)
+    for arr in (x, y):
+        arr['a'] = rng.standard_normal(40); arr['b'] = rng.standard_normal((40, 2)); arr['c'] = rng.standard_normal(40)
+    r2 = (x['a'] - y['a']) ** 2
+    r2 = r2 + np.sum((x['b'] - y['b']) ** 2, axis=-1)
+    r2 = r2 + (x['c'] - y['c']) ** 2
+    np.testing.assert_array_equal(oracle.ExpQuad()(x, y), np.exp(-1/2 * r2))
+
+
+# ---- fasthash known-answer table ------------------------------------------------
+
+@pytest.fixture(scope='module')
+def kat():
+    with open(os.path.join(HERE, 'golden', 'fasthash_kat.json')) as f:
+        return json.load(f)
+
+
+def test_fasthash_kat(kat):
+    """ the reference's own golden vectors (``tests/test_jax.py:112-186``) """
+    for inp, h64, h32 in zip(kat['inputs'], kat['hashes64'], kat['hashes32']):
+        buf = np.array(inp, np.uint8)
+        assert int(ok.fasthash64(buf, kat['seed64'])) == h64
+        assert int(ok.fasthash32(buf, kat['seed32'])) == h32
+
+
+def test_fasthash_vs_reference_c(kat, rng):
+    """ the reference's C fixture compiled in place (oracle/Makefile -> oracle/_ref) against the restatement """
+    path = os.path.join(os.path.dirname(HERE), 'oracle', '_ref', 'libfasthash_ref.so')
+    if not os.path.exists(path):
+        pytest.skip('oracle/_ref/libfasthash_ref.so not built (needs /root/reference; run make -C oracle)')
+    lib = ctypes.CDLL(path)
+    lib.fasthash64.restype = ctypes.c_uint64
+    lib.fasthash64.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64]
+    lib.fasthash32.restype = ctypes.c_uint32
+    lib.fasthash32.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+    for inp, h64, h32 in zip(kat['inputs'], kat['hashes64'], kat['hashes32']):
+        buf = np.array(inp + [0], np.uint8)
+        assert lib.fasthash64(buf.ctypes.data, len(inp), kat['seed64']) == h64
+        assert lib.fasthash32(buf.ctypes.data, len(inp), kat['seed32']) == h32
+    for _ in range(50):
+        n = int(rng.integers(0, 200))
+        buf = rng.integers(0, 256, n + 1, dtype=np.uint8)
+        seed = int(rng.integers(0, 2 ** 63))
+        assert lib.fasthash64(buf.ctypes.data, n, seed) == int(ok.fasthash64(buf[:n], seed))
+
+
+def test_hash_equality_equals_vector_equality(rng):
+    """ BART uses the hash only as an equality test of index vectors (``_bart.py:674-681``): for the
+    vectors that occur, hash equality == exact equality, which is what the device kernel computes """
+    seed = np.uint64(16132933535611723338)
+    ix = rng.integers(0, 4, (200, 6)).astype(np.int64)
+    hashes = np.array([int(ok.fasthash64(row, seed)) for row in ix], dtype=np.uint64)
+    eq_hash = hashes[:, None] == hashes[None, :]
+    eq_vec = np.all(ix[:, None, :] == ix[None, :, :], axis=-1)
+    np.testing.assert_array_equal(eq_hash, eq_vec)
