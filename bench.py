@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""
+bench.py -- the hot path of BASELINE.json on MI355X: dense GP fit+predict in fp64
+(kernel Gram build -> scaling + Gershgorin jitter -> blocked Cholesky -> triangular solves ->
+posterior mean / covariance + log marginal likelihood), through the C-ABI of
+liblsqfitgp_hip.so with every buffer resident in HBM when the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4] [--no-cpu-baseline]
+
+One "step" = one full pass of the path over one batch of synthetic input:
+    c2  ExpQuad 1-D, N = 8192,  M = 100, y = sin(x/4) + noise, givencov 0.01 I
+    c3  Matern-5/2, 3-D covariates, N = 32768, M = 100, noise 0.01 I      (default at --gpus 1)
+    c4  ExpQuad 1-D, N = 65536, M = 100, noise 0.01 I
+With --gpus N > 1 (launched by torch.distributed.run, one process per GPU) every rank runs an independent
+replica of the workload on its own GPU ("replicas only" until the block-column distributed factorisation is
+the default) -- no data-path collective; torch.distributed (gloo) is used only for the barrier
+and the max-over-ranks of the timing.
+
+Prints ONE JSON line (rank 0): whole-job throughput in TFLOP/s over the algorithmic flop count
+N^3/3 + N^2 (M+1) + N M^2, the roofline of the dominant kernel (syrk trailing update of the Cholesky,
+timed live with HIP events on the stream it runs on) and a CPU baseline (the numpy/scipy oracle on a
+bounded sample of the same workload, on this box's host cores).
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # 256 CU x 4 SIMD x 2048 flop / 64 cycles x 2.4 GHz (v_mfma_f64_16x16x4_f64: 64 cycles
+                                 # per instruction, measured by tools/f64_rate_probe.hip; equals the MI355X datasheet figure)
+
+CONFIGS = {
+    'c2': dict(name='C2 ExpQuad 1-D fp64 N=8192 M=100: Gram build + Cholesky + solve', kernel='expquad', d=1, n=8192, m=100, seed=2),
+    'c3': dict(name='C3 Matern-5/2 3-D fp64 N=32768 M=100: Gram build + Cholesky + solve', kernel='matern52', d=3, n=32768, m=100, seed=3),
+    'c4': dict(name='C4 ExpQuad 1-D fp64 N=65536 M=100: Gram build + Cholesky + solve', kernel='expquad', d=1, n=65536, m=100, seed=4),
+}
+
+
+def synth(cfg, n=None):
+    """ synthetic inputs of SURVEY.md 8(d) """
+    n = n or cfg['n']
+    m = cfg['m']
+    rng = np.random.default_rng(cfg['seed'])
+    if cfg['kernel'] == 'expquad':
+        hi = n / 16.                               # 16 points per lengthscale
+        x = rng.uniform(0, hi, (1, n))
+        xs = rng.uniform(0, hi, (1, m))
+        y = np.sin(x[0] / 4) + 0.1 * rng.standard_normal(n)
+    else:
+        x = rng.uniform(0, 16, (3, n))
+        xs = rng.uniform(0, 16, (3, m))
+        y = np.sin(x).sum(axis=0) + 0.1 * rng.standard_normal(n)
+    return x, xs, y
+
+
+def flops_fit_predict(n, m):
+    return n ** 3 / 3 + n ** 2 * (m + 1) + n * m ** 2
+
+
+class Workload:
+    """ one replica of the path on one GPU, buffers preallocated """
+
+    def __init__(self, cfg, ctx):
+        import lsqfitgp_amd as lgp
+        from lsqfitgp_amd import _lib
+        self.lgp, self._lib, self.lib, self.ctx, self.cfg = lgp, _lib, _lib.load(), ctx, cfg
+        n, m, d = cfg['n'], cfg['m'], cfg['d']
+        x, xs, y = synth(cfg)
+        DA = lgp.DeviceArray
+        self.x = DA.from_host(x, ctx=ctx)            # SoA d x N
+        self.xs = DA.from_host(xs, ctx=ctx)
+        self.y = DA.from_host(y.reshape(n, 1), ctx=ctx)
+        self.K = DA.empty((n, n), ctx=ctx)           # Kxx + ycov
+        self.L = DA.empty((n, n), ctx=ctx)
+        self.dblk = DA.empty((self.lib.lgp_chol_dblk_size(n),), ctx=ctx)
+        self.W = DA.empty((n, m + 1), ctx=ctx)       # [Kxxs | y] -> L^-1 [Kxxs | y]
+        self.Kss = DA.empty((m, m), ctx=ctx)
+        self.mean = DA.empty((m,), ctx=ctx)
+        self.cov = DA.empty((m, m), ctx=ctx)
+        self.kind = _lib.LGP_KERNEL_EXPQUAD if cfg['kernel'] == 'expquad' else _lib.LGP_KERNEL_MATERNP
+        self.p = 0 if cfg['kernel'] == 'expquad' else 2
+        self.noise = 0.01
+        self.results = {}
+
+    def _gram(self, a, b, out):
+        ck = self._lib.check
+        d = self.cfg['d']
+        ck(self.lib.lgp_gram_isotropic_f64(self.ctx.handle, self.kind, self.p, d, a.ptr, a.ld, a.shape[1], b.ptr, b.ld, b.shape[1],
+                                           0, 0., 1, 1., 0, None, None, int(a is b), out.ptr, out.ld), 'gram')
+
+    def step(self, timers=None):
+        """ Gram build, decomposition, posterior, log marginal likelihood -- all enqueued on the context's stream """
+        lib, ctx, ck = self.lib, self.ctx, self._lib.check
+        n, m = self.cfg['n'], self.cfg['m']
+        ev = timers
+        if ev:
+            ctx.record(ev[0])
+        # ---- Gram build (_GP/_elements.py:575-577): Kxx, Kxxs, Kxsxs; noise on the diagonal (_compute.py:85)
+        self._gram(self.x, self.x, self.K)
+        ck(lib.lgp_add_diag_f64(ctx.handle, n, self.K.ptr, self.K.ld, None, self.noise), 'add_diag')
+        self._gram(self.x, self.xs, self.W.block(0, n, 0, m))
+        self._gram(self.xs, self.xs, self.Kss)
+        self.W.block(0, n, m, m + 1).assign(self.y)
+        if ev:
+            ctx.record(ev[1])
+        # ---- decomposition (_linalg/_decomp.py:380-393)
+        eps = ctypes.c_double()
+        info = ck(lib.lgp_chol_factor_f64(ctx.handle, n, self.K.ptr, self.K.ld, 0., 0., self._lib.LGP_EPS_AUTO_REL,
+                                          self.L.ptr, self.L.ld, self.dblk.ptr, ctypes.byref(eps)), 'chol_factor')
+        if info != 0:
+            raise np.linalg.LinAlgError('cholesky decomposition not finite, probably matrix not pos def numerically')
+        if ev:
+            ctx.record(ev[2])
+        # ---- posterior mean / covariance (_GP/_compute.py:259-260) and log marginal likelihood (:420-422)
+        # one forward solve of [Kxxs | y] serves the mean, the covariance and the likelihood
+        val = ctypes.c_double()
+        ck(lib.lgp_posterior_f64(ctx.handle, n, m, self.L.ptr, self.L.ld, self.dblk.ptr, self.W.ptr, self.W.ld,
+                                 self.Kss.ptr, self.Kss.ld, self.mean.ptr, self.cov.ptr, self.cov.ld, ctypes.byref(val)), 'posterior')
+        if ev:
+            ctx.record(ev[3])
+        self.results = dict(eps=eps.value, mll=-val.value)
+
+
+def cpu_baseline(cfg, budget_s=25.0):
+    """ the oracle (numpy/scipy restatement of the reference's path) on a bounded sample: the same workload at
+    a reduced N chosen so that the CPU work stays within ~10-30 s """
+    import oracle
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    m = cfg['m']
+    n = min(cfg['n'], 8192)
+    x, xs, y = synth(cfg, n)
+
+    def run(n_):
+        xx, xxs, yy = x[:, :n_], xs, y[:n_]
+        if cfg['kernel'] == 'expquad':
+            k = oracle.ExpQuad()
+            a, b = xx[0], xxs[0]
+        else:
+            k = oracle.Maternp(p=2, scale=1.)
+            dt = [('f0', float), ('f1', float), ('f2', float)]
+            a = np.empty(n_, dt); b = np.empty(m, dt)
+            for i, f in enumerate(('f0', 'f1', 'f2')):
+                a[f] = xx[i]; b[f] = xxs[i]
+        t0 = time.perf_counter()
+        gp = oracle.GP(k, checkpos=False, checksym=False).addx(a, 'data').addx(b, 'test')
+        gc = {('data', 'data'): 0.01 * np.eye(n_)}
+        mean, cov = gp.predfromdata({'data': yy}, 'test', gc, raw=True)
+        mll = gp.marginal_likelihood({'data': yy}, gc)
+        return time.perf_counter() - t0
+
+    t = run(n)
+    while t > budget_s and n > 1024:
+        n //= 2
+        t = run(n)
+    tf = flops_fit_predict(n, m) / t / 1e12
+    return dict(value=tf, unit='TFLOP/s', cores=int(threads), kind='port',
+                sample=f'{cfg["kernel"]} d={cfg["d"]} N={n} M={m} fit+predict with the numpy/scipy oracle (LAPACK potrf/trsm), {t:.2f} s wall, one run',
+                seconds=t, host_cpus=os.cpu_count())
+
+
+def pmc_traffic(config):
+    """ HBM bytes per trailing-update launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
+    x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, collected in their own runs of this same
+    command); counters cannot be read live from inside the process, so None when no committed pass matches """
+    path = os.path.join(ROOT, 'profiles', f'r01_{config}_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d['hbm_read_bytes_per_launch_corrected'] + d['hbm_write_bytes_per_launch']
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='c3')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch                       # plumbing only: rendezvous, barrier, max-over-ranks
+        import torch.distributed as dist
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        os.environ.setdefault('LGP_DEVICE', str(local_rank))
+
+    import lsqfitgp_amd as lgp              # fails loudly without the HIP library / a GPU
+    cfg = CONFIGS[args.config]
+    ctx = lgp.Context(int(os.environ.get('LGP_DEVICE', local_rank)))
+    wl = Workload(cfg, ctx)
+    lib, _lib = wl.lib, wl._lib
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+
+    # ---- timed region: exactly K steps
+    evs = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
+    _lib.check(lib.lgp_profile_begin(ctx.handle))
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        wl.step(evs[k])
+    barrier()
+    t1 = time.perf_counter()
+    launches = ctypes.c_size_t(); tot_ms = ctypes.c_double(); tot_fl = ctypes.c_double(); max_fl = ctypes.c_double(); max_ms = ctypes.c_double()
+    _lib.check(lib.lgp_profile_end(ctx.handle, ctypes.byref(launches), ctypes.byref(tot_ms), ctypes.byref(tot_fl), ctypes.byref(max_fl), ctypes.byref(max_ms)))
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    n, m = cfg['n'], cfg['m']
+    ms_per_step = elapsed / args.steps * 1e3
+    total_flops = flops_fit_predict(n, m) * args.steps * world
+    phases = np.array([[ctx.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in evs]).mean(axis=0)
+
+    if rank == 0:
+        achieved = tot_fl.value / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else None
+        out = {
+            'metric': 'GP fit+predict fp64 throughput (Gram build + Cholesky + solves; flops N^3/3 + N^2(M+1) + N M^2)',
+            'value': total_flops / elapsed / 1e12,
+            'unit': 'TFLOP/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': ms_per_step,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': cfg['name'], 'N': n, 'M': m, 'd': cfg['d'],
+                       'parallelism': 'single GPU' if world == 1 else f'{world} independent replicas, one per GPU (no collective)'},
+            'phases_ms': {'gram': float(phases[0]), 'decomposition': float(phases[1]), 'solves+likelihood': float(phases[2])},
+            'cholesky_tflops': (n ** 3 / 3) / (phases[1] * 1e-3) / 1e12,
+            'log_marginal_likelihood': wl.results.get('mll'),
+            'roofline': {
+                'kernel': 'gemm_kernel<double,NT> lower (syrk trailing update of the blocked Cholesky, v_mfma_f64_16x16x4_f64)',
+                'bound': 'mfma',
+                'achieved': achieved,
+                'peak': FP64_MFMA_PEAK_TFLOPS,
+                'unit': 'TFLOP/s',
+                'frac': achieved / FP64_MFMA_PEAK_TFLOPS if achieved else None,
+                'traffic': pmc_traffic(args.config),
+                'launches': int(launches.value),
+                'avg_launch_ms': tot_ms.value / max(launches.value, 1),
+                'avg_launch_gflop': tot_fl.value / max(launches.value, 1) / 1e9,
+                'largest_launch_tflops': (max_fl.value / (max_ms.value * 1e-3) / 1e12) if max_ms.value > 0 else None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

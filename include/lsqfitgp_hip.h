@@ -72,6 +72,15 @@ int lgp_event_destroy(lgp_ctx *ctx, void *event);
 int lgp_event_record(lgp_ctx *ctx, void *event);
 int lgp_event_elapsed_ms(lgp_ctx *ctx, void *start, void *stop, float *ms);   /* synchronises on stop */
 
+/* Live timing of the dominant kernel, the syrk trailing update of the blocked Cholesky: between
+ * lgp_profile_begin and lgp_profile_end every trailing-update launch is bracketed by a HIP event pair on the
+ * stream it is launched on.  lgp_profile_end synchronises and returns the number of launches, the sum of
+ * their durations, the sum of their algorithmic flops (2*k per produced lower-triangle entry) and the
+ * flops / duration of the largest launch. */
+int lgp_profile_begin(lgp_ctx *ctx);
+int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *total_flops,
+                    double *max_flops, double *max_ms);
+
 /* ---- Gram build: _GP/_elements.py:554-579 -> _Kernel/_crosskernel.py:192-200 ------- */
 
 #define LGP_KERNEL_EXPQUAD 0   /* _kernels/_basic.py:61-75   exp(-1/2 r2)                        */
@@ -225,13 +234,15 @@ int lgp_dot_f32(lgp_ctx *ctx, size_t n, const float *dx, const float *dy, float 
 /* _GP/_compute.py:259-260 with L^-1 Kxxs computed once:
  * dW: n x (m+1) workspace, on entry [Kxxs | y] (column m = y), overwritten with L^-1 [Kxxs | y];
  * mean (m) = (L^-1 Kxxs)^T (L^-1 y); cov (m x m, ld ldc) = Kxsxs - (L^-1 Kxxs)^T (L^-1 Kxxs).
- * dKxsxs may alias dcov.  dmean/dcov are device pointers. */
+ * dKxsxs may alias dcov.  dmean/dcov are device pointers.  hmlnd (host, may be NULL): if given, also returns
+ * minus_log_normal_density(y, value=True) (_decomp.py:484-488) from the already solved column L^-1 y, so that a
+ * fit+predict pass needs one forward solve in all; synchronises in that case. */
 int lgp_posterior_f64(lgp_ctx *ctx, size_t n, size_t m, const double *dL, size_t ldl, const double *ddblk,
                       double *dW, size_t ldw, const double *dKxsxs, size_t ldk,
-                      double *dmean, double *dcov, size_t ldc);
+                      double *dmean, double *dcov, size_t ldc, double *hmlnd);
 int lgp_posterior_f32(lgp_ctx *ctx, size_t n, size_t m, const float *dL, size_t ldl, const float *ddblk,
                       float *dW, size_t ldw, const float *dKxsxs, size_t ldk,
-                      float *dmean, float *dcov, size_t ldc);
+                      float *dmean, float *dcov, size_t ldc, float *hmlnd);
 /* minus_log_normal_density(r, value=True) (_decomp.py:466-488): 1/2 (n log 2pi + 2 sum log L_ii + |L^-1 r|^2).
  * dr (n) is overwritten with L^-1 r.  Synchronises. */
 int lgp_mlnd_value_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *ddblk,

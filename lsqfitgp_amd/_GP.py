@@ -608,7 +608,7 @@ class GP:
         Kss = _astype_dev(Kxsxs, dtype)
         f, _ = _lib.fn('lgp_posterior', dtype)
         _lib.check(f(self.ctx.handle, n, m, solver._L.ptr, solver._L.ld, solver._dblk.ptr, W.ptr, W.ld,
-                     Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld), 'lgp_posterior')
+                     Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld, None), 'lgp_posterior')
         if not fromdata and ycov_dev is not None:
             # cov += A' ycov A, A = K^-1 Kxxs = L^-T (L^-1 Kxxs)             (:262-269)
             A = W.block(0, n, 0, m).copy()

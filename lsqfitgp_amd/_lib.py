@@ -55,6 +55,8 @@ def _signatures():
         'lgp_event_record': (c_int, [c_void_p, c_void_p]),
         'lgp_event_elapsed_ms': (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float)]),
         'lgp_chol_dblk_size': (c_size_t, [_S]),
+        'lgp_profile_begin': (c_int, [c_void_p]),
+        'lgp_profile_end': (c_int, [c_void_p, POINTER(c_size_t), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
         'lgp_comm_unique_id': (c_int, [c_void_p]),
         'lgp_comm_init': (c_int, [c_void_p, c_int, c_int, c_void_p]),
         'lgp_comm_destroy': (c_int, [c_void_p]),
@@ -90,7 +92,7 @@ def _signatures():
             'lgp_colsumsq_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, _P]),
             'lgp_logdet_diag_' + suf: (c_int, [c_void_p, _S, _P, _S, POINTER(F)]),
             'lgp_dot_' + suf: (c_int, [c_void_p, _S, _P, _P, POINTER(F)]),
-            'lgp_posterior_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, _P, _P, _S, _P, _S, _P, _P, _S]),
+            'lgp_posterior_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, _P, _P, _S, _P, _S, _P, _P, _S, POINTER(F)]),
             'lgp_mlnd_value_' + suf: (c_int, [c_void_p, _S, _P, _S, _P, _P, POINTER(F)]),
         })
     return sig

@@ -87,6 +87,7 @@ int lgp_ctx_destroy(lgp_ctx *c) {
   (void)hipHostFree(c->h_pinned);
   (void)hipEventDestroy(c->ev_a);
   (void)hipEventDestroy(c->ev_b);
+  for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
   (void)hipStreamDestroy(c->stream2);
   delete c;
@@ -203,11 +204,65 @@ int lgp_event_elapsed_ms(lgp_ctx *c, void *start, void *stop, float *ms) {
 
 }  // extern "C"
 
+// ---- live timing of the trailing-update launches ----------------------------------------------------
+int lgp_prof_start(lgp_ctx *c, hipStream_t stream, double flops) {
+  if (!c->prof_on) return LGP_OK;
+  if (c->prof_used + 2 > c->prof_events.size()) {
+    hipEvent_t a, b;
+    LGP_HIP(hipEventCreate(&a));
+    LGP_HIP(hipEventCreate(&b));
+    c->prof_events.push_back(a);
+    c->prof_events.push_back(b);
+  }
+  c->prof_flops.push_back(flops);
+  LGP_HIP(hipEventRecord(c->prof_events[c->prof_used], stream));
+  return LGP_OK;
+}
+int lgp_prof_stop(lgp_ctx *c, hipStream_t stream) {
+  if (!c->prof_on) return LGP_OK;
+  LGP_HIP(hipEventRecord(c->prof_events[c->prof_used + 1], stream));
+  c->prof_used += 2;
+  return LGP_OK;
+}
+
+extern "C" int lgp_profile_begin(lgp_ctx *c) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  c->prof_on = 1;
+  c->prof_used = 0;
+  c->prof_flops.clear();
+  return LGP_OK;
+}
+
+extern "C" int lgp_profile_end(lgp_ctx *c, size_t *launches, double *total_ms, double *total_flops, double *max_flops, double *max_ms) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  DeviceGuard dg(c->device);
+  c->prof_on = 0;
+  LGP_HIP(hipStreamSynchronize(c->stream));
+  LGP_HIP(hipStreamSynchronize(c->stream2));
+  double ms_sum = 0, fl_sum = 0, fl_max = 0, ms_max = 0;
+  const size_t n = c->prof_used / 2;
+  for (size_t i = 0; i < n; ++i) {
+    float ms = 0;
+    LGP_HIP(hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+    ms_sum += ms;
+    fl_sum += c->prof_flops[i];
+    if (c->prof_flops[i] > fl_max) { fl_max = c->prof_flops[i]; ms_max = ms; }
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms_sum;
+  if (total_flops) *total_flops = fl_sum;
+  if (max_flops) *max_flops = fl_max;
+  if (max_ms) *max_ms = ms_max;
+  c->prof_used = 0;
+  c->prof_flops.clear();
+  return LGP_OK;
+}
+
 // ---- fused posterior / log density --------------------------------------------------------------
 
 template <typename T>
 static int posterior_impl(lgp_ctx *c, size_t n, size_t m, const T *L, size_t ldl, const T *dblk, T *W, size_t ldw, const T *Kxsxs,
-                          size_t ldk, T *mean, T *cov, size_t ldc) {
+                          size_t ldk, T *mean, T *cov, size_t ldc, T *hmlnd) {
   LGP_REQUIRE(c != nullptr, "null context");
   LGP_REQUIRE(n >= 1, "empty training set");
   LGP_REQUIRE(L != nullptr && dblk != nullptr && W != nullptr, "null pointer");
@@ -216,14 +271,26 @@ static int posterior_impl(lgp_ctx *c, size_t n, size_t m, const T *L, size_t ldl
   hipStream_t st = c->stream;
   // W <- L^-1 [Kxxs | y]   (the reference solves L^-1 Kxxs twice, _decomp.py:408 and :419; once is enough)
   LGP_CHECK(lgp_trsm_impl<T>(c, st, n, L, ldl, dblk, 0, W, ldw, m + 1));
-  if (m == 0) return LGP_OK;
+  if (hmlnd) {
+    // minus log density of y for free: column m of W is L^-1 y already           _decomp.py:484-488
+    T *d = reinterpret_cast<T *>(c->d_scratch);
+    LGP_CHECK(lgp_logdet_device<T>(c, st, n, L, ldl, d));
+    LGP_CHECK(lgp_dot_strided_device<T>(c, st, n, W + m, ldw, W + m, ldw, d + 1));
+    LGP_HIP(hipMemcpyAsync(c->h_pinned, d, 2 * sizeof(T), hipMemcpyDeviceToHost, st));
+  }
+  if (m == 0 && !hmlnd) return LGP_OK;
   // mean = (L^-1 Kxxs)^T (L^-1 y)                      _decomp.py:409
-  if (mean) LGP_CHECK(lgp_gemm_launch<T>(c, st, true, false, m, 1, n, T(1), W, ldw, W + m, ldw, T(0), mean, 1, false));
+  if (mean && m > 0) LGP_CHECK(lgp_gemm_launch<T>(c, st, true, false, m, 1, n, T(1), W, ldw, W + m, ldw, T(0), mean, 1, false));
   // cov = Kxsxs - (L^-1 Kxxs)^T (L^-1 Kxxs)            _decomp.py:420, _compute.py:260
-  if (cov) {
+  if (cov && m > 0) {
     LGP_REQUIRE(Kxsxs != nullptr && ldk >= m && ldc >= m, "bad covariance arguments");
     if (Kxsxs != cov) LGP_HIP(hipMemcpy2DAsync(cov, ldc * sizeof(T), Kxsxs, ldk * sizeof(T), m * sizeof(T), m, hipMemcpyDeviceToDevice, st));
     LGP_CHECK(lgp_gemm_launch<T>(c, st, true, false, m, m, n, T(-1), W, ldw, W, ldw, T(1), cov, ldc, false));
+  }
+  if (hmlnd) {
+    LGP_HIP(hipStreamSynchronize(st));
+    const T *h = reinterpret_cast<const T *>(c->h_pinned);
+    *hmlnd = T(0.5) * (T(n) * T(std::log(2 * M_PI)) + T(2) * h[0] + h[1]);
   }
   return LGP_OK;
 }
@@ -248,12 +315,12 @@ static int mlnd_impl(lgp_ctx *c, size_t n, const T *L, size_t ldl, const T *dblk
 
 extern "C" {
 int lgp_posterior_f64(lgp_ctx *c, size_t n, size_t m, const double *L, size_t ldl, const double *dblk, double *W, size_t ldw,
-                      const double *K, size_t ldk, double *mean, double *cov, size_t ldc) {
-  return posterior_impl<double>(c, n, m, L, ldl, dblk, W, ldw, K, ldk, mean, cov, ldc);
+                      const double *K, size_t ldk, double *mean, double *cov, size_t ldc, double *hmlnd) {
+  return posterior_impl<double>(c, n, m, L, ldl, dblk, W, ldw, K, ldk, mean, cov, ldc, hmlnd);
 }
 int lgp_posterior_f32(lgp_ctx *c, size_t n, size_t m, const float *L, size_t ldl, const float *dblk, float *W, size_t ldw,
-                      const float *K, size_t ldk, float *mean, float *cov, size_t ldc) {
-  return posterior_impl<float>(c, n, m, L, ldl, dblk, W, ldw, K, ldk, mean, cov, ldc);
+                      const float *K, size_t ldk, float *mean, float *cov, size_t ldc, float *hmlnd) {
+  return posterior_impl<float>(c, n, m, L, ldl, dblk, W, ldw, K, ldk, mean, cov, ldc, hmlnd);
 }
 int lgp_mlnd_value_f64(lgp_ctx *c, size_t n, const double *L, size_t ldl, const double *dblk, double *r, double *h) {
   return mlnd_impl<double>(c, n, L, ldl, dblk, r, h);

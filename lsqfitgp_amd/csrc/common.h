@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 #include "../../include/lsqfitgp_hip.h"
 
 struct lgp_ctx {
@@ -20,7 +21,16 @@ struct lgp_ctx {
   void *comm = nullptr;               // ncclComm_t
   int rank = 0, nranks = 1;
   int cus = 256;
+  // live kernel timing of the dominant kernel (trailing-update syrk) for bench.py: HIP event pairs on the
+  // stream the kernel is launched on, enabled by lgp_profile_begin
+  int prof_on = 0;
+  std::vector<hipEvent_t> prof_events;   // start/stop pairs
+  std::vector<double> prof_flops;        // algorithmic flops of each timed launch
+  size_t prof_used = 0;
 };
+
+int lgp_prof_start(lgp_ctx *ctx, hipStream_t stream, double flops);
+int lgp_prof_stop(lgp_ctx *ctx, hipStream_t stream);
 
 void lgp_set_error(const char *fmt, ...);
 

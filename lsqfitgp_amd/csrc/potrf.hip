@@ -584,7 +584,11 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk) {
         }
         const T *Pa = L + (base + c0) * ldl + k0;          // rows below and including the chunk's diagonal
         T *Cc = L + (base + c0) * ldl + (base + c0);
+        // algorithmic flops of this launch: 2 k per produced entry of the lower trapezoid
+        const double entries = (double)(c1 - c0) * ((double)(rows_r - c0) - 0.5 * (double)(c1 - c0 - 1));
+        LGP_CHECK(lgp_prof_start(ctx, s0, 2.0 * (double)kb * entries));
         LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r - c0, c1 - c0, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true));
+        LGP_CHECK(lgp_prof_stop(ctx, s0));
         c0 = c1;
       }
     }
