@@ -183,6 +183,53 @@ def pmc_traffic(config):
         return None
 
 
+def main_dist(args, cfg, ctx, dist, rank, world):
+    """ opt-in: Gram build + regularisation + Cholesky of ONE N x N problem sharded by block columns over the ranks
+    (lsqfitgp_amd/_dist.py); strong scaling, value = N^3/3 flops / time """
+    import torch
+    import lsqfitgp_amd as lgp
+    from lsqfitgp_amd._dist import DistributedChol
+    uid = [lgp.Context.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    ctx.comm_init(rank, world, uid[0])
+    lgp.Context._default = ctx
+    x, xs, y = synth(cfg)
+    kern = lgp.ExpQuad() if cfg['kernel'] == 'expquad' else lgp.Maternp(p=2, scale=1.)
+    if cfg['d'] == 1:
+        pts = x[0]
+    else:
+        pts = np.empty(cfg['n'], [(f'f{i}', float) for i in range(cfg['d'])])
+        for i in range(cfg['d']):
+            pts[f'f{i}'] = x[i]
+
+    def step():
+        d = DistributedChol(kern, pts, noise=0.01, nb=1024, ctx=ctx)
+        return d.logdet()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync(); dist.barrier(); ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ld = step()
+    ctx.sync(); dist.barrier(); ctx.sync()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
+    n = cfg['n']
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'distributed Gram build + regularised Cholesky fp64 throughput (flops N^3/3)',
+            'value': n ** 3 / 3 * args.steps / elapsed / 1e12, 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': cfg['name'] + ' (factorisation only)', 'N': n,
+                       'parallelism': f'1-D block-column-cyclic over {world} GPUs, nb=1024, RCCL panel broadcast with look-ahead'},
+            'sum_log_diag': ld, 'roofline': None, 'cpu_baseline': None}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -190,6 +237,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='c3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dist', action='store_true', default=os.environ.get('LGP_BENCH_DIST') == '1',
+                    help='N > 1: one block-column-cyclic factorisation sharded over the ranks (RCCL panel broadcasts) '
+                         'instead of independent replicas')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -205,6 +255,8 @@ def main():
     import lsqfitgp_amd as lgp              # fails loudly without the HIP library / a GPU
     cfg = CONFIGS[args.config]
     ctx = lgp.Context(int(os.environ.get('LGP_DEVICE', local_rank)))
+    if args.dist and world > 1:
+        return main_dist(args, cfg, ctx, dist, rank, world)
     wl = Workload(cfg, ctx)
     lib, _lib = wl.lib, wl._lib
 

@@ -260,6 +260,15 @@ int lgp_bcast(lgp_ctx *ctx, void *dbuf, size_t bytes, int root);        /* ncclB
 int lgp_allreduce_sum_f64(lgp_ctx *ctx, double *dbuf, size_t count);
 int lgp_allreduce_max_f64(lgp_ctx *ctx, double *dbuf, size_t count);
 
+/* The context owns two streams; entry points enqueue on the selected one (0 = main, default; 1 = auxiliary,
+ * highest priority).  The distributed driver puts the RCCL broadcasts on the auxiliary stream so that panel
+ * transfers overlap the trailing updates, ordering them with events (lgp_event_record / lgp_stream_wait_event). */
+int lgp_select_stream(lgp_ctx *ctx, int which);
+int lgp_stream_wait_event(lgp_ctx *ctx, void *event);      /* the selected stream waits for `event` */
+/* out[j] = sum_i |A[i,j]|: Gershgorin sums (_decomp.py:349-354) of a locally owned block column of a symmetric
+ * matrix (column sums = row sums), rows x cols */
+int lgp_colabssum_f64(lgp_ctx *ctx, size_t rows, size_t cols, const double *dA, size_t lda, double *dout);
+
 /* building blocks of the distributed factorisation (the single-GPU driver is built from the same ones):
  * factor one block-column panel held locally: dP is rows x nb (ld ldp), its top nb x nb block is the
  * diagonal block; on exit dP holds the L panel and ddblk its packed diagonal blocks (lgp_chol_dblk_size(nb)).

@@ -66,6 +66,9 @@ def _signatures():
         'lgp_panel_factor_f64': (c_int, [c_void_p, _S, _S, _P, _S, _P, _S]),
         'lgp_update_nt_f64': (c_int, [c_void_p, _S, _S, _S, _P, _S, _P, _S, _P, _S, c_int]),
         'lgp_get_info': (c_int, [c_void_p, POINTER(c_int)]),
+        'lgp_select_stream': (c_int, [c_void_p, c_int]),
+        'lgp_stream_wait_event': (c_int, [c_void_p, c_void_p]),
+        'lgp_colabssum_f64': (c_int, [c_void_p, _S, _S, _P, _S, _P]),
     }
     for suf, F in (('f64', c_double), ('f32', c_float)):
         sig.update({

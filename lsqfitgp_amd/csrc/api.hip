@@ -194,6 +194,23 @@ int lgp_event_record(lgp_ctx *c, void *event) {
   LGP_HIP(hipEventRecord(static_cast<hipEvent_t>(event), c->stream));
   return LGP_OK;
 }
+int lgp_select_stream(lgp_ctx *c, int which) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  LGP_REQUIRE(which == 0 || which == 1, "stream index must be 0 or 1");
+  if ((which == 1) != (c->swapped != 0)) {
+    hipStream_t t = c->stream;
+    c->stream = c->stream2;
+    c->stream2 = t;
+    c->swapped = which;
+  }
+  return LGP_OK;
+}
+int lgp_stream_wait_event(lgp_ctx *c, void *event) {
+  LGP_REQUIRE(c != nullptr && event != nullptr, "null pointer");
+  DeviceGuard dg(c->device);
+  LGP_HIP(hipStreamWaitEvent(c->stream, static_cast<hipEvent_t>(event), 0));
+  return LGP_OK;
+}
 int lgp_event_elapsed_ms(lgp_ctx *c, void *start, void *stop, float *ms) {
   LGP_REQUIRE(c != nullptr && start != nullptr && stop != nullptr && ms != nullptr, "null pointer");
   DeviceGuard dg(c->device);
@@ -424,7 +441,7 @@ int lgp_comm_destroy(lgp_ctx *c) {
 int lgp_bcast(lgp_ctx *c, void *dbuf, size_t bytes, int root) {
   LGP_REQUIRE(c != nullptr && (dbuf != nullptr || bytes == 0), "null pointer");
   LGP_REQUIRE(root >= 0 && root < c->nranks, "bad root");
-  if (c->nranks == 1 || bytes == 0) return LGP_OK;
+  if (bytes == 0 || (c->comm == nullptr && c->nranks == 1)) return LGP_OK;   // no communicator: single process
   LGP_REQUIRE(c->comm != nullptr, "communicator not initialised");
   DeviceGuard dg(c->device);
   LGP_NCCL(g_rccl.Broadcast(dbuf, dbuf, bytes, ncclUint8, root, static_cast<ncclComm_t>(c->comm), c->stream));
@@ -433,7 +450,7 @@ int lgp_bcast(lgp_ctx *c, void *dbuf, size_t bytes, int root) {
 
 int lgp_allreduce_sum_f64(lgp_ctx *c, double *dbuf, size_t count) {
   LGP_REQUIRE(c != nullptr && (dbuf != nullptr || count == 0), "null pointer");
-  if (c->nranks == 1 || count == 0) return LGP_OK;
+  if (count == 0 || (c->comm == nullptr && c->nranks == 1)) return LGP_OK;
   LGP_REQUIRE(c->comm != nullptr, "communicator not initialised");
   DeviceGuard dg(c->device);
   LGP_NCCL(g_rccl.AllReduce(dbuf, dbuf, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(c->comm), c->stream));
@@ -442,7 +459,7 @@ int lgp_allreduce_sum_f64(lgp_ctx *c, double *dbuf, size_t count) {
 
 int lgp_allreduce_max_f64(lgp_ctx *c, double *dbuf, size_t count) {
   LGP_REQUIRE(c != nullptr && (dbuf != nullptr || count == 0), "null pointer");
-  if (c->nranks == 1 || count == 0) return LGP_OK;
+  if (count == 0 || (c->comm == nullptr && c->nranks == 1)) return LGP_OK;
   LGP_REQUIRE(c->comm != nullptr, "communicator not initialised");
   DeviceGuard dg(c->device);
   LGP_NCCL(g_rccl.AllReduce(dbuf, dbuf, count, ncclDouble, ncclMax, static_cast<ncclComm_t>(c->comm), c->stream));

@@ -21,6 +21,7 @@ struct lgp_ctx {
   void *comm = nullptr;               // ncclComm_t
   int rank = 0, nranks = 1;
   int cus = 256;
+  int swapped = 0;                    // lgp_select_stream(1): `stream` and `stream2` exchanged
   // live kernel timing of the dominant kernel (trailing-update syrk) for bench.py: HIP event pairs on the
   // stream the kernel is launched on, enabled by lgp_profile_begin
   int prof_on = 0;

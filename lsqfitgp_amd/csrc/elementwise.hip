@@ -115,6 +115,20 @@ __global__ void __launch_bounds__(256) colsumsq_kernel(size_t rows, size_t cols,
   atomicAdd(&out[j], acc);
 }
 
+// out[j] = sum_i |A[i][j]| (Gershgorin sums of a block column of a symmetric matrix)
+template <typename T>
+__global__ void __launch_bounds__(256) colabssum_kernel(size_t rows, size_t cols, const T *A, size_t lda, T *out, size_t rows_per_blk) {
+  const size_t nbx = (cols + 255) / 256;
+  const size_t strip = blockIdx.x % nbx, chunk = blockIdx.x / nbx;
+  const size_t j = strip * 256 + threadIdx.x;
+  if (j >= cols) return;
+  const size_t r0 = chunk * rows_per_blk;
+  const size_t r1 = (r0 + rows_per_blk) < rows ? (r0 + rows_per_blk) : rows;
+  T acc = T(0);
+  for (size_t i = r0; i < r1; ++i) acc += fabs(A[i * lda + j]);
+  atomicAdd(&out[j], acc);
+}
+
 // single-workgroup reductions (n up to ~1e5: negligible), deterministic order
 template <typename T>
 __global__ void __launch_bounds__(1024) logdet_kernel(size_t n, const T *L, size_t ldl, T *out) {
@@ -297,6 +311,24 @@ int lgp_logdet_device(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, si
 }
 template int lgp_logdet_device<double>(lgp_ctx *, hipStream_t, size_t, const double *, size_t, double *);
 template int lgp_logdet_device<float>(lgp_ctx *, hipStream_t, size_t, const float *, size_t, float *);
+
+extern "C" int lgp_colabssum_f64(lgp_ctx *c, size_t rows, size_t cols, const double *A, size_t lda, double *out) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  if (cols == 0) return LGP_OK;
+  LGP_REQUIRE(out != nullptr && (rows == 0 || (A != nullptr && lda >= cols)), "bad argument");
+  DeviceGuard dg(c->device);
+  LGP_HIP(hipMemsetAsync(out, 0, cols * sizeof(double), c->stream));
+  if (rows == 0) return LGP_OK;
+  const size_t nbx = (cols + 255) / 256;
+  size_t chunks = (size_t)c->cus * 8 / nbx;
+  if (chunks < 1) chunks = 1;
+  if (chunks > rows) chunks = rows;
+  const size_t rpb = (rows + chunks - 1) / chunks;
+  chunks = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL((colabssum_kernel<double>), dim3((unsigned)(nbx * chunks)), dim3(256), 0, c->stream, rows, cols, A, lda, out, rpb);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
 
 extern "C" {
 int lgp_axpby_f64(lgp_ctx *c, size_t r, size_t n, double a, const double *A, size_t lda, double b, const double *B, size_t ldb, double *C, size_t ldc) { return axpby_impl<double>(c, r, n, a, A, lda, b, B, ldb, C, ldc); }

@@ -1,0 +1,76 @@
+"""
+GPU tests of the distributed pieces on ONE device: the device backend of the block-column schedule
+(``DeviceOps`` + ``DistributedChol`` with a single rank) against the oracle, and the RCCL plumbing through a
+one-rank communicator (ncclCommInitRank / ncclBroadcast / ncclAllReduce really run).  The multi-rank schedule
+itself is covered on CPU by tests/test_dist_gloo.py.
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from . import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lgp():
+    import lsqfitgp_amd
+    lsqfitgp_amd.Context.default()
+    return lsqfitgp_amd
+
+
+@pytest.mark.parametrize('n,nb,noise', [(300, 128, 0.01), (1500, 256, 0.01), (1100, 1024, 0.), (2500, 1024, 0.05)])
+def test_distributed_chol_single_rank(lgp, n, nb, noise, rng):
+    from lsqfitgp_amd._dist import DistributedChol
+    x = rng.uniform(0, n / 16, n)
+    d = DistributedChol(lgp.ExpQuad(), x, noise=noise, nb=nb)
+    K = oracle.ExpQuad()(x[:, None], x[None, :]) + noise * np.eye(n)
+    o = oracle.Chol(K)
+    util.assert_allclose(d.eps, o.eps, rtol=1e-13)
+    full = np.zeros((n, n))
+    for b, blk in d.local_factor().items():
+        c0 = d.layout.col0(b)
+        full[c0:, c0:c0 + blk.shape[1]] = blk
+    if noise:
+        util.assert_close_matrices(full, o._L, rtol=1e-11)
+    util.assert_close_matrices(full @ full.T, o._L @ o._L.T, rtol=1e-13)
+    # noise-free: the ~1e-6 pivots of the numerically singular matrix make the log-determinant itself ill conditioned
+    util.assert_allclose(d.logdet(), np.sum(np.log(np.diag(o._L))), rtol=1e-10 if noise else 1e-5, atol=1e-8)
+
+
+def test_distributed_matern_3d(lgp, rng):
+    from lsqfitgp_amd._dist import DistributedChol
+    n = 900
+    dt = [('a', float), ('b', float), ('c', float)]
+    x = np.empty(n, dt)
+    for f in 'abc':
+        x[f] = rng.uniform(0, 8, n)
+    d = DistributedChol(lgp.Maternp(p=2, scale=1.5), x, noise=0.01, nb=256)
+    K = oracle.Maternp(p=2, scale=1.5)(x[:, None], x[None, :]) + 0.01 * np.eye(n)
+    o = oracle.Chol(K)
+    full = np.zeros((n, n))
+    for b, blk in d.local_factor().items():
+        c0 = d.layout.col0(b)
+        full[c0:, c0:c0 + blk.shape[1]] = blk
+    util.assert_close_matrices(full, o._L, rtol=1e-11)
+
+
+def test_rccl_single_rank_communicator(lgp):
+    """ a 1-rank RCCL communicator on a private context: unique id, init, broadcast, all-reduce, destroy """
+    from lsqfitgp_amd import _lib
+    ctx = lgp.Context(0)
+    uid = lgp.Context.comm_unique_id()
+    assert len(uid) == _lib.LGP_COMM_ID_BYTES and any(uid)
+    ctx.comm_init(0, 1, uid)
+    a = lgp.DeviceArray.from_host(np.arange(1000.), ctx=ctx)
+    lib = _lib.load()
+    _lib.check(lib.lgp_bcast(ctx.handle, a.ptr, 8000, 0), 'lgp_bcast')
+    _lib.check(lib.lgp_allreduce_sum_f64(ctx.handle, a.ptr, 1000), 'allreduce sum')
+    _lib.check(lib.lgp_allreduce_max_f64(ctx.handle, a.ptr, 1000), 'allreduce max')
+    ctx.sync()
+    np.testing.assert_array_equal(a.to_host(), np.arange(1000.))
+    _lib.check(lib.lgp_comm_destroy(ctx.handle))
