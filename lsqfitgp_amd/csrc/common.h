@@ -75,7 +75,6 @@ struct DeviceGuard {
 // ---- blocked-algorithm geometry -------------------------------------------------------
 constexpr int LGP_DB = 128;    // diagonal block factored (and inverted) by one workgroup
 constexpr int LGP_NB = 1024;    // outer panel width of the right-looking factorisation
-constexpr int LGP_TRAIL_CHUNKS = 1;   // block-column chunks of the trailing update (1 = single launch)
 constexpr int LGP_DBLK = 2 * LGP_DB * LGP_DB + LGP_DB;   // per-diagonal-block workspace: D, D^T, 1/diag
 
 // ---- GEMM (gemm.hip) ---------------------------------------------------------------------

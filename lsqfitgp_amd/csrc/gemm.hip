@@ -22,6 +22,7 @@
 // share 8 A-panels and 8 B-panels through that XCD's L2 while they walk K together.  Placement only
 // affects speed, never results.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -301,7 +302,10 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   g.alignedA = ((reinterpret_cast<uintptr_t>(A) % 16) == 0 && (lda % VEC) == 0) ? 1 : 0;
   g.alignedB = ((reinterpret_cast<uintptr_t>(B) % 16) == 0 && (ldb % VEC) == 0) ? 1 : 0;
   size_t grid;
-  if ((size_t)g.tm * g.tn <= 64) {
+  static const int map_mode = getenv("LGP_GEMM_MAP") ? atoi(getenv("LGP_GEMM_MAP")) : 1;   // experiment knob
+  // super-tiles only pay when both tile dimensions are large; tall-skinny grids (panel updates, solves with a
+  // few hundred right-hand sides) are 3x faster with the plain row-major map (measured: 30000x101x1024)
+  if ((size_t)g.tm * g.tn <= 64 || g.tm < 16 || g.tn < 16 || (map_mode == 0 && !lower)) {
     g.nsm = g.nsn = 0;
     grid = (size_t)g.tm * g.tn;
   } else {

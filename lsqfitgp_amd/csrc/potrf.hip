@@ -22,9 +22,9 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------
 // Diagonal-block workspace ("dblk"): for every 128x128 diagonal block of L, LGP_DBLK elements:
-//   [0, 128*128)          D   = the block, row-major, zeros above the diagonal, identity padding past n
+//   [0, 128*128)          D   = the strictly lower part of the block, row-major (zero diagonal and above)
 //   [128*128, 2*128*128)  Dt  = its transpose, row-major
-//   [2*128*128, +128)     rd  = 1 / diag
+//   [2*128*128, +128)     rd  = 1 / diag (1 past n)
 // The triangular solves read D / Dt rows with wave-uniform (scalar) loads.
 
 // potf2 of one diagonal block (nb <= 128) by one 256-thread workgroup, matrix held in REGISTERS.
@@ -143,8 +143,9 @@ __global__ void __launch_bounds__(256, 1) potf2_kernel(T *A, long lda, int nb, T
       const int i = ti + 16 * p, c = tj + 16 * q;
       const T v = (c <= i) ? a[p][q] : T(0);
       if (i < nb && c <= i) A[(long)i * lda + c] = v;
-      dblk[i * D + c] = v;
-      dblk[D * D + c * D + i] = v;
+      const T off = (i == c) ? T(0) : v;     // the workspace images carry a ZERO diagonal, 1/diag is kept apart
+      dblk[i * D + c] = off;
+      dblk[D * D + c * D + i] = off;
       if (i == c) dblk[2 * D * D + i] = T(1) / v;
     }
 }
@@ -158,15 +159,13 @@ __global__ void __launch_bounds__(256) extract_dblk_kernel(const T *L, long ldl,
   const long j0 = (long)b * D;
   for (int idx = threadIdx.x; idx < D * D; idx += 256) {
     const int i = idx / D, c = idx % D;
-    // lower element (i, c), c <= i
-    T v = (i == c) ? T(1) : T(0);
-    if (c <= i && j0 + i < n) v = L[(j0 + i) * ldl + j0 + c];
-    if (c > i) v = T(0);
+    // strictly lower element (i, c), c < i (zero diagonal, see potf2_kernel)
+    T v = T(0);
+    if (c < i && j0 + i < n) v = L[(j0 + i) * ldl + j0 + c];
     w[idx] = v;
-    // transposed image: Dt[i][c] = D[c][i], nonzero for i <= c
-    T u = (i == c) ? T(1) : T(0);
-    if (i <= c && j0 + c < n) u = L[(j0 + c) * ldl + j0 + i];
-    if (i > c) u = T(0);
+    // transposed image: Dt[i][c] = D[c][i], nonzero for i < c
+    T u = T(0);
+    if (i < c && j0 + c < n) u = L[(j0 + c) * ldl + j0 + i];
     w[D * D + idx] = u;
   }
   if (threadIdx.x < D) {
@@ -178,198 +177,110 @@ __global__ void __launch_bounds__(256) extract_dblk_kernel(const T *L, long ldl,
 // ------------------------------------------------------------------------------------------------
 // Triangular solves with one diagonal block by SUBSTITUTION (backward stable, like LAPACK trsm/trsv; an
 // explicit inverse of the block loses cond(L_jj) * eps, which is fatal for the near-singular ExpQuad
-// Gram matrices the reference's jitter rule is tuned for).  One thread solves one right-hand side of
-// 128 unknowns held in registers; the matrix entries are wave-uniform and come through scalar loads.
-// Right-looking (axpy) form in 8 steps of 16 unknowns: the current 16 always sit in x[0..15]
-// (x[112..127] for the transposed solve), are solved against the 16x16 diagonal sub-block, applied to the
-// remaining unknowns (independent FMAs: the DP pipe stays full with one wave per SIMD), handed to
-// `emit`, and the register array is rotated by 16 -- so the step loop is a RUNTIME loop whose body is
-// ~2000 FMAs instead of an 8128-FMA straight line.
-constexpr int SUBST_NT = 128;   // threads (right-hand sides) per workgroup: 2 waves share one LDS image of the block
-constexpr int SUBST_HALF = LGP_DB / 2;
+// Gram matrices the reference's jitter rule is tuned for).
+//
+// One WAVE solves R = 4 right-hand sides at once; lane l holds unknowns l and 64 + l of each.  Step t
+// (forward: t = 0..127, L x = b, image Dt whose row t is column t of L; transposed: t = 127..0, image D):
+//     y   = x_half * rd_half          (all lanes; lane t&63 now holds the final x_t)
+//     x_t = readlane(y, t & 63)       (wave-uniform, goes to the FMA as a scalar operand)
+//     x  -= M[t][lane] * x_t          (the images have a ZERO diagonal and zeros on the finished side, so
+//                                      finished unknowns keep their unscaled value and no mask is needed)
+// and at the end x * rd is the solution in every lane.  The matrix rows stream straight from L2 (coalesced
+// 512-byte rows, software-prefetched 8 rows ahead); no LDS and ~50 registers, so these waves slot in beside
+// the two trailing-update workgroups resident on every CU and the look-ahead chain never waits for a CU.
+// With 4 independent chains per wave the 32-cycle fp64 latency is covered at any occupancy.
+constexpr int SUBST_R = 4;        // right-hand sides per wave
+constexpr int SUBST_PF = 8;       // matrix rows in flight
 
-// stage 64 rows (row0 .. row0+63) of the 128x128 image `src` into LDS (64 KB for fp64: the kernel must fit
-// beside a 73 KB trailing-update workgroup so that the look-ahead stream is never starved of a CU)
 template <typename T>
-__device__ __forceinline__ void subst_stage(const T *__restrict__ src, int row0, T *sM) {
-  constexpr int D = LGP_DB;
-  constexpr int VEC = 16 / sizeof(T);
-  typedef T vec_t __attribute__((ext_vector_type(VEC)));
-  const vec_t *s = reinterpret_cast<const vec_t *>(src + (long)row0 * D);
-  vec_t *d = reinterpret_cast<vec_t *>(sM);
-  for (int idx = threadIdx.x; idx < SUBST_HALF * D / VEC; idx += SUBST_NT) d[idx] = s[idx];
-}
+__device__ __forceinline__ T readlane_any(T v, int lane) { return readlane_t<T>(v, lane); }
 
-// 16 consecutive matrix entries from LDS into registers (ds_read_b128: all lanes read the same address)
-template <typename T>
-__device__ __forceinline__ void load16(const T *p, T (&m)[16]) {
-  constexpr int VEC = 16 / sizeof(T);
-  typedef T vec_t __attribute__((ext_vector_type(VEC)));
-#pragma unroll
-  for (int i = 0; i < 16 / VEC; ++i) {
-    const vec_t v = reinterpret_cast<const vec_t *>(p)[i];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) m[i * VEC + e] = v[e];
-  }
-}
-
-// xs[XO .. XO+15] -= sum_t M[t][0..15] * piv[PO + t], t = 0..15 (REV: 15..0), M rows `stride` apart in
-// LDS.  Software-pipelined by hand: the rows of steps t+1 and t+2 are already in flight while step t's 16
-// independent FMAs issue (an LDS read takes ~130 cycles, 16 fp64 FMAs 64: two rows ahead covers it).
-template <typename T, bool REV, int XO, int PO, int NX, int NP>
-__device__ __forceinline__ void rank16_update(const T *M, int stride, T (&xs)[NX], const T (&piv)[NP]) {
-  T m[3][16];
-  load16<T>(M + (REV ? 15 : 0) * stride, m[0]);
-  load16<T>(M + (REV ? 14 : 1) * stride, m[1]);
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    if (s + 2 < 16) load16<T>(M + (REV ? 15 - (s + 2) : s + 2) * stride, m[(s + 2) % 3]);
-    const int t = REV ? 15 - s : s;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) xs[XO + e] -= m[s % 3][e] * piv[PO + t];
-  }
-}
-
-constexpr int SUBST_W = 64;   // unknowns held in registers at a time
-
-// Solve the 64 unknowns of one register window against the 64x64 diagonal sub-block whose rows are the
-// staged LDS rows 0..63 and whose columns start at `coff`:  forward (L x = b, image = Dt) or backward
-// (L^T x = b, image = D), 16 unknowns at a time: substitution inside the 16x16 block, rank-16 updates of
-// the window's other groups.
-template <typename T, bool TRANS>
-__device__ __forceinline__ void solve_window(const T *sM, int coff, const T *rdw, T (&xw)[SUBST_W]) {
-  constexpr int D = LGP_DB, S = 16;
-  const T *M0 = sM + coff;
-  if (!TRANS) {
-#define LGP_FWD_GROUP(G)                                                                       \
-  {                                                                                            \
-    const T *Mb = M0 + (G * S) * D + G * S;                                                    \
-    _Pragma("unroll") for (int t = 0; t < S; ++t) {                                            \
-      const T xt = xw[G * S + t] * rdw[G * S + t];                                             \
-      xw[G * S + t] = xt;                                                                      \
-      _Pragma("unroll") for (int c = t + 1; c < S; ++c) xw[G * S + c] -= Mb[t * D + c] * xt;   \
-    }                                                                                          \
-  }
-    LGP_FWD_GROUP(0)
-    rank16_update<T, false, 1 * S, 0 * S>(M0 + (0 * S) * D + 1 * S, D, xw, xw);
-    rank16_update<T, false, 2 * S, 0 * S>(M0 + (0 * S) * D + 2 * S, D, xw, xw);
-    rank16_update<T, false, 3 * S, 0 * S>(M0 + (0 * S) * D + 3 * S, D, xw, xw);
-    LGP_FWD_GROUP(1)
-    rank16_update<T, false, 2 * S, 1 * S>(M0 + (1 * S) * D + 2 * S, D, xw, xw);
-    rank16_update<T, false, 3 * S, 1 * S>(M0 + (1 * S) * D + 3 * S, D, xw, xw);
-    LGP_FWD_GROUP(2)
-    rank16_update<T, false, 3 * S, 2 * S>(M0 + (2 * S) * D + 3 * S, D, xw, xw);
-    LGP_FWD_GROUP(3)
-#undef LGP_FWD_GROUP
-  } else {
-#define LGP_BWD_GROUP(G)                                                                       \
-  {                                                                                            \
-    const T *Mr = M0 + (G * S) * D + G * S;                                                    \
-    _Pragma("unroll") for (int t = S - 1; t >= 0; --t) {                                       \
-      const T xt = xw[G * S + t] * rdw[G * S + t];                                             \
-      xw[G * S + t] = xt;                                                                      \
-      _Pragma("unroll") for (int c = 0; c < t; ++c) xw[G * S + c] -= Mr[t * D + c] * xt;       \
-    }                                                                                          \
-  }
-    LGP_BWD_GROUP(3)
-    rank16_update<T, true, 2 * S, 3 * S>(M0 + (3 * S) * D + 2 * S, D, xw, xw);
-    rank16_update<T, true, 1 * S, 3 * S>(M0 + (3 * S) * D + 1 * S, D, xw, xw);
-    rank16_update<T, true, 0 * S, 3 * S>(M0 + (3 * S) * D + 0 * S, D, xw, xw);
-    LGP_BWD_GROUP(2)
-    rank16_update<T, true, 1 * S, 2 * S>(M0 + (2 * S) * D + 1 * S, D, xw, xw);
-    rank16_update<T, true, 0 * S, 2 * S>(M0 + (2 * S) * D + 0 * S, D, xw, xw);
-    LGP_BWD_GROUP(1)
-    rank16_update<T, true, 0 * S, 1 * S>(M0 + (1 * S) * D + 0 * S, D, xw, xw);
-    LGP_BWD_GROUP(0)
-#undef LGP_BWD_GROUP
-  }
-}
-
-// One right-hand side of 128 unknowns per thread, processed as two register windows of 64 (the kernel
-// must stay below ~270 registers so that its waves can be placed on a SIMD next to a wave of the trailing
-// update: otherwise the look-ahead stream starves).  ld(i) / st(i, v) access unknown i of this thread's
-// right-hand side in memory; the already solved window is re-read from there (L2) 16 values at a time.
 template <typename T, bool TRANS, typename Ld, typename St>
-__device__ __forceinline__ void subst128(const T *__restrict__ w, T *sM, Ld ld, St st) {
-  constexpr int D = LGP_DB, S = 16, W = SUBST_W;
-  T *rd = sM + SUBST_HALF * D;
-  for (int idx = threadIdx.x; idx < D; idx += SUBST_NT) rd[idx] = w[2 * D * D + idx];
-  const T *__restrict__ img = TRANS ? w : w + D * D;   // D for the transposed solve, Dt for the forward one
-  subst_stage<T>(img, TRANS ? SUBST_HALF : 0, sM);
-  __syncthreads();
-  T xw[W];
-#pragma unroll 1
-  for (int win = 0; win < 2; ++win) {
-    const int wbase = (TRANS ? 1 - win : win) * W;       // first unknown of this window
-    const int obase = W - wbase;                         // first unknown of the other (already solved) window
+__device__ __forceinline__ void subst_wave(const T *__restrict__ w, Ld ld, St st) {
+  constexpr int D = LGP_DB, R = SUBST_R, PF = SUBST_PF;
+  const int lane = threadIdx.x & 63;
+  const T *__restrict__ M = TRANS ? w : w + D * D;
+  const T rd0 = w[2 * D * D + lane], rd1 = w[2 * D * D + 64 + lane];
+  T x0[R], x1[R];
 #pragma unroll
-    for (int i = 0; i < W; ++i) xw[i] = ld(wbase + i);
-    if (win == 1) {
-      // contributions of the solved window: staged rows are the solved unknowns, columns this window's
-#pragma unroll 1
-      for (int gg = 0; gg < 4; ++gg) {
-        const int g = TRANS ? 3 - gg : gg;
-        T piv[S];
+  for (int r = 0; r < R; ++r) {
+    x0[r] = ld(r, lane);
+    x1[r] = ld(r, 64 + lane);
+  }
+  // prefetch ring: row of step s lives in slot s % PF
+  T m0[PF], m1[PF];
 #pragma unroll
-        for (int t = 0; t < S; ++t) piv[t] = ld(obase + g * S + t);
-        const T *Mg = sM + (g * S) * D + wbase;
-        rank16_update<T, TRANS, 0 * S, 0>(Mg + 0 * S, D, xw, piv);
-        rank16_update<T, TRANS, 1 * S, 0>(Mg + 1 * S, D, xw, piv);
-        rank16_update<T, TRANS, 2 * S, 0>(Mg + 2 * S, D, xw, piv);
-        rank16_update<T, TRANS, 3 * S, 0>(Mg + 3 * S, D, xw, piv);
+  for (int s = 0; s < PF; ++s) {
+    const int t = TRANS ? D - 1 - s : s;
+    m0[s] = M[t * D + lane];
+    m1[s] = M[t * D + 64 + lane];
+  }
+#pragma unroll 1
+  for (int s0 = 0; s0 < D; s0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int s = s0 + u;
+      const int t = TRANS ? D - 1 - s : s;
+      const T a0 = m0[u], a1 = m1[u];
+      // refill this slot with the row of step s + PF (clamped: the last refills are harmless repeats)
+      {
+        const int sn = (s + PF) < D ? (s + PF) : (D - 1);
+        const int tn = TRANS ? D - 1 - sn : sn;
+        m0[u] = M[tn * D + lane];
+        m1[u] = M[tn * D + 64 + lane];
       }
-      __syncthreads();
-      subst_stage<T>(img, wbase, sM);
-      __syncthreads();
-    }
-    solve_window<T, TRANS>(sM, wbase, rd + wbase, xw);
+      const bool hi = t >= 64;          // wave-uniform
 #pragma unroll
-    for (int i = 0; i < W; ++i) st(wbase + i, xw[i]);
+      for (int r = 0; r < R; ++r) {
+        const T yv = hi ? x1[r] * rd1 : x0[r] * rd0;
+        const T xt = readlane_any<T>(yv, t & 63);
+        // the half on the finished side only sees zeros of the image: skip it (wave-uniform)
+        if (TRANS || !hi) x0[r] -= a0 * xt;
+        if (!TRANS || hi) x1[r] -= a1 * xt;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    st(r, lane, x0[r] * rd0);
+    st(r, 64 + lane, x1[r] * rd1);
   }
 }
 
-// left side: B (jb x nrhs, ld ldb) <- L_jj^-1 B or L_jj^-T B; thread per column (coalesced across lanes).
-// FULL (jb == 128): branch-free body.  Lanes past the last column recompute that column and store the same
-// values to the same addresses, so no lane guard is needed.
-template <typename T, bool TRANS, bool FULL>
-__global__ void __launch_bounds__(SUBST_NT) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(136)))
-subst_left_kernel(const T *__restrict__ w, int jb, T *B, long ldb, int nrhs) {
-  __shared__ __attribute__((aligned(16))) T sM[SUBST_HALF * LGP_DB + LGP_DB];
-  int c = blockIdx.x * SUBST_NT + threadIdx.x;
-  if (c >= nrhs) c = nrhs - 1;
-  T *col = B + c;
-  if (FULL) {
-    subst128<T, TRANS>(
-        w, sM, [&](int i) { return col[(long)i * ldb]; }, [&](int i, T v) { col[(long)i * ldb] = v; });
-  } else {
-    subst128<T, TRANS>(
-        w, sM, [&](int i) { return (i < jb) ? col[(long)i * ldb] : T(0); },
-        [&](int i, T v) {
-          if (i < jb) col[(long)i * ldb] = v;
-        });
-  }
+constexpr int SUBST_NT = 256;     // 4 waves = 16 right-hand sides per workgroup
+
+// left side: B (jb x nrhs, ld ldb) <- L_jj^-1 B or L_jj^-T B; right-hand sides are the columns of B
+template <typename T, bool TRANS>
+__global__ void __launch_bounds__(SUBST_NT) subst_left_kernel(const T *__restrict__ w, int jb, T *B, long ldb, int nrhs) {
+  const int c0 = (blockIdx.x * (SUBST_NT / 64) + (threadIdx.x >> 6)) * SUBST_R;
+  if (c0 >= nrhs) return;     // wave-uniform
+  subst_wave<T, TRANS>(
+      w,
+      [&](int r, int i) {
+        const int c = c0 + r;
+        return (i < jb && c < nrhs) ? B[(long)i * ldb + c] : T(0);
+      },
+      [&](int r, int i, T v) {
+        const int c = c0 + r;
+        if (i < jb && c < nrhs) B[(long)i * ldb + c] = v;
+      });
 }
 
-// right side: X (rows x jb, ld ldx) <- X L_jj^-T, i.e. every row solves L_jj x = b; thread per row
-// (each lane streams its own contiguous row: 16-byte loads, whole 128-byte lines consumed through L1)
-template <typename T, bool FULL>
-__global__ void __launch_bounds__(SUBST_NT) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(136)))
-subst_right_kernel(const T *__restrict__ w, int jb, T *X, long ldx, long rows) {
-  constexpr int D = LGP_DB;
-  __shared__ __attribute__((aligned(16))) T sM[SUBST_HALF * D + D];
-  long r = (long)blockIdx.x * SUBST_NT + threadIdx.x;
-  if (r >= rows) r = rows - 1;
-  T *row = X + r * ldx;
-  if (FULL) {
-    subst128<T, false>(
-        w, sM, [&](int i) { return row[i]; }, [&](int i, T v) { row[i] = v; });
-  } else {
-    subst128<T, false>(
-        w, sM, [&](int i) { return (i < jb) ? row[i] : T(0); },
-        [&](int i, T v) {
-          if (i < jb) row[i] = v;
-        });
-  }
+// right side: X (rows x jb, ld ldx) <- X L_jj^-T, i.e. every row of X solves L_jj x = b (coalesced row access)
+template <typename T>
+__global__ void __launch_bounds__(SUBST_NT) subst_right_kernel(const T *__restrict__ w, int jb, T *X, long ldx, long rows) {
+  const long r0 = ((long)blockIdx.x * (SUBST_NT / 64) + (threadIdx.x >> 6)) * SUBST_R;
+  if (r0 >= rows) return;     // wave-uniform
+  subst_wave<T, false>(
+      w,
+      [&](int r, int i) {
+        const long row = r0 + r;
+        return (i < jb && row < rows) ? X[row * ldx + i] : T(0);
+      },
+      [&](int r, int i, T v) {
+        const long row = r0 + r;
+        if (i < jb && row < rows) X[row * ldx + i] = v;
+      });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -515,9 +426,9 @@ int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t 
     const size_t below = rows - (j0 + jb);
     if (below > 0) {
       T *X = P + (j0 + jb) * ldp + j0;   // below x jb, solved in place: X <- X * L_jj^-T
-      const dim3 gr((unsigned)((below + SUBST_NT - 1) / SUBST_NT)), br(SUBST_NT);
-      if (jb == (size_t)LGP_DB) hipLaunchKernelGGL((subst_right_kernel<T, true>), gr, br, 0, stream, w, (int)jb, X, (long)ldp, (long)below);
-      else hipLaunchKernelGGL((subst_right_kernel<T, false>), gr, br, 0, stream, w, (int)jb, X, (long)ldp, (long)below);
+      constexpr size_t per_wg = (size_t)(SUBST_NT / 64) * SUBST_R;
+      hipLaunchKernelGGL((subst_right_kernel<T>), dim3((unsigned)((below + per_wg - 1) / per_wg)), dim3(SUBST_NT), 0, stream, w, (int)jb, X,
+                         (long)ldp, (long)below);
       LGP_LAUNCH_CHECK();
       const size_t wc = nb - (j0 + jb);
       if (wc > 0) {
@@ -549,48 +460,26 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk) {
     const size_t rows_t = n - t0;
     const T *Pt = L + t0 * ldl + k0;            // rows_t x kb: the panel rows below the diagonal block
     const size_t nb1 = rows_t < NB ? rows_t : NB;  // width of the next panel
-    // s1: wait for panel k0, update the next panel's columns, factor it
+    // s0: update the next panel's block column first (a full-GPU MFMA gemm of its own), then hand it to s1,
+    // whose latency-bound factorisation chain (potf2 / substitution / K=128 updates) runs beside the rest of
+    // the trailing update
+    T *C1 = L + t0 * ldl + t0;                  // rows_t x nb1 block column (lower part)
+    LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_t, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
     LGP_HIP(hipEventRecord(ctx->ev_a, s0));
     LGP_HIP(hipStreamWaitEvent(s1, ctx->ev_a, 0));
-    T *C1 = L + t0 * ldl + t0;                  // rows_t x nb1 block column (lower part)
-    LGP_CHECK(lgp_gemm_launch<T>(ctx, s1, false, true, rows_t, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
     LGP_CHECK(lgp_panel_factor_impl<T>(ctx, s1, rows_t, nb1, C1, ldl, dblk + (t0 / LGP_DB) * (size_t)LGP_DBLK, t0));
     LGP_HIP(hipEventRecord(ctx->ev_b, s1));
-    // s0: rest of the trailing update (columns beyond the next panel), issued as block-column chunks of
-    // roughly equal area.  A single launch would keep every CU's registers and LDS occupied until its
-    // grid drains, and the (few, large-footprint) panel workgroups of s1 would only be placed then; at
-    // each chunk boundary the high-priority stream gets its next kernel in, so the panel chain advances
-    // one kernel per chunk while the chunks keep the other CUs busy.
+    // s0: rest of the trailing update (everything right of the next panel): the N^3/3 flops.  One launch
+    // (splitting it into block-column chunks to give s1 more scheduling points was measured 30 % slower).
     if (rows_t > nb1) {
       const size_t rows_r = rows_t - nb1;
-      const size_t base = t0 + nb1;
-      size_t nch = rows_r / 1024;
-      if (nch > LGP_TRAIL_CHUNKS) nch = LGP_TRAIL_CHUNKS;
-      if (nch < 1) nch = 1;
-      const double total = 0.5 * (double)rows_r * (double)rows_r;
-      size_t c0 = 0;
-      for (size_t ch = 0; ch < nch && c0 < rows_r; ++ch) {
-        size_t c1 = rows_r;
-        if (ch + 1 < nch) {
-          // smallest multiple of 128 such that area(c0, c1) >= total / nch
-          const double want = total / (double)nch;
-          c1 = c0;
-          double area = 0;
-          while (c1 < rows_r && area < want) {
-            c1 += 128;
-            if (c1 > rows_r) c1 = rows_r;
-            area = (double)(c1 - c0) * ((double)rows_r - 0.5 * (double)(c0 + c1));
-          }
-        }
-        const T *Pa = L + (base + c0) * ldl + k0;          // rows below and including the chunk's diagonal
-        T *Cc = L + (base + c0) * ldl + (base + c0);
-        // algorithmic flops of this launch: 2 k per produced entry of the lower trapezoid
-        const double entries = (double)(c1 - c0) * ((double)(rows_r - c0) - 0.5 * (double)(c1 - c0 - 1));
-        LGP_CHECK(lgp_prof_start(ctx, s0, 2.0 * (double)kb * entries));
-        LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r - c0, c1 - c0, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true));
-        LGP_CHECK(lgp_prof_stop(ctx, s0));
-        c0 = c1;
-      }
+      const T *Pa = L + (t0 + nb1) * ldl + k0;          // rows_r x kb
+      T *Cc = L + (t0 + nb1) * ldl + (t0 + nb1);
+      // algorithmic flops of this launch: 2 k per produced entry of the lower triangle
+      const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0);
+      LGP_CHECK(lgp_prof_start(ctx, s0, 2.0 * (double)kb * entries));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true));
+      LGP_CHECK(lgp_prof_stop(ctx, s0));
     }
     LGP_HIP(hipStreamWaitEvent(s0, ctx->ev_b, 0));
   }
@@ -602,31 +491,48 @@ int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t
   if (n == 0 || nrhs == 0) return LGP_OK;
   LGP_REQUIRE(ldl >= n && ldb >= nrhs, "leading dimension too small");
   LGP_REQUIRE(nrhs < (1u << 30), "too many right-hand sides");
-  const size_t nblk = (n + LGP_DB - 1) / LGP_DB;
-  const dim3 gs((unsigned)((nrhs + SUBST_NT - 1) / SUBST_NT)), bs(SUBST_NT);
+  // Two-level blocking.  The chain of dependent steps is one substitution (128 unknowns, a few microseconds)
+  // plus one SMALL gemm that only touches the rest of the current 1024-row outer block; everything below
+  // (above, for the transposed solve) the outer block is updated once per outer block by one deep (K = 1024)
+  // MFMA gemm off the per-block chain.
+  constexpr size_t OB = 1024;
+  constexpr size_t per_wg = (size_t)(SUBST_NT / 64) * SUBST_R;
+  const dim3 gs((unsigned)((nrhs + per_wg - 1) / per_wg)), bs(SUBST_NT);
   if (!trans) {
-    // forward: B_j <- L_jj^-1 B_j (substitution), then B_below -= L[below, j] B_j (MFMA gemm)
-    for (size_t b = 0; b < nblk; ++b) {
-      const size_t j0 = b * LGP_DB, jb = (n - j0) < (size_t)LGP_DB ? (n - j0) : (size_t)LGP_DB;
-      T *Bj = B + j0 * ldb;
-      if (jb == (size_t)LGP_DB) hipLaunchKernelGGL((subst_left_kernel<T, false, true>), gs, bs, 0, stream, dblk + b * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
-      else hipLaunchKernelGGL((subst_left_kernel<T, false, false>), gs, bs, 0, stream, dblk + b * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
-      LGP_LAUNCH_CHECK();
-      const size_t below = n - (j0 + jb);
-      if (below > 0)
-        LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, false, false, below, nrhs, jb, T(-1), L + (j0 + jb) * ldl + j0, ldl, Bj, ldb, T(1),
-                                     B + (j0 + jb) * ldb, ldb, false));
+    // forward: B_j <- L_jj^-1 B_j (substitution), B_below -= L[below, j] B_j (MFMA gemm)
+    for (size_t o0 = 0; o0 < n; o0 += OB) {
+      const size_t o1 = (o0 + OB) < n ? (o0 + OB) : n;
+      for (size_t j0 = o0; j0 < o1; j0 += LGP_DB) {
+        const size_t jb = (o1 - j0) < (size_t)LGP_DB ? (o1 - j0) : (size_t)LGP_DB;
+        T *Bj = B + j0 * ldb;
+        hipLaunchKernelGGL((subst_left_kernel<T, false>), gs, bs, 0, stream, dblk + (j0 / LGP_DB) * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
+        LGP_LAUNCH_CHECK();
+        const size_t in_block = o1 - (j0 + jb);
+        if (in_block > 0)
+          LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, false, false, in_block, nrhs, jb, T(-1), L + (j0 + jb) * ldl + j0, ldl, Bj, ldb, T(1),
+                                       B + (j0 + jb) * ldb, ldb, false));
+      }
+      if (o1 < n)
+        LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, false, false, n - o1, nrhs, o1 - o0, T(-1), L + o1 * ldl + o0, ldl, B + o0 * ldb, ldb, T(1),
+                                     B + o1 * ldb, ldb, false));
     }
   } else {
-    // backward: B_j <- L_jj^-T B_j, then B_above -= L[j, above]^T B_j
-    for (size_t bb = nblk; bb-- > 0;) {
-      const size_t j0 = bb * LGP_DB, jb = (n - j0) < (size_t)LGP_DB ? (n - j0) : (size_t)LGP_DB;
-      T *Bj = B + j0 * ldb;
-      if (jb == (size_t)LGP_DB) hipLaunchKernelGGL((subst_left_kernel<T, true, true>), gs, bs, 0, stream, dblk + bb * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
-      else hipLaunchKernelGGL((subst_left_kernel<T, true, false>), gs, bs, 0, stream, dblk + bb * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
-      LGP_LAUNCH_CHECK();
-      if (j0 > 0)
-        LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, true, false, j0, nrhs, jb, T(-1), L + j0 * ldl, ldl, Bj, ldb, T(1), B, ldb, false));
+    // backward: B_j <- L_jj^-T B_j, B_above -= L[j, above]^T B_j
+    const size_t nob = (n + OB - 1) / OB;
+    for (size_t ob = nob; ob-- > 0;) {
+      const size_t o0 = ob * OB, o1 = (o0 + OB) < n ? (o0 + OB) : n;
+      const size_t nin = (o1 - o0 + LGP_DB - 1) / LGP_DB;
+      for (size_t jj = nin; jj-- > 0;) {
+        const size_t j0 = o0 + jj * LGP_DB, jb = (o1 - j0) < (size_t)LGP_DB ? (o1 - j0) : (size_t)LGP_DB;
+        T *Bj = B + j0 * ldb;
+        hipLaunchKernelGGL((subst_left_kernel<T, true>), gs, bs, 0, stream, dblk + (j0 / LGP_DB) * (size_t)LGP_DBLK, (int)jb, Bj, (long)ldb, (int)nrhs);
+        LGP_LAUNCH_CHECK();
+        if (j0 > o0)   // rows o0 .. j0 of the same outer block
+          LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, true, false, j0 - o0, nrhs, jb, T(-1), L + j0 * ldl + o0, ldl, Bj, ldb, T(1), B + o0 * ldb, ldb,
+                                       false));
+      }
+      if (o0 > 0)      // everything above the outer block: B[0:o0] -= L[o0:o1, 0:o0]^T B[o0:o1]
+        LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, true, false, o0, nrhs, o1 - o0, T(-1), L + o0 * ldl, ldl, B + o0 * ldb, ldb, T(1), B, ldb, false));
     }
   }
   return LGP_OK;

@@ -48,7 +48,7 @@ int main() {
     double *dX; CK(hipMalloc(&dX, rows * 128 * 8)); CK(hipMemset(dX, 0, rows * 128 * 8));
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipEventRecord(e0));
-      subst_right_kernel<double, true><<<(rows + SUBST_NT - 1) / SUBST_NT, SUBST_NT>>>(dW, 128, dX, 128, rows);
+      subst_right_kernel<double><<<(rows + 15) / 16, SUBST_NT>>>(dW, 128, dX, 128, rows);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       CK(hipEventElapsedTime(&ms, e0, e1));
       printf("subst_right rows=%ld: %.1f us\n", rows, ms * 1e3);
