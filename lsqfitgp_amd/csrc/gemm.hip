@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BK = 16;        // K-step; the output tile is TS x TS with TS = 128 (bulk) or 64 (latency-bound small products)
 constexpr int NTHREADS = 256;
 
 template <typename T> struct Mfma;
@@ -48,7 +48,7 @@ template <> struct Mfma<float> {
   static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
   static constexpr int SMK = BK + 4;
 };
-constexpr int SKM = 128 + 16;          // [k][row] image stride (elements)
+template <int TS> struct Skm { static constexpr int value = TS + 16; };   // [k][row] image stride: 2*stride = 32 mod 64
 
 template <typename T>
 struct GemmArgs {
@@ -68,11 +68,13 @@ struct GemmArgs {
 
 // One operand tile: 128 "rows" (m or n index) x BK k-values.
 // TR = false: memory is [row][k] (k contiguous);  TR = true: memory is [k][row] (row contiguous).
-template <typename T, bool TR>
+template <typename T, bool TR, int TS>
 struct Tile {
   static constexpr int VEC = 16 / sizeof(T);
-  static constexpr int NV = 128 * BK / VEC / NTHREADS;
-  static constexpr int IMG = TR ? BK * SKM : 128 * Mfma<T>::SMK;   // elements per LDS image
+  static constexpr int NV = TS * BK / VEC / NTHREADS;
+  static constexpr int SKM = Skm<TS>::value;
+  static constexpr int IMG = TR ? BK * SKM : TS * Mfma<T>::SMK;   // elements per LDS image
+  static_assert(NV >= 1, "tile too small for 256 threads");
   typedef T vec_t __attribute__((ext_vector_type(VEC)));
 
   vec_t reg[NV];
@@ -81,7 +83,7 @@ struct Tile {
     const int t = threadIdx.x;
     if (!TR) {
       constexpr int VPR = BK / VEC;   // vectors per row
-      const bool fast = aligned && (row0 + 128 <= R) && (k0 + BK <= K);
+      const bool fast = aligned && (row0 + TS <= R) && (k0 + BK <= K);
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int v = t + NTHREADS * i;
@@ -96,8 +98,8 @@ struct Tile {
         }
       }
     } else {
-      constexpr int VPR = 128 / VEC;  // vectors per k-row
-      const bool fast = aligned && (row0 + 128 <= R) && (k0 + BK <= K);
+      constexpr int VPR = TS / VEC;  // vectors per k-row
+      const bool fast = aligned && (row0 + TS <= R) && (k0 + BK <= K);
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int v = t + NTHREADS * i;
@@ -125,7 +127,7 @@ struct Tile {
         *reinterpret_cast<vec_t *>(lds + row * Mfma<T>::SMK + kv) = reg[i];
       }
     } else {
-      constexpr int VPR = 128 / VEC;
+      constexpr int VPR = TS / VEC;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int v = t + NTHREADS * i;
@@ -135,9 +137,15 @@ struct Tile {
     }
   }
 
-  // fragment element for MFMA: row index r (0..127), k index kk (0..BK-1)
+  // fragment element for MFMA: row index r (0..TS-1), k index kk (0..BK-1)
+  // volatile: keeps each fragment a separate ds_read_b64.  Left alone, the compiler pairs them into
+  // ds_read2_b64, whose banking (32 banks, 16-lane groups) turns the stride-18 image into a 2-way conflict
+  // (measured: SQ_LDS_BANK_CONFLICT = 40 % of SQ_LDS_IDX_ACTIVE); ds_read_b64 (64 banks, 32-lane groups) is
+  // conflict-free on both images.
   static __device__ __forceinline__ T frag(const T *lds, int r, int kk) {
-    return TR ? lds[kk * SKM + r] : lds[r * Mfma<T>::SMK + kk];
+    typedef const volatile T __attribute__((address_space(3))) * lds_ptr_t;   // explicit LDS address space: a
+    const T *q = TR ? lds + kk * SKM + r : lds + r * Mfma<T>::SMK + kk;       // volatile generic access would
+    return *(lds_ptr_t)(q);                                                   // become a flat_load
   }
 };
 
@@ -173,12 +181,15 @@ __device__ __forceinline__ bool map_tile(int tm, int tn, int nsm, int nsn, int l
   return !(lower && ti < tj);
 }
 
-template <typename T, bool TA, bool TB>
+template <typename T, bool TA, bool TB, int TS>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) {
+  constexpr int BM = TS, BN = TS;
+  constexpr int WT = TS / 2;          // per-wave output tile (2 x 2 waves)
+  constexpr int NF = WT / 16;         // MFMA tiles per wave and dimension: 4 (TS = 128) or 2 (TS = 64)
   // A operand: op(A) is m x k.  TA=false: A stored [m][k] -> Tile<T,false>; TA=true: A stored [k][m] -> Tile<T,true>
   // B operand: op(B) is k x n.  TB=false: B stored [k][n] -> Tile<T,true>;  TB=true: B stored [n][k] -> Tile<T,false>
-  typedef Tile<T, TA> TileA;
-  typedef Tile<T, !TB> TileB;
+  typedef Tile<T, TA, TS> TileA;
+  typedef Tile<T, !TB, TS> TileB;
   typedef typename Mfma<T>::acc_t acc_t;
   constexpr int IMG_A = TileA::IMG, IMG_B = TileB::IMG;
   __shared__ __attribute__((aligned(16))) T lds[2 * IMG_A + 2 * IMG_B];
@@ -188,14 +199,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   const int row0 = ti * BM, col0 = tj * BN;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * WT, wn = (wave & 1) * WT;
   const int fr = lane & 15, fk = lane >> 4;
 
-  acc_t acc[4][4];
+  acc_t acc[NF][NF];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NF; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    for (int j = 0; j < NF; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
   TileA ta;
   TileB tb;
@@ -224,15 +235,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
     const T *lb = ldsB + cur * IMG_B;
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
-      T af[4], bf[4];
+      T af[NF], bf[NF];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = TileA::frag(la, wm + i * 16 + fr, ks + fk);
+      for (int i = 0; i < NF; ++i) af[i] = TileA::frag(la, wm + i * 16 + fr, ks + fk);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = TileB::frag(lb, wn + j * 16 + fr, ks + fk);
+      for (int j = 0; j < NF; ++j) bf[j] = TileB::frag(lb, wn + j * 16 + fr, ks + fk);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < NF; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
     }
     if (more) {
       ta.store(ldsA + (cur ^ 1) * IMG_A);
@@ -248,12 +259,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   T *Cbase = split ? g.Cpart + (long)blockIdx.y * g.m * g.n : g.C;
   const long ldc = split ? (long)g.n : g.ldc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NF; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + wm + i * 16 + Mfma<T>::crow(lane, r);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NF; ++j) {
         const int col = col0 + wn + j * 16 + fr;
         if (interior || (row < g.m && col < g.n && !(g.lower && col > row))) {
           T *p = Cbase + row * ldc + col;
@@ -281,15 +292,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const T *part, int n
 
 }  // namespace
 
-template <typename T>
-int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
-                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower) {
-  if (m == 0 || n == 0) return LGP_OK;
-  LGP_REQUIRE(m < (1u << 30) && n < (1u << 30) && k < (1u << 30), "gemm dimension too large");
-  LGP_REQUIRE(C != nullptr && (k == 0 || (A != nullptr && B != nullptr)), "null matrix pointer");
-  LGP_REQUIRE(ldc >= n, "ldc < n");
-  LGP_REQUIRE(k == 0 || lda >= (ta ? m : k), "lda too small");
-  LGP_REQUIRE(k == 0 || ldb >= (tb ? k : n), "ldb too small");
+template <typename T, int TS>
+static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha, const T *A, size_t lda,
+                          const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower) {
   constexpr size_t VEC = 16 / sizeof(T);
   GemmArgs<T> g;
   g.A = A; g.B = B; g.C = C;
@@ -297,8 +302,8 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   g.m = (int)m; g.n = (int)n; g.k = (int)k;
   g.alpha = alpha; g.beta = beta;
   g.lower = lower ? 1 : 0;
-  g.tm = (int)((m + BM - 1) / BM);
-  g.tn = (int)((n + BN - 1) / BN);
+  g.tm = (int)((m + TS - 1) / TS);
+  g.tn = (int)((n + TS - 1) / TS);
   g.alignedA = ((reinterpret_cast<uintptr_t>(A) % 16) == 0 && (lda % VEC) == 0) ? 1 : 0;
   g.alignedB = ((reinterpret_cast<uintptr_t>(B) % 16) == 0 && (ldb % VEC) == 0) ? 1 : 0;
   size_t grid;
@@ -338,10 +343,10 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
     }
   }
   dim3 gd((unsigned)grid, (unsigned)g.nsplit), bd(NTHREADS);
-  if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true>), gd, bd, 0, stream, g);
-  else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false>), gd, bd, 0, stream, g);
-  else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false>), gd, bd, 0, stream, g);
-  else hipLaunchKernelGGL((gemm_kernel<T, true, true>), gd, bd, 0, stream, g);
+  if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, TS>), gd, bd, 0, stream, g);
+  else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, TS>), gd, bd, 0, stream, g);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false, TS>), gd, bd, 0, stream, g);
+  else hipLaunchKernelGGL((gemm_kernel<T, true, true, TS>), gd, bd, 0, stream, g);
   LGP_LAUNCH_CHECK();
   if (g.nsplit > 1) {
     const long mn = (long)m * (long)n;
@@ -351,6 +356,26 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
     LGP_HIP(hipFreeAsync(g.Cpart, stream));
   }
   return LGP_OK;
+}
+
+template <typename T>
+int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
+                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower) {
+  if (m == 0 || n == 0) return LGP_OK;
+  LGP_REQUIRE(m < (1u << 30) && n < (1u << 30) && k < (1u << 30), "gemm dimension too large");
+  LGP_REQUIRE(C != nullptr && (k == 0 || (A != nullptr && B != nullptr)), "null matrix pointer");
+  LGP_REQUIRE(ldc >= n, "ldc < n");
+  LGP_REQUIRE(k == 0 || lda >= (ta ? m : k), "lda too small");
+  LGP_REQUIRE(k == 0 || ldb >= (tb ? k : n), "ldb too small");
+  // Small outputs sit on the dependent chains of the panel factorisation and of the triangular solves: with
+  // 128x128 tiles they would occupy a handful of CUs for 8+ K-steps of 4096 cycles each; 64x64 tiles quarter
+  // the per-workgroup latency and spread the product over 4x more CUs.  In-place products (C aliasing an
+  // operand) rely on one tile covering the aliased dimension, which the callers guarantee for 128 only.
+  const size_t t128 = ((m + 127) / 128) * ((n + 127) / 128);
+  const bool aliased = (static_cast<const void *>(A) == static_cast<const void *>(C)) || (static_cast<const void *>(B) == static_cast<const void *>(C));
+  if (t128 <= 64 && k <= 2048 && !aliased)
+    return gemm_launch_ts<T, 64>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower);
+  return gemm_launch_ts<T, 128>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower);
 }
 
 template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t,

@@ -380,24 +380,25 @@ __global__ void __launch_bounds__(256) eps_kernel(const T *rows, const T *s, int
 template <typename T>
 __global__ void __launch_bounds__(256) prep_lower_kernel(const T *K, long ldk, int n, int nbx, const T *s, int unit_scale,
                                                          const T *epsp, T *L, long ldl) {
+  // one workgroup per 2048-column segment of a row (grid.x * 256 must stay below 2^32: N = 65536 rows)
   const int i = blockIdx.x / nbx;
-  const int j = (blockIdx.x % nbx) * 256 + threadIdx.x;
-  if (j >= n) return;
-  T v = T(0);
-  if (j <= i) {
-    v = K[(long)i * ldk + j];
-    if (!unit_scale) v = v / s[j] / s[i];
-    if (j == i) v += epsp[0];
+  const int jbeg = (blockIdx.x % nbx) * 2048;
+  for (int j = jbeg + threadIdx.x; j < jbeg + 2048 && j < n; j += 256) {
+    T v = T(0);
+    if (j <= i) {
+      v = K[(long)i * ldk + j];
+      if (!unit_scale) v = v / s[j] / s[i];
+      if (j == i) v += epsp[0];
+    }
+    L[(long)i * ldl + j] = v;
   }
-  L[(long)i * ldl + j] = v;
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) scale_rows_kernel(T *L, long ldl, int n, int nbx, const T *s) {
   const int i = blockIdx.x / nbx;
-  const int j = (blockIdx.x % nbx) * 256 + threadIdx.x;
-  if (j > i || j >= n) return;
-  L[(long)i * ldl + j] *= s[i];
+  const int jbeg = (blockIdx.x % nbx) * 2048;
+  for (int j = jbeg + threadIdx.x; j < jbeg + 2048 && j <= i && j < n; j += 256) L[(long)i * ldl + j] *= s[i];
 }
 
 }  // namespace
@@ -565,7 +566,7 @@ static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T ep
   LGP_LAUNCH_CHECK();
   hipLaunchKernelGGL((eps_kernel<T>), dim3(1), dim3(256), 0, st, rows, s, ni, epsrel, epsabs, flags, stats);
   LGP_LAUNCH_CHECK();
-  const int nbx = (int)((n + 255) / 256);
+  const int nbx = (int)((n + 2047) / 2048);
   hipLaunchKernelGGL((prep_lower_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, st, K, (long)ldk, ni, nbx, s, unit,
                      stats, L, (long)ldl);
   LGP_LAUNCH_CHECK();

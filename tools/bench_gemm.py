@@ -29,10 +29,7 @@ def bench(m, n, k, lower, reps=5, ta=0, tb=1):
         ms = ctx.elapsed_ms(e0, e1); best = min(best, ms)
     flops = 2.0 * m * n * k * (0.5 if lower else 1.0)
     print(f'm={m} n={n} k={k} lower={lower} ta={ta} tb={tb}: {best:.3f} ms  {flops / best / 1e9:.1f} TFLOP/s', flush=True)
-import os
-bench(16384, 16384, 1024, 0)
-bench(30720, 30720, 1024, 1)
-bench(30720, 30720, 1024, 0, reps=3)
-bench(16384, 16384, 4096, 0, reps=3)
-bench(896, 101, 128, 0, ta=0, tb=0)
-bench(30000, 101, 1024, 0, ta=0, tb=0)
+for r in (2048, 4096, 6144, 8192, 12288, 16384, 20480, 24576, 30720):
+    bench(r, r, 1024, 1, reps=3)
+for r in (4096, 16384, 30720):
+    bench(r, 1024, 1024, 1, reps=3)
