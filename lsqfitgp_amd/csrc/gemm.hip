@@ -373,7 +373,7 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   // operand) rely on one tile covering the aliased dimension, which the callers guarantee for 128 only.
   const size_t t128 = ((m + 127) / 128) * ((n + 127) / 128);
   const bool aliased = (static_cast<const void *>(A) == static_cast<const void *>(C)) || (static_cast<const void *>(B) == static_cast<const void *>(C));
-  if (t128 <= 64 && k <= 2048 && !aliased)
+  if (!aliased && ((t128 <= 64 && k <= 2048) || (t128 <= 512 && k <= 256)))
     return gemm_launch_ts<T, 64>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower);
   return gemm_launch_ts<T, 128>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower);
 }
