@@ -107,6 +107,23 @@ def factor_schedule(layout, ops):
     ops.finish()
 
 
+def forward_solve_schedule(layout, ops):
+    """
+    Fan-in forward solve  X = L^-1 W  with L sharded by block columns and W (N x k, k small) replicated:
+    every rank keeps the updates it generates in a local accumulator S (N x k); for block b the pending rows
+    S[rows_b] are summed over the ranks (one small all-reduce of nb x k values), the owner subtracts them,
+    solves with its diagonal block and adds L[below, b] X_b to its accumulator.  X_b stays on owner(b):
+    the quadratic forms that follow are local partial sums plus one all-reduce.  ``ops`` provides
+    ``sum_pending(b)`` (every rank), ``solve_block(b)`` and ``accumulate(b)`` (owner only).
+    """
+    for b in range(layout.nblocks):
+        ops.sum_pending(b)
+        if layout.owner(b) == layout.rank:
+            ops.solve_block(b)
+            if b + 1 < layout.nblocks:
+                ops.accumulate(b)
+
+
 class DeviceOps:
     """ product backend: C-ABI kernels on the local GPU, RCCL broadcasts on the auxiliary stream """
 
@@ -286,3 +303,68 @@ class DistributedChol:
             blk[:w] = numpy.tril(blk[:w])
             out[b] = blk
         return out
+
+
+    # ---- posterior / likelihood on the sharded factor --------------------------------------------------
+
+    def _gemm(self, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc):
+        _lib.check(self.lib.lgp_gemm_f64(self.ctx.handle, int(ta), int(tb), m, n, k, ctypes.c_double(alpha), A, lda, B, ldb,
+                                         ctypes.c_double(beta), C, ldc), 'lgp_gemm')
+
+    def posterior(self, kernel, x, xs, y):
+        """
+        Posterior mean and covariance at ``xs`` and minus-log-density of ``y`` (``_GP/_compute.py:254-260``,
+        ``_linalg/_decomp.py:405-420,484-488``) with the factor sharded over the ranks: W = [Kxxs | y] is built
+        on every rank (the Gram build is O(N M)), the forward solve is `forward_solve_schedule`, and
+        mean = X' x_y, Q = X' X, |x_y|^2 are local partial sums over the owned row blocks + one all-reduce.
+        Every rank returns the same (mean, cov, mlnd).
+        """
+        L, lib, ctx = self.layout, self.lib, self.ctx
+        n, nb = L.n, L.nb
+        xs = numpy.asarray(xs).reshape(-1)
+        m = len(xs)
+        k = m + 1
+        Kxxs = kernel.gram(numpy.asarray(x).reshape(-1), xs, ctx=ctx)
+        Kss = kernel.gram(xs, xs, ctx=ctx)
+        W = DeviceArray.empty((n, k), numpy.float64, ctx)
+        W.block(0, n, 0, m).assign(Kxxs)
+        W.block(0, n, m, k).assign(DeviceArray.from_host(numpy.asarray(y, float).reshape(n, 1), ctx=ctx))
+        S = DeviceArray.zeros((n, k), numpy.float64, ctx)
+        dist = self
+
+        class Ops:
+            def sum_pending(self, b):
+                c0, w = L.col0(b), L.width(b)
+                _lib.check(lib.lgp_allreduce_sum_f64(ctx.handle, S.ptr + c0 * k * 8, w * k), 'lgp_allreduce_sum')
+
+            def solve_block(self, b):
+                c0, w, lb = L.col0(b), L.width(b), L.local_index(b)
+                Wb = W.block(c0, c0 + w, 0, k)
+                Sb = S.block(c0, c0 + w, 0, k)
+                _lib.check(lib.lgp_axpby_f64(ctx.handle, w, k, ctypes.c_double(1.), Wb.ptr, Wb.ld, ctypes.c_double(-1.), Sb.ptr, Sb.ld, Wb.ptr, Wb.ld))
+                D = dist.Lloc.block(c0, c0 + w, lb * nb, lb * nb + w)
+                wsp = dist.dblk.rows(lb * dist.ops.dblk_per_block, (lb + 1) * dist.ops.dblk_per_block)
+                _lib.check(lib.lgp_trsm_f64(ctx.handle, w, D.ptr, D.ld, wsp.ptr, 0, Wb.ptr, Wb.ld, k), 'lgp_trsm')
+
+            def accumulate(self, b):
+                c0, w, lb = L.col0(b), L.width(b), L.local_index(b)
+                below = n - (c0 + w)
+                A = dist.Lloc.block(c0 + w, n, lb * nb, lb * nb + w)
+                Wb = W.block(c0, c0 + w, 0, k)
+                Sbel = S.block(c0 + w, n, 0, k)
+                dist._gemm(False, False, below, k, w, 1., A.ptr, A.ld, Wb.ptr, Wb.ld, 1., Sbel.ptr, Sbel.ld)
+
+        forward_solve_schedule(L, Ops())
+        # local partial sums over the owned (solved) row blocks: [X'X | X'x_y ; . | x_y'x_y] = Xfull' Xfull
+        acc = DeviceArray.zeros((k, k), numpy.float64, ctx)
+        for b in L.owned():
+            c0, w = L.col0(b), L.width(b)
+            Wb = W.block(c0, c0 + w, 0, k)
+            self._gemm(True, False, k, k, w, 1., Wb.ptr, Wb.ld, Wb.ptr, Wb.ld, 1., acc.ptr, acc.ld)
+        _lib.check(lib.lgp_allreduce_sum_f64(ctx.handle, acc.ptr, k * k), 'lgp_allreduce_sum')
+        ctx.sync()
+        G = acc.to_host()
+        mean = G[:m, m].copy()
+        cov = Kss.to_host() - G[:m, :m]
+        mlnd = 0.5 * (n * numpy.log(2 * numpy.pi) + 2 * self.logdet() + G[m, m])
+        return mean, cov, mlnd

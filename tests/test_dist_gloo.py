@@ -152,3 +152,75 @@ def test_schedule_gloo(world, n, nb, tmp_path):
             blk = data[key].copy(); blk[:w] = np.tril(blk[:w])
             full[L.col0(b):, L.col0(b):L.col0(b) + w] = blk
     np.testing.assert_allclose(full, ref, rtol=1e-12, atol=1e-14)
+
+
+# ---- fan-in forward solve ------------------------------------------------------------------------------
+
+class NumpySolveOps:
+    def __init__(self, layout, Lfull, W, dist=None):
+        import torch
+        self.torch, self.dist, self.layout = torch, dist, layout
+        L = layout
+        self.cols = {b: Lfull[:, L.col0(b):L.col0(b) + L.width(b)].copy() for b in L.owned()}
+        self.W = W.copy()
+        self.S = np.zeros_like(W)
+        self.solved = {}
+
+    def sum_pending(self, b):
+        L = self.layout
+        c0, w = L.col0(b), L.width(b)
+        buf = np.ascontiguousarray(self.S[c0:c0 + w])
+        if self.dist is not None:
+            t = self.torch.from_numpy(buf)
+            self.dist.all_reduce(t)
+        self.S[c0:c0 + w] = buf
+
+    def solve_block(self, b):
+        L = self.layout
+        c0, w = L.col0(b), L.width(b)
+        rhs = self.W[c0:c0 + w] - self.S[c0:c0 + w]
+        self.W[c0:c0 + w] = linalg.solve_triangular(self.cols[b][c0:c0 + w], rhs, lower=True)
+        self.solved[b] = self.W[c0:c0 + w].copy()
+
+    def accumulate(self, b):
+        L = self.layout
+        c0, w = L.col0(b), L.width(b)
+        self.S[c0 + w:] += self.cols[b][c0 + w:] @ self.W[c0:c0 + w]
+
+
+def _solve_worker(rank, world, port, n, nb, tmpdir):
+    import torch.distributed as dist
+    from lsqfitgp_amd._dist import forward_solve_schedule
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        K = _matrix(n)
+        Lf = linalg.cholesky(K, lower=True)
+        W = np.random.default_rng(3).standard_normal((n, 5))
+        L = Layout(n, nb, rank, world)
+        ops = NumpySolveOps(L, Lf, W, dist)
+        forward_solve_schedule(L, ops)
+        np.savez(os.path.join(tmpdir, f'solve{rank}.npz'), **{str(b): v for b, v in ops.solved.items()})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n,nb', [(2, 45, 8), (3, 41, 6)])
+def test_forward_solve_gloo(world, n, nb, tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_solve_worker, args=(world, port, n, nb, str(tmp_path)), nprocs=world, join=True)
+    K = _matrix(n)
+    Lf = linalg.cholesky(K, lower=True)
+    W = np.random.default_rng(3).standard_normal((n, 5))
+    ref = linalg.solve_triangular(Lf, W, lower=True)
+    got = np.zeros_like(ref)
+    for rank in range(world):
+        data = np.load(os.path.join(tmp_path, f'solve{rank}.npz'))
+        L = Layout(n, nb, rank, world)
+        for key in data.files:
+            b = int(key)
+            got[L.col0(b):L.col0(b) + L.width(b)] = data[key]
+    np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-13)

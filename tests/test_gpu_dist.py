@@ -74,3 +74,21 @@ def test_rccl_single_rank_communicator(lgp):
     ctx.sync()
     np.testing.assert_array_equal(a.to_host(), np.arange(1000.))
     _lib.check(lib.lgp_comm_destroy(ctx.handle))
+
+
+def test_distributed_posterior_single_rank(lgp, rng):
+    """ fan-in solve + partial quadratic forms on the device backend (one rank) against the oracle """
+    from lsqfitgp_amd._dist import DistributedChol
+    n, m = 1300, 40
+    x = rng.uniform(0, n / 16, n); xs = rng.uniform(0, n / 16, m)
+    y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
+    kern = lgp.ExpQuad()
+    d = DistributedChol(kern, x, noise=0.01, nb=256)
+    mean, cov, mlnd = d.posterior(kern, x, xs, y)
+    go = oracle.GP(oracle.ExpQuad(), checkpos=False, checksym=False).addx(x, 'data').addx(xs, 'test')
+    gc = {('data', 'data'): 0.01 * np.eye(n)}
+    mo, co = go.predfromdata({'data': y}, 'test', gc, raw=True)
+    lo = go.marginal_likelihood({'data': y}, gc)
+    assert np.linalg.norm(mean - mo) <= 1e-8 * np.linalg.norm(mo)
+    assert np.linalg.norm(cov - co, 2) <= 1e-8 * np.linalg.norm(go.prior('test', raw=True), 2)
+    assert abs(-mlnd - lo) <= 1e-8 * abs(lo) + 1e-6
