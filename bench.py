@@ -263,7 +263,12 @@ def main():
     import lsqfitgp_amd as lgp              # fails loudly without the HIP library / a GPU
     cfg = CONFIGS[args.config]
     ctx = lgp.Context(int(os.environ.get('LGP_DEVICE', local_rank)))
-    if args.dist and world > 1:
+    if args.dist:
+        if dist is None:                      # single process: still goes through the sharded code path (1 rank)
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29511')
+            dist.init_process_group('gloo', rank=0, world_size=1)
         return main_dist(args, cfg, ctx, dist, rank, world)
     wl = Workload(cfg, ctx)
     lib, _lib = wl.lib, wl._lib
