@@ -116,7 +116,8 @@ struct Tile {
     }
   }
 
-  __device__ __forceinline__ void store(T *lds) const {
+  // neg: stage -x (sign-bit flip, exact), used to fold alpha = -1 into the operand
+  __device__ __forceinline__ void store(T *lds, bool neg = false) const {
     const int t = threadIdx.x;
     if (!TR) {
       constexpr int VPR = BK / VEC;
@@ -124,7 +125,7 @@ struct Tile {
       for (int i = 0; i < NV; ++i) {
         const int v = t + NTHREADS * i;
         const int row = v / VPR, kv = (v % VPR) * VEC;
-        *reinterpret_cast<vec_t *>(lds + row * Mfma<T>::SMK + kv) = reg[i];
+        *reinterpret_cast<vec_t *>(lds + row * Mfma<T>::SMK + kv) = neg ? -reg[i] : reg[i];
       }
     } else {
       constexpr int VPR = TS / VEC;
@@ -132,7 +133,7 @@ struct Tile {
       for (int i = 0; i < NV; ++i) {
         const int v = t + NTHREADS * i;
         const int kr = v / VPR, rv = (v % VPR) * VEC;
-        *reinterpret_cast<vec_t *>(lds + kr * SKM + rv) = reg[i];
+        *reinterpret_cast<vec_t *>(lds + kr * SKM + rv) = neg ? -reg[i] : reg[i];
       }
     }
   }
@@ -202,12 +203,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   const int wm = (wave >> 1) * WT, wn = (wave & 1) * WT;
   const int fr = lane & 15, fk = lane >> 4;
 
+  // Accumulate-in-place mode (C = C +- A.B, the Cholesky trailing update and the solve updates): the C tile is
+  // loaded straight into the accumulators while the first operand tiles are in flight and alpha = -1 is folded into
+  // the staged A operand, so the epilogue is stores only.  (A read-modify-write epilogue on the same pointer
+  // serialises into 64 dependent global round trips per lane.)
+  const bool interior = (row0 + BM <= g.m) && (col0 + BN <= g.n) && !(g.lower && ti == tj);
+  const bool accinit = g.nsplit <= 1 && g.beta == T(1) && (g.alpha == T(1) || g.alpha == T(-1));
+  const bool negA = accinit && g.alpha == T(-1);
+
   acc_t acc[NF][NF];
 #pragma unroll
   for (int i = 0; i < NF; ++i)
 #pragma unroll
     for (int j = 0; j < NF; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-
   TileA ta;
   TileB tb;
   // K range of this workgroup (split-K slices are multiples of BK, so vector loads stay aligned)
@@ -219,7 +227,35 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   if (nk > 0) {
     ta.load(g.A, g.lda, row0, kbeg, g.m, kend, g.alignedA);
     tb.load(g.B, g.ldb, col0, kbeg, g.n, kend, g.alignedB);
-    ta.store(ldsA);
+  }
+  if (accinit) {
+    if (interior) {   // uniform branch: 16 * NF * NF / 4 independent loads in flight, no per-element control flow
+#pragma unroll
+      for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < NF; ++j)
+            acc[i][j][r] = g.C[(row0 + wm + i * 16 + Mfma<T>::crow(lane, r)) * g.ldc + (col0 + wn + j * 16 + fr)];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + wm + i * 16 + Mfma<T>::crow(lane, r);
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            const int col = col0 + wn + j * 16 + fr;
+            const bool ok = row < g.m && col < g.n && !(g.lower && col > row);
+            const T v = g.C[ok ? row * g.ldc + col : 0];   // clamped address instead of a branch around the load
+            acc[i][j][r] = ok ? v : T(0);
+          }
+        }
+      }
+    }
+  }
+  if (nk > 0) {
+    ta.store(ldsA, negA);
     tb.store(ldsB);
   }
   __syncthreads();
@@ -246,20 +282,42 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
         for (int j = 0; j < NF; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
     }
     if (more) {
-      ta.store(ldsA + (cur ^ 1) * IMG_A);
+      ta.store(ldsA + (cur ^ 1) * IMG_A, negA);
       tb.store(ldsB + (cur ^ 1) * IMG_B);
     }
     __syncthreads();
   }
 
   // epilogue: C = alpha * acc + beta * C   (split-K: raw partial sums into this slice's slab)
-  const bool interior = (row0 + BM <= g.m) && (col0 + BN <= g.n) && !(g.lower && ti == tj);
   const bool split = g.nsplit > 1;
-  const T alpha = split ? T(1) : g.alpha, beta = split ? T(0) : g.beta;
+  const T alpha = (split || accinit) ? T(1) : g.alpha, beta = (split || accinit) ? T(0) : g.beta;
   T *Cbase = split ? g.Cpart + (long)blockIdx.y * g.m * g.n : g.C;
   const long ldc = split ? (long)g.n : g.ldc;
+  if (interior && beta == T(0)) {   // stores only (accumulate-in-place, split-K slabs, beta = 0)
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+          Cbase[(row0 + wm + i * 16 + Mfma<T>::crow(lane, r)) * ldc + (col0 + wn + j * 16 + fr)] = alpha * acc[i][j][r];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
+    T cv[4][NF];   // general beta: all loads of a 16-row band before its stores (same pointer, the compiler must keep order)
+    if (beta != T(0)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + wm + i * 16 + Mfma<T>::crow(lane, r);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const int col = col0 + wn + j * 16 + fr;
+          const bool ok = interior || (row < g.m && col < g.n && !(g.lower && col > row));
+          cv[r][j] = Cbase[ok ? row * ldc + col : 0];   // clamped address instead of a branch around the load
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + wm + i * 16 + Mfma<T>::crow(lane, r);
@@ -267,10 +325,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
       for (int j = 0; j < NF; ++j) {
         const int col = col0 + wn + j * 16 + fr;
         if (interior || (row < g.m && col < g.n && !(g.lower && col > row))) {
-          T *p = Cbase + row * ldc + col;
           T v = alpha * acc[i][j][r];
-          if (beta != T(0)) v += beta * (*p);
-          *p = v;
+          if (beta != T(0)) v += beta * cv[r][j];
+          Cbase[row * ldc + col] = v;
         }
       }
     }
