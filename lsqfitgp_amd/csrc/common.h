@@ -85,7 +85,8 @@ constexpr int LGP_DBLK = 2 * LGP_DB * LGP_DB + LGP_DB;   // per-diagonal-block w
 // (k covers it) before the epilogue -- used by the in-place triangular kernels.
 template <typename T>
 int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
-                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower);
+                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag = 0);
+// tag = 1 launches the separately named instantiation used for the Cholesky trailing update (profiling label only)
 
 // ---- factorisation pieces (potrf.hip) ------------------------------------------------------
 template <typename T>

@@ -27,7 +27,6 @@
 namespace {
 
 constexpr int BK = 16;        // K-step; the output tile is TS x TS with TS = 128 (bulk) or 64 (latency-bound small products)
-constexpr int NTHREADS = 256;
 
 template <typename T> struct Mfma;
 template <> struct Mfma<double> {
@@ -61,6 +60,7 @@ struct GemmArgs {
   int lower;
   int tm, tn;          // tile counts
   int nsm, nsn;        // super-tile counts (0: direct mapping)
+  int nbulk;           // super-tiles mapped XCD-wise (a multiple of 8); the rest is dealt out slot by slot
   int alignedA, alignedB;
   int nsplit, kchunk;  // split-K: blockIdx.y = K slice, partial tiles go to Cpart[slice] (dense m x n), reduced afterwards
   T *Cpart;
@@ -68,7 +68,7 @@ struct GemmArgs {
 
 // One operand tile: 128 "rows" (m or n index) x BK k-values.
 // TR = false: memory is [row][k] (k contiguous);  TR = true: memory is [k][row] (row contiguous).
-template <typename T, bool TR, int TS>
+template <typename T, bool TR, int TS, int NTHREADS>
 struct Tile {
   static constexpr int VEC = 16 / sizeof(T);
   static constexpr int NV = TS * BK / VEC / NTHREADS;
@@ -150,15 +150,26 @@ struct Tile {
   }
 };
 
-__device__ __forceinline__ bool map_tile(int tm, int tn, int nsm, int nsn, int lower, int &ti, int &tj) {
+__device__ __forceinline__ bool map_tile(int tm, int tn, int nsm, int nsn, int nbulk, int lower, int &ti, int &tj) {
   const int bid = blockIdx.x;
   if (nsm == 0) {   // direct map, small grids
     ti = bid / tn;
     tj = bid % tn;
     return !(lower && ti < tj);
   }
-  const int xcd = bid & 7, local = bid >> 3;
-  const int sidx = (local >> 6) * 8 + xcd, slot = local & 63;
+  // bulk: whole super-tiles per XCD, the same number on each.  The remaining (< 8) super-tiles are dealt out slot by
+  // slot over all XCDs, so the last round of a launch is spread over the whole chip instead of leaving the XCDs
+  // without a super-tile idle for a full tile time.
+  int sidx, slot;
+  if (bid < nbulk * 64) {
+    const int xcd = bid & 7, local = bid >> 3;
+    sidx = (local >> 6) * 8 + xcd;
+    slot = local & 63;
+  } else {
+    const int t = bid - nbulk * 64;
+    sidx = nbulk + (t >> 6);
+    slot = t & 63;
+  }
   int I, J;
   if (!lower) {
     if (sidx >= nsm * nsn) return false;
@@ -182,25 +193,30 @@ __device__ __forceinline__ bool map_tile(int tm, int tn, int nsm, int nsn, int l
   return !(lower && ti < tj);
 }
 
-template <typename T, bool TA, bool TB, int TS>
+// NTHREADS = 256: 2 x 2 waves, 64 x 64 (TS = 128) or 32 x 32 (TS = 64) per wave.
+// NTHREADS = 512: 4 x 2 waves, 32 x 64 per wave: half the accumulators per wave, so 4 waves per SIMD instead of 2
+// to cover barrier and LDS latency.
+// TAG only names the instantiation: TAG = 1 is the Cholesky trailing update, so that profilers list it as its own row.
+template <typename T, bool TA, bool TB, int TS, int NTHREADS, int TAG = 0>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) {
   constexpr int BM = TS, BN = TS;
-  constexpr int WT = TS / 2;          // per-wave output tile (2 x 2 waves)
-  constexpr int NF = WT / 16;         // MFMA tiles per wave and dimension: 4 (TS = 128) or 2 (TS = 64)
+  constexpr int WGM = NTHREADS / 128;   // wave grid WGM x 2
+  constexpr int WTM = TS / WGM, WTN = TS / 2;          // per-wave output tile
+  constexpr int NFM = WTM / 16, NFN = WTN / 16;        // MFMA tiles per wave in m and n
   // A operand: op(A) is m x k.  TA=false: A stored [m][k] -> Tile<T,false>; TA=true: A stored [k][m] -> Tile<T,true>
   // B operand: op(B) is k x n.  TB=false: B stored [k][n] -> Tile<T,true>;  TB=true: B stored [n][k] -> Tile<T,false>
-  typedef Tile<T, TA, TS> TileA;
-  typedef Tile<T, !TB, TS> TileB;
+  typedef Tile<T, TA, TS, NTHREADS> TileA;
+  typedef Tile<T, !TB, TS, NTHREADS> TileB;
   typedef typename Mfma<T>::acc_t acc_t;
   constexpr int IMG_A = TileA::IMG, IMG_B = TileB::IMG;
   __shared__ __attribute__((aligned(16))) T lds[2 * IMG_A + 2 * IMG_B];
 
   int ti, tj;
-  if (!map_tile(g.tm, g.tn, g.nsm, g.nsn, g.lower, ti, tj)) return;
+  if (!map_tile(g.tm, g.tn, g.nsm, g.nsn, g.nbulk, g.lower, ti, tj)) return;
   const int row0 = ti * BM, col0 = tj * BN;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * WT, wn = (wave & 1) * WT;
+  const int wm = (wave >> 1) * WTM, wn = (wave & 1) * WTN;
   const int fr = lane & 15, fk = lane >> 4;
 
   // Accumulate-in-place mode (C = C +- A.B, the Cholesky trailing update and the solve updates): the C tile is
@@ -211,11 +227,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   const bool accinit = g.nsplit <= 1 && g.beta == T(1) && (g.alpha == T(1) || g.alpha == T(-1));
   const bool negA = accinit && g.alpha == T(-1);
 
-  acc_t acc[NF][NF];
+  acc_t acc[NFM][NFN];
 #pragma unroll
-  for (int i = 0; i < NF; ++i)
+  for (int i = 0; i < NFM; ++i)
 #pragma unroll
-    for (int j = 0; j < NF; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+    for (int j = 0; j < NFN; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
   TileA ta;
   TileB tb;
   // K range of this workgroup (split-K slices are multiples of BK, so vector loads stay aligned)
@@ -229,22 +245,22 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
     tb.load(g.B, g.ldb, col0, kbeg, g.n, kend, g.alignedB);
   }
   if (accinit) {
-    if (interior) {   // uniform branch: 16 * NF * NF / 4 independent loads in flight, no per-element control flow
+    if (interior) {   // uniform branch: 4 * NFM * NFN independent loads in flight, no per-element control flow
 #pragma unroll
-      for (int i = 0; i < NF; ++i)
+      for (int i = 0; i < NFM; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int j = 0; j < NF; ++j)
+          for (int j = 0; j < NFN; ++j)
             acc[i][j][r] = g.C[(row0 + wm + i * 16 + Mfma<T>::crow(lane, r)) * g.ldc + (col0 + wn + j * 16 + fr)];
     } else {
 #pragma unroll
-      for (int i = 0; i < NF; ++i) {
+      for (int i = 0; i < NFM; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = row0 + wm + i * 16 + Mfma<T>::crow(lane, r);
 #pragma unroll
-          for (int j = 0; j < NF; ++j) {
+          for (int j = 0; j < NFN; ++j) {
             const int col = col0 + wn + j * 16 + fr;
             const bool ok = row < g.m && col < g.n && !(g.lower && col > row);
             const T v = g.C[ok ? row * g.ldc + col : 0];   // clamped address instead of a branch around the load
@@ -271,15 +287,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
     const T *lb = ldsB + cur * IMG_B;
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
-      T af[NF], bf[NF];
+      T af[NFM], bf[NFN];
 #pragma unroll
-      for (int i = 0; i < NF; ++i) af[i] = TileA::frag(la, wm + i * 16 + fr, ks + fk);
+      for (int i = 0; i < NFM; ++i) af[i] = TileA::frag(la, wm + i * 16 + fr, ks + fk);
 #pragma unroll
-      for (int j = 0; j < NF; ++j) bf[j] = TileB::frag(lb, wn + j * 16 + fr, ks + fk);
+      for (int j = 0; j < NFN; ++j) bf[j] = TileB::frag(lb, wn + j * 16 + fr, ks + fk);
 #pragma unroll
-      for (int i = 0; i < NF; ++i)
+      for (int i = 0; i < NFM; ++i)
 #pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < NFN; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
     }
     if (more) {
       ta.store(ldsA + (cur ^ 1) * IMG_A, negA);
@@ -295,23 +311,23 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   const long ldc = split ? (long)g.n : g.ldc;
   if (interior && beta == T(0)) {   // stores only (accumulate-in-place, split-K slabs, beta = 0)
 #pragma unroll
-    for (int i = 0; i < NF; ++i)
+    for (int i = 0; i < NFM; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int j = 0; j < NF; ++j)
+        for (int j = 0; j < NFN; ++j)
           Cbase[(row0 + wm + i * 16 + Mfma<T>::crow(lane, r)) * ldc + (col0 + wn + j * 16 + fr)] = alpha * acc[i][j][r];
     return;
   }
 #pragma unroll
-  for (int i = 0; i < NF; ++i) {
-    T cv[4][NF];   // general beta: all loads of a 16-row band before its stores (same pointer, the compiler must keep order)
+  for (int i = 0; i < NFM; ++i) {
+    T cv[4][NFN];   // general beta: all loads of a 16-row band before its stores (same pointer, the compiler must keep order)
     if (beta != T(0)) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = row0 + wm + i * 16 + Mfma<T>::crow(lane, r);
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
+        for (int j = 0; j < NFN; ++j) {
           const int col = col0 + wn + j * 16 + fr;
           const bool ok = interior || (row < g.m && col < g.n && !(g.lower && col > row));
           cv[r][j] = Cbase[ok ? row * ldc + col : 0];   // clamped address instead of a branch around the load
@@ -322,7 +338,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + wm + i * 16 + Mfma<T>::crow(lane, r);
 #pragma unroll
-      for (int j = 0; j < NF; ++j) {
+      for (int j = 0; j < NFN; ++j) {
         const int col = col0 + wn + j * 16 + fr;
         if (interior || (row < g.m && col < g.n && !(g.lower && col > row))) {
           T v = alpha * acc[i][j][r];
@@ -349,9 +365,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const T *part, int n
 
 }  // namespace
 
-template <typename T, int TS>
+template <typename T, int TS, int NTHREADS>
 static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha, const T *A, size_t lda,
-                          const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower) {
+                          const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag) {
   constexpr size_t VEC = 16 / sizeof(T);
   GemmArgs<T> g;
   g.A = A; g.B = B; g.C = C;
@@ -369,6 +385,7 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
   // few hundred right-hand sides) are 3x faster with the plain row-major map (measured: 30000x101x1024)
   if ((size_t)g.tm * g.tn <= 64 || g.tm < 16 || g.tn < 16 || (map_mode == 0 && !lower)) {
     g.nsm = g.nsn = 0;
+    g.nbulk = 0;
     grid = (size_t)g.tm * g.tn;
   } else {
     g.nsm = (g.tm + 7) / 8;
@@ -381,7 +398,8 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
       nsuper = 0;
       for (int J = 0; J < jmax; ++J) nsuper += (size_t)(g.nsm - J);
     }
-    grid = ((nsuper + 7) / 8) * 8 * 64;
+    g.nbulk = (int)((nsuper / 8) * 8);
+    grid = nsuper * 64;
   }
   LGP_REQUIRE(grid < (1ull << 31), "gemm grid too large");
   // split-K for few-tile, deep-K products (X^T X, X^T y over N rows): deterministic slab reduction
@@ -400,10 +418,11 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
     }
   }
   dim3 gd((unsigned)grid, (unsigned)g.nsplit), bd(NTHREADS);
-  if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, TS>), gd, bd, 0, stream, g);
-  else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, TS>), gd, bd, 0, stream, g);
-  else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false, TS>), gd, bd, 0, stream, g);
-  else hipLaunchKernelGGL((gemm_kernel<T, true, true, TS>), gd, bd, 0, stream, g);
+  if (!ta && tb && tag == 1) hipLaunchKernelGGL((gemm_kernel<T, false, true, TS, NTHREADS, 1>), gd, bd, 0, stream, g);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, TS, NTHREADS>), gd, bd, 0, stream, g);
+  else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, TS, NTHREADS>), gd, bd, 0, stream, g);
+  else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false, TS, NTHREADS>), gd, bd, 0, stream, g);
+  else hipLaunchKernelGGL((gemm_kernel<T, true, true, TS, NTHREADS>), gd, bd, 0, stream, g);
   LGP_LAUNCH_CHECK();
   if (g.nsplit > 1) {
     const long mn = (long)m * (long)n;
@@ -417,7 +436,7 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
 
 template <typename T>
 int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
-                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower) {
+                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag) {
   if (m == 0 || n == 0) return LGP_OK;
   LGP_REQUIRE(m < (1u << 30) && n < (1u << 30) && k < (1u << 30), "gemm dimension too large");
   LGP_REQUIRE(C != nullptr && (k == 0 || (A != nullptr && B != nullptr)), "null matrix pointer");
@@ -431,14 +450,15 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   const size_t t128 = ((m + 127) / 128) * ((n + 127) / 128);
   const bool aliased = (static_cast<const void *>(A) == static_cast<const void *>(C)) || (static_cast<const void *>(B) == static_cast<const void *>(C));
   if (!aliased && ((t128 <= 64 && k <= 2048) || (t128 <= 512 && k <= 256)))
-    return gemm_launch_ts<T, 64>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower);
-  return gemm_launch_ts<T, 128>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower);
+    return gemm_launch_ts<T, 64, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, 0);
+  // (a 512-thread variant, 4 x 2 waves of 32 x 64 at 4 waves per SIMD, was measured equal: 61.3 vs 61.7 TFLOP/s)
+  return gemm_launch_ts<T, 128, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, tag);
 }
 
 template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t,
-                                     const double *, size_t, double, double *, size_t, bool);
+                                     const double *, size_t, double, double *, size_t, bool, int);
 template int lgp_gemm_launch<float>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, float, const float *, size_t,
-                                    const float *, size_t, float, float *, size_t, bool);
+                                    const float *, size_t, float, float *, size_t, bool, int);
 
 extern "C" int lgp_gemm_f64(lgp_ctx *ctx, int ta, int tb, size_t m, size_t n, size_t k, double alpha, const double *dA,
                             size_t lda, const double *dB, size_t ldb, double beta, double *dC, size_t ldc) {

@@ -479,7 +479,7 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk) {
       // algorithmic flops of this launch: 2 k per produced entry of the lower triangle
       const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0);
       LGP_CHECK(lgp_prof_start(ctx, s0, 2.0 * (double)kb * entries));
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 1));
       LGP_CHECK(lgp_prof_stop(ctx, s0));
     }
     LGP_HIP(hipStreamWaitEvent(s0, ctx->ev_b, 0));

@@ -29,7 +29,21 @@ def bench(m, n, k, lower, reps=5, ta=0, tb=1):
         ms = ctx.elapsed_ms(e0, e1); best = min(best, ms)
     flops = 2.0 * m * n * k * (0.5 if lower else 1.0)
     print(f'm={m} n={n} k={k} lower={lower} ta={ta} tb={tb}: {best:.3f} ms  {flops / best / 1e9:.1f} TFLOP/s', flush=True)
-for r in (2048, 4096, 6144, 8192, 12288, 16384, 20480, 24576, 30720):
+import os
+if os.environ.get('QUICK'):
+  for r in (4096, 8192, 16384, 30720):
+    bench(r, r, 1024, 1, reps=3)
+  bench(16384, 16384, 2048, 1, reps=3)
+  bench(16384, 16384, 4096, 1, reps=3)
+  bench(30720, 1024, 1024, 0, reps=3)
+  bench(30720, 128, 1024, 0, reps=3)
+  sys.exit(0)
+if not os.environ.get('SKINNY'):
+  for r in (2048, 4096, 6144, 8192, 12288, 16384, 20480, 24576, 30720):
     bench(r, r, 1024, 1, reps=3)
 for r in (4096, 16384, 30720):
     bench(r, 1024, 1024, 1, reps=3)
+for r in (4096, 16384, 30720):
+    bench(r, 1024, 1024, 0, reps=3)
+    bench(r, 128, 1024, 0, reps=3)
+    bench(r, 2048, 1024, 0, reps=3)
