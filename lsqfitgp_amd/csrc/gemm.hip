@@ -23,6 +23,7 @@
 // affects speed, never results.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -64,7 +65,24 @@ struct GemmArgs {
   int alignedA, alignedB;
   int nsplit, kchunk;  // split-K: blockIdx.y = K slice, partial tiles go to Cpart[slice] (dense m x n), reduced afterwards
   T *Cpart;
+#ifdef LGP_GEMM_TRACE
+  unsigned long long *trace;   // tools/gemm_trace.hip: s_memtime stamps of wave 0 of each traced workgroup
+  int noload;                  // experiment: skip the global loads of the main loop (timing only, wrong results)
+#endif
 };
+
+#ifdef LGP_GEMM_TRACE
+#define LGP_STAMP(slot)                                                                   \
+  do {                                                                                    \
+    if (g.trace && threadIdx.x == 0 && blockIdx.x < 8) {                                  \
+      unsigned long long now_;                                                            \
+      asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");         \
+      g.trace[blockIdx.x * 1024 + (slot)] = now_;                                         \
+    }                                                                                     \
+  } while (0)
+#else
+#define LGP_STAMP(slot) do { } while (0)
+#endif
 
 // One operand tile: 128 "rows" (m or n index) x BK k-values.
 // TR = false: memory is [row][k] (k contiguous);  TR = true: memory is [k][row] (row contiguous).
@@ -78,6 +96,34 @@ struct Tile {
   typedef T vec_t __attribute__((ext_vector_type(VEC)));
 
   vec_t reg[NV];
+  unsigned goff[NV];   // fast path: byte offset of this thread's vectors from the (uniform) tile origin
+
+  // Fast path (interior tile, 16-byte aligned operand, 128 * ld * sizeof(T) < 4 GB): the address is a uniform 64-bit
+  // base that advances with k (scalar ALU) plus a per-thread 32-bit offset that never changes, i.e. the
+  // global_load saddr + voffset form: no vector ALU work per K-step.  An fp64 MFMA stream does not share its SIMD
+  // with other waves' vector instructions (measured with tools/gemm_trace.hip: every non-MFMA VALU instruction of
+  // the loop shows up as idle matrix-core time), so the hot loop is kept free of them.
+  __device__ __forceinline__ void init_fast(long ld) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = t + NTHREADS * i;
+      if (!TR) {
+        constexpr int VPR = BK / VEC;
+        goff[i] = (unsigned)(((long)(v / VPR) * ld + (v % VPR) * VEC) * (long)sizeof(T));
+      } else {
+        constexpr int VPR = TS / VEC;
+        goff[i] = (unsigned)(((long)(v / VPR) * ld + (v % VPR) * VEC) * (long)sizeof(T));
+      }
+    }
+  }
+  __device__ __forceinline__ void load_fast(const char *base) {
+    // raw buffer load: scalar resource (base advanced with s_add) + per-thread 32-bit offset, no address VALU at all
+    typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, -1, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) reg[i] = __builtin_bit_cast(vec_t, (u4_t)__builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[i], 0, 0));
+  }
 
   __device__ __forceinline__ void load(const T *base, long ld, int row0, int k0, int R, int K, bool aligned) {
     const int t = threadIdx.x;
@@ -116,8 +162,7 @@ struct Tile {
     }
   }
 
-  // neg: stage -x (sign-bit flip, exact), used to fold alpha = -1 into the operand
-  __device__ __forceinline__ void store(T *lds, bool neg = false) const {
+  __device__ __forceinline__ void store(T *lds) const {
     const int t = threadIdx.x;
     if (!TR) {
       constexpr int VPR = BK / VEC;
@@ -125,7 +170,7 @@ struct Tile {
       for (int i = 0; i < NV; ++i) {
         const int v = t + NTHREADS * i;
         const int row = v / VPR, kv = (v % VPR) * VEC;
-        *reinterpret_cast<vec_t *>(lds + row * Mfma<T>::SMK + kv) = neg ? -reg[i] : reg[i];
+        *reinterpret_cast<vec_t *>(lds + row * Mfma<T>::SMK + kv) = reg[i];
       }
     } else {
       constexpr int VPR = TS / VEC;
@@ -133,7 +178,7 @@ struct Tile {
       for (int i = 0; i < NV; ++i) {
         const int v = t + NTHREADS * i;
         const int kr = v / VPR, rv = (v % VPR) * VEC;
-        *reinterpret_cast<vec_t *>(lds + kr * SKM + rv) = neg ? -reg[i] : reg[i];
+        *reinterpret_cast<vec_t *>(lds + kr * SKM + rv) = reg[i];
       }
     }
   }
@@ -212,6 +257,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   __shared__ __attribute__((aligned(16))) T lds[2 * IMG_A + 2 * IMG_B];
 
   int ti, tj;
+  LGP_STAMP(0);
   if (!map_tile(g.tm, g.tn, g.nsm, g.nsn, g.nbulk, g.lower, ti, tj)) return;
   const int row0 = ti * BM, col0 = tj * BN;
 
@@ -220,12 +266,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   const int fr = lane & 15, fk = lane >> 4;
 
   // Accumulate-in-place mode (C = C +- A.B, the Cholesky trailing update and the solve updates): the C tile is
-  // loaded straight into the accumulators while the first operand tiles are in flight and alpha = -1 is folded into
-  // the staged A operand, so the epilogue is stores only.  (A read-modify-write epilogue on the same pointer
-  // serialises into 64 dependent global round trips per lane.)
+  // loaded straight into the accumulators while the first operand tiles are in flight, so the epilogue is stores
+  // only.  (A read-modify-write epilogue on the same pointer serialises into 64 dependent global round trips per
+  // lane.)  alpha = -1 costs nothing in the loop: the accumulators start at -C and the epilogue stores -acc.
   const bool interior = (row0 + BM <= g.m) && (col0 + BN <= g.n) && !(g.lower && ti == tj);
   const bool accinit = g.nsplit <= 1 && g.beta == T(1) && (g.alpha == T(1) || g.alpha == T(-1));
-  const bool negA = accinit && g.alpha == T(-1);
+  const bool negC = accinit && g.alpha == T(-1);
 
   acc_t acc[NFM][NFN];
 #pragma unroll
@@ -240,9 +286,26 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   T *ldsA = lds, *ldsB = lds + 2 * IMG_A;
 
+  // whole-tile fast path: both operand tiles inside the matrices, aligned, K range a multiple of BK
+  const bool allfast = g.alignedA && g.alignedB && (row0 + BM <= g.m) && (col0 + BN <= g.n) && ((kend - kbeg) % BK == 0) &&
+                       g.lda < (1l << 21) && g.ldb < (1l << 21);
+  const char *pa = reinterpret_cast<const char *>(TA ? g.A + (long)kbeg * g.lda + row0 : g.A + (long)row0 * g.lda + kbeg);
+  const char *pb = reinterpret_cast<const char *>(!TB ? g.B + (long)kbeg * g.ldb + col0 : g.B + (long)col0 * g.ldb + kbeg);
+  const long stepA = (TA ? (long)BK * g.lda : (long)BK) * (long)sizeof(T);
+  const long stepB = (!TB ? (long)BK * g.ldb : (long)BK) * (long)sizeof(T);
+  if (allfast) {
+    ta.init_fast(g.lda);
+    tb.init_fast(g.ldb);
+  }
+
   if (nk > 0) {
-    ta.load(g.A, g.lda, row0, kbeg, g.m, kend, g.alignedA);
-    tb.load(g.B, g.ldb, col0, kbeg, g.n, kend, g.alignedB);
+    if (allfast) {
+      ta.load_fast(pa);
+      tb.load_fast(pb);
+    } else {
+      ta.load(g.A, g.lda, row0, kbeg, g.m, kend, g.alignedA);
+      tb.load(g.B, g.ldb, col0, kbeg, g.n, kend, g.alignedB);
+    }
   }
   if (accinit) {
     if (interior) {   // uniform branch: 4 * NFM * NFN independent loads in flight, no per-element control flow
@@ -269,19 +332,40 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
         }
       }
     }
+    if (negC) {
+#pragma unroll
+      for (int i = 0; i < NFM; ++i)
+#pragma unroll
+        for (int j = 0; j < NFN; ++j) acc[i][j] = -acc[i][j];
+    }
   }
   if (nk > 0) {
-    ta.store(ldsA, negA);
+    ta.store(ldsA);
     tb.store(ldsB);
   }
   __syncthreads();
+  LGP_STAMP(1);
 
-  for (int t = 0; t < nk; ++t) {
-    const int cur = t & 1;
+  // One K-step with a compile-time LDS buffer index (the loop is unrolled by two), so that every LDS address of
+  // the step is a per-thread constant plus an immediate.
+  auto kstep = [&](auto curc, int t) {
+    constexpr int cur = decltype(curc)::value;
+    LGP_STAMP(4 + 4 * t);
     const bool more = (t + 1) < nk;
+#ifdef LGP_GEMM_TRACE
+    if (more && !g.noload) {
+#else
     if (more) {
-      ta.load(g.A, g.lda, row0, kbeg + (t + 1) * BK, g.m, kend, g.alignedA);
-      tb.load(g.B, g.ldb, col0, kbeg + (t + 1) * BK, g.n, kend, g.alignedB);
+#endif
+      if (allfast) {
+        pa += stepA;
+        pb += stepB;
+        ta.load_fast(pa);
+        tb.load_fast(pb);
+      } else {
+        ta.load(g.A, g.lda, row0, kbeg + (t + 1) * BK, g.m, kend, g.alignedA);
+        tb.load(g.B, g.ldb, col0, kbeg + (t + 1) * BK, g.n, kend, g.alignedB);
+      }
     }
     const T *la = ldsA + cur * IMG_A;
     const T *lb = ldsB + cur * IMG_B;
@@ -297,16 +381,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
 #pragma unroll
         for (int j = 0; j < NFN; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
     }
+    LGP_STAMP(5 + 4 * t);
     if (more) {
-      ta.store(ldsA + (cur ^ 1) * IMG_A, negA);
+      ta.store(ldsA + (cur ^ 1) * IMG_A);
       tb.store(ldsB + (cur ^ 1) * IMG_B);
     }
+    LGP_STAMP(6 + 4 * t);
     __syncthreads();
+    LGP_STAMP(7 + 4 * t);
+  };
+  {
+    int t = 0;
+    for (; t + 2 <= nk; t += 2) {
+      kstep(std::integral_constant<int, 0>{}, t);
+      kstep(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < nk) kstep(std::integral_constant<int, 0>{}, t);
   }
+  LGP_STAMP(2);
 
   // epilogue: C = alpha * acc + beta * C   (split-K: raw partial sums into this slice's slab)
   const bool split = g.nsplit > 1;
-  const T alpha = (split || accinit) ? T(1) : g.alpha, beta = (split || accinit) ? T(0) : g.beta;
+  const T alpha = split ? T(1) : (accinit ? (negC ? T(-1) : T(1)) : g.alpha), beta = (split || accinit) ? T(0) : g.beta;
   T *Cbase = split ? g.Cpart + (long)blockIdx.y * g.m * g.n : g.C;
   const long ldc = split ? (long)g.n : g.ldc;
   if (interior && beta == T(0)) {   // stores only (accumulate-in-place, split-K slabs, beta = 0)
