@@ -1,6 +1,8 @@
 // api.hip -- context, memory, timing, the fused posterior / log-density conveniences and the RCCL
 // plumbing of liblsqfitgp_hip.so.  See include/lsqfitgp_hip.h for the contract of every entry point.
 #include "common.h"
+#include <cstdlib>
+#include <vector>
 #include <dlfcn.h>
 #include <cmath>
 #include <rccl/rccl.h>

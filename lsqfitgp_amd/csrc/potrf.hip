@@ -17,6 +17,11 @@
 // A non-positive or non-finite pivot is recorded in ctx->d_info (first one wins) and the factor goes
 // NaN from there on, like LAPACK-in-jax; the host turns info != 0 into the reference's LinAlgError.
 #include "common.h"
+#include <cstdlib>
+
+#ifndef LGP_CHAIN_PRIO
+#define LGP_CHAIN_PRIO 3
+#endif
 
 namespace {
 
@@ -109,6 +114,10 @@ __global__ void __launch_bounds__(256, 1) potf2_kernel(T *A, long lda, int nb, T
   // to the 73 KB workgroups of the trailing update running on the other stream (look-ahead).
   constexpr int D = LGP_DB;        // 128
   __shared__ T scol[2][D];
+  // This workgroup is the head of the factorisation's dependent chain and shares its CU with two long-running
+  // workgroups of the trailing update; VALU issue is arbitrated by priority, then age, so without this the
+  // (younger) chain waves only get the slots the MFMA streams leave over (3x slower in situ than alone).
+  __builtin_amdgcn_s_setprio(LGP_CHAIN_PRIO);
 
   const int tid = threadIdx.x;
   const int ti = tid & 15, tj = tid >> 4;
@@ -254,6 +263,7 @@ template <typename T, bool TRANS>
 __global__ void __launch_bounds__(SUBST_NT) subst_left_kernel(const T *__restrict__ w, int jb, T *B, long ldb, int nrhs) {
   const int c0 = (blockIdx.x * (SUBST_NT / 64) + (threadIdx.x >> 6)) * SUBST_R;
   if (c0 >= nrhs) return;     // wave-uniform
+  __builtin_amdgcn_s_setprio(LGP_CHAIN_PRIO);   // latency chain next to MFMA streams, see potf2_kernel
   subst_wave<T, TRANS>(
       w,
       [&](int r, int i) {
@@ -271,6 +281,7 @@ template <typename T>
 __global__ void __launch_bounds__(SUBST_NT) subst_right_kernel(const T *__restrict__ w, int jb, T *X, long ldx, long rows) {
   const long r0 = ((long)blockIdx.x * (SUBST_NT / 64) + (threadIdx.x >> 6)) * SUBST_R;
   if (r0 >= rows) return;     // wave-uniform
+  __builtin_amdgcn_s_setprio(LGP_CHAIN_PRIO);   // latency chain next to MFMA streams, see potf2_kernel
   subst_wave<T, false>(
       w,
       [&](int r, int i) {
