@@ -18,7 +18,8 @@ LIBPATH = os.path.join(HERE, LIBNAME)
 UNITS = [
     ('api.hip', []),
     ('gemm.hip', []),
-    ('potrf.hip', []),
+    # accumulators that alternate between MFMA and vector ops stay in VGPRs (no AGPR copies)
+    ('potrf.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form=1']),
     ('elementwise.hip', []),
     # the Gram kernels follow the reference's unfused square-then-add evaluation
     ('gram.hip', ['-ffp-contract=off']),

@@ -75,7 +75,9 @@ struct DeviceGuard {
 // ---- blocked-algorithm geometry -------------------------------------------------------
 constexpr int LGP_DB = 128;    // diagonal block factored (and inverted) by one workgroup
 constexpr int LGP_NB = 1024;    // outer panel width of the right-looking factorisation
-constexpr int LGP_DBLK = 2 * LGP_DB * LGP_DB + LGP_DB;   // per-diagonal-block workspace: D, D^T, 1/diag
+constexpr int LGP_NFRAG = 264;   // MFMA operand fragments of one diagonal block (potrf.hip, pack_frag_kernel), 64 elements each
+constexpr int LGP_FRAG0 = 2 * LGP_DB * LGP_DB + LGP_DB;   // offset of the fragment image inside a block's workspace
+constexpr int LGP_DBLK = LGP_FRAG0 + LGP_NFRAG * 64;   // per-diagonal-block workspace: D, D^T, 1/diag, fragment image
 
 // ---- GEMM (gemm.hip) ---------------------------------------------------------------------
 // C (m x n) = alpha * op(A) op(B) + beta * C, row-major; ta/tb: operand stored transposed.

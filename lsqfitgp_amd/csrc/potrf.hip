@@ -276,22 +276,155 @@ __global__ void __launch_bounds__(SUBST_NT) subst_left_kernel(const T *__restric
       });
 }
 
-// right side: X (rows x jb, ld ldx) <- X L_jj^-T, i.e. every row of X solves L_jj x = b (coalesced row access)
+// ------------------------------------------------------------------------------------------------
+// Right-side substitution on the matrix cores: X (rows x 128) <- X L_jj^-T for the panel rows below a diagonal
+// block.  While the trailing update owns the chip, every vector-ALU instruction of a co-resident wave waits for a
+// 64-cycle fp64 MFMA slot (tools/coexec_probe.hip: the plain substitution above, ~3000 VALU instructions per
+// wave, goes from 61 us alone to 300-430 us), so this kernel is organised to need as few VALU instructions as
+// possible: ~300 per wave for FOUR TIMES the rows.
+//
+// One wave owns 16 rows of X, i.e. 16 columns of Y = X^T (128 x 16), kept in registers as eight 16x16 MFMA
+// accumulator tiles: lane (n = lane & 15, g = lane >> 4), register r of tile c holds unknown 16c + 4r + g of row n.
+// With the rows of L pre-scaled by 1/diag (M = diag^-1 L, unit diagonal) the forward substitution
+//     y_c = x~_c - sum_{i<c} M_ci y_i            (16x16 tiles; x~ = x / diag)
+// is  (a) 4 MFMAs per tile pair (c, i): the accumulator registers of tile i ARE the B operand of k-step s = r
+//         (unknowns 4s + g), the A operand is a 512-byte fragment of -M in lane order, read straight from L2;
+//     (b) inside a diagonal tile, register r (unknowns 4r .. 4r+3, one per lane group) is a 4x4 unit-triangular
+//         solve: 3 x (ds_bpermute broadcast of the finished group + 1 FMA), followed by ONE MFMA that applies the
+//         four finished unknowns to the later registers (A operand masked to those rows).
+// No LDS memory and no address arithmetic: every operand is `fragment base + lane * sizeof(T)` with a scalar
+// fragment offset (raw buffer loads).  pack_frag_kernel lays the fragments out once per diagonal block.
+//
+// Fragment ids (64 elements each, element = lane):
+//   off(c,i,s)  = (c(c-1)/2 + i) * 4 + s     -M[16c + u(n)][16i + 4s + g]                         112 fragments
+//   diag(c,r)   = 112 + 3c + r  (r < 3)      -M[16c + u(n)][16c + 4r + g]  if u(n) >= 4(r+1) else 0   24
+//   coef(c,r,a) = 136 + (4c + r) 3 + a       -M[16c + 4r + g][16c + 4r + a] if g > a else 0            96
+//   rdv(c,r)    = 232 + 4c + r               1 / L[16c + 4r + g][16c + 4r + g]                         32
+// u(n) is the unknown-in-tile that MFMA output row n carries: n for fp64 (row = g + 4r), 4(n & 3) + (n >> 2) for
+// fp32 (row = 4g + r): with it both types share the (g, r) -> unknown 4r + g register map.
 template <typename T>
-__global__ void __launch_bounds__(SUBST_NT) subst_right_kernel(const T *__restrict__ w, int jb, T *X, long ldx, long rows) {
-  const long r0 = ((long)blockIdx.x * (SUBST_NT / 64) + (threadIdx.x >> 6)) * SUBST_R;
+__device__ __forceinline__ int frag_urow(int n) { return sizeof(T) == 8 ? n : 4 * (n & 3) + (n >> 2); }
+
+// one wave per fragment (the fragment id is wave-uniform, so its decoding is scalar work); grid = LGP_NFRAG / 4
+template <typename T>
+__global__ void __launch_bounds__(256) pack_frag_kernel(T *dblk) {
+  constexpr int D = LGP_DB;
+  T *w = dblk;
+  const T *Dl = w;                 // strictly lower block, zero diagonal
+  const T *rd = w + 2 * D * D;
+  T *F = w + LGP_FRAG0;
+  const int f = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (f >= LGP_NFRAG) return;
+  const int l = threadIdx.x & 63, n = l & 15, g = l >> 4;
+  int u, v;          // element (u, v) of -M = -diag^-1 L, or rd[u] for the last group
+  bool live = true;
+  if (f < 112) {
+    const int pair = f >> 2, s = f & 3;
+    int c = 1;
+    while ((c + 1) * c / 2 <= pair) ++c;      // pair = c(c-1)/2 + i, i < c
+    const int i = pair - c * (c - 1) / 2;
+    u = 16 * c + frag_urow<T>(n);
+    v = 16 * i + 4 * s + g;
+  } else if (f < 136) {
+    const int c = (f - 112) / 3, r = (f - 112) % 3, ur = frag_urow<T>(n);
+    live = ur >= 4 * (r + 1);
+    u = 16 * c + ur;
+    v = 16 * c + 4 * r + g;
+  } else if (f < 232) {
+    const int q = (f - 136) / 3, a = (f - 136) % 3, c = q >> 2, r = q & 3;
+    live = g > a;
+    u = 16 * c + 4 * r + g;
+    v = 16 * c + 4 * r + a;
+  } else {
+    const int c = (f - 232) >> 2, r = (f - 232) & 3;
+    u = 16 * c + 4 * r + g;
+    F[f * 64 + l] = rd[u];
+    return;
+  }
+  F[f * 64 + l] = live ? -(Dl[u * D + v] * rd[u]) : T(0);
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(double, (u2_t)__builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+  }
+  static __device__ __forceinline__ double bpermute(int addr, double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)bits), hi = __builtin_amdgcn_ds_bpermute(addr, (int)(bits >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+  }
+};
+template <> struct Mma<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    return __builtin_bit_cast(float, (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+  }
+  static __device__ __forceinline__ float bpermute(int addr, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
+  }
+};
+
+constexpr int SUBSTM_ROWS = 64;   // rows per 256-thread workgroup (16 per wave)
+
+template <typename T>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) subst_right_mfma_kernel(const T *__restrict__ w, int jb, T *X, long ldx, long rows) {
+  typedef typename Mma<T>::acc_t acc_t;
+  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
   if (r0 >= rows) return;     // wave-uniform
-  __builtin_amdgcn_s_setprio(LGP_CHAIN_PRIO);   // latency chain next to MFMA streams, see potf2_kernel
-  subst_wave<T, false>(
-      w,
-      [&](int r, int i) {
-        const long row = r0 + r;
-        return (i < jb && row < rows) ? X[row * ldx + i] : T(0);
-      },
-      [&](int r, int i, T v) {
-        const long row = r0 + r;
-        if (i < jb && row < rows) X[row * ldx + i] = v;
-      });
+  __builtin_amdgcn_s_setprio(LGP_CHAIN_PRIO);
+  const long row = r0 + n;
+  const bool rok = row < rows;
+  T *xrow = X + (rok ? row : r0) * ldx;     // clamped: out-of-range lanes read a valid row and never store
+  const __amdgpu_buffer_rsrc_t frag = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(w + LGP_FRAG0), 0, LGP_NFRAG * 64 * (int)sizeof(T), 0x00020000);
+  const int voff = lane * (int)sizeof(T);
+  auto F = [&](int id) -> T { return Mma<T>::load(frag, voff, id * 64 * (int)sizeof(T)); };
+
+  acc_t t[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = 16 * c + 4 * r + g;
+      t[c][r] = (col < jb) ? xrow[col] : T(0);
+    }
+  int baddr[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) baddr[a] = (a * 16 + n) * 4;
+
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[c][r] *= F(232 + 4 * c + r);            // x~ = x / diag
+#pragma unroll
+    for (int i = 0; i < c; ++i)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) t[c] = Mma<T>::run(F((c * (c - 1) / 2 + i) * 4 + s), t[i][s], t[c]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const T yb = Mma<T>::bpermute(baddr[a], t[c][r]);                 // unknown 4r + a of this row, to every lane group
+        t[c][r] = __builtin_fma(F(136 + (4 * c + r) * 3 + a), yb, t[c][r]);   // zero coefficient for groups <= a
+      }
+      if (r < 3) t[c] = Mma<T>::run(F(112 + 3 * c + r), t[c][r], t[c]);    // finished unknowns -> later registers of the tile
+    }
+  }
+
+  if (rok) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 16 * c + 4 * r + g;
+        if (col < jb) xrow[col] = t[c][r];
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -438,8 +571,9 @@ int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t 
     const size_t below = rows - (j0 + jb);
     if (below > 0) {
       T *X = P + (j0 + jb) * ldp + j0;   // below x jb, solved in place: X <- X * L_jj^-T
-      constexpr size_t per_wg = (size_t)(SUBST_NT / 64) * SUBST_R;
-      hipLaunchKernelGGL((subst_right_kernel<T>), dim3((unsigned)((below + per_wg - 1) / per_wg)), dim3(SUBST_NT), 0, stream, w, (int)jb, X,
+      hipLaunchKernelGGL((pack_frag_kernel<T>), dim3((LGP_NFRAG + 3) / 4), dim3(256), 0, stream, w);
+      LGP_LAUNCH_CHECK();
+      hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((below + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, stream, w, (int)jb, X,
                          (long)ldp, (long)below);
       LGP_LAUNCH_CHECK();
       const size_t wc = nb - (j0 + jb);

@@ -6,9 +6,9 @@
 void lgp_set_error(const char *fmt, ...) {}
 int lgp_prof_start(lgp_ctx *, hipStream_t, double) { return 0; }
 int lgp_prof_stop(lgp_ctx *, hipStream_t) { return 0; }
-template <typename T> int lgp_gemm_launch(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, T, const T *, size_t, const T *, size_t, T, T *, size_t, bool) { return 0; }
-template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t, const double *, size_t, double, double *, size_t, bool);
-template int lgp_gemm_launch<float>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, float, const float *, size_t, const float *, size_t, float, float *, size_t, bool);
+template <typename T> int lgp_gemm_launch(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, T, const T *, size_t, const T *, size_t, T, T *, size_t, bool, int) { return 0; }
+template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t, const double *, size_t, double, double *, size_t, bool, int);
+template int lgp_gemm_launch<float>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, float, const float *, size_t, const float *, size_t, float, float *, size_t, bool, int);
 
 __global__ void clock_probe(unsigned long long *out, int iters) {
   unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -50,7 +50,7 @@ int main() {
     double *dX; CK(hipMalloc(&dX, rows * 128 * 8)); CK(hipMemset(dX, 0, rows * 128 * 8));
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipEventRecord(e0));
-      subst_right_kernel<double><<<(rows + 15) / 16, SUBST_NT>>>(dW, 128, dX, 128, rows);
+      subst_right_mfma_kernel<double><<<(rows + SUBSTM_ROWS - 1) / SUBSTM_ROWS, 256>>>(dW, 128, dX, 128, rows);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       CK(hipEventElapsedTime(&ms, e0, e1));
       printf("subst_right rows=%ld: %.1f us\n", rows, ms * 1e3);
