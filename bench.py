@@ -5,12 +5,13 @@ bench.py -- the hot path of BASELINE.json on MI355X: dense GP fit+predict in fp6
 posterior mean / covariance + log marginal likelihood), through the C-ABI of
 liblsqfitgp_hip.so with every buffer resident in HBM when the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--no-cpu-baseline]
 
 One "step" = one full pass of the path over one batch of synthetic input:
     c2  ExpQuad 1-D, N = 8192,  M = 100, y = sin(x/4) + noise, givencov 0.01 I
     c3  Matern-5/2, 3-D covariates, N = 32768, M = 100, noise 0.01 I      (default at --gpus 1)
     c4  ExpQuad 1-D, N = 65536, M = 100, noise 0.01 I
+    c5  BART p = 10 (fp32 Gram), N = 4096, M = 100, through the GP / BART / Chol host classes
 With --gpus N > 1 (launched by torch.distributed.run, one process per GPU) every rank runs an independent
 replica of the workload on its own GPU ("replicas only" until the block-column distributed factorisation is
 the default) -- no data-path collective; torch.distributed (gloo) is used only for the barrier
@@ -170,6 +171,95 @@ def cpu_baseline(cfg, budget_s=25.0):
                 seconds=t, host_cpus=os.cpu_count())
 
 
+def size_sweep(ctx, main_cfg):
+    """ "vs N" part of BASELINE.json's metric: the same step at smaller sizes and on configuration C2, 1 warmup + 3 timed
+    steps each (a fraction of a second in all); not part of `value` """
+    out = []
+    cases = [dict(CONFIGS['c2'])]
+    for n in (4096, 8192, 16384):
+        if n < main_cfg['n']:
+            c = dict(main_cfg)
+            c['n'] = n
+            c['name'] = f"{main_cfg['kernel']} {main_cfg['d']}-D fp64 N={n} M={main_cfg['m']}"
+            cases.append(c)
+    for c in cases:
+        wl = Workload(c, ctx)
+        wl.step()
+        ctx.sync()
+        evs = [[ctx.event() for _ in range(4)] for _ in range(3)]
+        t0 = time.perf_counter()
+        for k in range(3):
+            wl.step(evs[k])
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / 3
+        ph = np.array([[ctx.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in evs]).mean(axis=0)
+        out.append({'workload': c['name'], 'N': c['n'], 'ms_per_step': dt * 1e3, 'value': flops_fit_predict(c['n'], c['m']) / dt / 1e12,
+                    'cholesky_ms': float(ph[1]), 'cholesky_tflops': (c['n'] ** 3 / 3) / (ph[1] * 1e-3) / 1e12})
+        del wl
+    return out
+
+
+def main_c5(args, ctx):
+    """ configuration C5: the GP that bayestree.bart builds (``bayestree/_bart.py:187-205``) at fixed hyperparameters on
+    synthetic Abalone-like covariates (p = 10, N = 4096 train, M = 100 test), driven through the host classes
+    (``GP`` / ``BART`` / ``Chol``) exactly as a user of the reference would: fp32 BART Gram, fp64 assembly and solve.
+    One step = new GP -> predfromdata(testmean) + marginal_likelihood.  Roofline object: the BART Gram kernel (HBM). """
+    import lsqfitgp_amd as lgp
+    rng = np.random.default_rng(5)
+    n, nt, p = 4096, 100, 10
+    f = np.float32
+    X = np.concatenate([rng.integers(0, 2, (n + nt, 3)), rng.integers(0, 200, (n + nt, 7)) / 200.], axis=1).astype(f)
+    yv = (10 * X[:n, 4] + 3 * X[:n, 0] + rng.standard_normal(n)).astype(f)
+    k_sigma_mu = f((yv.max() - yv.min()) / 2)
+    lam2 = f((k_sigma_mu / f(2)) ** 2)
+    sigma2 = f(np.mean((yv - yv.mean()) ** 2))
+    splits = lgp.BART.splits_from_coord(X[:n])
+    ix = lgp.BART.indices_from_coord(X, splits).astype(np.int32)
+    pts = np.array([tuple(r) for r in ix], dtype=[(f'f{i}', np.int32) for i in range(p)])
+    kern = lgp.BART(splits=(splits[0], None), indices=True, alpha=f(0.95), beta=f(2), gamma=f(1), maxd=10, reset=[2, 4, 6, 8],
+                    weights=np.ones(p, f)) * lam2
+    noise = np.diag(np.full(n, sigma2)).astype(f)
+    given = {'train': yv - f(yv.mean())}
+
+    def step():
+        gp = (lgp.GP(kern, checkpos=False, checksym=False, solver='chol')
+              .addx(pts[:n], 'trainmean').addx(pts[n:], 'testmean')
+              .addcov(noise, 'trainnoise').addcov(np.asarray(k_sigma_mu ** 2, f), 'mean')
+              .addtransf({'trainmean': 1, 'trainnoise': 1, 'mean': 1}, 'train'))
+        mean, cov = gp.predfromdata(given, 'testmean', raw=True)
+        return mean, cov, gp.marginal_likelihood(given, epsrel=0)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    # the BART Gram kernel alone, N x N fp32, HIP events on the context's stream
+    e0, e1 = ctx.event(), ctx.event()
+    kern.gram(pts[:n], pts[:n], ctx=ctx)
+    best = 1e9
+    for _ in range(5):
+        ctx.record(e0)
+        kern.gram(pts[:n], pts[:n], ctx=ctx)
+        ctx.record(e1)
+        best = min(best, ctx.elapsed_ms(e0, e1))
+    gbps = 4. * n * n / (best * 1e-3) / 1e9
+    print(json.dumps({
+        'metric': 'GP fit+predict throughput (Gram build + Cholesky + solves; flops N^3/3 + N^2(M+1) + N M^2)',
+        'value': flops_fit_predict(n, nt) / dt / 1e12, 'unit': 'TFLOP/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 Gram, f64 assembly and solve (as the reference: zero cross blocks are float64)', 'data': 'synthetic',
+        'config': {'workload': 'C5 BART kernel p=10 N=4096 M=100 via GP/BART/Chol host classes (bayestree.bart GP at fixed hyperparameters)',
+                   'N': n, 'M': nt, 'p': p, 'parallelism': 'single GPU'},
+        'log_marginal_likelihood': float(res[2]),
+        'roofline': {'kernel': 'gram_bart_kernel<float> (N x N, includes the host-side per-call setup of kernel.gram)', 'bound': 'hbm',
+                     'achieved': gbps, 'peak': 8000., 'unit': 'GB/s', 'frac': gbps / 8000., 'traffic': None, 'avg_launch_ms': best},
+        'cpu_baseline': None}), flush=True)
+
+
 def pmc_traffic(config):
     """ HBM bytes per trailing-update launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
     x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, collected in their own runs of this same
@@ -243,8 +333,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', choices=sorted(CONFIGS), default='c3')
+    ap.add_argument('--config', choices=sorted(CONFIGS) + ['c5'], default='c3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sweep', action='store_true', help='skip the smaller-N / C2 runs reported under "vs_N"')
     ap.add_argument('--dist', action='store_true', default=os.environ.get('LGP_BENCH_DIST') == '1',
                     help='N > 1: one block-column-cyclic factorisation sharded over the ranks (RCCL panel broadcasts) '
                          'instead of independent replicas')
@@ -261,8 +352,11 @@ def main():
         os.environ.setdefault('LGP_DEVICE', str(local_rank))
 
     import lsqfitgp_amd as lgp              # fails loudly without the HIP library / a GPU
-    cfg = CONFIGS[args.config]
     ctx = lgp.Context(int(os.environ.get('LGP_DEVICE', local_rank)))
+    if args.config == 'c5':
+        lgp.Context._default = ctx
+        return main_c5(args, ctx)
+    cfg = CONFIGS[args.config]
     if args.dist:
         if dist is None:                      # single process: still goes through the sharded code path (1 rank)
             import torch.distributed as dist
@@ -324,6 +418,8 @@ def main():
                        'parallelism': 'single GPU' if world == 1 else f'{world} independent replicas, one per GPU (no collective)'},
             'phases_ms': {'gram': float(phases[0]), 'decomposition': float(phases[1]), 'solves+likelihood': float(phases[2])},
             'cholesky_tflops': (n ** 3 / 3) / (phases[1] * 1e-3) / 1e12,
+            # Gram build against the HBM roofline: bytes written for Kxx, Kxxs, Kxsxs / time of the phase
+            'gram_build': {'bound': 'hbm', 'achieved': 8. * (n * n + n * m + m * m) / (phases[0] * 1e-3) / 1e9, 'peak': 8000., 'unit': 'GB/s'},
             'log_marginal_likelihood': wl.results.get('mll'),
             'roofline': {
                 'kernel': 'gemm_kernel<double,NT> lower (syrk trailing update of the blocked Cholesky, v_mfma_f64_16x16x4_f64)',
@@ -339,6 +435,8 @@ def main():
                 'largest_launch_tflops': (max_fl.value / (max_ms.value * 1e-3) / 1e12) if max_ms.value > 0 else None,
             },
         }
+        if world == 1 and not args.no_sweep:
+            out['vs_N'] = size_sweep(ctx, cfg)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
         else:

@@ -66,6 +66,11 @@ int lgp_copy2d(lgp_ctx *ctx, void *ddst, size_t ldd, const void *dsrc, size_t ld
 int lgp_transpose_f64(lgp_ctx *ctx, double *ddst, size_t ldd, const double *dsrc, size_t lds, size_t rows, size_t cols);
 int lgp_transpose_f32(lgp_ctx *ctx, float *ddst, size_t ldd, const float *dsrc, size_t lds, size_t rows, size_t cols);
 
+/* dst = (type of dst) src, rows x cols: the dtype promotion of mixed-precision block assembly -- the reference's
+ * float32 BART blocks meet float64 zero / noise blocks in jnp.block and tensordot (_GP/_elements.py:332-344,642-649) */
+int lgp_convert_f32_f64(lgp_ctx *ctx, size_t rows, size_t cols, double *ddst, size_t ldd, const float *dsrc, size_t lds);
+int lgp_convert_f64_f32(lgp_ctx *ctx, size_t rows, size_t cols, float *ddst, size_t ldd, const double *dsrc, size_t lds);
+
 /* HIP-event timing on the context's stream (bench.py measures kernels with these) */
 int lgp_event_create(lgp_ctx *ctx, void **event);
 int lgp_event_destroy(lgp_ctx *ctx, void *event);

@@ -95,10 +95,16 @@ def _gemm(ta, tb, A, B, alpha=1., beta=0., C=None):
 
 
 def _astype_dev(A, dtype):
-    """ dtype conversion through the host: only on the rare mixed-precision assembly path """
+    """ dtype conversion on the device (mixed-precision assembly: float32 kernel blocks next to float64 blocks) """
+    dtype = numpy.dtype(dtype)
     if A.dtype == dtype:
         return A
-    return DeviceArray.from_host(A.to_host().astype(dtype), ctx=A.ctx)
+    out = DeviceArray.empty(A.shape, dtype, A.ctx)
+    if A.size:
+        A2, o2 = A.as2d(), out.as2d()
+        name = 'lgp_convert_f32_f64' if dtype == numpy.float64 else 'lgp_convert_f64_f32'
+        _lib.check(getattr(_lib.load(), name)(A.ctx.handle, A2.shape[0], A2.shape[1], o2.ptr, o2.ld, A2.ptr, A2.ld), name)
+    return out
 
 
 class GP:

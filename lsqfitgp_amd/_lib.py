@@ -50,6 +50,8 @@ def _signatures():
         'lgp_upload': (c_int, [c_void_p, _P, c_void_p, _S]),
         'lgp_download': (c_int, [c_void_p, c_void_p, _P, _S]),
         'lgp_copy2d': (c_int, [c_void_p, _P, _S, _P, _S, _S, _S, _S]),
+        'lgp_convert_f32_f64': (c_int, [c_void_p, _S, _S, _P, _S, _P, _S]),
+        'lgp_convert_f64_f32': (c_int, [c_void_p, _S, _S, _P, _S, _P, _S]),
         'lgp_event_create': (c_int, [c_void_p, POINTER(c_void_p)]),
         'lgp_event_destroy': (c_int, [c_void_p, c_void_p]),
         'lgp_event_record': (c_int, [c_void_p, c_void_p]),

@@ -43,6 +43,16 @@ __global__ void __launch_bounds__(256) add_scalar_kernel(size_t rows, size_t col
   }
 }
 
+// dst = (TD) src, rows x cols with leading dimensions (mixed-precision block assembly)
+template <typename TD, typename TS>
+__global__ void __launch_bounds__(256) convert_kernel(size_t rows, size_t cols, TD *dst, size_t ldd, const TS *src, size_t lds) {
+  const size_t nbx = (cols + 255) / 256;
+  for (size_t blk = blockIdx.x; blk < rows * nbx; blk += gridDim.x) {
+    const size_t i = blk / nbx, j = (blk % nbx) * 256 + threadIdx.x;
+    if (j < cols) dst[i * ldd + j] = (TD)src[i * lds + j];
+  }
+}
+
 // 32x32 LDS-tiled transpose: dst (cols x rows) = src^T
 template <typename T>
 __global__ void __launch_bounds__(256) transpose_kernel(T *dst, size_t ldd, const T *src, size_t lds, size_t rows, size_t cols) {
@@ -199,6 +209,17 @@ int add_scalar_impl(lgp_ctx *ctx, size_t rows, size_t cols, T *A, size_t lda, T 
   return LGP_OK;
 }
 
+template <typename TD, typename TS>
+int convert_impl(lgp_ctx *ctx, size_t rows, size_t cols, TD *dst, size_t ldd, const TS *src, size_t lds) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  if (rows == 0 || cols == 0) return LGP_OK;
+  LGP_REQUIRE(dst != nullptr && src != nullptr && ldd >= cols && lds >= cols, "bad matrix");
+  DeviceGuard dg(ctx->device);
+  hipLaunchKernelGGL((convert_kernel<TD, TS>), dim3(grid_for(rows, cols)), dim3(256), 0, ctx->stream, rows, cols, dst, ldd, src, lds);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
 template <typename T>
 int transpose_impl(lgp_ctx *ctx, T *dst, size_t ldd, const T *src, size_t lds, size_t rows, size_t cols) {
   LGP_REQUIRE(ctx != nullptr, "null context");
@@ -337,6 +358,8 @@ int lgp_add_diag_f64(lgp_ctx *c, size_t n, double *A, size_t lda, const double *
 int lgp_add_diag_f32(lgp_ctx *c, size_t n, float *A, size_t lda, const float *v, float a) { return add_diag_impl<float>(c, n, A, lda, v, a); }
 int lgp_add_scalar_f64(lgp_ctx *c, size_t r, size_t n, double *A, size_t lda, double v) { return add_scalar_impl<double>(c, r, n, A, lda, v); }
 int lgp_add_scalar_f32(lgp_ctx *c, size_t r, size_t n, float *A, size_t lda, float v) { return add_scalar_impl<float>(c, r, n, A, lda, v); }
+int lgp_convert_f32_f64(lgp_ctx *c, size_t rows, size_t cols, double *d, size_t ldd, const float *s, size_t lds) { return convert_impl<double, float>(c, rows, cols, d, ldd, s, lds); }
+int lgp_convert_f64_f32(lgp_ctx *c, size_t rows, size_t cols, float *d, size_t ldd, const double *s, size_t lds) { return convert_impl<float, double>(c, rows, cols, d, ldd, s, lds); }
 int lgp_transpose_f64(lgp_ctx *c, double *d, size_t ldd, const double *s, size_t lds, size_t r, size_t n) { return transpose_impl<double>(c, d, ldd, s, lds, r, n); }
 int lgp_transpose_f32(lgp_ctx *c, float *d, size_t ldd, const float *s, size_t lds, size_t r, size_t n) { return transpose_impl<float>(c, d, ldd, s, lds, r, n); }
 int lgp_check_matrix_f64(lgp_ctx *c, size_t r, size_t n, const double *A, size_t lda, int sym, double rtol, double atol, int *f) { return check_impl<double>(c, r, n, A, lda, sym, rtol, atol, f); }

@@ -11,7 +11,7 @@ tag=${2:-r01}
 out=gpurun_out/prof_$cfg
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_stats.json 2> $out/stats.log
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline > $out/bench_fetch.json 2> $out/fetch.log
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline > $out/bench_write.json 2> $out/write.log
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > $out/bench_stats.json 2> $out/stats.log
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-sweep > $out/bench_fetch.json 2> $out/fetch.log
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py --config $cfg --steps 1 --warmup 0 --no-cpu-baseline --no-sweep > $out/bench_write.json 2> $out/write.log
 python3 tools/profile_summarise.py $out $cfg $tag
