@@ -143,6 +143,25 @@ def test_device_operands(lgp, rng):
     util.assert_close_matrices(d.ginv_quad(sub), oracle.Chol(K).ginv_quad(A), rtol=1e-11)
 
 
+def test_convert_dtype(lgp, rng):
+    """ lgp_convert_f32_f64 / f64_f32 on strided views: bit-exact against numpy's casts """
+    from lsqfitgp_amd import _lib
+    lib = _lib.load()
+    ctx = lgp.Context.default()
+    a = rng.standard_normal((37, 300))
+    a[3, 5], a[0, 0], a[36, 299] = np.inf, 1e-50, 3e38
+    src = lgp.DeviceArray.from_host(np.pad(a, ((0, 0), (1, 2)))).block(0, 37, 1, 301)          # ld = 303
+    dst = lgp.DeviceArray.from_host(np.zeros((37, 310), np.float32)).block(0, 37, 4, 304)
+    _lib.check(lib.lgp_convert_f64_f32(ctx.handle, 37, 300, dst.ptr, dst.ld, src.ptr, src.ld))
+    with np.errstate(over='ignore'):
+        np.testing.assert_array_equal(dst.to_host(), a.astype(np.float32))
+    back = lgp.DeviceArray.empty((37, 300))
+    _lib.check(lib.lgp_convert_f32_f64(ctx.handle, 37, 300, back.ptr, back.ld, dst.ptr, dst.ld))
+    with np.errstate(over='ignore'):
+        np.testing.assert_array_equal(back.to_host(), a.astype(np.float32).astype(np.float64))
+    assert lib.lgp_convert_f32_f64(ctx.handle, 2, 8, back.ptr, 4, dst.ptr, dst.ld) < 0      # ld < cols is refused
+
+
 def test_full_size_properties(lgp):
     """ N = 8192 (config C2 size): size-independent properties instead of an O(N^3) CPU recomputation:
     (L L') v == (K + eps) v on random vectors, K^-1 (K v) == v, log-det against the diagonal """
