@@ -182,3 +182,40 @@ def test_full_size_properties(lgp):
     val = d.minus_log_normal_density(KV[:, 0], value=True)[0]
     expected = 0.5 * (n * np.log(2 * np.pi) + 2 * np.sum(np.log(Ldiag)) + KV[:, 0] @ V[:, 0])
     util.assert_allclose(val, expected, rtol=1e-10)
+
+
+def test_full_size_c3_properties(lgp):
+    """ BASELINE configuration C3 at full size (Matern-5/2, 3-D, N = 32768) through size-independent identities:
+    L L^T V = (K + eps I) V with K V formed by an independent device product, K^-1 (K V) = V, and the
+    log-density against its definition from diag(L) and v^T K v """
+    from lsqfitgp_amd import _lib
+    from lsqfitgp_amd._GP import _gemm
+    n = 32768
+    rng = np.random.default_rng(3)
+    pts = np.empty(n, [('f0', float), ('f1', float), ('f2', float)])
+    for f in pts.dtype.names:
+        pts[f] = rng.uniform(0, 16, n)
+    K = lgp.Maternp(p=2, scale=1.).gram(pts, pts)
+    lib = _lib.load()
+    ctx = lgp.Context.default()
+    assert lib.lgp_add_diag_f64(ctx.handle, n, K.ptr, K.ld, None, ctypes.c_double(0.01)) == 0
+    d = lgp.Chol(K)
+    assert 0 < d.eps < 1e-6
+    V = rng.standard_normal((n, 3))
+    KV = _gemm(False, False, K, lgp.DeviceArray.from_host(V)).to_host() + d.eps * V
+    LLV = d.correlate(d.back_correlate(V))
+    util.assert_close_matrices(LLV, KV, rtol=1e-12)
+    util.assert_close_matrices(d.ginv_linear(KV), V, rtol=1e-8)
+    Lf = d.factor()
+    val = d.minus_log_normal_density(KV[:, 0], value=True)[0]
+    # the log-determinant part of the density against its definition from the diagonal of the factor
+    quad = KV[:, 0] @ V[:, 0]
+    logdet = 2 * val - n * np.log(2 * np.pi) - quad
+    full_diag = np.empty(n)
+    for r0 in range(0, n, 4096):          # the diagonal in 8 strips of 4096 x 4096 blocks
+        full_diag[r0:r0 + 4096] = np.diag(Lf.block(r0, r0 + 4096, r0, r0 + 4096).to_host())
+    assert np.all(full_diag > 0)
+    util.assert_allclose(logdet, 2 * np.sum(np.log(full_diag)), rtol=1e-10)
+    # strict upper triangle of the factor is zero (first strip)
+    blk = Lf.block(0, 2048, 0, 4096).to_host()
+    assert np.all(np.triu(blk, 1) == 0)
