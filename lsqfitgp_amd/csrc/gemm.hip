@@ -289,8 +289,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   // whole-tile fast path: both operand tiles inside the matrices, aligned, K range a multiple of BK
   const bool allfast = g.alignedA && g.alignedB && (row0 + BM <= g.m) && (col0 + BN <= g.n) && ((kend - kbeg) % BK == 0) &&
                        g.lda < (1l << 21) && g.ldb < (1l << 21);
-  const char *pa = reinterpret_cast<const char *>(TA ? g.A + (long)kbeg * g.lda + row0 : g.A + (long)row0 * g.lda + kbeg);
-  const char *pb = reinterpret_cast<const char *>(!TB ? g.B + (long)kbeg * g.ldb + col0 : g.B + (long)col0 * g.ldb + kbeg);
+#ifdef LGP_GEMM_TRACE
+  const int lrow0 = g.noload == 2 ? 0 : row0, lcol0 = g.noload == 2 ? 0 : col0;   // experiment: every tile reads the same operand tiles
+#else
+  const int lrow0 = row0, lcol0 = col0;
+#endif
+  const char *pa = reinterpret_cast<const char *>(TA ? g.A + (long)kbeg * g.lda + lrow0 : g.A + (long)lrow0 * g.lda + kbeg);
+  const char *pb = reinterpret_cast<const char *>(!TB ? g.B + (long)kbeg * g.ldb + lcol0 : g.B + (long)lcol0 * g.ldb + kbeg);
   const long stepA = (TA ? (long)BK * g.lda : (long)BK) * (long)sizeof(T);
   const long stepB = (!TB ? (long)BK * g.ldb : (long)BK) * (long)sizeof(T);
   if (allfast) {
@@ -353,7 +358,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
     LGP_STAMP(4 + 4 * t);
     const bool more = (t + 1) < nk;
 #ifdef LGP_GEMM_TRACE
-    if (more && !g.noload) {
+    if (more && g.noload != 1) {
 #else
     if (more) {
 #endif

@@ -23,10 +23,15 @@ int main(int argc, char **argv) {
   if (g.tm >= 16) { g.nsm = g.nsn = (g.tm + 7) / 8; size_t ns = 0; for (int J = 0; J < g.nsm; ++J) ns += g.nsm - J; g.nbulk = (int)(ns / 8 * 8); }
   size_t grid = g.nsm ? 0 : (size_t)g.tm * g.tn;
   if (g.nsm) { size_t ns = 0; for (int J = 0; J < g.nsm; ++J) ns += g.nsm - J; grid = ns * 64; }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipMemset(tr, 0, 8 * 1024 * 8);
+    hipEventRecord(e0, 0);
     hipLaunchKernelGGL((gemm_kernel<double, false, true, 128, 256, 1>), dim3((unsigned)grid), dim3(256), 0, 0, g);
+    hipEventRecord(e1, 0);
     hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("launch %d: %.3f ms (%.1f TFLOP/s with the stamps in)\n", rep, ms, (double)m * (m + 128) * k / ms / 1e9);
   }
   std::vector<unsigned long long> t(8 * 1024);
   hipMemcpy(t.data(), tr, t.size() * 8, hipMemcpyDeviceToHost);
