@@ -1,0 +1,121 @@
+"""
+GPU tests of the MFMA gemm entry points (lgp_gemm_f64/f32, lgp_update_nt_f64) against numpy on the same seeded
+inputs: every transpose combination, accumulate-in-place (alpha = +-1, beta = 1) and general alpha/beta epilogues,
+64- and 128-tile paths, edge tiles, unaligned leading dimensions (general load path), split-K shapes, k = 0,
+and the lower-trapezoid update used by the factorisation (reference: the `@` products of
+src/lsqfitgp/_linalg/_decomp.py:409,420,431,435 and the trailing update inside jlinalg.cholesky, :388).
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lgp():
+    import lsqfitgp_amd
+    lsqfitgp_amd.Context.default()
+    return lsqfitgp_amd
+
+
+def dev_view(lgp, a, pad):
+    """ device copy of `a` embedded in a wider allocation: leading dimension = cols + pad, offset 1 element when pad is odd
+    (16-byte misaligned rows -> the kernel's general load path) """
+    rows, cols = a.shape
+    left = 1 if pad % 2 else 0
+    wide = np.zeros((rows, cols + pad), a.dtype)
+    wide[:, left:left + cols] = a
+    return lgp.DeviceArray.from_host(wide).block(0, rows, left, left + cols)
+
+
+def run_gemm(lgp, ta, tb, alpha, A, B, beta, C, pad=0):
+    from lsqfitgp_amd import _lib
+    lib = _lib.load()
+    ctx = lgp.Context.default()
+    f, F = _lib.fn('lgp_gemm', A.dtype)
+    m = A.shape[1] if ta else A.shape[0]
+    k = A.shape[0] if ta else A.shape[1]
+    n = B.shape[0] if tb else B.shape[1]
+    Ad, Bd, Cd = dev_view(lgp, A, pad), dev_view(lgp, B, pad), dev_view(lgp, C, pad)
+    _lib.check(f(ctx.handle, int(ta), int(tb), m, n, k, F(alpha), Ad.ptr, Ad.ld, Bd.ptr, Bd.ld, F(beta), Cd.ptr, Cd.ld))
+    return Cd.to_host()
+
+
+SHAPES = [(1, 1, 1), (16, 16, 4), (64, 64, 16), (128, 128, 16), (129, 127, 33), (200, 72, 130), (257, 300, 64), (1024, 101, 256),
+          (640, 640, 1024), (96, 1100, 48), (2100, 2050, 40)]
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('m,n,k', SHAPES)
+def test_gemm_shapes(lgp, rng, dtype, ta, tb, m, n, k):
+    tol = 1e-12 if dtype == np.float64 else 2e-5
+    for alpha, beta, pad in [(1., 0., 0), (-1., 1., 0), (1., 1., 4), (0.5, -2., 3), (-1., 1., 1)]:
+        A = rng.standard_normal((k, m) if ta else (m, k)).astype(dtype)
+        B = rng.standard_normal((n, k) if tb else (k, n)).astype(dtype)
+        C = rng.standard_normal((m, n)).astype(dtype)
+        opA = A.T if ta else A
+        opB = B.T if tb else B
+        want = alpha * (opA.astype(float) @ opB.astype(float)) + beta * C.astype(float)
+        got = run_gemm(lgp, ta, tb, alpha, A, B, beta, C, pad)
+        scale = np.abs(opA.astype(float)) @ np.abs(opB.astype(float)) * abs(alpha) + abs(beta) * np.abs(C)
+        assert np.all(np.abs(got - want) <= tol * np.maximum(scale, 1e-300) * max(k, 1) ** 0.5 + 0), (alpha, beta, pad)
+
+
+def test_gemm_beta_zero_ignores_nan_in_c(lgp, rng):
+    A = rng.standard_normal((70, 40)); B = rng.standard_normal((40, 90))
+    C = np.full((70, 90), np.nan)
+    got = run_gemm(lgp, 0, 0, 1., A, B, 0., C)
+    np.testing.assert_allclose(got, A @ B, rtol=1e-12, atol=1e-12)
+
+
+def test_gemm_k_zero(lgp, rng):
+    from lsqfitgp_amd import _lib
+    lib = _lib.load(); ctx = lgp.Context.default()
+    C = rng.standard_normal((33, 45))
+    Cd = lgp.DeviceArray.from_host(C)
+    dummy = lgp.DeviceArray.zeros((1, 1))
+    _lib.check(lib.lgp_gemm_f64(ctx.handle, 0, 0, 33, 45, 0, 1.0, dummy.ptr, 1, dummy.ptr, 45, 2.0, Cd.ptr, Cd.ld))
+    np.testing.assert_allclose(Cd.to_host(), 2 * C, rtol=1e-15)
+
+
+def test_gemm_split_k(lgp, rng):
+    """ few tiles, deep K: the deterministic split-K slab path (X^T X over N rows) """
+    n, m = 20000, 101
+    X = rng.standard_normal((n, m))
+    got = run_gemm(lgp, 1, 0, 1., X, X, 0., np.zeros((m, m)))
+    np.testing.assert_allclose(got, X.T @ X, rtol=1e-11, atol=1e-9)
+    again = run_gemm(lgp, 1, 0, 1., X, X, 0., np.zeros((m, m)))
+    np.testing.assert_array_equal(got, again)          # deterministic reduction order
+
+
+@pytest.mark.parametrize('rows,cols,k', [(300, 300, 128), (1000, 260, 128), (2304, 2304, 1024), (2500, 1024, 1024), (4000, 4000, 200), (130, 5, 7)])
+def test_update_nt_lower(lgp, rng, rows, cols, k):
+    """ C (rows x cols, C(0,0) on the diagonal) -= A B^T on and below the diagonal only; the strict upper part is untouched """
+    from lsqfitgp_amd import _lib
+    lib = _lib.load(); ctx = lgp.Context.default()
+    A = rng.standard_normal((rows, k)); B = rng.standard_normal((cols, k)); C = rng.standard_normal((rows, cols))
+    Ad, Bd, Cd = (lgp.DeviceArray.from_host(v) for v in (A, B, C))
+    _lib.check(lib.lgp_update_nt_f64(ctx.handle, rows, cols, k, Ad.ptr, Ad.ld, Bd.ptr, Bd.ld, Cd.ptr, Cd.ld, 1))
+    got = Cd.to_host()
+    full = C - A @ B.T
+    mask = np.tril(np.ones((rows, cols), bool))
+    np.testing.assert_allclose(got[mask], full[mask], rtol=1e-11, atol=1e-10)
+    np.testing.assert_array_equal(got[~mask], C[~mask])
+    # general (non-lower) form of the same entry point
+    Cd2 = lgp.DeviceArray.from_host(C)
+    _lib.check(lib.lgp_update_nt_f64(ctx.handle, rows, cols, k, Ad.ptr, Ad.ld, Bd.ptr, Bd.ld, Cd2.ptr, Cd2.ld, 0))
+    np.testing.assert_allclose(Cd2.to_host(), full, rtol=1e-11, atol=1e-10)
+
+
+def test_gemm_argument_errors(lgp):
+    from lsqfitgp_amd import _lib
+    lib = _lib.load(); ctx = lgp.Context.default()
+    a = lgp.DeviceArray.zeros((8, 8))
+    assert lib.lgp_gemm_f64(ctx.handle, 0, 0, 8, 8, 8, 1.0, a.ptr, 4, a.ptr, 8, 0.0, a.ptr, 8) < 0     # lda < k
+    assert lib.lgp_gemm_f64(ctx.handle, 0, 0, 8, 8, 8, 1.0, a.ptr, 8, a.ptr, 8, 0.0, a.ptr, 4) < 0     # ldc < n
+    assert lib.lgp_gemm_f64(ctx.handle, 0, 0, 8, 8, 8, 1.0, None, 8, a.ptr, 8, 0.0, a.ptr, 8) < 0      # null operand
+    assert lib.lgp_gemm_f64(None, 0, 0, 8, 8, 8, 1.0, a.ptr, 8, a.ptr, 8, 0.0, a.ptr, 8) < 0           # null context
