@@ -80,9 +80,16 @@ class Workload:
         self.xs = DA.from_host(xs, ctx=ctx)
         self.y = DA.from_host(y.reshape(n, 1), ctx=ctx)
         self.K = DA.empty((n, n), ctx=ctx)           # Kxx + ycov
-        self.L = DA.empty((n, n), ctx=ctx)
+        self.fused = not os.environ.get('LGP_BENCH_SEPARATE_SOLVE')
+        # fused: the factor with m + 1 extra rows [Kxxs | y]^T that the factorisation turns into (L^-1 [Kxxs | y])^T
+        # (m + 1 padded with zero rows to whole 128-row tiles, so that the extra tiles take the kernels' aligned fast path)
+        self.nx = -(-(m + 1) // 128) * 128
+        self.L = DA.empty((n + self.nx, n) if self.fused else (n, n), ctx=ctx)
+        if self.fused:
+            self.L.block(n, n + self.nx, 0, n).fill_zero()
+        self.yrow = DA.from_host(y.reshape(1, n), ctx=ctx)
         self.dblk = DA.empty((self.lib.lgp_chol_dblk_size(n),), ctx=ctx)
-        self.W = DA.empty((n, m + 1), ctx=ctx)       # [Kxxs | y] -> L^-1 [Kxxs | y]
+        self.W = DA.empty((n, m + 1), ctx=ctx)       # separate-solve path: [Kxxs | y] -> L^-1 [Kxxs | y]
         self.Kss = DA.empty((m, m), ctx=ctx)
         self.mean = DA.empty((m,), ctx=ctx)
         self.cov = DA.empty((m, m), ctx=ctx)
@@ -107,15 +114,23 @@ class Workload:
         # ---- Gram build (_GP/_elements.py:575-577): Kxx, Kxxs, Kxsxs; noise on the diagonal (_compute.py:85)
         self._gram(self.x, self.x, self.K)
         ck(lib.lgp_add_diag_f64(ctx.handle, n, self.K.ptr, self.K.ld, None, self.noise), 'add_diag')
-        self._gram(self.x, self.xs, self.W.block(0, n, 0, m))
+        if self.fused:
+            self._gram(self.xs, self.x, self.L.block(n, n + m, 0, n))        # Kxxs^T straight into the extra rows
+            self.L.block(n + m, n + m + 1, 0, n).assign(self.yrow)
+        else:
+            self._gram(self.x, self.xs, self.W.block(0, n, 0, m))
+            self.W.block(0, n, m, m + 1).assign(self.y)
         self._gram(self.xs, self.xs, self.Kss)
-        self.W.block(0, n, m, m + 1).assign(self.y)
         if ev:
             ctx.record(ev[1])
-        # ---- decomposition (_linalg/_decomp.py:380-393)
+        # ---- decomposition (_linalg/_decomp.py:380-393); fused: the forward solve of [Kxxs | y] rides along
         eps = ctypes.c_double()
-        info = ck(lib.lgp_chol_factor_f64(ctx.handle, n, self.K.ptr, self.K.ld, 0., 0., self._lib.LGP_EPS_AUTO_REL,
-                                          self.L.ptr, self.L.ld, self.dblk.ptr, ctypes.byref(eps)), 'chol_factor')
+        if self.fused:
+            info = ck(lib.lgp_chol_factor_rhs_f64(ctx.handle, n, self.K.ptr, self.K.ld, 0., 0., self._lib.LGP_EPS_AUTO_REL,
+                                                  self.L.ptr, self.L.ld, self.nx, self.dblk.ptr, ctypes.byref(eps)), 'chol_factor_rhs')
+        else:
+            info = ck(lib.lgp_chol_factor_f64(ctx.handle, n, self.K.ptr, self.K.ld, 0., 0., self._lib.LGP_EPS_AUTO_REL,
+                                              self.L.ptr, self.L.ld, self.dblk.ptr, ctypes.byref(eps)), 'chol_factor')
         if info != 0:
             raise np.linalg.LinAlgError('cholesky decomposition not finite, probably matrix not pos def numerically')
         if ev:
@@ -123,11 +138,19 @@ class Workload:
         # ---- posterior mean / covariance (_GP/_compute.py:259-260) and log marginal likelihood (:420-422)
         # one forward solve of [Kxxs | y] serves the mean, the covariance and the likelihood
         val = ctypes.c_double()
-        ck(lib.lgp_posterior_f64(ctx.handle, n, m, self.L.ptr, self.L.ld, self.dblk.ptr, self.W.ptr, self.W.ld,
-                                 self.Kss.ptr, self.Kss.ld, self.mean.ptr, self.cov.ptr, self.cov.ld, ctypes.byref(val)), 'posterior')
+        if self.fused:
+            Wt = self.L.block(n, n + m + 1, 0, n)
+            ck(lib.lgp_posterior_solved_f64(ctx.handle, n, m, self.L.ptr, self.L.ld, Wt.ptr, Wt.ld,
+                                            self.Kss.ptr, self.Kss.ld, self.mean.ptr, self.cov.ptr, self.cov.ld, ctypes.byref(val)), 'posterior')
+        else:
+            ck(lib.lgp_posterior_f64(ctx.handle, n, m, self.L.ptr, self.L.ld, self.dblk.ptr, self.W.ptr, self.W.ld,
+                                     self.Kss.ptr, self.Kss.ld, self.mean.ptr, self.cov.ptr, self.cov.ld, ctypes.byref(val)), 'posterior')
         if ev:
             ctx.record(ev[3])
         self.results = dict(eps=eps.value, mll=-val.value)
+
+    def posterior_host(self):
+        return self.mean.to_host(), self.cov.to_host()
 
 
 def cpu_baseline(cfg, budget_s=25.0):

@@ -248,6 +248,21 @@ int lgp_posterior_f64(lgp_ctx *ctx, size_t n, size_t m, const double *dL, size_t
 int lgp_posterior_f32(lgp_ctx *ctx, size_t n, size_t m, const float *dL, size_t ldl, const float *ddblk,
                       float *dW, size_t ldw, const float *dKxsxs, size_t ldk,
                       float *dmean, float *dcov, size_t ldc, float *hmlnd);
+/* The same pass with the forward solve carried through the factorisation.  Chol.__init__ + the L^-1 products of
+ * GPCompute.pred (_linalg/_decomp.py:380-393 + :408,:419,:467): dL has n + nrhs rows; rows n .. n+nrhs-1 hold B^T
+ * (nrhs x n, e.g. [Kxxs | y]^T) on entry and (L^-1 B)^T on exit, L (rows 0..n-1) being exactly the factor that
+ * lgp_chol_factor returns.  The extra rows are "rows below" for every panel of the blocked factorisation, so the
+ * solve is done by its MFMA trailing updates instead of a chain of 2n/128 small triangular kernels. */
+int lgp_chol_factor_rhs_f64(lgp_ctx *ctx, size_t n, const double *dK, size_t ldk, double epsrel, double epsabs, int eps_flags,
+                            double *dL, size_t ldl, size_t nrhs, double *ddblk, double *heps_out);
+int lgp_chol_factor_rhs_f32(lgp_ctx *ctx, size_t n, const float *dK, size_t ldk, float epsrel, float epsabs, int eps_flags,
+                            float *dL, size_t ldl, size_t nrhs, float *ddblk, float *heps_out);
+/* lgp_posterior for right-hand sides solved that way: dWt = (m+1) x n, rows 0..m-1 = (L^-1 Kxxs)^T, row m = (L^-1 y)^T
+ * (typically dL + n * ldl); same outputs as lgp_posterior. */
+int lgp_posterior_solved_f64(lgp_ctx *ctx, size_t n, size_t m, const double *dL, size_t ldl, const double *dWt, size_t ldw,
+                             const double *dKxsxs, size_t ldk, double *dmean, double *dcov, size_t ldc, double *hmlnd);
+int lgp_posterior_solved_f32(lgp_ctx *ctx, size_t n, size_t m, const float *dL, size_t ldl, const float *dWt, size_t ldw,
+                             const float *dKxsxs, size_t ldk, float *dmean, float *dcov, size_t ldc, float *hmlnd);
 /* minus_log_normal_density(r, value=True) (_decomp.py:466-488): 1/2 (n log 2pi + 2 sum log L_ii + |L^-1 r|^2).
  * dr (n) is overwritten with L^-1 r.  Synchronises. */
 int lgp_mlnd_value_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *ddblk,

@@ -115,16 +115,19 @@ class GP:
     kernel object of this package, ``solver`` must be ``'chol'``, the
     ``check*`` flags and ``posepsfac``/``halfmatrix`` keep their meaning, and
     extra keyword arguments (``epsrel``, ``epsabs``) go to the decomposition.
+    ``fuse_solve=True`` (not in the reference) lets `pred` carry ``[Kxxs | y]`` through the factorisation of
+    ``Kxx + ycov`` (`Chol` ``rhs=``) instead of solving afterwards.
     """
 
     DefaultProcess = 'default'
 
     def __init__(self, covfun=None, *, solver='chol', checkpos=True, checksym=True,
-        checkfinite=True, checklin=True, posepsfac=1, halfmatrix=False, ctx=None, **kw):
+        checkfinite=True, checklin=True, posepsfac=1, halfmatrix=False, ctx=None, fuse_solve=False, **kw):
         if covfun is not None and not isinstance(covfun, _kernels.Kernel):
             raise TypeError('covariance function must be a lsqfitgp_amd kernel object')
         self._covfun = covfun
         self._ctx = ctx
+        self._fuse_solve = bool(fuse_solve)
         self._elements = {}        # key -> _Element
         self._covblocks = {}       # (key, key) -> DeviceArray (2d flattened)
         self._decompcache = {}     # tuple of keys -> Decomposition
@@ -137,6 +140,7 @@ class GP:
         assert not (halfmatrix and checksym)
         self._dtype = None
         decomp = self._getdecomp(solver)
+        self._decomptype = decomp
         self._decompclass = lambda K, **kwargs: decomp(K, **kwargs, **kw)
         self._checkpos_cache = []
 
@@ -492,9 +496,10 @@ class GP:
         """ ``_compute.py:424-428`` """
         return {'chol': Chol}[solver]
 
-    def _solver(self, keys, ycov=None, **kw):
+    def _solver(self, keys, ycov=None, rhs_builder=None, **kw):
         """ Decomposition of the covariance of ``keys`` plus ``ycov``
-        (``_compute.py:45-94``): HOT LOOP 2 """
+        (``_compute.py:45-94``): HOT LOOP 2.  ``rhs_builder(dtype)`` (optional) supplies right-hand sides to carry
+        through a factorisation that is not already cached """
         keys = tuple(keys)
         if ycov is None:
             cache = self._decompcache.get(keys)
@@ -506,6 +511,8 @@ class GP:
                 dt = numpy.result_type(ycov.dtype, Kxx.dtype)
                 ycov, Kxx = _astype_dev(ycov, dt), _astype_dev(Kxx, dt)
             Kxx = _axpby(1., Kxx, 1., ycov)                               # Kxx + ycov, :85
+        if rhs_builder is not None:
+            kw = dict(kw, rhs=rhs_builder(Kxx.dtype))
         decomp = self._decompclass(Kxx, **kw)                              # :88
         if ycov is None:
             self._decompcache[keys] = decomp
@@ -598,26 +605,45 @@ class GP:
 
         Kxsxs = self._assemblecovblocks(outkeys)                          # :252
         ycov_dev = None if ycov is None else self._upload_block(ycov)
+        n, m = Kxxs.shape
+        built = {}
+
+        def build_rhs(dtype):
+            # W = [Kxxs | y]; one forward solve serves mean and covariance (:259-260)
+            W = DeviceArray.empty((n, m + 1), dtype, self.ctx)
+            W.block(0, n, 0, m).assign(_astype_dev(Kxxs, dtype))
+            W.block(0, n, m, m + 1).assign(DeviceArray.from_host(ymean.reshape(n, 1), dtype=dtype, ctx=self.ctx))
+            built['W'] = W
+            return W
+
+        # fuse_solve=True (extension, off by default): a factorisation that is computed for this call only (ycov
+        # given: never cached, :55-58) carries W through it and the solve is free.  It is opt-in because it rounds
+        # differently from the separate solve, and the reference pins "zero givencov == no givencov" and "cache hit ==
+        # first call" bit for bit (tests/GP/test_GP.py:587-596,652-660).
+        carry = build_rhs if (self._fuse_solve and issubclass(self._decomptype, Chol) and fromdata and ycov_dev is not None) else None
         if fromdata:
-            solver = self._solver(inkeys, ycov_dev)                       # :255
+            solver = self._solver(inkeys, ycov_dev, rhs_builder=carry)   # :255
         else:
             solver = self._solver(inkeys)
 
         dtype = solver._dtype
-        n, m = Kxxs.shape
-        # W = [Kxxs | y]; one forward solve serves mean and covariance (:259-260)
-        W = DeviceArray.empty((n, m + 1), dtype, self.ctx)
-        W.block(0, n, 0, m).assign(_astype_dev(Kxxs, dtype))
-        W.block(0, n, m, m + 1).assign(DeviceArray.from_host(ymean.reshape(n, 1), dtype=dtype, ctx=self.ctx))
         mean_d = DeviceArray.empty((m,), dtype, self.ctx)
         cov_d = DeviceArray.empty((m, m), dtype, self.ctx)
         Kss = _astype_dev(Kxsxs, dtype)
-        f, _ = _lib.fn('lgp_posterior', dtype)
-        _lib.check(f(self.ctx.handle, n, m, solver._L.ptr, solver._L.ld, solver._dblk.ptr, W.ptr, W.ld,
-                     Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld, None), 'lgp_posterior')
+        carried = 'W' in built and getattr(solver, '_solved_for', None) is built['W']
+        if carried:
+            Wt = solver._solved                                           # (m + 1, n) = (L^-1 [Kxxs | y])^T
+            f, _ = _lib.fn('lgp_posterior_solved', dtype)
+            _lib.check(f(self.ctx.handle, n, m, solver._L.ptr, solver._L.ld, Wt.ptr, Wt.ld,
+                         Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld, None), 'lgp_posterior_solved')
+        else:
+            W = build_rhs(dtype)
+            f, _ = _lib.fn('lgp_posterior', dtype)
+            _lib.check(f(self.ctx.handle, n, m, solver._L.ptr, solver._L.ld, solver._dblk.ptr, W.ptr, W.ld,
+                         Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld, None), 'lgp_posterior')
         if not fromdata and ycov_dev is not None:
             # cov += A' ycov A, A = K^-1 Kxxs = L^-T (L^-1 Kxxs)             (:262-269)
-            A = W.block(0, n, 0, m).copy()
+            A = solver._solved.block(0, m, 0, n).transpose() if carried else W.block(0, n, 0, m).copy()
             solver._trsm(A, 1)
             yA = _gemm(False, False, _astype_dev(ycov_dev, dtype), A)
             _gemm(True, False, A, yA, 1., 1., cov_d)

@@ -91,6 +91,7 @@ def _signatures():
             'lgp_add_scalar_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, F]),
             'lgp_check_matrix_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, c_int, F, F, POINTER(c_int)]),
             'lgp_chol_factor_' + suf: (c_int, [c_void_p, _S, _P, _S, F, F, c_int, _P, _S, _P, POINTER(F)]),
+            'lgp_chol_factor_rhs_' + suf: (c_int, [c_void_p, _S, _P, _S, F, F, c_int, _P, _S, _S, _P, POINTER(F)]),
             'lgp_potrf_' + suf: (c_int, [c_void_p, _S, _P, _S, _P]),
             'lgp_trsm_' + suf: (c_int, [c_void_p, _S, _P, _S, _P, c_int, _P, _S, _S]),
             'lgp_gemm_' + suf: (c_int, [c_void_p, c_int, c_int, _S, _S, _S, F, _P, _S, _P, _S, F, _P, _S]),
@@ -98,6 +99,7 @@ def _signatures():
             'lgp_logdet_diag_' + suf: (c_int, [c_void_p, _S, _P, _S, POINTER(F)]),
             'lgp_dot_' + suf: (c_int, [c_void_p, _S, _P, _P, POINTER(F)]),
             'lgp_posterior_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, _P, _P, _S, _P, _S, _P, _P, _S, POINTER(F)]),
+            'lgp_posterior_solved_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, _P, _S, _P, _S, _P, _P, _S, POINTER(F)]),
             'lgp_mlnd_value_' + suf: (c_int, [c_void_p, _S, _P, _S, _P, _P, POINTER(F)]),
         })
     return sig

@@ -131,7 +131,10 @@ class Chol(Decomposition):
     its 128x128 diagonal blocks and the original K stay resident in HBM.
     """
 
-    def __init__(self, K, *, epsrel='auto', epsabs=0, ctx=None):
+    def __init__(self, K, *, epsrel='auto', epsabs=0, ctx=None, rhs=None):
+        """ ``rhs`` (optional, (n, q) host or device matrix): right-hand sides carried through the factorisation;
+        ``L^-1 rhs`` is then available from `solved` at no extra cost (the forward solve that ``pinv_bilinear`` /
+        ``ginv_quad`` / ``minus_log_normal_density`` would do, done by the MFMA updates of the factorisation) """
         if not isinstance(K, DeviceArray):
             K = numpy.asarray(K)
             if K.ndim != 2 or K.shape[0] != K.shape[1] or K.shape[0] == 0:
@@ -156,18 +159,58 @@ class Chol(Decomposition):
                 raise ValueError(f'epsabs={epsabs!r}')
             flags |= _lib.LGP_EPS_AUTO_ABS                             # :250-251
             epsabs = 0.
-        f, F = _lib.fn('lgp_chol_factor', self._dtype)
-        L = DeviceArray.empty((n, n), self._dtype, self._ctx)
         dblk = DeviceArray.empty((_lib.load().lgp_chol_dblk_size(n),), self._dtype, self._ctx)
-        eps = F()
-        info = _lib.check(f(self._ctx.handle, n, K.ptr, K.ld, F(epsrel), F(epsabs), flags, L.ptr, L.ld, dblk.ptr, ctypes.byref(eps)), 'lgp_chol_factor')
+        self._solved = None
+        self._solved_for = None
+        if rhs is None:
+            f, F = _lib.fn('lgp_chol_factor', self._dtype)
+            L = DeviceArray.empty((n, n), self._dtype, self._ctx)
+            eps = F()
+            info = _lib.check(f(self._ctx.handle, n, K.ptr, K.ld, F(epsrel), F(epsabs), flags, L.ptr, L.ld, dblk.ptr, ctypes.byref(eps)), 'lgp_chol_factor')
+        else:
+            B, _ = self._rhs_any(rhs, n)
+            q = B.shape[1]
+            nx = -(-q // 128) * 128          # whole 128-row tiles: the extra rows take the kernels' aligned fast path
+            f, F = _lib.fn('lgp_chol_factor_rhs', self._dtype)
+            Lfull = DeviceArray.empty((n + nx, n), self._dtype, self._ctx)
+            Lfull.block(n + q, n + nx, 0, n).fill_zero()
+            if q:
+                ft, _ = _lib.fn('lgp_transpose', self._dtype)
+                Bt = Lfull.block(n, n + q, 0, n)
+                _lib.check(ft(self._ctx.handle, Bt.ptr, Bt.ld, B.ptr, B.ld, n, q), 'lgp_transpose')
+            eps = F()
+            info = _lib.check(f(self._ctx.handle, n, K.ptr, K.ld, F(epsrel), F(epsabs), flags, Lfull.ptr, Lfull.ld, nx, dblk.ptr,
+                                ctypes.byref(eps)), 'lgp_chol_factor_rhs')
+            L = Lfull.block(0, n, 0, n)
+            self._solved = Lfull.block(n, n + q, 0, n)                 # (q, n) = (L^-1 rhs)^T
+            self._solved_for = rhs
         if info != 0:                                                  # :389-391
             raise numpy.linalg.LinAlgError('cholesky decomposition not finite, probably matrix not pos def numerically')
         self._L = L
         self._dblk = dblk
         self._eps = self._dtype.type(eps.value)                        # :393
 
+    def solved(self, *, device=False):
+        """ ``L^-1 rhs`` for the ``rhs`` given at construction, shape (n, q) """
+        if self._solved is None:
+            raise ValueError('the decomposition was built without rhs')
+        out = self._solved.transpose()
+        return out if device else out.to_host()
+
     # ---- helpers ---------------------------------------------------------
+
+    def _rhs_any(self, X, n):
+        """ (n, q) device matrix of the decomposition's dtype from a host or device operand (no copy of device data) """
+        if isinstance(X, DeviceArray):
+            dev = X.as2d()
+            if dev.dtype != self._dtype:
+                raise TypeError(f'device operand has dtype {dev.dtype}, decomposition is {self._dtype}')
+        else:
+            X = numpy.asarray(X)
+            dev = DeviceArray.from_host(X.reshape(len(X), -1), dtype=self._dtype, ctx=self._ctx)
+        if dev.shape[0] != n:
+            raise ValueError(f'operand has {dev.shape[0]} rows, the decomposed matrix has {n}')
+        return dev, None
 
     def _rhs(self, X, copy):
         """ right-hand side as a device (n, k) matrix; returns (dev, was_vector) """

@@ -314,6 +314,40 @@ static int posterior_impl(lgp_ctx *c, size_t n, size_t m, const T *L, size_t ldl
   return LGP_OK;
 }
 
+// posterior from right-hand sides that were carried through the factorisation (lgp_chol_factor_rhs): Wt is
+// (m+1) x n, rows 0..m-1 = (L^-1 Kxxs)^T, row m = (L^-1 y)^T
+template <typename T>
+static int posterior_solved_impl(lgp_ctx *c, size_t n, size_t m, const T *L, size_t ldl, const T *Wt, size_t ldw, const T *Kxsxs,
+                                 size_t ldk, T *mean, T *cov, size_t ldc, T *hmlnd) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  LGP_REQUIRE(n >= 1, "empty training set");
+  LGP_REQUIRE(L != nullptr && Wt != nullptr, "null pointer");
+  LGP_REQUIRE(ldw >= n && ldl >= n, "leading dimension too small");
+  DeviceGuard dg(c->device);
+  hipStream_t st = c->stream;
+  const T *yrow = Wt + m * ldw;
+  if (hmlnd) {
+    T *d = reinterpret_cast<T *>(c->d_scratch);
+    LGP_CHECK(lgp_logdet_device<T>(c, st, n, L, ldl, d));
+    LGP_CHECK(lgp_dot_strided_device<T>(c, st, n, yrow, 1, yrow, 1, d + 1));
+    LGP_HIP(hipMemcpyAsync(c->h_pinned, d, 2 * sizeof(T), hipMemcpyDeviceToHost, st));
+  }
+  // mean = (L^-1 Kxxs)^T (L^-1 y)                      _decomp.py:409
+  if (mean && m > 0) LGP_CHECK(lgp_gemm_launch<T>(c, st, false, true, m, 1, n, T(1), Wt, ldw, yrow, ldw, T(0), mean, 1, false));
+  // cov = Kxsxs - (L^-1 Kxxs)^T (L^-1 Kxxs)            _decomp.py:420, _compute.py:260
+  if (cov && m > 0) {
+    LGP_REQUIRE(Kxsxs != nullptr && ldk >= m && ldc >= m, "bad covariance arguments");
+    if (Kxsxs != cov) LGP_HIP(hipMemcpy2DAsync(cov, ldc * sizeof(T), Kxsxs, ldk * sizeof(T), m * sizeof(T), m, hipMemcpyDeviceToDevice, st));
+    LGP_CHECK(lgp_gemm_launch<T>(c, st, false, true, m, m, n, T(-1), Wt, ldw, Wt, ldw, T(1), cov, ldc, false));
+  }
+  if (hmlnd) {
+    LGP_HIP(hipStreamSynchronize(st));
+    const T *h = reinterpret_cast<const T *>(c->h_pinned);
+    *hmlnd = T(0.5) * (T(n) * T(std::log(2 * M_PI)) + T(2) * h[0] + h[1]);
+  }
+  return LGP_OK;
+}
+
 template <typename T>
 static int mlnd_impl(lgp_ctx *c, size_t n, const T *L, size_t ldl, const T *dblk, T *r, T *hvalue) {
   LGP_REQUIRE(c != nullptr && L != nullptr && dblk != nullptr && r != nullptr && hvalue != nullptr, "null pointer");
@@ -340,6 +374,14 @@ int lgp_posterior_f64(lgp_ctx *c, size_t n, size_t m, const double *L, size_t ld
 int lgp_posterior_f32(lgp_ctx *c, size_t n, size_t m, const float *L, size_t ldl, const float *dblk, float *W, size_t ldw,
                       const float *K, size_t ldk, float *mean, float *cov, size_t ldc, float *hmlnd) {
   return posterior_impl<float>(c, n, m, L, ldl, dblk, W, ldw, K, ldk, mean, cov, ldc, hmlnd);
+}
+int lgp_posterior_solved_f64(lgp_ctx *c, size_t n, size_t m, const double *L, size_t ldl, const double *Wt, size_t ldw,
+                             const double *K, size_t ldk, double *mean, double *cov, size_t ldc, double *hmlnd) {
+  return posterior_solved_impl<double>(c, n, m, L, ldl, Wt, ldw, K, ldk, mean, cov, ldc, hmlnd);
+}
+int lgp_posterior_solved_f32(lgp_ctx *c, size_t n, size_t m, const float *L, size_t ldl, const float *Wt, size_t ldw,
+                             const float *K, size_t ldk, float *mean, float *cov, size_t ldc, float *hmlnd) {
+  return posterior_solved_impl<float>(c, n, m, L, ldl, Wt, ldw, K, ldk, mean, cov, ldc, hmlnd);
 }
 int lgp_mlnd_value_f64(lgp_ctx *c, size_t n, const double *L, size_t ldl, const double *dblk, double *r, double *h) {
   return mlnd_impl<double>(c, n, L, ldl, dblk, r, h);

@@ -588,46 +588,49 @@ int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t 
 }
 
 template <typename T>
-int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk) {
+int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx) {
   LGP_REQUIRE(ldl >= n, "ldl < n");
   hipStream_t s0 = ctx->stream, s1 = ctx->stream2;
   const size_t NB = LGP_NB;
+  // Rows n .. n+nx-1 (optional) ride along: they are "rows below" for every panel, so the right-side substitutions and
+  // the trailing updates turn B^T into (L^-1 B)^T -- the forward solve of the posterior done by the MFMA updates of
+  // the factorisation instead of a separate latency chain of 2 n / 128 small kernels.
   // look-ahead: panel k+1 is updated and factored on s1 while s0 finishes the trailing update of step k
   for (size_t k0 = 0; k0 < n; k0 += NB) {
     const size_t kb = (n - k0) < NB ? (n - k0) : NB;
     T *P = L + k0 * ldl + k0;
     T *Yk = dblk + (k0 / LGP_DB) * (size_t)LGP_DBLK;
     if (k0 == 0) {
-      LGP_CHECK(lgp_panel_factor_impl<T>(ctx, s0, n - k0, kb, P, ldl, Yk, k0));
+      LGP_CHECK(lgp_panel_factor_impl<T>(ctx, s0, n + nx - k0, kb, P, ldl, Yk, k0));
     }
     // (panel k0 is complete on s0 at this point: either factored above or joined from s1 below)
     const size_t t0 = k0 + kb;
     if (t0 >= n) break;
     const size_t rows_t = n - t0;
-    const T *Pt = L + t0 * ldl + k0;            // rows_t x kb: the panel rows below the diagonal block
+    const T *Pt = L + t0 * ldl + k0;            // (rows_t + nx) x kb: the panel rows below the diagonal block
     const size_t nb1 = rows_t < NB ? rows_t : NB;  // width of the next panel
     // s0: update the next panel's block column first (a full-GPU MFMA gemm of its own), then hand it to s1,
     // whose latency-bound factorisation chain (potf2 / substitution / K=128 updates) runs beside the rest of
     // the trailing update
-    T *C1 = L + t0 * ldl + t0;                  // rows_t x nb1 block column (lower part)
-    LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_t, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
+    T *C1 = L + t0 * ldl + t0;                  // (rows_t + nx) x nb1 block column (lower part)
+    LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_t + nx, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
     LGP_HIP(hipEventRecord(ctx->ev_a, s0));
     LGP_HIP(hipStreamWaitEvent(s1, ctx->ev_a, 0));
-    LGP_CHECK(lgp_panel_factor_impl<T>(ctx, s1, rows_t, nb1, C1, ldl, dblk + (t0 / LGP_DB) * (size_t)LGP_DBLK, t0));
+    LGP_CHECK(lgp_panel_factor_impl<T>(ctx, s1, rows_t + nx, nb1, C1, ldl, dblk + (t0 / LGP_DB) * (size_t)LGP_DBLK, t0));
     LGP_HIP(hipEventRecord(ctx->ev_b, s1));
     // s0: rest of the trailing update (everything right of the next panel): the N^3/3 flops.  One launch
     // (splitting it into block-column chunks to give s1 more scheduling points was measured 30 % slower).
     if (rows_t > nb1) {
       const size_t rows_r = rows_t - nb1;
-      const T *Pa = L + (t0 + nb1) * ldl + k0;          // rows_r x kb
+      const T *Pa = L + (t0 + nb1) * ldl + k0;          // (rows_r + nx) x kb
       T *Cc = L + (t0 + nb1) * ldl + (t0 + nb1);
-      // algorithmic flops of this launch: 2 k per produced entry of the lower triangle
-      const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0);
+      // algorithmic flops of this launch: 2 k per produced entry of the lower trapezoid
+      const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0) + (double)nx * (double)rows_r;
       // (timed for bench.py when it is the 128-tile instantiation that profilers list as gemm_kernel<..., 128, 256, 1>;
       // the last, <= 1024-row update of a factorisation goes to the 64-tile kernel and is left out of both)
       const bool timed = rows_r > 1024;
       if (timed) LGP_CHECK(lgp_prof_start(ctx, s0, 2.0 * (double)kb * entries));
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 1));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 1));
       if (timed) LGP_CHECK(lgp_prof_stop(ctx, s0));
     }
     LGP_HIP(hipStreamWaitEvent(s0, ctx->ev_b, 0));
@@ -688,8 +691,17 @@ int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t
 }
 
 template <typename T>
+__global__ void __launch_bounds__(256) scale_cols_kernel(T *W, long ldw, int rows, int n, const T *s) {
+  // extra rows B^T (rows x n): column j /= s[j], so that they carry (S^-1 B)^T into the factorisation of K/s/s'
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)rows * n; idx += (long)gridDim.x * 256) {
+    const long r = idx / n, j = idx % n;
+    W[r * ldw + j] /= s[j];
+  }
+}
+
+template <typename T>
 static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T epsrel, T epsabs, int flags, T *L, size_t ldl,
-                            T *dblk, T *heps_out) {
+                            T *dblk, T *heps_out, size_t nrhs = 0) {
   LGP_REQUIRE(ctx != nullptr, "null context");
   LGP_REQUIRE(n >= 1 && n < (1u << 30), "matrix size out of range");
   LGP_REQUIRE(K != nullptr && L != nullptr && dblk != nullptr, "null pointer");
@@ -718,7 +730,12 @@ static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T ep
   hipLaunchKernelGGL((prep_lower_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, st, K, (long)ldk, ni, nbx, s, unit,
                      stats, L, (long)ldl);
   LGP_LAUNCH_CHECK();
-  LGP_CHECK(lgp_potrf_impl<T>(ctx, n, L, ldl, dblk));
+  if (!unit && nrhs > 0) {
+    hipLaunchKernelGGL((scale_cols_kernel<T>), dim3((unsigned)((nrhs * n + 255) / 256 < 65536 ? (nrhs * n + 255) / 256 : 65536)), dim3(256), 0, st,
+                       L + n * ldl, (long)ldl, (int)nrhs, ni, s);
+    LGP_LAUNCH_CHECK();
+  }
+  LGP_CHECK(lgp_potrf_impl<T>(ctx, n, L, ldl, dblk, nrhs));
   if (!unit) {
     hipLaunchKernelGGL((scale_rows_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, st, L, (long)ldl, ni, nbx, s);
     LGP_LAUNCH_CHECK();
@@ -733,6 +750,15 @@ static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T ep
   LGP_HIP(hipStreamSynchronize(st));
   if (heps_out) *heps_out = hstats[1];
   return info;
+}
+
+extern "C" int lgp_chol_factor_rhs_f64(lgp_ctx *ctx, size_t n, const double *dK, size_t ldk, double epsrel, double epsabs, int eps_flags,
+                                       double *dL, size_t ldl, size_t nrhs, double *ddblk, double *heps_out) {
+  return chol_factor_impl<double>(ctx, n, dK, ldk, epsrel, epsabs, eps_flags, dL, ldl, ddblk, heps_out, nrhs);
+}
+extern "C" int lgp_chol_factor_rhs_f32(lgp_ctx *ctx, size_t n, const float *dK, size_t ldk, float epsrel, float epsabs, int eps_flags,
+                                       float *dL, size_t ldl, size_t nrhs, float *ddblk, float *heps_out) {
+  return chol_factor_impl<float>(ctx, n, dK, ldk, epsrel, epsabs, eps_flags, dL, ldl, ddblk, heps_out, nrhs);
 }
 
 extern "C" size_t lgp_chol_dblk_size(size_t n) { return ((n + LGP_DB - 1) / LGP_DB) * (size_t)LGP_DBLK; }
@@ -791,7 +817,7 @@ extern "C" int lgp_get_info(lgp_ctx *ctx, int *hinfo) {
 
 template int lgp_panel_factor_impl<double>(lgp_ctx *, hipStream_t, size_t, size_t, double *, size_t, double *, size_t);
 template int lgp_panel_factor_impl<float>(lgp_ctx *, hipStream_t, size_t, size_t, float *, size_t, float *, size_t);
-template int lgp_potrf_impl<double>(lgp_ctx *, size_t, double *, size_t, double *);
-template int lgp_potrf_impl<float>(lgp_ctx *, size_t, float *, size_t, float *);
+template int lgp_potrf_impl<double>(lgp_ctx *, size_t, double *, size_t, double *, size_t);
+template int lgp_potrf_impl<float>(lgp_ctx *, size_t, float *, size_t, float *, size_t);
 template int lgp_trsm_impl<double>(lgp_ctx *, hipStream_t, size_t, const double *, size_t, const double *, int, double *, size_t, size_t);
 template int lgp_trsm_impl<float>(lgp_ctx *, hipStream_t, size_t, const float *, size_t, const float *, int, float *, size_t, size_t);

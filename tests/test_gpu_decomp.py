@@ -219,3 +219,34 @@ def test_full_size_c3_properties(lgp):
     # strict upper triangle of the factor is zero (first strip)
     blk = Lf.block(0, 2048, 0, 4096).to_host()
     assert np.all(np.triu(blk, 1) == 0)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('n,q', [(130, 1), (300, 5), (1024, 101), (1500, 130), (2600, 101), (3333, 7)])
+def test_carried_rhs(lgp, rng, dtype, n, q):
+    """ Chol(K, rhs=B): the forward solve carried through the factorisation (lgp_chol_factor_rhs) gives the same
+    factor, bit for bit, as Chol(K) and L^-1 B as good as the separate substitution (reference semantics:
+    pinv_correlate, _linalg/_decomp.py:437-439) """
+    K = randpd(rng, n)
+    d = np.exp(rng.uniform(-3, 3, n))                  # non-trivial diagonal: the power-of-two scaling path
+    K = (K * d[:, None] * d[None, :]).astype(dtype)
+    B = rng.standard_normal((n, q)).astype(dtype)
+    plain = lgp.Chol(K)
+    carried = lgp.Chol(K, rhs=B)
+    np.testing.assert_array_equal(carried.factor().to_host(), plain.factor().to_host())
+    assert carried.eps == plain.eps
+    want = oracle.Chol(K.astype(float)).pinv_correlate(B.astype(float))
+    got = carried.solved()
+    sep = plain.pinv_correlate(B)
+    # float32: the automatic jitter n * eps32 * (Gershgorin bound) of the float32 decomposition alone moves the
+    # solution by ~1e-2 relative to the float64 oracle; carried vs separate (same matrix) differ by rounding only
+    tol_oracle, tol_same = (1e-9, 1e-10) if dtype == np.float64 else (6e-2, 1e-2)
+    scale = np.linalg.norm(want, axis=0)
+    assert np.all(np.linalg.norm(got - want, axis=0) <= tol_oracle * scale)
+    assert np.all(np.linalg.norm(got - sep, axis=0) <= tol_same * scale)
+    # the other methods work on the carried factor as on the plain one
+    util.assert_close_matrices(carried.ginv_quad(B[:, :1]), plain.ginv_quad(B[:, :1]), rtol=1e-9 if dtype == np.float64 else 1e-2)
+    with pytest.raises(ValueError):
+        plain.solved()
+    with pytest.raises(ValueError):
+        lgp.Chol(K, rhs=B[:-1])

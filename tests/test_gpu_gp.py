@@ -193,3 +193,23 @@ def test_config_c5_bart_structure(lgp):
     ld = gd.marginal_likelihood(given, epsrel=0)          # mlkw=dict(epsrel=0), bayestree/_bart.py:222
     lo = go.marginal_likelihood(given, epsrel=0)
     assert abs(ld - lo) <= 1e-3 * abs(lo)
+
+
+def test_fuse_solve_matches_separate_solve(lgp):
+    """ GP(..., fuse_solve=True): pred carries [Kxxs | y] through the factorisation; same posterior as the separate solve """
+    rng = np.random.default_rng(11)
+    n, m = 3000, 57
+    x = rng.uniform(0, n / 16, n); xs = rng.uniform(0, n / 16, m)
+    y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
+    gc = {('data', 'data'): 0.01 * np.eye(n)}
+    out = []
+    for fuse in (False, True):
+        gp = lgp.GP(lgp.ExpQuad(), checkpos=False, checksym=False, fuse_solve=fuse).addx(x, 'data').addx(xs, 'test')
+        out.append(gp.predfromdata({'data': y}, 'test', gc, raw=True))
+        # fromdata=False uses a cacheable decomposition: never fused, identical in both
+        out[-1] += gp.predfromfit({'data': y}, 'test', gc, raw=True)
+    (m0, c0, mf0, cf0), (m1, c1, mf1, cf1) = out
+    assert np.linalg.norm(m1 - m0) <= 1e-12 * np.linalg.norm(m0)
+    assert np.linalg.norm(c1 - c0, 2) <= 1e-12
+    np.testing.assert_array_equal(mf0, mf1)
+    np.testing.assert_array_equal(cf0, cf1)
