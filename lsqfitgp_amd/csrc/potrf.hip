@@ -5,7 +5,7 @@
 // Structure (row-major, lower):
 //   prep      : s = diag_scale_pow2(K) (:356-361); Gershgorin bound of K/s/s' (:349-354); eps (:245-255);
 //               L <- tril(K/s/s') + eps*I with the strict upper triangle zeroed      [HBM-bound passes]
-//   potrf     : right-looking, outer panel LGP_NB = 512, inner diagonal blocks LGP_DB = 128:
+//   potrf     : right-looking, outer panel LGP_NB = 1024, inner diagonal blocks LGP_DB = 128:
 //                 potf2       : one workgroup factors a 128x128 diagonal block held in REGISTERS
 //                               (8x8 cyclic tile per thread);
 //                 panel trsm  : X = B * L_jj^-T by substitution, one thread per row, L_jj through scalar loads;
