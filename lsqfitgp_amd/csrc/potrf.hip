@@ -627,8 +627,8 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx)
       // algorithmic flops of this launch: 2 k per produced entry of the lower trapezoid
       const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0) + (double)nx * (double)rows_r;
       // (timed for bench.py when it is the 128-tile instantiation that profilers list as gemm_kernel<..., 128, 256, 1>;
-      // the last, <= 1024-row update of a factorisation goes to the 64-tile kernel and is left out of both)
-      const bool timed = rows_r > 1024;
+      // the last, <= 64-tile update of a factorisation goes to the 64-tile kernel and is left out of both)
+      const bool timed = ((rows_r + nx + 127) / 128) * ((rows_r + 127) / 128) > 64;   // lgp_gemm_launch's 128-tile criterion at K = 1024
       if (timed) LGP_CHECK(lgp_prof_start(ctx, s0, 2.0 * (double)kb * entries));
       LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 1));
       if (timed) LGP_CHECK(lgp_prof_stop(ctx, s0));
