@@ -199,6 +199,8 @@ def size_sweep(ctx, main_cfg):
     steps each (a fraction of a second in all); not part of `value` """
     out = []
     cases = [dict(CONFIGS['c2'])]
+    if main_cfg['n'] < CONFIGS['c4']['n']:
+        cases.append(dict(CONFIGS['c4']))           # N = 65536 on this one GPU (2 x 32 GiB)
     for n in (4096, 8192, 16384):
         if n < main_cfg['n']:
             c = dict(main_cfg)
@@ -209,12 +211,13 @@ def size_sweep(ctx, main_cfg):
         wl = Workload(c, ctx)
         wl.step()
         ctx.sync()
-        evs = [[ctx.event() for _ in range(4)] for _ in range(3)]
+        reps = 3 if c['n'] <= 32768 else 2
+        evs = [[ctx.event() for _ in range(4)] for _ in range(reps)]
         t0 = time.perf_counter()
-        for k in range(3):
+        for k in range(reps):
             wl.step(evs[k])
         ctx.sync()
-        dt = (time.perf_counter() - t0) / 3
+        dt = (time.perf_counter() - t0) / reps
         ph = np.array([[ctx.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in evs]).mean(axis=0)
         out.append({'workload': c['name'], 'N': c['n'], 'ms_per_step': dt * 1e3, 'value': flops_fit_predict(c['n'], c['m']) / dt / 1e12,
                     'cholesky_ms': float(ph[1]), 'cholesky_tflops': (c['n'] ** 3 / 3) / (ph[1] * 1e-3) / 1e12})
