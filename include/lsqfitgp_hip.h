@@ -276,6 +276,12 @@ int lgp_mlnd_value_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, cons
 int lgp_comm_unique_id(void *hid128);                                   /* ncclGetUniqueId on rank 0 */
 int lgp_comm_init(lgp_ctx *ctx, int rank, int nranks, const void *hid128);  /* ncclCommInitRank */
 int lgp_comm_destroy(lgp_ctx *ctx);
+/* Alternative transport (bring your own collective, e.g. MPI or gloo; also how the multi-rank schedule is tested on
+ * a single GPU): lgp_bcast / lgp_allreduce_* then stage the buffer through host memory on the context's current
+ * stream and call fn(user, op, host_buffer, count, root), op 0 = broadcast `count` bytes from `root`, 1 = all-reduce
+ * sum of `count` doubles, 2 = all-reduce max of `count` doubles; fn returns 0 on success. */
+int lgp_comm_init_host(lgp_ctx *ctx, int rank, int nranks, int (*fn)(void *user, int op, void *hbuf, size_t count, int root),
+                       void *user);
 int lgp_bcast(lgp_ctx *ctx, void *dbuf, size_t bytes, int root);        /* ncclBroadcast on the ctx stream */
 int lgp_allreduce_sum_f64(lgp_ctx *ctx, double *dbuf, size_t count);
 int lgp_allreduce_max_f64(lgp_ctx *ctx, double *dbuf, size_t count);

@@ -90,6 +90,30 @@ class Context:
         _lib.check(self._lib.lgp_comm_init(self._handle, int(rank), int(nranks), buf), 'lgp_comm_init')
         self.rank, self.nranks = int(rank), int(nranks)
 
+    def comm_init_host(self, rank, nranks, collective):
+        """ alternative transport: ``collective(op, array, root)`` performs the collective in place on a host numpy
+        view (op 0: broadcast of a uint8 array from ``root``; 1 / 2: all-reduce sum / max of a float64 array) """
+        import numpy
+
+        def trampoline(user, op, hbuf, count, root):
+            try:
+                if op == 0:
+                    arr = numpy.ctypeslib.as_array((ctypes.c_ubyte * count).from_address(hbuf))
+                else:
+                    arr = numpy.ctypeslib.as_array((ctypes.c_double * count).from_address(hbuf))
+                collective(int(op), arr, int(root))
+                return 0
+            except Exception:      # reported through the library's error path
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        cbtype = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
+        self._hostcb = cbtype(trampoline)           # keep the callback object alive as long as the context
+        _lib.check(self._lib.lgp_comm_init_host(self._handle, int(rank), int(nranks), ctypes.cast(self._hostcb, ctypes.c_void_p), None),
+                   'lgp_comm_init_host')
+        self.rank, self.nranks = int(rank), int(nranks)
+
     @staticmethod
     def comm_unique_id():
         buf = ctypes.create_string_buffer(_lib.LGP_COMM_ID_BYTES)

@@ -61,6 +61,7 @@ def _signatures():
         'lgp_profile_end': (c_int, [c_void_p, POINTER(c_size_t), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
         'lgp_comm_unique_id': (c_int, [c_void_p]),
         'lgp_comm_init': (c_int, [c_void_p, c_int, c_int, c_void_p]),
+        'lgp_comm_init_host': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
         'lgp_comm_destroy': (c_int, [c_void_p]),
         'lgp_bcast': (c_int, [c_void_p, _P, _S, c_int]),
         'lgp_allreduce_sum_f64': (c_int, [c_void_p, _P, _S]),

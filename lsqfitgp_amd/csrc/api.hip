@@ -482,9 +482,47 @@ int lgp_comm_destroy(lgp_ctx *c) {
   return LGP_OK;
 }
 
+// host-staged transport: device -> host copy on the current stream, the caller's collective, host -> device copy
+static int host_collective(lgp_ctx *c, int op, void *dbuf, size_t count, size_t bytes, int root) {
+  DeviceGuard dg(c->device);
+  void *h = malloc(bytes);
+  LGP_REQUIRE(h != nullptr, "out of host memory for the staged collective");
+  hipError_t e = hipMemcpyAsync(h, dbuf, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  int rc = LGP_OK;
+  if (e != hipSuccess) {
+    lgp_set_error("staged collective: %s", hipGetErrorString(e));
+    rc = LGP_EHIP;
+  } else if (c->hostfn(c->hostuser, op, h, count, root) != 0) {
+    lgp_set_error("host collective callback failed (op %d)", op);
+    rc = LGP_ECOMM;
+  } else {
+    e = hipMemcpyAsync(dbuf, h, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+      lgp_set_error("staged collective: %s", hipGetErrorString(e));
+      rc = LGP_EHIP;
+    }
+  }
+  free(h);
+  return rc;
+}
+
+int lgp_comm_init_host(lgp_ctx *c, int rank, int nranks, int (*fn)(void *, int, void *, size_t, int), void *user) {
+  LGP_REQUIRE(c != nullptr && fn != nullptr, "null pointer");
+  LGP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank");
+  LGP_REQUIRE(c->comm == nullptr, "an RCCL communicator is already initialised");
+  c->hostfn = fn;
+  c->hostuser = user;
+  c->rank = rank;
+  c->nranks = nranks;
+  return LGP_OK;
+}
+
 int lgp_bcast(lgp_ctx *c, void *dbuf, size_t bytes, int root) {
   LGP_REQUIRE(c != nullptr && (dbuf != nullptr || bytes == 0), "null pointer");
   LGP_REQUIRE(root >= 0 && root < c->nranks, "bad root");
+  if (bytes && c->hostfn) return host_collective(c, 0, dbuf, bytes, bytes, root);
   if (bytes == 0 || (c->comm == nullptr && c->nranks == 1)) return LGP_OK;   // no communicator: single process
   LGP_REQUIRE(c->comm != nullptr, "communicator not initialised");
   DeviceGuard dg(c->device);
@@ -494,6 +532,7 @@ int lgp_bcast(lgp_ctx *c, void *dbuf, size_t bytes, int root) {
 
 int lgp_allreduce_sum_f64(lgp_ctx *c, double *dbuf, size_t count) {
   LGP_REQUIRE(c != nullptr && (dbuf != nullptr || count == 0), "null pointer");
+  if (count && c->hostfn) return host_collective(c, 1, dbuf, count, count * sizeof(double), 0);
   if (count == 0 || (c->comm == nullptr && c->nranks == 1)) return LGP_OK;
   LGP_REQUIRE(c->comm != nullptr, "communicator not initialised");
   DeviceGuard dg(c->device);
@@ -503,6 +542,7 @@ int lgp_allreduce_sum_f64(lgp_ctx *c, double *dbuf, size_t count) {
 
 int lgp_allreduce_max_f64(lgp_ctx *c, double *dbuf, size_t count) {
   LGP_REQUIRE(c != nullptr && (dbuf != nullptr || count == 0), "null pointer");
+  if (count && c->hostfn) return host_collective(c, 2, dbuf, count, count * sizeof(double), 0);
   if (count == 0 || (c->comm == nullptr && c->nranks == 1)) return LGP_OK;
   LGP_REQUIRE(c->comm != nullptr, "communicator not initialised");
   DeviceGuard dg(c->device);

@@ -19,6 +19,9 @@ struct lgp_ctx {
   size_t scratch_bytes = 0;
   void *h_pinned = nullptr;           // pinned host staging for scalar results (4 KiB)
   void *comm = nullptr;               // ncclComm_t
+  // alternative transport: collectives done by a caller-supplied host function on a staged copy (lgp_comm_init_host)
+  int (*hostfn)(void *user, int op, void *hbuf, size_t count, int root) = nullptr;
+  void *hostuser = nullptr;
   int rank = 0, nranks = 1;
   int cus = 256;
   int swapped = 0;                    // lgp_select_stream(1): `stream` and `stream2` exchanged

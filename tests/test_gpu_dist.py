@@ -2,7 +2,8 @@
 GPU tests of the distributed pieces on ONE device: the device backend of the block-column schedule
 (``DeviceOps`` + ``DistributedChol`` with a single rank) against the oracle, and the RCCL plumbing through a
 one-rank communicator (ncclCommInitRank / ncclBroadcast / ncclAllReduce really run).  The multi-rank schedule
-itself is covered on CPU by tests/test_dist_gloo.py.
+itself is covered on CPU by tests/test_dist_gloo.py, and on the device by two processes that share the GPU and
+exchange panels through the host-callback transport (gloo), since RCCL refuses two ranks on one device.
 """
 
 import ctypes
@@ -92,3 +93,50 @@ def test_distributed_posterior_single_rank(lgp, rng):
     assert np.linalg.norm(mean - mo) <= 1e-8 * np.linalg.norm(mo)
     assert np.linalg.norm(cov - co, 2) <= 1e-8 * np.linalg.norm(go.prior('test', raw=True), 2)
     assert abs(-mlnd - lo) <= 1e-8 * abs(lo) + 1e-6
+
+
+@pytest.mark.parametrize('n,nb,world', [(1500, 256, 2), (2600, 1024, 2), (2900, 256, 3)])
+def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world):
+    """ world size 2 and 3 on the device: real kernels, real stream/event choreography of the panel look-ahead, panels
+    exchanged through the host-callback transport; factor, posterior and likelihood against the oracle """
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    m = 37
+    # separate interpreters (not torch.multiprocessing: torch must not be loaded into this process next to the library)
+    script = os.path.join(os.path.dirname(__file__), 'two_rank_worker.py')
+    procs = [subprocess.Popen([sys.executable, script, str(rank), str(world), str(port), str(n), str(nb), str(m), str(tmp_path)],
+                              cwd=os.path.dirname(os.path.dirname(__file__))) for rank in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    rng = np.random.default_rng(7)
+    x = rng.uniform(0, n / 16, n)
+    xs = rng.uniform(0, n / 16, m)
+    y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
+    K = oracle.ExpQuad()(x[:, None], x[None, :]) + 0.01 * np.eye(n)
+    o = oracle.Chol(K)
+    Kxs = oracle.ExpQuad()(x[:, None], xs[None, :])
+    Kss = oracle.ExpQuad()(xs[:, None], xs[None, :])
+    mean_o = o.pinv_bilinear(Kxs, y)
+    cov_o = Kss - o.ginv_quad(Kxs)
+    mlnd_o = o.minus_log_normal_density(y, value=True)[0]
+    full = np.zeros((n, n))
+    seen = set()
+    for rank in range(world):
+        r = np.load(tmp_path / f'rank{rank}.npz')
+        util.assert_allclose(r['eps'], o.eps, rtol=1e-13)
+        assert np.linalg.norm(r['mean'] - mean_o) <= 1e-8 * np.linalg.norm(mean_o)
+        assert np.linalg.norm(r['cov'] - cov_o, 2) <= 1e-8 * np.linalg.norm(Kss, 2)
+        util.assert_allclose(r['mlnd'], mlnd_o, rtol=1e-10)
+        for b in r['owned']:
+            assert int(b) not in seen and int(b) % world == rank      # block-column cyclic ownership
+            seen.add(int(b))
+            blk = r[f'b{b}']
+            c0 = int(b) * nb
+            full[c0:, c0:c0 + blk.shape[1]] = blk
+    assert len(seen) == -(-n // nb)
+    util.assert_close_matrices(full, o._L, rtol=1e-11)

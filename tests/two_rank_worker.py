@@ -1,0 +1,51 @@
+"""
+One rank of the two-rank on-device test of tests/test_gpu_dist.py (run as a script, one process per rank, both on
+the single GPU of the box): DistributedChol + posterior with panels exchanged through the host-callback transport
+(gloo), results written to <tmpdir>/rank<r>.npz.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main(rank, world, port, n, nb, m, tmpdir):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import lsqfitgp_amd as lgp
+    from lsqfitgp_amd._dist import DistributedChol
+    ctx = lgp.Context(0)                      # both ranks on the one GPU of the box
+    lgp.Context._default = ctx
+
+    def collective(op, arr, root):
+        t = torch.from_numpy(arr)
+        if op == 0:
+            dist.broadcast(t, src=root)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 1 else dist.ReduceOp.MAX)
+
+    ctx.comm_init_host(rank, world, collective)
+    rng = np.random.default_rng(7)
+    x = rng.uniform(0, n / 16, n)
+    xs = rng.uniform(0, n / 16, m)
+    y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
+    d = DistributedChol(lgp.ExpQuad(), x, noise=0.01, nb=nb, ctx=ctx)
+    mean, cov, mlnd = d.posterior(lgp.ExpQuad(), x, xs, y)
+    blocks = {b: blk for b, blk in d.local_factor().items()}
+    np.savez(os.path.join(tmpdir, f'rank{rank}.npz'), mean=mean, cov=cov, mlnd=mlnd, eps=d.eps,
+             owned=np.array(sorted(blocks)), **{f'b{b}': blk for b, blk in blocks.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+
+
+if __name__ == '__main__':
+    a = sys.argv[1:]
+    main(int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), a[6])
