@@ -305,9 +305,20 @@ def main_dist(args, cfg, ctx, dist, rank, world):
     import torch
     import lsqfitgp_amd as lgp
     from lsqfitgp_amd._dist import DistributedChol
-    uid = [lgp.Context.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    ctx.comm_init(rank, world, uid[0])
+    if os.environ.get('LGP_DIST_TRANSPORT') == 'host':
+        # panels through host memory and gloo (lgp_comm_init_host): lets several ranks share one GPU, e.g. to rehearse the
+        # multi-rank path on a single-GPU box; the default is RCCL over xGMI
+        def collective(op, arr, root):
+            t = torch.from_numpy(arr)
+            if op == 0:
+                dist.broadcast(t, src=root)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 1 else dist.ReduceOp.MAX)
+        ctx.comm_init_host(rank, world, collective)
+    else:
+        uid = [lgp.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(rank, world, uid[0])
     lgp.Context._default = ctx
     x, xs, y = synth(cfg)
     kern = lgp.ExpQuad() if cfg['kernel'] == 'expquad' else lgp.Maternp(p=2, scale=1.)
@@ -348,7 +359,7 @@ def main_dist(args, cfg, ctx, dist, rank, world):
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': cfg['name'], 'N': n, 'M': cfg['m'],
-                       'parallelism': f'1-D block-column-cyclic over {world} GPUs, nb=1024, RCCL panel broadcast with look-ahead'},
+                       'parallelism': f'1-D block-column-cyclic over {world} GPUs, nb=1024, ' + ('host-staged gloo' if os.environ.get('LGP_DIST_TRANSPORT') == 'host' else 'RCCL') + ' panel broadcast with look-ahead'},
             'log_marginal_likelihood': ld, 'roofline': None, 'cpu_baseline': None}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
