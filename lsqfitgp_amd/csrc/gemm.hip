@@ -243,8 +243,7 @@ __device__ __forceinline__ bool map_tile(int tm, int tn, int nsm, int nsn, int n
 }
 
 // NTHREADS = 256: 2 x 2 waves, 64 x 64 (TS = 128) or 32 x 32 (TS = 64) per wave.
-// NTHREADS = 512: 4 x 2 waves, 32 x 64 per wave: half the accumulators per wave, so 4 waves per SIMD instead of 2
-// to cover barrier and LDS latency.
+// (NTHREADS = 512, 4 x 2 waves of 32 x 64 at 4 waves per SIMD, is supported by the code and was measured equal.)
 // TAG only names the instantiation: TAG = 1 is the Cholesky trailing update, so that profilers list it as its own row.
 template <typename T, bool TA, bool TB, int TS, int NTHREADS, int TAG = 0>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) {
@@ -495,10 +494,9 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
   g.alignedA = ((reinterpret_cast<uintptr_t>(A) % 16) == 0 && (lda % VEC) == 0) ? 1 : 0;
   g.alignedB = ((reinterpret_cast<uintptr_t>(B) % 16) == 0 && (ldb % VEC) == 0) ? 1 : 0;
   size_t grid;
-  static const int map_mode = getenv("LGP_GEMM_MAP") ? atoi(getenv("LGP_GEMM_MAP")) : 1;   // experiment knob
   // super-tiles only pay when both tile dimensions are large; tall-skinny grids (panel updates, solves with a
   // few hundred right-hand sides) are 3x faster with the plain row-major map (measured: 30000x101x1024)
-  if ((size_t)g.tm * g.tn <= 64 || g.tm < 16 || g.tn < 16 || (map_mode == 0 && !lower)) {
+  if ((size_t)g.tm * g.tn <= 64 || g.tm < 16 || g.tn < 16) {
     g.nsm = g.nsn = 0;
     g.nbulk = 0;
     grid = (size_t)g.tm * g.tn;
