@@ -8,11 +8,12 @@
 //   potrf     : right-looking, outer panel LGP_NB = 1024, inner diagonal blocks LGP_DB = 128:
 //                 potf2       : one workgroup factors a 128x128 diagonal block held in REGISTERS
 //                               (8x8 cyclic tile per thread);
-//                 panel trsm  : X = B * L_jj^-T by substitution, one thread per row, L_jj through scalar loads;
+//                 panel trsm  : X = B * L_jj^-T by substitution on the matrix cores (16 rows per wave as 16x16
+//                               accumulator tiles, operands from a fragment image packed per diagonal block);
 //                 panel update: gemm NT, K = 128;
-//                 trailing    : syrk (gemm NT, lower tiles only), K = 512 -- the N^3/3 flops, MFMA-bound;
+//                 trailing    : syrk (gemm NT, lower tiles only), K = 1024 -- the N^3/3 flops, MFMA-bound;
 //               the next panel is factored on a second stream while the rest of the trailing update
-//               runs (look-ahead).
+//               runs (look-ahead); optional extra rows (right-hand sides) ride through all of it.
 //   finish    : L <- L * s[:,None], diagonal-block workspace re-extracted, eps_out = eps * min(s^2).
 // A non-positive or non-finite pivot is recorded in ctx->d_info (first one wins) and the factor goes
 // NaN from there on, like LAPACK-in-jax; the host turns info != 0 into the reference's LinAlgError.
