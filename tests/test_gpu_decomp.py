@@ -250,3 +250,29 @@ def test_carried_rhs(lgp, rng, dtype, n, q):
         plain.solved()
     with pytest.raises(ValueError):
         lgp.Chol(K, rhs=B[:-1])
+
+
+def test_odd_size_many_panels_with_carried_rhs(lgp):
+    """ N = 9001 (9 outer panels, ragged last panel and edge tiles everywhere) with 37 carried right-hand sides:
+    factorisation identities instead of the oracle (O(N^3) on the CPU) """
+    from lsqfitgp_amd._GP import _gemm
+    n, q = 9001, 37
+    rng = np.random.default_rng(9)
+    x = rng.uniform(0, n / 16, n)
+    K = lgp.ExpQuad().gram(x, x)
+    lib = __import__('lsqfitgp_amd')._lib.load()
+    ctx = lgp.Context.default()
+    assert lib.lgp_add_diag_f64(ctx.handle, n, K.ptr, K.ld, None, ctypes.c_double(0.02)) == 0
+    B = rng.standard_normal((n, q))
+    d = lgp.Chol(K, rhs=B)
+    plain = lgp.Chol(K)
+    np.testing.assert_array_equal(d.factor().to_host(), plain.factor().to_host())
+    W = d.solved()                                          # L^-1 B
+    # L W = B and the separate substitution agree
+    util.assert_close_matrices(d.correlate(W), B, rtol=1e-11)
+    util.assert_close_matrices(W, plain.pinv_correlate(B), rtol=1e-10)
+    # L L^T V = (K + eps) V with K V from an independent product
+    V = rng.standard_normal((n, 2))
+    KV = _gemm(False, False, K, lgp.DeviceArray.from_host(V)).to_host() + d.eps * V
+    util.assert_close_matrices(d.correlate(d.back_correlate(V)), KV, rtol=1e-12)
+    util.assert_close_matrices(d.ginv_linear(KV), V, rtol=1e-9)
