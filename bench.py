@@ -101,7 +101,7 @@ class Workload:
     def _gram(self, a, b, out):
         ck = self._lib.check
         d = self.cfg['d']
-        ck(self.lib.lgp_gram_isotropic_f64(self.ctx.handle, self.kind, self.p, d, a.ptr, a.ld, a.shape[1], b.ptr, b.ld, b.shape[1],
+        ck(self.lib.lgp_gram_isotropic_f64(self.ctx.handle, self.kind, self.p, 0, None, d, a.ptr, a.ld, a.shape[1], b.ptr, b.ld, b.shape[1],
                                            0, 0., 1, 1., 0, None, None, int(a is b), out.ptr, out.ld), 'gram')
 
     def step(self, timers=None):

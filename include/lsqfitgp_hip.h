@@ -90,6 +90,8 @@ int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *to
 
 #define LGP_KERNEL_EXPQUAD 0   /* _kernels/_basic.py:61-75   exp(-1/2 r2)                        */
 #define LGP_KERNEL_MATERNP 1   /* _kernels/_matern.py:29-49 + _special/_bessel.py:101-110 (p)  */
+#define LGP_KERNEL_GAMMAEXP 2  /* _kernels/_basic.py:94-115   exp(-r2^(gamma/2)); hpar = {gamma, gamma/2}                              */
+#define LGP_KERNEL_CAUCHY 3    /* _kernels/_basic.py:315-344  (1 + r2^(alpha/2)/beta)^(-beta/alpha); hpar = {alpha, beta, -beta/alpha}  */
 #define LGP_OP_MUL 0           /* kernel * c  (_Kernel/_alg.py:58-82)  */
 #define LGP_OP_ADD 1           /* kernel + c  (_Kernel/_alg.py:32-56)  */
 
@@ -98,16 +100,18 @@ int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *to
  * (_Kernel/_ops.py:292-326; has_loc/has_scale = 0 skips the operation like loc=None/scale=None).
  * dx: d field arrays of n values, SoA: field f at dx + f*ldx  (columnar StructuredArray, _array.py:104-105)
  * dy: same for the m column points.  out: n x m, ld ldo.
+ * hpar (HOST array of npar values, NULL/0 for ExpQuad and Maternp): the real parameters of the kernel and the
+ * exponents the reference forms from them as Python floats (so that float32 kernels round them the same way).
  * nops output algops (hops_code/hops_val are HOST arrays, nops <= 8) applied in order.
  * symmetric != 0 (requires dx == dy, n == m): evaluate tiles on/below the diagonal and mirror them
  * (the `halfmatrix` option of _elements.py:567-573). */
-int lgp_gram_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int d,
+int lgp_gram_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d,
                            const double *dx, size_t ldx, size_t n,
                            const double *dy, size_t ldy, size_t m,
                            int has_loc, double loc, int has_scale, double scale,
                            int nops, const int *hops_code, const double *hops_val,
                            int symmetric, double *dout, size_t ldo);
-int lgp_gram_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int d,
+int lgp_gram_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int d,
                            const float *dx, size_t ldx, size_t n,
                            const float *dy, size_t ldy, size_t m,
                            int has_loc, float loc, int has_scale, float scale,
@@ -142,11 +146,11 @@ int lgp_gram_bart_f64(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const i
  * BART: dnpair (npairs x p int32, or NULL to use hnsplits for every pair) gives per-pair split totals, which
  * makes it the fully vectorised BART.correlation(..., altinput=True) of _kernels/_bart.py:301-455;
  * dgamma_vec (npairs, may alias dout) chains recursion slices. */
-int lgp_pairs_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int d, const double *dx, size_t ldx,
+int lgp_pairs_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d, const double *dx, size_t ldx,
                             const double *dy, size_t ldy, size_t npairs,
                             int has_loc, double loc, int has_scale, double scale,
                             int nops, const int *hops_code, const double *hops_val, double *dout);
-int lgp_pairs_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int d, const float *dx, size_t ldx,
+int lgp_pairs_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int d, const float *dx, size_t ldx,
                             const float *dy, size_t ldy, size_t npairs,
                             int has_loc, float loc, int has_scale, float scale,
                             int nops, const int *hops_code, const float *hops_val, float *dout);

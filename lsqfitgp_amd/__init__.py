@@ -10,7 +10,7 @@ surface (raw outputs).  Python host code -> ctypes -> ``liblsqfitgp_hip.so``
 from ._lib import LibraryError
 from ._device import Context, DeviceArray, asdevice
 from ._linalg import Decomposition, Chol
-from ._kernels import Kernel, ExpQuad, Maternp, BART
+from ._kernels import Kernel, ExpQuad, Maternp, GammaExp, Cauchy, BART
 from ._GP import GP
 from . import _linalg
 

@@ -235,7 +235,7 @@ class DistributedChol:
             lb, w, c0 = L.local_index(b), L.width(b), L.col0(b)
             out = self.Lloc.block(0, n, lb * nb, lb * nb + w)
             yb = xd.block(0, d, c0, c0 + w)
-            _lib.check(lib.lgp_gram_isotropic_f64(self.ctx.handle, kernel._kind, int(kernel._p), d, xd.ptr, xd.ld, n, yb.ptr, yb.ld, w,
+            _lib.check(lib.lgp_gram_isotropic_f64(self.ctx.handle, kernel._kind, int(kernel._p), *kernel._par_args(F), d, xd.ptr, xd.ld, n, yb.ptr, yb.ld, w,
                                                   int(kernel._loc is not None), F(kernel._loc or 0), int(kernel._scale is not None), F(kernel._scale or 1),
                                                   0, None, None, 0, out.ptr, out.ld), 'lgp_gram_isotropic')
             if noise:

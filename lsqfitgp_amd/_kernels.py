@@ -152,6 +152,13 @@ class _Isotropic(Kernel):
 
     _kind = None
     _p = 0
+    _par = ()          # real parameters handed to the device core (host-evaluated Python floats, like the reference)
+
+    def _par_args(self, F):
+        """ (npar, hpar) of the C-ABI """
+        if not self._par:
+            return 0, None
+        return len(self._par), (F * len(self._par))(*self._par)
 
     def _result_dtype(self, x, y):
         return _float_dtype_of(_leaf_columns(x.reshape(-1)[:0]) + _leaf_columns(y.reshape(-1)[:0]), self._scale, self._loc)
@@ -179,7 +186,7 @@ class _Isotropic(Kernel):
             return out
         f, F = _lib.fn('lgp_gram_isotropic', dtype)
         nops, codes, vals = _ops_arrays(self._outops, F)
-        _lib.check(f(ctx.handle, self._kind, int(self._p), d, xd.ptr, xd.ld, n, yd.ptr, yd.ld, m,
+        _lib.check(f(ctx.handle, self._kind, int(self._p), *self._par_args(F), d, xd.ptr, xd.ld, n, yd.ptr, yd.ld, m,
                      int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
                      nops, codes, vals, int(xd is yd), out.ptr, out.ld), 'lgp_gram_isotropic')
         return out
@@ -193,7 +200,7 @@ class _Isotropic(Kernel):
             return out
         f, F = _lib.fn('lgp_pairs_isotropic', dtype)
         nops, codes, vals = _ops_arrays(self._outops, F)
-        _lib.check(f(ctx.handle, self._kind, int(self._p), d, xd.ptr, xd.ld, yd.ptr, yd.ld, n,
+        _lib.check(f(ctx.handle, self._kind, int(self._p), *self._par_args(F), d, xd.ptr, xd.ld, yd.ptr, yd.ld, n,
                      int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
                      nops, codes, vals, out.ptr), 'lgp_pairs_isotropic')
         return out
@@ -218,6 +225,33 @@ class Maternp(_Isotropic):
             raise NotImplementedError('Maternp order above 16')
         super().__init__(scale=scale, loc=loc)
         self._p = int(p)
+
+
+class GammaExp(_Isotropic):
+    """ Gamma exponential kernel, k(r) = exp(-r^γ), γ ∈ (0, 2] (``_kernels/_basic.py:94-115``) """
+    _kind = _lib.LGP_KERNEL_GAMMAEXP
+
+    def __init__(self, *, gamma=1, scale=None, loc=None):
+        if not 0 < gamma <= 2:                                     # _basic.py:109-110
+            raise AssertionError(gamma)
+        super().__init__(scale=scale, loc=loc)
+        self._gamma = gamma
+        self._par = (float(gamma), float(gamma / 2))
+
+
+class Cauchy(_Isotropic):
+    """ Generalized Cauchy kernel, k(r) = (1 + r^α/β)^(-β/α), α ∈ (0, 2], β > 0 (``_kernels/_basic.py:315-344``);
+    α = 2 is the rational quadratic kernel """
+    _kind = _lib.LGP_KERNEL_CAUCHY
+
+    def __init__(self, *, alpha=2, beta=2, scale=None, loc=None):
+        if not 0 < alpha <= 2:                                     # _basic.py:336-338
+            raise AssertionError(alpha)
+        if not 0 < beta:
+            raise AssertionError(beta)
+        super().__init__(scale=scale, loc=loc)
+        self._alpha, self._beta = alpha, beta
+        self._par = (float(alpha), float(beta), float(-beta / alpha))
 
 
 # ------------------------------------------------------------------------------

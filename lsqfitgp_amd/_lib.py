@@ -24,6 +24,8 @@ class LibraryError(RuntimeError):
 LGP_OK = 0
 LGP_KERNEL_EXPQUAD = 0
 LGP_KERNEL_MATERNP = 1
+LGP_KERNEL_GAMMAEXP = 2
+LGP_KERNEL_CAUCHY = 3
 LGP_OP_MUL = 0
 LGP_OP_ADD = 1
 LGP_EPS_AUTO_REL = 1
@@ -76,12 +78,12 @@ def _signatures():
     for suf, F in (('f64', c_double), ('f32', c_float)):
         sig.update({
             'lgp_transpose_' + suf: (c_int, [c_void_p, _P, _S, _P, _S, _S, _S]),
-            'lgp_gram_isotropic_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, _P, _S, _S, _P, _S, _S,
+            'lgp_gram_isotropic_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, _P, _S, _S, _P, _S, _S,
                                                  c_int, F, c_int, F, c_int, POINTER(c_int), POINTER(F), c_int, _P, _S]),
             'lgp_gram_bart_' + suf: (c_int, [c_void_p, c_int, _P, _S, _P, _S, POINTER(c_int32), POINTER(F),
                                             c_int, c_int, POINTER(F), F, _P, _P, _S,
                                             c_int, POINTER(c_int), POINTER(F), _P, _S]),
-            'lgp_pairs_isotropic_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, _P, _S, _P, _S, _S,
+            'lgp_pairs_isotropic_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, _P, _S, _P, _S, _S,
                                                   c_int, F, c_int, F, c_int, POINTER(c_int), POINTER(F), _P]),
             'lgp_pairs_bart_' + suf: (c_int, [c_void_p, c_int, _P, _P, _S, POINTER(c_int32), _P, POINTER(F),
                                              c_int, c_int, POINTER(F), F, _P, _P, _S,

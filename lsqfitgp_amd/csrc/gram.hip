@@ -46,6 +46,8 @@ struct IsoArgs {
   T loc, scale;
   T coef[MAX_P];   // Horner coefficients c_{k+1}/c_k, k = p-1..0 in evaluation order
   T twop1;         // 2p+1
+  T par[3];        // GammaExp: gamma, gamma/2;  Cauchy: alpha/2, beta, -beta/alpha  (host-evaluated like the reference's Python floats)
+  int flag;        // GammaExp: gamma == 2;  Cauchy: alpha == 2  (the branches that act on r2 itself)
   OutOps<T> ops;
 };
 
@@ -57,6 +59,11 @@ template <typename T>
 __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2) {
   if (g.kernel == LGP_KERNEL_EXPQUAD) {
     return exp(T(-0.5) * r2);
+  } else if (g.kernel == LGP_KERNEL_GAMMAEXP) {          // _kernels/_basic.py:111-113
+    return g.flag ? exp(-r2) : exp(-pow(r2, g.par[1]));
+  } else if (g.kernel == LGP_KERNEL_CAUCHY) {            // _kernels/_basic.py:340-344
+    const T power = g.flag ? r2 : pow(r2, g.par[0]);
+    return pow(T(1) + power / g.par[1], g.par[2]);
   } else {
     T r2s = g.twop1 * r2;
     T x = sqrt(r2s + T(1e-30));
@@ -168,14 +175,15 @@ __global__ void __launch_bounds__(256) gram_iso_pairs_kernel(const IsoArgs<T> g)
 }
 
 template <typename T>
-int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int d, const T *dx, size_t ldx, size_t n, const T *dy, size_t ldy, size_t m,
+int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, int d, const T *dx, size_t ldx, size_t n, const T *dy, size_t ldy, size_t m,
                     int has_loc, T loc, int has_scale, T scale, int nops, const int *hops_code, const T *hops_val, T *dout,
                     size_t ldo, bool pairs = false) {
   LGP_REQUIRE(ctx != nullptr, "null context");
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_MATERNP, "unknown isotropic kernel");
+  LGP_REQUIRE(kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_MATERNP || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY,
+              "unknown isotropic kernel");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
   LGP_REQUIRE(p >= 0 && p <= MAX_P, "Maternp order must be in [0,16]");
   LGP_REQUIRE(nops >= 0 && nops <= MAX_OPS, "at most 8 output operations");
@@ -195,6 +203,21 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int d, const T *dx, size_t 
   int pos = 0;
   for (int k = p - 1; k >= 0; --k) g.coef[pos++] = (T)((double)(p - k) / ((double)(2 * p - k) * (double)(k + 1)));
   g.twop1 = (T)(2 * p + 1);
+  g.par[0] = g.par[1] = g.par[2] = T(0);
+  g.flag = 0;
+  if (kernel == LGP_KERNEL_GAMMAEXP) {            // hpar = {gamma, gamma / 2}
+    LGP_REQUIRE(npar == 2 && hpar != nullptr, "GammaExp takes {gamma, gamma/2}");
+    LGP_REQUIRE(hpar[0] > T(0) && hpar[0] <= T(2), "gamma must be in (0, 2]");                 // _basic.py:109-110
+    g.par[0] = hpar[0]; g.par[1] = hpar[1];
+    g.flag = hpar[0] == T(2);
+  } else if (kernel == LGP_KERNEL_CAUCHY) {       // hpar = {alpha, beta, -beta / alpha}
+    LGP_REQUIRE(npar == 3 && hpar != nullptr, "Cauchy takes {alpha, beta, -beta/alpha}");
+    LGP_REQUIRE(hpar[0] > T(0) && hpar[0] <= T(2) && hpar[1] > T(0), "alpha must be in (0, 2], beta positive");   // _basic.py:336-338
+    g.par[0] = hpar[0] / T(2); g.par[1] = hpar[1]; g.par[2] = hpar[2];
+    g.flag = hpar[0] == T(2);
+  } else {
+    LGP_REQUIRE(npar == 0, "this kernel takes no real parameters");
+  }
   g.ops.n = nops;
   for (int i = 0; i < MAX_OPS; ++i) { g.ops.code[i] = 0; g.ops.val[i] = T(0); }
   for (int i = 0; i < nops; ++i) {
@@ -424,18 +447,18 @@ int gram_bart_launch(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const in
 
 }  // namespace
 
-extern "C" int lgp_gram_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int d, const double *dx, size_t ldx, size_t n, const double *dy,
+extern "C" int lgp_gram_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d, const double *dx, size_t ldx, size_t n, const double *dy,
                                       size_t ldy, size_t m, int has_loc, double loc, int has_scale, double scale, int nops,
                                       const int *hops_code, const double *hops_val, int symmetric, double *dout, size_t ldo) {
   (void)symmetric;   // (u-v)^2 == (v-u)^2 bit for bit: the full evaluation is already exactly symmetric
-  return gram_iso_launch<double>(ctx, kernel, p, d, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val,
+  return gram_iso_launch<double>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val,
                                  dout, ldo);
 }
-extern "C" int lgp_gram_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int d, const float *dx, size_t ldx, size_t n, const float *dy,
+extern "C" int lgp_gram_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int d, const float *dx, size_t ldx, size_t n, const float *dy,
                                       size_t ldy, size_t m, int has_loc, float loc, int has_scale, float scale, int nops,
                                       const int *hops_code, const float *hops_val, int symmetric, float *dout, size_t ldo) {
   (void)symmetric;
-  return gram_iso_launch<float>(ctx, kernel, p, d, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val,
+  return gram_iso_launch<float>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val,
                                 dout, ldo);
 }
 extern "C" int lgp_gram_bart_f32(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const int32_t *diy, size_t m,
@@ -454,16 +477,16 @@ extern "C" int lgp_gram_bart_f64(lgp_ctx *ctx, int p, const int32_t *dix, size_t
 }
 
 // ---- elementwise ("pairs") forms: out[i] = k(x_i, y_i) ------------------------------------------------
-extern "C" int lgp_pairs_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int d, const double *dx, size_t ldx, const double *dy, size_t ldy,
+extern "C" int lgp_pairs_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d, const double *dx, size_t ldx, const double *dy, size_t ldy,
                                        size_t npairs, int has_loc, double loc, int has_scale, double scale, int nops,
                                        const int *hops_code, const double *hops_val, double *dout) {
-  return gram_iso_launch<double>(ctx, kernel, p, d, dx, ldx, npairs, dy, ldy, npairs, has_loc, loc, has_scale, scale, nops, hops_code,
+  return gram_iso_launch<double>(ctx, kernel, p, npar, hpar, d, dx, ldx, npairs, dy, ldy, npairs, has_loc, loc, has_scale, scale, nops, hops_code,
                                  hops_val, dout, npairs, true);
 }
-extern "C" int lgp_pairs_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int d, const float *dx, size_t ldx, const float *dy, size_t ldy,
+extern "C" int lgp_pairs_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int d, const float *dx, size_t ldx, const float *dy, size_t ldy,
                                        size_t npairs, int has_loc, float loc, int has_scale, float scale, int nops,
                                        const int *hops_code, const float *hops_val, float *dout) {
-  return gram_iso_launch<float>(ctx, kernel, p, d, dx, ldx, npairs, dy, ldy, npairs, has_loc, loc, has_scale, scale, nops, hops_code,
+  return gram_iso_launch<float>(ctx, kernel, p, npar, hpar, d, dx, ldx, npairs, dy, ldy, npairs, has_loc, loc, has_scale, scale, nops, hops_code,
                                 hops_val, dout, npairs, true);
 }
 extern "C" int lgp_pairs_bart_f32(lgp_ctx *ctx, int p, const int32_t *dix, const int32_t *diy, size_t npairs, const int32_t *hnsplits,

@@ -7,7 +7,7 @@ Follows (reference paths):
 ``src/lsqfitgp/_Kernel/_crosskernel.py:152-200`` (call contract, ctor xtransf chain),
 ``_Kernel/_ops.py:292-326`` (loc, scale), ``_Kernel/_alg.py:32-82`` (scalar add/mul),
 ``_Kernel/_isotropic.py:61-81`` + ``_Kernel/_util.py:74-99`` (r^2 over fields),
-``_kernels/_basic.py:61-75`` (ExpQuad), ``_kernels/_matern.py:29-49`` +
+``_kernels/_basic.py:61-75`` (ExpQuad), ``:94-115`` (GammaExp), ``:315-344`` (Cauchy), ``_kernels/_matern.py:29-49`` +
 ``_special/_bessel.py:101-110`` (Maternp), ``_kernels/_bart.py`` (BART),
 ``_jaxext/_fasthash.py:56-102`` (fasthash64/32).
 """
@@ -144,8 +144,32 @@ def maternp_core(r2, p):
     return kvmodx2_hi(r2 + 1e-30, p)
 
 
+def gammaexp_core(r2, gamma=1):
+    """ ``_kernels/_basic.py:94-115``: exp(-r^gamma), gamma in (0, 2]; the gamma == 2 branch is evaluated on r2 """
+    assert 0 < gamma <= 2, gamma
+    nondiff = numpy.exp(-(r2 ** (gamma / 2)))
+    diff = numpy.exp(-r2)
+    return numpy.where(gamma == 2, diff, nondiff)
+
+
+def cauchy_core(r2, alpha=2, beta=2):
+    """ ``_kernels/_basic.py:315-344``: (1 + r^alpha / beta)^(-beta / alpha), alpha in (0, 2], beta > 0 """
+    assert 0 < alpha <= 2, alpha
+    assert 0 < beta, beta
+    power = numpy.where(alpha == 2, r2, r2 ** (alpha / 2))
+    return (1 + power / beta) ** (-beta / alpha)
+
+
 def ExpQuad(*, scale=None, loc=None):
     return Kernel(_isotropic(expquad_core), scale=scale, loc=loc)
+
+
+def GammaExp(*, gamma=1, scale=None, loc=None):
+    return Kernel(_isotropic(lambda r2: gammaexp_core(r2, gamma)), scale=scale, loc=loc)
+
+
+def Cauchy(*, alpha=2, beta=2, scale=None, loc=None):
+    return Kernel(_isotropic(lambda r2: cauchy_core(r2, alpha, beta)), scale=scale, loc=loc)
 
 
 def Maternp(*, p=None, scale=None, loc=None):

@@ -7,6 +7,8 @@ entry-wise comparison with the CPU oracle and the committed golden fixtures.
 
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -33,13 +35,15 @@ def _factories():
         'Maternp1': lambda **kw: lgp.Maternp(p=1, **kw),
         'Maternp2': lambda **kw: lgp.Maternp(p=2, **kw),
         'Maternp5': lambda **kw: lgp.Maternp(p=5, **kw),
+        'GammaExp1.5': lambda **kw: lgp.GammaExp(gamma=1.5, **kw),
+        'Cauchy1-3': lambda **kw: lgp.Cauchy(alpha=1, beta=3, **kw),
     }
 
 
 class TestDeviceKernelPins(KernelPins):
     """ the reference's generic kernel tests, run on the device kernels """
 
-    @pytest.fixture(params=['ExpQuad', 'Maternp0', 'Maternp1', 'Maternp2', 'Maternp5'])
+    @pytest.fixture(params=['ExpQuad', 'Maternp0', 'Maternp1', 'Maternp2', 'Maternp5', 'GammaExp1.5', 'Cauchy1-3'])
     def make(self, request):
         return _factories()[request.param]
 
@@ -48,6 +52,60 @@ PAIRS = [
     ('ExpQuad', {}, {}), ('ExpQuad', dict(scale=2.5, loc=0.3), {}), ('Maternp', dict(p=2, scale=1.3), dict(p=2, scale=1.3)),
     ('Maternp', dict(p=0), dict(p=0)), ('Maternp', dict(p=7, loc=-1.), dict(p=7, loc=-1.)),
 ]
+
+
+POW_KERNELS = [('GammaExp', {}), ('GammaExp', dict(gamma=0.7, scale=2.)), ('GammaExp', dict(gamma=2, loc=0.5)), ('GammaExp', dict(gamma=1.9)),
+               ('Cauchy', {}), ('Cauchy', dict(alpha=2, beta=0.5, scale=0.7)), ('Cauchy', dict(alpha=1.3, beta=4.)), ('Cauchy', dict(alpha=0.5, beta=30., loc=-2.))]
+
+
+@pytest.mark.parametrize('name,kw', POW_KERNELS, ids=[f'{n}-{k}' for n, k in POW_KERNELS])
+@pytest.mark.parametrize('flt', [np.float64, np.float32])
+def test_gammaexp_cauchy_vs_oracle(lgp, name, kw, flt, rng):
+    """ GammaExp / Cauchy (_kernels/_basic.py:94-115,315-344) against the oracle: the device `pow`/`exp` against libm's,
+    through exp(-pow(.)) and pow(1 + pow(.)/beta, .) -- a few ulp of the exponent t = -log k, i.e. (8 + 4 t) eps relative;
+    exact where the reference branches on the parameter (gamma == 2, alpha == 2 act on r2 itself); k(x, x) = 1 exactly """
+    n, m = 257, 130
+    x = rng.uniform(-4, 4, (n, 2)).astype(flt); y = rng.uniform(-4, 4, (m, 2)).astype(flt)
+    dt = [('a', flt), ('b', flt)]
+    xs = np.empty(n, dt); ys = np.empty(m, dt)
+    xs['a'], xs['b'], ys['a'], ys['b'] = x[:, 0], x[:, 1], y[:, 0], y[:, 1]
+    kd = getattr(lgp, name)(**kw); ko = getattr(oracle, name)(**kw)
+    G = kd.gram(xs, ys).to_host()
+    R = ko(xs[:, None], ys[None, :])
+    assert G.dtype == flt and R.dtype == flt and G.shape == (n, m)
+    eps = np.finfo(flt).eps
+
+    amp = kw.get('beta', 2) / kw.get('alpha', 2) if name == 'Cauchy' else 0       # (1 + u)^(-beta/alpha): ulps of 1 + u times beta/alpha
+
+    def close(a, b):
+        # a few ulp in the exponent t = -log k of exp(-t) / pow(., .): relative error (8 + 4 t + 2 beta/alpha) eps
+        b64 = np.asarray(b, float)
+        tol = (8 + 4 * np.abs(np.log(np.maximum(b64, 1e-300))) + 2 * amp) * eps * b64 + np.finfo(flt).tiny     # (+ tiny: float32 results below the normal range are flushed to zero on the device)
+        assert np.all(np.abs(np.asarray(a, float) - b64) <= tol)
+
+    close(G, R)
+    D = kd.gram(xs, xs).to_host()
+    np.testing.assert_array_equal(np.diag(D), np.ones(n, flt))
+    np.testing.assert_array_equal(D, D.T)
+    Gp = kd.pairs(xs[:m], ys).to_host()
+    close(Gp, ko(xs[:m], ys))
+    # algops and the broadcasting call contract go through the same core
+    np.testing.assert_allclose((kd * 2.5 + 1)(xs[:5, None], ys[None, :7]), (ko * 2.5 + 1)(xs[:5, None], ys[None, :7]), rtol=(64 + 2 * amp) * eps)
+
+
+def test_gammaexp_cauchy_arguments(lgp):
+    for bad in (dict(gamma=0), dict(gamma=2.5), dict(gamma=-1)):
+        with pytest.raises(AssertionError):
+            lgp.GammaExp(**bad)
+    for bad in (dict(alpha=0), dict(alpha=2.1), dict(beta=0), dict(beta=-3)):
+        with pytest.raises(AssertionError):
+            lgp.Cauchy(**bad)
+    from lsqfitgp_amd import _lib
+    lib = _lib.load(); ctx = lgp.Context.default()
+    a = lgp.DeviceArray.zeros((1, 4)); o = lgp.DeviceArray.zeros((4, 4))
+    par = (ctypes.c_double * 2)(3.0, 1.5)          # gamma out of range is refused by the library as well
+    assert lib.lgp_gram_isotropic_f64(ctx.handle, _lib.LGP_KERNEL_GAMMAEXP, 0, 2, par, 1, a.ptr, a.ld, 4, a.ptr, a.ld, 4, 0, 0., 0, 1., 0, None, None, 0, o.ptr, o.ld) < 0
+    assert lib.lgp_gram_isotropic_f64(ctx.handle, _lib.LGP_KERNEL_EXPQUAD, 0, 2, par, 1, a.ptr, a.ld, 4, a.ptr, a.ld, 4, 0, 0., 0, 1., 0, None, None, 0, o.ptr, o.ld) < 0
 
 
 @pytest.mark.parametrize('name,kw,_', PAIRS)

@@ -25,6 +25,11 @@ KERNELS = {
     'Maternp1': lambda **kw: oracle.Maternp(p=1, **kw),
     'Maternp2': lambda **kw: oracle.Maternp(p=2, **kw),
     'Maternp5': lambda **kw: oracle.Maternp(p=5, **kw),
+    'GammaExp1': lambda **kw: oracle.GammaExp(**kw),
+    'GammaExp1.5': lambda **kw: oracle.GammaExp(gamma=1.5, **kw),
+    'GammaExp2': lambda **kw: oracle.GammaExp(gamma=2, **kw),
+    'Cauchy': lambda **kw: oracle.Cauchy(**kw),
+    'Cauchy1-3': lambda **kw: oracle.Cauchy(alpha=1, beta=3, **kw),
 }
 
 
@@ -189,3 +194,25 @@ def test_hash_equality_equals_vector_equality(rng):
     eq_hash = hashes[:, None] == hashes[None, :]
     eq_vec = np.all(ix[:, None, :] == ix[None, :, :], axis=-1)
     np.testing.assert_array_equal(eq_hash, eq_vec)
+
+
+def test_gammaexp_cauchy_closed_forms(rng):
+    """ the definitions of ``_kernels/_basic.py:94-115,315-344`` and the relations their docstrings state:
+    GammaExp(gamma=1) is Matern 1/2, GammaExp(gamma=2) is exp(-r^2), Cauchy(alpha=2) is the rational quadratic """
+    x = rng.standard_normal(50)
+    y = rng.standard_normal(50)
+    r = np.abs(x - y)
+    np.testing.assert_allclose(oracle.GammaExp()(x, y), np.exp(-r), rtol=1e-15)
+    np.testing.assert_allclose(oracle.GammaExp()(x, y), oracle.Maternp(p=0)(x, y), rtol=1e-14)
+    np.testing.assert_array_equal(oracle.GammaExp(gamma=2)(x, y), np.exp(-(x - y) ** 2))
+    np.testing.assert_allclose(oracle.GammaExp(gamma=0.7)(x, y), np.exp(-r ** 0.7), rtol=1e-14)
+    np.testing.assert_allclose(oracle.Cauchy(alpha=2, beta=5)(x, y), (1 + r ** 2 / 5) ** -2.5, rtol=1e-14)
+    np.testing.assert_allclose(oracle.Cauchy(alpha=1.3, beta=0.4)(x, y), (1 + r ** 1.3 / 0.4) ** (-0.4 / 1.3), rtol=1e-14)
+    big = oracle.Cauchy(alpha=1.5, beta=1e9)(x, y)          # beta -> inf: GammaExp(gamma=alpha, scale=alpha^(1/alpha))
+    np.testing.assert_allclose(big, oracle.GammaExp(gamma=1.5, scale=1.5 ** (1 / 1.5))(x, y), rtol=1e-7)
+    for bad in (dict(gamma=0), dict(gamma=2.1)):
+        with pytest.raises(AssertionError):
+            oracle.GammaExp(**bad)(x, y)
+    for bad in (dict(alpha=0), dict(alpha=3), dict(beta=0)):
+        with pytest.raises(AssertionError):
+            oracle.Cauchy(**bad)(x, y)
