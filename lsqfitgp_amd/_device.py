@@ -37,7 +37,10 @@ class Context:
         self.device = int(device)
         self.rank = 0
         self.nranks = 1
-        self._finalizer = weakref.finalize(self, lib.lgp_ctx_destroy, handle)
+        # lgp_free synchronises the device (hipFree does); the buffers that the host classes drop all the time are
+        # therefore collected here and freed in batches, large ones at once
+        self._graveyard = _Graveyard(lib, handle)
+        self._finalizer = weakref.finalize(self, _destroy_context, lib, handle, self._graveyard)
 
     @property
     def handle(self):
@@ -121,16 +124,48 @@ class Context:
         return buf.raw
 
 
+class _Graveyard:
+    """ device pointers waiting for lgp_free: flushed when more than LIMIT_BYTES or LIMIT_COUNT are pending, when an
+    allocation fails, and when the context goes away """
+
+    LIMIT_BYTES = 1 << 30
+    LIMIT_COUNT = 256
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+        self.pending, self.nbytes = [], 0
+
+    def bury(self, ptr, nbytes):
+        self.pending.append(ptr)
+        self.nbytes += nbytes
+        if self.nbytes > self.LIMIT_BYTES or len(self.pending) > self.LIMIT_COUNT:
+            self.flush()
+
+    def flush(self):
+        pending, self.pending, self.nbytes = self.pending, [], 0
+        for ptr in pending:
+            self.lib.lgp_free(self.handle, ctypes.c_void_p(ptr))
+
+
+def _destroy_context(lib, handle, graveyard):
+    graveyard.flush()
+    lib.lgp_ctx_destroy(handle)
+
+
 class _Buffer:
     """ owns one lgp_malloc allocation """
 
     def __init__(self, ctx, nbytes):
         ptr = ctypes.c_void_p()
-        _lib.check(ctx._lib.lgp_malloc(ctx.handle, int(nbytes), ctypes.byref(ptr)), f'lgp_malloc({nbytes})')
+        st = ctx._lib.lgp_malloc(ctx.handle, int(nbytes), ctypes.byref(ptr))
+        if st == _lib.LGP_ENOMEM and ctx._graveyard.pending:      # give back what is waiting to be freed and retry
+            ctx._graveyard.flush()
+            st = ctx._lib.lgp_malloc(ctx.handle, int(nbytes), ctypes.byref(ptr))
+        _lib.check(st, f'lgp_malloc({nbytes})')
         self.ctx = ctx
         self.ptr = ptr.value
         self.nbytes = int(nbytes)
-        self._finalizer = weakref.finalize(self, ctx._lib.lgp_free, ctx.handle, ctypes.c_void_p(ptr.value))
+        self._finalizer = weakref.finalize(self, ctx._graveyard.bury, ptr.value, int(nbytes))
 
 
 _ALLOWED = (numpy.dtype(numpy.float64), numpy.dtype(numpy.float32), numpy.dtype(numpy.int32))

@@ -22,6 +22,7 @@ class LibraryError(RuntimeError):
 
 
 LGP_OK = 0
+LGP_ENOMEM = -4
 LGP_KERNEL_EXPQUAD = 0
 LGP_KERNEL_MATERNP = 1
 LGP_KERNEL_GAMMAEXP = 2
