@@ -304,6 +304,12 @@ int lgp_colabssum_f64(lgp_ctx *ctx, size_t rows, size_t cols, const double *dA, 
  * diagonal block; on exit dP holds the L panel and ddblk its packed diagonal blocks (lgp_chol_dblk_size(nb)).
  * info offset `row0` is added to pivot indices. */
 int lgp_panel_factor_f64(lgp_ctx *ctx, size_t rows, size_t nb, double *dP, size_t ldp, double *ddblk, size_t row0);
+/* The same update for ALL block columns a rank owns in a 1-D block-column-cyclic layout, in one launch: dC is the
+ * rank's local storage from its first not yet finished block column on (rows x cols, local block q of width nb =
+ * global block (q0 + q) * nranks + rank), dP the panel rows from the global row of C(0,0) on (rows x k).  Element (i, j)
+ * is updated with P[i] . P[j + nb (nranks-1) (j / nb)] where that global column is <= i ("staircase" lower). */
+int lgp_update_nt_cyclic_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dP, size_t ldp,
+                             double *dC, size_t ldc, size_t nb, size_t nranks);
 /* C (rows x cols, ldc) -= A (rows x k) * B (cols x k)^T, `lower` != 0 restricts to row >= col + diag_offset */
 int lgp_update_nt_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dA, size_t lda,
                       const double *dB, size_t ldb, double *dC, size_t ldc, int lower);

@@ -71,6 +71,7 @@ def factor_schedule(layout, ops):
         panel_factor(b), pack_panel(b, slot)                      compute stream, owner(b) only
         update(c, b, slot)                                        compute stream, owner(c) only:
                                                                   block column c -= P_b[rows of c] P_b[block rows of c]'
+        update_rest(cols, b, slot)   (optional)                   the same for a run of consecutive owned block columns
         bcast_panel(b, slot)                                      comm stream, every rank
         compute_mark_ready(slot) / comm_wait_ready(slot)          owner: panel packed before it is sent
         comm_mark_received(slot) / compute_wait_received(slot)    panel arrived before it is used
@@ -100,9 +101,13 @@ def factor_schedule(layout, ops):
                 ops.comm_wait_free(nslot)
             ops.bcast_panel(nxt, nslot)
             ops.comm_mark_received(nslot)
-        for c in mine:
-            if c > b and not (c == nxt):
-                ops.update(c, b, slot)
+        rest = [c for c in mine if c > b and c != nxt]
+        if rest:
+            if hasattr(ops, 'update_rest'):
+                ops.update_rest(rest, b, slot)          # all of them in one launch
+            else:
+                for c in rest:
+                    ops.update(c, b, slot)
         ops.compute_mark_free(slot)
     ops.finish()
 
@@ -198,6 +203,22 @@ class DeviceOps:
         A = self.P[slot].ptr + off * kb * 8
         blk = self._block(c)
         _lib.check(self.lib.lgp_update_nt_f64(self.ctx.handle, L.rows(c), L.width(c), kb, A, kb, A, kb, blk.ptr, blk.ld, 1), 'lgp_update_nt')
+
+    def update_rest(self, cols, b, slot):
+        """ every remaining owned block column with panel b in one "staircase" launch (lgp_update_nt_cyclic_f64) """
+        L = self.layout
+        kb = L.width(b)
+        lb0 = L.local_index(cols[0])
+        assert [L.local_index(c) for c in cols] == list(range(lb0, lb0 + len(cols)))
+        g0 = L.col0(cols[0])
+        A = self.P[slot].ptr + (g0 - L.col0(b)) * kb * 8
+        ncols = sum(L.width(c) for c in cols)
+        C = self.Lloc.block(g0, L.n, lb0 * L.nb, lb0 * L.nb + ncols)
+        if L.nb % 128:
+            for c in cols:                              # block widths that are not whole tiles: one launch per block column
+                self.update(c, b, slot)
+            return
+        _lib.check(self.lib.lgp_update_nt_cyclic_f64(self.ctx.handle, L.n - g0, ncols, kb, A, kb, C.ptr, C.ld, L.nb, L.nranks), 'lgp_update_nt_cyclic')
 
     def finish(self):
         self._compute()

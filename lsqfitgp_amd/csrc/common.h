@@ -90,7 +90,9 @@ constexpr int LGP_DBLK = LGP_FRAG0 + LGP_NFRAG * 64;   // per-diagonal-block wor
 // (k covers it) before the epilogue -- used by the in-place triangular kernels.
 template <typename T>
 int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
-                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag = 0);
+                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag = 0, int cyc_nb = 0,
+                    int cyc_g1 = 0);
+// cyc_nb > 0: block-column-cyclic lower update (see GemmArgs in gemm.hip); only for the NT lower form with A == B rows
 // tag = 1 launches the separately named instantiation used for the Cholesky trailing update (profiling label only)
 
 // ---- factorisation pieces (potrf.hip) ------------------------------------------------------

@@ -63,6 +63,10 @@ struct GemmArgs {
   int m, n, k;
   T alpha, beta;
   int lower;
+  // block-column-cyclic lower mode (lower != 0, cyc_nb > 0): local column block q of width cyc_nb holds the global
+  // block (q0 + q) * G + rank, i.e. global column = local column + cyc_nb * cyc_g1 * (local column / cyc_nb), cyc_g1 = G - 1;
+  // the B operand rows and the lower mask follow the global column (0, 0: plain lower)
+  int cyc_nb, cyc_g1;
   int tm, tn;          // tile counts
   int nsm, nsn;        // super-tile counts (0: direct mapping)
   int nbulk;           // super-tiles mapped XCD-wise (a multiple of 8); the rest is dealt out slot by slot
@@ -263,6 +267,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   LGP_STAMP(0);
   if (!map_tile(g.tm, g.tn, g.nsm, g.nsn, g.nbulk, g.lower, ti, tj)) return;
   const int row0 = ti * BM, col0 = tj * BN;
+  const int cshift = g.cyc_nb ? g.cyc_nb * g.cyc_g1 * (col0 / g.cyc_nb) : 0;   // global column - local column of this tile
+  if (g.lower && row0 + BM - 1 < col0 + cshift) return;                        // entirely above the (global) diagonal
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * WTM, wn = (wave & 1) * WTN;
@@ -272,7 +278,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   // loaded straight into the accumulators while the first operand tiles are in flight, so the epilogue is stores
   // only.  (A read-modify-write epilogue on the same pointer serialises into 64 dependent global round trips per
   // lane.)  alpha = -1 costs nothing in the loop: the accumulators start at -C and the epilogue stores -acc.
-  const bool interior = (row0 + BM <= g.m) && (col0 + BN <= g.n) && !(g.lower && ti == tj);
+  const bool interior = (row0 + BM <= g.m) && (col0 + BN <= g.n) && !(g.lower && row0 < col0 + cshift + BN - 1);
   const bool accinit = g.nsplit <= 1 && g.beta == T(1) && (g.alpha == T(1) || g.alpha == T(-1));
   const bool negC = accinit && g.alpha == T(-1);
 
@@ -292,10 +298,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   // whole-tile fast path: both operand tiles inside the matrices, aligned, K range a multiple of BK
   const bool allfast = g.alignedA && g.alignedB && (row0 + BM <= g.m) && (col0 + BN <= g.n) && ((kend - kbeg) % BK == 0) &&
                        g.lda < (1l << 21) && g.ldb < (1l << 21);
+  const int bcol0 = col0 + cshift;        // B operand rows of this tile (cyclic mode: the global column)
+  const int bn = g.n + cshift;            // ... and their end
 #ifdef LGP_GEMM_TRACE
-  const int lrow0 = g.noload == 2 ? 0 : row0, lcol0 = g.noload == 2 ? 0 : col0;   // experiment: every tile reads the same operand tiles
+  const int lrow0 = g.noload == 2 ? 0 : row0, lcol0 = g.noload == 2 ? 0 : bcol0;   // experiment: every tile reads the same operand tiles
 #else
-  const int lrow0 = row0, lcol0 = col0;
+  const int lrow0 = row0, lcol0 = bcol0;
 #endif
   const char *pa = reinterpret_cast<const char *>(TA ? g.A + (long)kbeg * g.lda + lrow0 : g.A + (long)lrow0 * g.lda + kbeg);
   const char *pb = reinterpret_cast<const char *>(!TB ? g.B + (long)kbeg * g.ldb + lcol0 : g.B + (long)lcol0 * g.ldb + kbeg);
@@ -312,7 +320,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
       tb.load_fast(pb);
     } else {
       ta.load(g.A, g.lda, row0, kbeg, g.m, kend, g.alignedA);
-      tb.load(g.B, g.ldb, col0, kbeg, g.n, kend, g.alignedB);
+      tb.load(g.B, g.ldb, bcol0, kbeg, bn, kend, g.alignedB);
     }
   }
   if (accinit) {
@@ -333,7 +341,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
 #pragma unroll
           for (int j = 0; j < NFN; ++j) {
             const int col = col0 + wn + j * 16 + fr;
-            const bool ok = row < g.m && col < g.n && !(g.lower && col > row);
+            const bool ok = row < g.m && col < g.n && !(g.lower && col + cshift > row);
             const T v = g.C[ok ? row * g.ldc + col : 0];   // clamped address instead of a branch around the load
             acc[i][j][r] = ok ? v : T(0);
           }
@@ -372,7 +380,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
         tb.load_fast(pb);
       } else {
         ta.load(g.A, g.lda, row0, kbeg + (t + 1) * BK, g.m, kend, g.alignedA);
-        tb.load(g.B, g.ldb, col0, kbeg + (t + 1) * BK, g.n, kend, g.alignedB);
+        tb.load(g.B, g.ldb, bcol0, kbeg + (t + 1) * BK, bn, kend, g.alignedB);
       }
     }
     const T *la = ldsA + cur * IMG_A;
@@ -443,7 +451,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
 #pragma unroll
         for (int j = 0; j < NFN; ++j) {
           const int col = col0 + wn + j * 16 + fr;
-          const bool ok = interior || (row < g.m && col < g.n && !(g.lower && col > row));
+          const bool ok = interior || (row < g.m && col < g.n && !(g.lower && col + cshift > row));
           cv[r][j] = Cbase[ok ? row * ldc + col : 0];   // clamped address instead of a branch around the load
         }
       }
@@ -454,7 +462,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
 #pragma unroll
       for (int j = 0; j < NFN; ++j) {
         const int col = col0 + wn + j * 16 + fr;
-        if (interior || (row < g.m && col < g.n && !(g.lower && col > row))) {
+        if (interior || (row < g.m && col < g.n && !(g.lower && col + cshift > row))) {
           T v = alpha * acc[i][j][r];
           if (beta != T(0)) v += beta * cv[r][j];
           Cbase[row * ldc + col] = v;
@@ -481,7 +489,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const T *part, int n
 
 template <typename T, int TS, int NTHREADS>
 static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha, const T *A, size_t lda,
-                          const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag) {
+                          const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag, int cyc_nb, int cyc_g1) {
   constexpr size_t VEC = 16 / sizeof(T);
   GemmArgs<T> g;
   g.A = A; g.B = B; g.C = C;
@@ -489,6 +497,8 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
   g.m = (int)m; g.n = (int)n; g.k = (int)k;
   g.alpha = alpha; g.beta = beta;
   g.lower = lower ? 1 : 0;
+  g.cyc_nb = cyc_nb;
+  g.cyc_g1 = cyc_g1;
   g.tm = (int)((m + TS - 1) / TS);
   g.tn = (int)((n + TS - 1) / TS);
   g.alignedA = ((reinterpret_cast<uintptr_t>(A) % 16) == 0 && (lda % VEC) == 0) ? 1 : 0;
@@ -549,8 +559,9 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
 
 template <typename T>
 int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
-                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag) {
+                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag, int cyc_nb, int cyc_g1) {
   if (m == 0 || n == 0) return LGP_OK;
+  LGP_REQUIRE(cyc_nb == 0 || (lower && cyc_nb % 128 == 0 && cyc_g1 >= 0 && !ta && tb), "cyclic mode: lower NT update, block width a multiple of 128");
   LGP_REQUIRE(m < (1u << 30) && n < (1u << 30) && k < (1u << 30), "gemm dimension too large");
   LGP_REQUIRE(C != nullptr && (k == 0 || (A != nullptr && B != nullptr)), "null matrix pointer");
   LGP_REQUIRE(ldc >= n, "ldc < n");
@@ -563,15 +574,15 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   const size_t t128 = ((m + 127) / 128) * ((n + 127) / 128);
   const bool aliased = (static_cast<const void *>(A) == static_cast<const void *>(C)) || (static_cast<const void *>(B) == static_cast<const void *>(C));
   if (!aliased && ((t128 <= 64 && k <= 2048) || (t128 <= 512 && k <= 256)))
-    return gemm_launch_ts<T, 64, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, 0);
+    return gemm_launch_ts<T, 64, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, 0, cyc_nb, cyc_g1);
   // (a 512-thread variant, 4 x 2 waves of 32 x 64 at 4 waves per SIMD, was measured equal: 61.3 vs 61.7 TFLOP/s)
-  return gemm_launch_ts<T, 128, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, tag);
+  return gemm_launch_ts<T, 128, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, tag, cyc_nb, cyc_g1);
 }
 
 template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t,
-                                     const double *, size_t, double, double *, size_t, bool, int);
+                                     const double *, size_t, double, double *, size_t, bool, int, int, int);
 template int lgp_gemm_launch<float>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, float, const float *, size_t,
-                                    const float *, size_t, float, float *, size_t, bool, int);
+                                    const float *, size_t, float, float *, size_t, bool, int, int, int);
 
 extern "C" int lgp_gemm_f64(lgp_ctx *ctx, int ta, int tb, size_t m, size_t n, size_t k, double alpha, const double *dA,
                             size_t lda, const double *dB, size_t ldb, double beta, double *dC, size_t ldc) {
@@ -585,6 +596,15 @@ extern "C" int lgp_gemm_f32(lgp_ctx *ctx, int ta, int tb, size_t m, size_t n, si
   LGP_REQUIRE(ctx != nullptr, "null context");
   DeviceGuard dg(ctx->device);
   return lgp_gemm_launch<float>(ctx, ctx->stream, ta != 0, tb != 0, m, n, k, alpha, dA, lda, dB, ldb, beta, dC, ldc, false);
+}
+
+extern "C" int lgp_update_nt_cyclic_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dP, size_t ldp, double *dC, size_t ldc,
+                                        size_t nb, size_t nranks) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  LGP_REQUIRE(nb >= 128 && nb % 128 == 0 && nranks >= 1 && nb < (1u << 24) && nranks < 4096, "bad block layout");
+  DeviceGuard dg(ctx->device);
+  return lgp_gemm_launch<double>(ctx, ctx->stream, false, true, rows, cols, k, -1.0, dP, ldp, dP, ldp, 1.0, dC, ldc, true, 0, (int)nb,
+                                 (int)(nranks - 1));
 }
 
 extern "C" int lgp_update_nt_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dA, size_t lda,

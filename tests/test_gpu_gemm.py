@@ -119,3 +119,42 @@ def test_gemm_argument_errors(lgp):
     assert lib.lgp_gemm_f64(ctx.handle, 0, 0, 8, 8, 8, 1.0, a.ptr, 8, a.ptr, 8, 0.0, a.ptr, 4) < 0     # ldc < n
     assert lib.lgp_gemm_f64(ctx.handle, 0, 0, 8, 8, 8, 1.0, None, 8, a.ptr, 8, 0.0, a.ptr, 8) < 0      # null operand
     assert lib.lgp_gemm_f64(None, 0, 0, 8, 8, 8, 1.0, a.ptr, 8, a.ptr, 8, 0.0, a.ptr, 8) < 0           # null context
+
+
+@pytest.mark.parametrize('n,nb,G,rank,q0,k', [(1500, 128, 2, 1, 0, 128), (2600, 256, 3, 0, 1, 256), (4000, 1024, 2, 0, 0, 1024), (3000, 128, 4, 3, 2, 130),
+                                              (5000, 256, 1, 0, 3, 256)])
+def test_update_nt_cyclic(lgp, rng, n, nb, G, rank, q0, k):
+    """ lgp_update_nt_cyclic_f64: one launch updates every block column a rank owns (from local block q0 on) in a
+    block-column-cyclic layout; against a per-block numpy restatement.  Local block q = global block q * G + rank. """
+    from lsqfitgp_amd import _lib
+    lib = _lib.load(); ctx = lgp.Context.default()
+    nblocks = -(-n // nb)
+    owned = [b for b in range(nblocks) if b % G == rank]
+    widths = [min(nb, n - b * nb) for b in owned]
+    if q0 >= len(owned):
+        pytest.skip('no block to update')
+    g0 = owned[q0] * nb                                    # global row/col of C(0, 0)
+    rows = n - g0
+    ncols = sum(widths[q0:])
+    P = rng.standard_normal((rows, k))                     # panel rows g0 .. n-1
+    Cloc = rng.standard_normal((rows, ncols))
+    want = Cloc.copy()
+    col = 0
+    for q in range(q0, len(owned)):
+        c0 = owned[q] * nb - g0                            # row (relative to g0) of this block's diagonal
+        w = widths[q]
+        upd = P[c0:] @ P[c0:c0 + w].T                      # rows c0.., lower trapezoid of the block column
+        mask = np.tril(np.ones((rows - c0, w), bool))
+        want[c0:, col:col + w][mask] -= upd[mask]
+        col += w
+    Pd, Cd = lgp.DeviceArray.from_host(P), lgp.DeviceArray.from_host(Cloc)
+    _lib.check(lib.lgp_update_nt_cyclic_f64(ctx.handle, rows, ncols, k, Pd.ptr, Pd.ld, Cd.ptr, Cd.ld, nb, G))
+    got = Cd.to_host()
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-10)
+    # everything above the staircase is untouched, bit for bit
+    col = 0
+    for q in range(q0, len(owned)):
+        c0 = owned[q] * nb - g0
+        w = widths[q]
+        np.testing.assert_array_equal(got[:c0, col:col + w], Cloc[:c0, col:col + w])
+        col += w
