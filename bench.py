@@ -337,7 +337,7 @@ def main_dist(args, cfg, ctx, dist, rank, world):
             tpts[f'f{i}'] = xs[i]
 
     def step():
-        d = DistributedChol(kern, pts, noise=0.01, nb=1024, ctx=ctx)         # Gram build + jitter + factorisation
+        d = DistributedChol(kern, pts, noise=0.01, nb=1024, ctx=ctx, carry=(tpts, y))   # Gram build + jitter + factorisation, solve carried
         mean, cov, mlnd = d.posterior(kern, pts, tpts, y)                     # fan-in solve, mean, covariance, likelihood
         return -mlnd
 

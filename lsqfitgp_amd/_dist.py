@@ -132,11 +132,13 @@ def forward_solve_schedule(layout, ops):
 class DeviceOps:
     """ product backend: C-ABI kernels on the local GPU, RCCL broadcasts on the auxiliary stream """
 
-    def __init__(self, ctx, layout, Lloc, dblk):
-        self.ctx, self.layout, self.Lloc, self.dblk = ctx, layout, Lloc, dblk
+    def __init__(self, ctx, layout, Lloc, dblk, nx=0):
+        """ nx: extra rows below the n matrix rows of ``Lloc`` (right-hand sides carried through the factorisation:
+        they are "rows below" for every panel, like in lgp_chol_factor_rhs) """
+        self.ctx, self.layout, self.Lloc, self.dblk, self.nx = ctx, layout, Lloc, dblk, int(nx)
         self.lib = _lib.load()
         n, nb = layout.n, layout.nb
-        self.P = [DeviceArray.empty((n, nb), numpy.float64, ctx) for _ in range(2)]
+        self.P = [DeviceArray.empty((n + self.nx, nb), numpy.float64, ctx) for _ in range(2)]
         self.ev = {k: [ctx.event(), ctx.event()] for k in ('ready', 'recv', 'free')}
         self.dblk_per_block = self.lib.lgp_chol_dblk_size(nb)
 
@@ -176,24 +178,24 @@ class DeviceOps:
         """ device view of the locally owned block column b from its diagonal down: rows(b) x width(b) """
         L = self.layout
         lb = L.local_index(b)
-        return self.Lloc.block(L.col0(b), L.n, lb * L.nb, lb * L.nb + L.width(b))
+        return self.Lloc.block(L.col0(b), L.n + self.nx, lb * L.nb, lb * L.nb + L.width(b))
 
     def panel_factor(self, b):
         L = self.layout
         blk = self._block(b)
         w = self.dblk.rows(L.local_index(b) * self.dblk_per_block, (L.local_index(b) + 1) * self.dblk_per_block)
-        _lib.check(self.lib.lgp_panel_factor_f64(self.ctx.handle, L.rows(b), L.width(b), blk.ptr, blk.ld, w.ptr, L.col0(b)), 'lgp_panel_factor')
+        _lib.check(self.lib.lgp_panel_factor_f64(self.ctx.handle, L.rows(b) + self.nx, L.width(b), blk.ptr, blk.ld, w.ptr, L.col0(b)), 'lgp_panel_factor')
 
     def pack_panel(self, b, slot):
         L = self.layout
         blk = self._block(b)
         dst = self.P[slot]
-        _lib.check(self.lib.lgp_copy2d(self.ctx.handle, dst.ptr, L.width(b), blk.ptr, blk.ld, L.rows(b), L.width(b), 8), 'lgp_copy2d')
+        _lib.check(self.lib.lgp_copy2d(self.ctx.handle, dst.ptr, L.width(b), blk.ptr, blk.ld, L.rows(b) + self.nx, L.width(b), 8), 'lgp_copy2d')
 
     def bcast_panel(self, b, slot):
         L = self.layout
         self._comm()
-        _lib.check(self.lib.lgp_bcast(self.ctx.handle, self.P[slot].ptr, L.rows(b) * L.width(b) * 8, L.owner(b)), 'lgp_bcast')
+        _lib.check(self.lib.lgp_bcast(self.ctx.handle, self.P[slot].ptr, (L.rows(b) + self.nx) * L.width(b) * 8, L.owner(b)), 'lgp_bcast')
         self._compute()
 
     def update(self, c, b, slot):
@@ -202,7 +204,7 @@ class DeviceOps:
         off = L.col0(c) - L.col0(b)                 # first row of block c inside panel b
         A = self.P[slot].ptr + off * kb * 8
         blk = self._block(c)
-        _lib.check(self.lib.lgp_update_nt_f64(self.ctx.handle, L.rows(c), L.width(c), kb, A, kb, A, kb, blk.ptr, blk.ld, 1), 'lgp_update_nt')
+        _lib.check(self.lib.lgp_update_nt_f64(self.ctx.handle, L.rows(c) + self.nx, L.width(c), kb, A, kb, A, kb, blk.ptr, blk.ld, 1), 'lgp_update_nt')
 
     def update_rest(self, cols, b, slot):
         """ every remaining owned block column with panel b in one "staircase" launch (lgp_update_nt_cyclic_f64) """
@@ -213,12 +215,12 @@ class DeviceOps:
         g0 = L.col0(cols[0])
         A = self.P[slot].ptr + (g0 - L.col0(b)) * kb * 8
         ncols = sum(L.width(c) for c in cols)
-        C = self.Lloc.block(g0, L.n, lb0 * L.nb, lb0 * L.nb + ncols)
+        C = self.Lloc.block(g0, L.n + self.nx, lb0 * L.nb, lb0 * L.nb + ncols)
         if L.nb % 128:
             for c in cols:                              # block widths that are not whole tiles: one launch per block column
                 self.update(c, b, slot)
             return
-        _lib.check(self.lib.lgp_update_nt_cyclic_f64(self.ctx.handle, L.n - g0, ncols, kb, A, kb, C.ptr, C.ld, L.nb, L.nranks), 'lgp_update_nt_cyclic')
+        _lib.check(self.lib.lgp_update_nt_cyclic_f64(self.ctx.handle, L.n - g0 + self.nx, ncols, kb, A, kb, C.ptr, C.ld, L.nb, L.nranks), 'lgp_update_nt_cyclic')
 
     def finish(self):
         self._compute()
@@ -234,7 +236,10 @@ class DistributedChol:
     bound reduced (max) over the ranks.
     """
 
-    def __init__(self, kernel, x, *, noise=0., epsrel='auto', epsabs=0, nb=1024, ctx=None):
+    def __init__(self, kernel, x, *, noise=0., epsrel='auto', epsabs=0, nb=1024, ctx=None, carry=None):
+        """ ``carry=(xs, y)`` (optional): test points and data whose forward solve ``L^-1 [K(x, xs) | y]`` rides through the
+        factorisation as extra rows of every rank's block columns (as in ``lgp_chol_factor_rhs``); `posterior` then
+        needs no solve and no per-panel all-reduce """
         from ._kernels import _Isotropic, _leaf_columns
         if not isinstance(kernel, _Isotropic):
             raise NotImplementedError('the distributed Gram build covers the isotropic kernels')
@@ -248,7 +253,18 @@ class DistributedChol:
         self.n = n
         xd = DeviceArray.from_host(numpy.stack([numpy.asarray(c, float) for c in cols]), ctx=self.ctx)   # replicated covariates: 8 d N bytes
         d = len(cols)
-        self.Lloc = DeviceArray.zeros((n, L.local_cols), numpy.float64, self.ctx)
+        self._carry = None
+        nx = 0
+        if carry is not None:
+            xs_c = numpy.asarray(carry[0]).reshape(-1)
+            y_c = numpy.asarray(carry[1], float).reshape(-1)
+            if len(y_c) != n:
+                raise ValueError(f'y has {len(y_c)} values, x has {n} points')
+            mq = len(xs_c) + 1
+            nx = -(-mq // 128) * 128                     # whole 128-row tiles
+            self._carry = (xs_c, y_c, mq)
+        self.nx = nx
+        self.Lloc = DeviceArray.zeros((n + nx, L.local_cols), numpy.float64, self.ctx)
         self.dblk = DeviceArray.empty((max(L.nlocal, 1) * lib.lgp_chol_dblk_size(nb),), numpy.float64, self.ctx)
         F = ctypes.c_double
         # ---- Gram build: every rank evaluates its own block columns in place, no communication
@@ -262,6 +278,15 @@ class DistributedChol:
             if noise:
                 diag = self.Lloc.block(c0, c0 + w, lb * nb, lb * nb + w)
                 _lib.check(lib.lgp_add_diag_f64(self.ctx.handle, w, diag.ptr, diag.ld, None, F(noise)), 'lgp_add_diag')
+            if self._carry is not None:                  # K(xs, x[block]) and y[block] below the matrix rows
+                xs_c, y_c, mq = self._carry
+                xsd = DeviceArray.from_host(numpy.stack([numpy.asarray(c_, float) for c_ in _leaf_columns(xs_c)]), ctx=self.ctx)
+                rows_k = self.Lloc.block(n, n + mq - 1, lb * nb, lb * nb + w)
+                _lib.check(lib.lgp_gram_isotropic_f64(self.ctx.handle, kernel._kind, int(kernel._p), *kernel._par_args(F), d, xsd.ptr, xsd.ld, mq - 1,
+                                                      yb.ptr, yb.ld, w, int(kernel._loc is not None), F(kernel._loc or 0),
+                                                      int(kernel._scale is not None), F(kernel._scale or 1), 0, None, None, 0, rows_k.ptr, rows_k.ld),
+                           'lgp_gram_isotropic')
+                self.Lloc.block(n + mq - 1, n + mq, lb * nb, lb * nb + w).assign(DeviceArray.from_host(y_c[c0:c0 + w].reshape(1, w), ctx=self.ctx))
         if 1 + noise > 2 or 1 + noise < 0.5:
             raise NotImplementedError('distributed path assumes diag_scale_pow2 == 1 (diagonal in [0.5, 2))')
         # ---- jitter: eps = epsrel * max_i sum_j |K_ij| + epsabs, column sums of the owned block columns
@@ -274,7 +299,7 @@ class DistributedChol:
         gmax = 0.
         for b in L.owned():
             lb, w = L.local_index(b), L.width(b)
-            blk = self.Lloc.block(0, n, lb * nb, lb * nb + w)
+            blk = self.Lloc.block(0, n, lb * nb, lb * nb + w)          # matrix rows only (not the carried rows)
             _lib.check(lib.lgp_colabssum_f64(self.ctx.handle, n, w, blk.ptr, blk.ld, sums.ptr + lb * nb * 8), 'lgp_colabssum')
         if L.nlocal:
             gmax = float(numpy.max(sums.to_host()[:L.nlocal * nb]))
@@ -287,7 +312,7 @@ class DistributedChol:
             diag = self.Lloc.block(c0, c0 + w, lb * nb, lb * nb + w)
             _lib.check(lib.lgp_add_diag_f64(self.ctx.handle, w, diag.ptr, diag.ld, None, F(self.eps)), 'lgp_add_diag')
         # ---- factorisation
-        self.ops = DeviceOps(self.ctx, L, self.Lloc, self.dblk)
+        self.ops = DeviceOps(self.ctx, L, self.Lloc, self.dblk, nx)
         info0 = ctypes.c_int()
         _lib.check(lib.lgp_get_info(self.ctx.handle, ctypes.byref(info0)))       # reset
         factor_schedule(L, self.ops)
@@ -345,8 +370,23 @@ class DistributedChol:
         xs = numpy.asarray(xs).reshape(-1)
         m = len(xs)
         k = m + 1
-        Kxxs = kernel.gram(numpy.asarray(x).reshape(-1), xs, ctx=ctx)
         Kss = kernel.gram(xs, xs, ctx=ctx)
+        if self._carry is not None and self._carry[2] == k and numpy.array_equal(self._carry[0], xs) \
+                and numpy.array_equal(self._carry[1], numpy.asarray(y, float).reshape(-1)):
+            # the solve was carried through the factorisation: rows n .. n+k-1 of the owned block columns hold
+            # (L^-1 [Kxxs | y])^T restricted to those columns; [X'X | X'x_y ; . | x_y'x_y] = sum over columns + one all-reduce
+            acc = DeviceArray.zeros((k, k), numpy.float64, ctx)
+            if L.nlocal:
+                Wt = self.Lloc.block(n, n + k, 0, L.local_cols)         # (the padding columns of a ragged last block are zero)
+                self._gemm(False, True, k, k, Wt.shape[1], 1., Wt.ptr, Wt.ld, Wt.ptr, Wt.ld, 0., acc.ptr, acc.ld)
+            _lib.check(lib.lgp_allreduce_sum_f64(ctx.handle, acc.ptr, k * k), 'lgp_allreduce_sum')
+            ctx.sync()
+            G = acc.to_host()
+            mean = G[:m, m].copy()
+            cov = Kss.to_host() - G[:m, :m]
+            mlnd = 0.5 * (n * numpy.log(2 * numpy.pi) + 2 * self.logdet() + G[m, m])
+            return mean, cov, mlnd
+        Kxxs = kernel.gram(numpy.asarray(x).reshape(-1), xs, ctx=ctx)
         W = DeviceArray.empty((n, k), numpy.float64, ctx)
         W.block(0, n, 0, m).assign(Kxxs)
         W.block(0, n, m, k).assign(DeviceArray.from_host(numpy.asarray(y, float).reshape(n, 1), ctx=ctx))

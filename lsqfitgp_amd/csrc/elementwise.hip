@@ -136,7 +136,17 @@ __global__ void __launch_bounds__(256) colabssum_kernel(size_t rows, size_t cols
   const size_t r1 = (r0 + rows_per_blk) < rows ? (r0 + rows_per_blk) : rows;
   T acc = T(0);
   for (size_t i = r0; i < r1; ++i) acc += fabs(A[i * lda + j]);
-  atomicAdd(&out[j], acc);
+  out[chunk * cols + j] = acc;          // partial of this row chunk; summed in chunk order by colabssum_reduce_kernel
+}
+
+// out[j] = sum over chunks, in chunk order: the Gershgorin bound (hence the jitter) is reproducible bit for bit
+template <typename T>
+__global__ void __launch_bounds__(256) colabssum_reduce_kernel(size_t cols, size_t chunks, const T *part, T *out) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= cols) return;
+  T acc = T(0);
+  for (size_t ch = 0; ch < chunks; ++ch) acc += part[ch * cols + j];
+  out[j] = acc;
 }
 
 // single-workgroup reductions (n up to ~1e5: negligible), deterministic order
@@ -338,16 +348,23 @@ extern "C" int lgp_colabssum_f64(lgp_ctx *c, size_t rows, size_t cols, const dou
   if (cols == 0) return LGP_OK;
   LGP_REQUIRE(out != nullptr && (rows == 0 || (A != nullptr && lda >= cols)), "bad argument");
   DeviceGuard dg(c->device);
-  LGP_HIP(hipMemsetAsync(out, 0, cols * sizeof(double), c->stream));
-  if (rows == 0) return LGP_OK;
+  if (rows == 0) {
+    LGP_HIP(hipMemsetAsync(out, 0, cols * sizeof(double), c->stream));
+    return LGP_OK;
+  }
   const size_t nbx = (cols + 255) / 256;
   size_t chunks = (size_t)c->cus * 8 / nbx;
   if (chunks < 1) chunks = 1;
   if (chunks > rows) chunks = rows;
   const size_t rpb = (rows + chunks - 1) / chunks;
   chunks = (rows + rpb - 1) / rpb;
-  hipLaunchKernelGGL((colabssum_kernel<double>), dim3((unsigned)(nbx * chunks)), dim3(256), 0, c->stream, rows, cols, A, lda, out, rpb);
+  double *part = nullptr;
+  LGP_HIP(hipMallocAsync(reinterpret_cast<void **>(&part), chunks * cols * sizeof(double), c->stream));
+  hipLaunchKernelGGL((colabssum_kernel<double>), dim3((unsigned)(nbx * chunks)), dim3(256), 0, c->stream, rows, cols, A, lda, part, rpb);
   LGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL((colabssum_reduce_kernel<double>), dim3((unsigned)nbx), dim3(256), 0, c->stream, cols, chunks, part, out);
+  LGP_LAUNCH_CHECK();
+  LGP_HIP(hipFreeAsync(part, c->stream));
   return LGP_OK;
 }
 

@@ -43,6 +43,30 @@ def test_distributed_chol_single_rank(lgp, n, nb, noise, rng):
     util.assert_allclose(d.logdet(), np.sum(np.log(np.diag(o._L))), rtol=1e-10 if noise else 1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize('n,nb', [(1500, 256), (2500, 1024), (1100, 128)])
+def test_distributed_carried_posterior_single_rank(lgp, n, nb, rng):
+    """ DistributedChol(carry=(xs, y)): posterior from the carried rows equals the fan-in solve and the oracle """
+    from lsqfitgp_amd._dist import DistributedChol
+    x = rng.uniform(0, n / 16, n); xs = rng.uniform(0, n / 16, 23)
+    y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
+    k = lgp.ExpQuad()
+    a = DistributedChol(k, x, noise=0.01, nb=nb, carry=(xs, y))
+    b = DistributedChol(k, x, noise=0.01, nb=nb)
+    ma, ca, la = a.posterior(k, x, xs, y)
+    mb, cb, lb_ = b.posterior(k, x, xs, y)
+    assert a.eps == b.eps
+    assert np.linalg.norm(ma - mb) <= 1e-11 * np.linalg.norm(mb)
+    assert np.linalg.norm(ca - cb, 2) <= 1e-11
+    util.assert_allclose(la, lb_, rtol=1e-12)
+    K = oracle.ExpQuad()(x[:, None], x[None, :]) + 0.01 * np.eye(n)
+    o = oracle.Chol(K)
+    mo = o.pinv_bilinear(oracle.ExpQuad()(x[:, None], xs[None, :]), y)
+    assert np.linalg.norm(ma - mo) <= 1e-8 * np.linalg.norm(mo)
+    # different xs or y than the carried ones: falls back to the fan-in solve
+    m2, _, _ = a.posterior(k, x, xs[:5], y)
+    assert np.linalg.norm(m2 - mo[:5]) <= 1e-8 * np.linalg.norm(mo[:5])
+
+
 def test_distributed_matern_3d(lgp, rng):
     from lsqfitgp_amd._dist import DistributedChol
     n = 900
@@ -95,8 +119,8 @@ def test_distributed_posterior_single_rank(lgp, rng):
     assert abs(-mlnd - lo) <= 1e-8 * abs(lo) + 1e-6
 
 
-@pytest.mark.parametrize('n,nb,world', [(1500, 256, 2), (2600, 1024, 2), (2900, 256, 3)])
-def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world):
+@pytest.mark.parametrize('n,nb,world,carry', [(1500, 256, 2, 0), (2600, 1024, 2, 1), (2900, 256, 3, 1)])
+def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry):
     """ world size 2 and 3 on the device: real kernels, real stream/event choreography of the panel look-ahead, panels
     exchanged through the host-callback transport; factor, posterior and likelihood against the oracle """
     import os
@@ -109,8 +133,9 @@ def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world):
     m = 37
     # separate interpreters (not torch.multiprocessing: torch must not be loaded into this process next to the library)
     script = os.path.join(os.path.dirname(__file__), 'two_rank_worker.py')
+    env = dict(os.environ, LGP_TEST_CARRY=str(carry))        # carry = 1: [Kxxs | y] rides through the factorisation
     procs = [subprocess.Popen([sys.executable, script, str(rank), str(world), str(port), str(n), str(nb), str(m), str(tmp_path)],
-                              cwd=os.path.dirname(os.path.dirname(__file__))) for rank in range(world)]
+                              cwd=os.path.dirname(os.path.dirname(__file__)), env=env) for rank in range(world)]
     for p in procs:
         assert p.wait(timeout=900) == 0      # a first `import torch` on a fresh box can take minutes
     rng = np.random.default_rng(7)

@@ -35,7 +35,8 @@ def main(rank, world, port, n, nb, m, tmpdir):
     x = rng.uniform(0, n / 16, n)
     xs = rng.uniform(0, n / 16, m)
     y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
-    d = DistributedChol(lgp.ExpQuad(), x, noise=0.01, nb=nb, ctx=ctx)
+    carry = (xs, y) if os.environ.get('LGP_TEST_CARRY') == '1' else None
+    d = DistributedChol(lgp.ExpQuad(), x, noise=0.01, nb=nb, ctx=ctx, carry=carry)
     mean, cov, mlnd = d.posterior(lgp.ExpQuad(), x, xs, y)
     blocks = {b: blk for b, blk in d.local_factor().items()}
     np.savez(os.path.join(tmpdir, f'rank{rank}.npz'), mean=mean, cov=cov, mlnd=mlnd, eps=d.eps,
