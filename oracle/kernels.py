@@ -428,7 +428,21 @@ class BART:
         fast = (altinput and not debug and pnt.ndim == 1 and w.ndim == 1
                 and pnt.size // (repeat or 1) <= 3)
         if fast:
-            return cls._correlation_fast(a0, a1, a2, pnt, numpy.broadcast_to(gamma, bshape), w, repeat or 1, flt)
+            gb = numpy.broadcast_to(gamma, bshape)
+            nlead = bshape[0] if len(bshape) >= 2 else 0
+            chunk = max(1, (1 << 17) // max(1, int(numpy.prod(bshape[1:], dtype=int)) * max(1, a0.shape[-1]))) if nlead else 0
+            if nlead and chunk < nlead:
+                # elementwise over the leading axes: evaluating slabs of leading rows bounds the temporaries
+                # (N x M x p arrays otherwise) without changing any value
+                a0b = numpy.broadcast_to(a0, bshape + a0.shape[-1:])
+                a1b = numpy.broadcast_to(a1, bshape + a1.shape[-1:])
+                a2b = numpy.broadcast_to(a2, bshape + a2.shape[-1:])
+                out = numpy.empty(bshape, flt)
+                for r0 in range(0, nlead, chunk):
+                    sl = slice(r0, r0 + chunk)
+                    out[sl] = cls._correlation_fast(a0b[sl], a1b[sl], a2b[sl], pnt, gb[sl], w, repeat or 1, flt)
+                return out
+            return cls._correlation_fast(a0, a1, a2, pnt, gb, w, repeat or 1, flt)
         a0b = numpy.broadcast_to(a0, bshape + a0.shape[-1:])
         a1b = numpy.broadcast_to(a1, bshape + a1.shape[-1:])
         a2b = numpy.broadcast_to(a2, bshape + a2.shape[-1:])
@@ -497,9 +511,12 @@ class BART:
             terms1 = (S[..., None] + t) * (inv_Wnminus + inv_Wnplus + inv_Wn * (nout - 2))
             terms2 = numpy.where(nplus0, w * inv_Wn * n0 / nplus0, w * inv_Wnmod)
             terms2 = terms2 + numpy.where(nminus0, w * inv_Wn * n0 / nminus0, w * inv_Wnmod)
-            psin = special.digamma(numpy.where(n, n, 1).astype(flt))
-            psiminus = numpy.where(xlty, special.digamma((1 + iy).astype(flt)), special.digamma((1 + ix).astype(flt)))
-            psiplus = numpy.where(xlty, special.digamma((1 + n - ix).astype(flt)), special.digamma((1 + n - iy).astype(flt)))
+            # digamma is only ever taken at integers cast to `flt`: a table of scipy's values at those integers,
+            # indexed by the integer, gives bit for bit what evaluating the function elementwise does
+            psi = _digamma_at_integers(int(numpy.max(n, initial=0)) + 2, flt)
+            psin = psi[numpy.where(n, n, 1)]
+            psiminus = numpy.where(xlty, psi[1 + iy], psi[1 + ix])
+            psiplus = numpy.where(xlty, psi[1 + n - ix], psi[1 + n - iy])
             terms3 = w * inv_Wn * n0 * (2 * psin - psiminus - psiplus)
             terms = terms1 - terms2 - terms3
             sumi = numpy.sum(wn * terms, axis=-1, dtype=flt)
@@ -626,6 +643,20 @@ class BART:
                 sump += w[i] * sumn / ni
             return flt.type(1 - pnt[0] * (1 - sump / Wn))
         return flt.type(1)
+
+
+_PSI_CACHE = {}
+
+
+def _digamma_at_integers(count, flt):
+    """ ``special.digamma(numpy.arange(count).astype(flt))`` (index 0 holds the pole, never used), cached """
+    key = numpy.dtype(flt).char
+    tab = _PSI_CACHE.get(key)
+    if tab is None or len(tab) < count:
+        with numpy.errstate(divide='ignore', invalid='ignore'):
+            tab = special.digamma(numpy.arange(max(count, 4096)).astype(flt))
+        _PSI_CACHE[key] = tab
+    return tab
 
 
 def _make_bart_kernel(*, alpha=0.95, beta=2, maxd=2, gamma=1, splits=None, pnt=None,

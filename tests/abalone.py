@@ -1,0 +1,52 @@
+"""
+Configuration C5 on its real workload (shared by tests/golden/make_golden.py, the GPU parity test and bench.py's
+parity self-check): the reference's data file and the GP that ``bayestree.bart`` builds from it.
+"""
+
+import os
+
+import numpy as np
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_abalone():
+    """ ``bart-data.txt.gz`` is a byte-for-byte gzip of the reference's data file ``examples/bart-data.txt`` (the UCI
+    Abalone table, 4177 rows: Sex, Length, Diameter, Height, Whole, Shucked, Viscera, Shell, Rings).  Covariates as
+    ``examples/bart.py:37-55`` builds them: Sex -> 3 one-hot columns (F, I, M) followed by the 7 numeric columns
+    (p = 10); outcome = Rings.  Everything float32 (config C5 of SURVEY.md 8(d)). """
+    import gzip
+    with gzip.open(os.path.join(HERE, 'bart-data.txt.gz'), 'rt') as f:
+        rows = [line.strip().split(',') for line in f if line.strip()]
+    sex = np.array([r[0] for r in rows])
+    num = np.array([[float(v) for v in r[1:8]] for r in rows])
+    y = np.array([float(r[8]) for r in rows])
+    X = np.concatenate([(sex[:, None] == np.array(['F', 'I', 'M'])[None, :]).astype(float), num], axis=1)
+    return X.astype(np.float32), y.astype(np.float32)
+
+
+def c5_problem(mod, X, y, n):
+    """ the GP that ``bayestree.bart`` builds (``bayestree/_bart.py:163-205``) at the fixed hyperparameters of
+    SURVEY.md 8(d): splits from the n training rows, alpha = 0.95, beta = 2, maxd = 10, reset = [2, 4, 6, 8], gamma = 1,
+    k = 2, sigma2 = mean((y - ybar)^2), unit weights, marginalised mean; test block = the rows after the first n.
+    ``mod`` is the oracle or the device package (same surface).  Returns (gp, given). """
+    f = np.float32
+    p = X.shape[1]
+    ytr = y[:n]
+    ymin, ymax = ytr.min(), ytr.max()
+    mu_mu = f((ymax + ymin) / 2)
+    k_sigma_mu = f((ymax - ymin) / 2)
+    lam2 = f((k_sigma_mu / f(2)) ** 2)
+    sigma2 = f(np.mean((ytr - ytr.mean()) ** 2))
+    splits = mod.BART.splits_from_coord(X[:n])
+    ix = mod.BART.indices_from_coord(X, splits).astype(np.int32)
+    pts = np.array([tuple(r) for r in ix], dtype=[(f'f{i}', np.int32) for i in range(p)])
+    kern = mod.BART(splits=(splits[0], None), indices=True, alpha=f(0.95), beta=f(2), gamma=f(1), maxd=10,
+                    reset=[2, 4, 6, 8], weights=np.ones(p, f)) * lam2
+    gp = (mod.GP(kern, checkpos=False, checksym=False, solver='chol')
+          .addx(pts[:n], 'trainmean')
+          .addcov(np.diag(np.full(n, sigma2)).astype(f), 'trainnoise')
+          .addcov(np.asarray(k_sigma_mu ** 2, f), 'mean')
+          .addtransf({'trainmean': 1, 'trainnoise': 1, 'mean': 1}, 'train')
+          .addx(pts[n:], 'testmean'))
+    return gp, {'train': ytr - mu_mu}, kern, pts

@@ -88,6 +88,44 @@ def c5small():
     np.savez_compressed(os.path.join(HERE, 'c5_bart_n256.npz'), X=X, nsplits=splits[0], ix=ix, **out)
 
 
+from tests.abalone import load_abalone, c5_problem  # noqa: E402
+
+
+C5_GRAM_ROWS = [0, 1, 2, 3, 500, 1777, 3000, 4095]
+
+
+def c5full():
+    """ config C5 on its real workload: first 4096 rows of the Abalone table for training, the remaining 81 rows
+    held out (the file has 4177 rows, so the "100-row" test block of SURVEY.md 8(d) is the 81 rows there are);
+    outputs of the oracle: posterior mean at 'trainmean' (M = N) with the diagonal and one 64 x 64 corner of its
+    covariance, mean and covariance at 'testmean', log marginal likelihood (epsrel = 0, ``bayestree/_bart.py:222``),
+    8 rows of the unscaled fp32 BART Gram matrix, and the norms the GPU test derives its fp32 tolerance from """
+    X, y = load_abalone()
+    n = 4096
+    gp, given, kern, pts = c5_problem(oracle, X, y, n)
+    mt, ct = gp.predfromdata(given, 'trainmean', raw=True)
+    ms, cs = gp.predfromdata(given, 'testmean', raw=True)
+    mll = gp.marginal_likelihood(given, epsrel=0)
+    base = oracle.BART(splits=(oracle.BART.splits_from_coord(X[:n])[0], None), indices=True, alpha=np.float32(0.95),
+                       beta=np.float32(2), gamma=np.float32(1), maxd=10, reset=[2, 4, 6, 8], weights=np.ones(10, np.float32))
+    rows = base(pts[C5_GRAM_ROWS][:, None], pts[None, :n])
+    # sensitivity of the posterior mean to a relative perturbation of the Gram entries (see tests/test_gpu_gp.py):
+    # K = Kxx (train x train, assembled, float64), alpha = K^-1 r
+    Kxx = np.asarray(gp.prior('train', raw=True), float)
+    r = np.asarray(given['train'], float)
+    alpha = np.linalg.solve(Kxx, r)
+    Ktt = np.asarray(gp.prior('trainmean', raw=True), float)
+    evmin = np.linalg.eigvalsh(Kxx)[0]
+    np.savez_compressed(os.path.join(HERE, 'c5_abalone_n4096.npz'),
+                        mean_train=mt, covdiag_train=np.diag(ct).copy(), covcorner_train=ct[:64, :64].copy(),
+                        mean_test=ms, cov_test=cs, mll=mll, gram_rows=rows, gram_row_index=np.array(C5_GRAM_ROWS),
+                        norm_alpha=np.linalg.norm(alpha), fro_Ktt=np.linalg.norm(Ktt), norm2_Ktt=np.linalg.norm(Ktt, 2),
+                        evmin_Kxx=evmin, norm_mean_train=np.linalg.norm(mt))
+
+
 if __name__ == '__main__':
-    c1(); c2small(); c3small(); c5small()
+    import sys as _sys
+    which = _sys.argv[1:] or ['c1', 'c2small', 'c3small', 'c5small', 'c5full']
+    for name in which:
+        globals()[name]()
     print('written', sorted(f for f in os.listdir(HERE) if f.endswith('.npz')))

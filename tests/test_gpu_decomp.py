@@ -276,3 +276,57 @@ def test_odd_size_many_panels_with_carried_rhs(lgp):
     KV = _gemm(False, False, K, lgp.DeviceArray.from_host(V)).to_host() + d.eps * V
     util.assert_close_matrices(d.correlate(d.back_correlate(V)), KV, rtol=1e-12)
     util.assert_close_matrices(d.ginv_linear(KV), V, rtol=1e-9)
+
+
+def test_full_size_c4_properties(lgp):
+    """ BASELINE configuration C4 at full size on one GPU (ExpQuad 1-D fp64, N = 65536, seed 4, x = U(0, 4096),
+    noise 0.01; K and L are 32 GiB each): the identities of test_full_size_c3_properties -- L L^T V = (K + eps I) V with
+    K V from an independent device product, K^-1 (K V) = V, the log-density against its definition from diag(L) -- and
+    the posterior/likelihood of the carried solve (lgp_chol_factor_rhs) against the separate solve (lgp_posterior) """
+    from lsqfitgp_amd import _lib
+    from lsqfitgp_amd._GP import _gemm
+    n, m = 65536, 100
+    rng = np.random.default_rng(4)
+    x = rng.uniform(0, 4096, n)
+    xs = rng.uniform(0, 4096, m)
+    y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
+    kern = lgp.ExpQuad()
+    K = kern.gram(x, x)
+    lib = _lib.load()
+    ctx = lgp.Context.default()
+    assert lib.lgp_add_diag_f64(ctx.handle, n, K.ptr, K.ld, None, ctypes.c_double(0.01)) == 0
+    Kxs = kern.gram(x, xs)
+    W = lgp.DeviceArray.empty((n, m + 1))
+    W.block(0, n, 0, m).assign(Kxs)
+    W.block(0, n, m, m + 1).assign(lgp.DeviceArray.from_host(y.reshape(n, 1)))
+    d = lgp.Chol(K, rhs=W)                       # factor with [Kxxs | y] carried through it
+    assert 0 < d.eps < 1e-5
+    V = rng.standard_normal((n, 3))
+    KV = _gemm(False, False, K, lgp.DeviceArray.from_host(V)).to_host() + d.eps * V
+    LLV = d.correlate(d.back_correlate(V))
+    util.assert_close_matrices(LLV, KV, rtol=1e-12)
+    util.assert_close_matrices(d.ginv_linear(KV), V, rtol=1e-8)
+    Lf = d.factor()
+    val = d.minus_log_normal_density(KV[:, 0], value=True)[0]
+    quad = KV[:, 0] @ V[:, 0]
+    logdet = 2 * val - n * np.log(2 * np.pi) - quad
+    full_diag = np.empty(n)
+    for r0 in range(0, n, 4096):
+        full_diag[r0:r0 + 4096] = np.diag(Lf.block(r0, r0 + 4096, r0, r0 + 4096).to_host())
+    assert np.all(full_diag > 0)
+    util.assert_allclose(logdet, 2 * np.sum(np.log(full_diag)), rtol=1e-10)
+    assert np.all(np.triu(Lf.block(0, 2048, 0, 4096).to_host(), 1) == 0)
+    # posterior and likelihood: carried solve vs the separate forward solve on the same factor
+    S = d.solved()                                # L^-1 [Kxxs | y], (n, m + 1)
+    mean_c = S[:, :m].T @ S[:, m]
+    Kss = np.exp(-0.5 * (xs[:, None] - xs[None, :]) ** 2)
+    cov_c = Kss - S[:, :m].T @ S[:, :m]
+    mlnd_c = 0.5 * (n * np.log(2 * np.pi) + 2 * np.sum(np.log(full_diag)) + S[:, m] @ S[:, m])
+    mean_s = d.pinv_bilinear(Kxs, y)
+    cov_s = Kss - d.ginv_quad(Kxs)
+    mlnd_s = d.minus_log_normal_density(y, value=True)[0]
+    assert np.linalg.norm(mean_c - mean_s) <= 1e-10 * np.linalg.norm(mean_s)
+    assert np.linalg.norm(cov_c - cov_s, 2) <= 1e-10 * np.linalg.norm(Kss, 2)
+    util.assert_allclose(mlnd_c, mlnd_s, rtol=1e-12)
+    # the posterior mean interpolates the smooth signal at in-sample density 16 points per lengthscale
+    assert np.sqrt(np.mean((mean_s - np.sin(xs / 4)) ** 2)) < 0.05

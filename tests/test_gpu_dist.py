@@ -165,3 +165,62 @@ def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry):
             full[c0:, c0:c0 + blk.shape[1]] = blk
     assert len(seen) == -(-n // nb)
     util.assert_close_matrices(full, o._L, rtol=1e-11)
+
+
+def test_sharded_path_two_ranks_large(lgp, tmp_path):
+    """ the sharded factorisation of configuration C4's workload at N = 16384 (16 block columns of 1024, 2 ranks sharing the
+    GPU, panels through the host-staged transport, [Kxxs | y] carried through the factorisation) against the single-GPU
+    driver on the same inputs: eps, the action of the factor on random vectors (L Z, L^T Z), its diagonal, posterior mean /
+    covariance and the log-density """
+    import os
+    import socket
+    import subprocess
+    import sys
+    from lsqfitgp_amd import _lib
+    n, nb, world, m = 16384, 1024, 2, 37
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    script = os.path.join(os.path.dirname(__file__), 'two_rank_worker.py')
+    env = dict(os.environ, LGP_TEST_CARRY='1', LGP_TEST_BIG='1')
+    procs = [subprocess.Popen([sys.executable, script, str(rank), str(world), str(port), str(n), str(nb), str(m), str(tmp_path)],
+                              cwd=os.path.dirname(os.path.dirname(__file__)), env=env) for rank in range(world)]
+    # single-GPU reference while the ranks run (the same inputs as tests/two_rank_worker.py)
+    rng = np.random.default_rng(7)
+    x = rng.uniform(0, n / 16, n)
+    xs = rng.uniform(0, n / 16, m)
+    y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
+    kern = lgp.ExpQuad()
+    K = kern.gram(x, x)
+    ctx = lgp.Context.default()
+    assert _lib.load().lgp_add_diag_f64(ctx.handle, n, K.ptr, K.ld, None, ctypes.c_double(0.01)) == 0
+    Kxs = kern.gram(x, xs).to_host()
+    one = lgp.Chol(K, rhs=np.concatenate([Kxs, y[:, None]], axis=1))
+    S = one.solved()
+    mean1 = S[:, :m].T @ S[:, m]
+    Kss = np.exp(-0.5 * (xs[:, None] - xs[None, :]) ** 2)
+    cov1 = Kss - S[:, :m].T @ S[:, :m]
+    mlnd1 = one.minus_log_normal_density(y, value=True)[0]
+    Z = np.random.default_rng(11).standard_normal((n, 2))
+    LZ1 = one.correlate(Z)
+    LtZ1 = one.back_correlate(Z)
+    diag1 = np.concatenate([np.diag(one.factor().block(r0, r0 + 4096, r0, r0 + 4096).to_host()) for r0 in range(0, n, 4096)])
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    LZ = np.zeros((n, 2))
+    seen = set()
+    for rank in range(world):
+        r = np.load(tmp_path / f'rank{rank}.npz')
+        util.assert_allclose(r['eps'], one.eps, rtol=1e-13)
+        assert np.linalg.norm(r['mean'] - mean1) <= 1e-10 * np.linalg.norm(mean1)
+        assert np.linalg.norm(r['cov'] - cov1, 2) <= 1e-10 * np.linalg.norm(Kss, 2)
+        util.assert_allclose(r['mlnd'], mlnd1, rtol=1e-12)
+        LZ += r['LZ']
+        for b in r['owned']:
+            b = int(b)
+            assert b not in seen and b % world == rank
+            seen.add(b)
+            util.assert_close_matrices(r[f'lt{b}'], LtZ1[b * nb:(b + 1) * nb], rtol=1e-11)
+            util.assert_allclose(r[f'dg{b}'], diag1[b * nb:(b + 1) * nb], rtol=1e-11)
+    assert len(seen) == n // nb
+    util.assert_close_matrices(LZ, LZ1, rtol=1e-12)

@@ -195,6 +195,75 @@ def test_config_c5_bart_structure(lgp):
     assert abs(ld - lo) <= 1e-3 * abs(lo)
 
 
+def test_config_c5_abalone_full(lgp):
+    """ config C5 on its real workload: bayestree.bart's GP (``bayestree/_bart.py:163-205``) at the fixed
+    hyperparameters of SURVEY.md 8(d) on the first 4096 rows of the reference's ``examples/bart-data.txt`` (fixture
+    ``tests/golden/bart-data.txt.gz``), p = 10 (Sex one-hot + 7 numeric), fp32 kernel, predict 'trainmean' (M = N),
+    the held-out 'testmean' rows and ``marginal_likelihood(epsrel=0)``.
+
+    Three layers, each with its own justified tolerance:
+
+    (a) Gram entries, device vs the oracle's rows in the fixture: <= 64 ulp32, the bound the reference itself puts on
+        re-orderings of the same fp32 evaluation (``tests/kernels/test_bart.py:135-159``).  The measured maximum
+        relative deviation ``delta`` feeds (c).
+    (b) Same matrix, different solver: the oracle's float64 linear algebra applied to the DEVICE's Gram blocks must
+        give the device's posterior to the north-star tolerances (mean 1e-8, covariance 1e-8 ||Kxsxs||, likelihood
+        1e-8 |v| + 1e-6) -- the whole fp32 question is taken out of the comparison.
+    (c) End to end against the oracle outputs frozen in ``c5_abalone_n4096.npz``: first-order perturbation bound
+        ``|dm| <= (|dKts| + |Kts K^-1| |dK|) |alpha| <= 2 delta |Ktt|_F |alpha|`` (``|Kts K^-1| <= 1`` because
+        ``Ktt <= K`` in the positive-definite order; ``|dK|_2 <= |dK|_F <= delta |Ktt|_F``), with ``|Ktt|_F`` and
+        ``|alpha| = |K^-1 r|`` stored in the fixture.  For the likelihood ``|dv| <= 1/2 |alpha|^2 |dK|_F + 1/2
+        |K^-1|_2 |dK|_F sqrt(n)`` (quadratic form + log-determinant). """
+    from .abalone import load_abalone, c5_problem
+    g = np.load(os.path.join(HERE, 'golden', 'c5_abalone_n4096.npz'))
+    X, y = load_abalone()
+    n = 4096
+    gd, given, kern, pts = c5_problem(lgp, X, y, n)
+    # (a) Gram rows
+    rows = [int(i) for i in g['gram_row_index']]
+    base = lgp.BART(splits=(lgp.BART.splits_from_coord(X[:n])[0], None), indices=True, alpha=np.float32(0.95),
+                    beta=np.float32(2), gamma=np.float32(1), maxd=10, reset=[2, 4, 6, 8], weights=np.ones(10, np.float32))
+    Kd_rows = base(pts[rows][:, None], pts[None, :n])
+    assert Kd_rows.dtype == np.float32
+    assert util.ulp_distance(Kd_rows, g['gram_rows']) <= 64
+    delta = float(np.max(np.abs(Kd_rows.astype(float) - g['gram_rows']) / np.abs(g['gram_rows'])))
+    delta = max(delta, 2.0 ** -24)
+    # device outputs
+    mt, ct = gd.predfromdata(given, 'trainmean', raw=True)
+    ms, cs = gd.predfromdata(given, 'testmean', raw=True)
+    mll = gd.marginal_likelihood(given, epsrel=0)
+    assert mt.shape == (n,) and ct.shape == (n, n) and ms.shape == (81,) and mt.dtype == np.float64
+    # (b) the oracle's solver on the device's Gram blocks
+    prior = gd.prior(['trainmean', 'testmean'], raw=True)
+    f = np.float32
+    k_sigma_mu = f((y[:n].max() - y[:n].min()) / 2)
+    sigma2 = f(np.mean((y[:n] - y[:n].mean()) ** 2))
+    go = (oracle.GP(checkpos=False, checksym=False, solver='chol')
+          .addcov({('trainmean', 'trainmean'): prior['trainmean', 'trainmean'], ('testmean', 'testmean'): prior['testmean', 'testmean'],
+                   ('trainmean', 'testmean'): prior['trainmean', 'testmean']})
+          .addcov(np.diag(np.full(n, sigma2)).astype(f), 'trainnoise')
+          .addcov(np.asarray(k_sigma_mu ** 2, f), 'mean')
+          .addtransf({'trainmean': 1, 'trainnoise': 1, 'mean': 1}, 'train'))
+    mto, cto = go.predfromdata(given, 'trainmean', raw=True)
+    mso, cso = go.predfromdata(given, 'testmean', raw=True)
+    check_posterior(mt, ct, mto, cto, np.linalg.norm(prior['trainmean', 'trainmean'], 2))
+    check_posterior(ms, cs, mso, cso, np.linalg.norm(prior['testmean', 'testmean'], 2))
+    check_mll(mll, go.marginal_likelihood(given, epsrel=0))
+    # (c) end to end against the frozen oracle outputs, tolerance from the measured Gram deviation
+    dK = delta * float(g['fro_Ktt'])
+    tol_mean = 2 * dK * float(g['norm_alpha'])
+    assert tol_mean <= 2e-2 * float(g['norm_mean_train'])              # the bound itself stays meaningful
+    assert np.linalg.norm(mt - g['mean_train']) <= tol_mean
+    assert np.linalg.norm(ms - g['mean_test']) <= tol_mean
+    # covariance: |dC| <= |dKss| + 2 |dKst| + |dK| (first order, smoother norms <= 1) <= 4 dK
+    assert np.linalg.norm(cs - g['cov_test'], 2) <= 4 * dK
+    assert np.linalg.norm(np.diag(ct) - g['covdiag_train']) <= 4 * dK * np.sqrt(n)
+    assert np.linalg.norm(ct[:64, :64] - g['covcorner_train'], 2) <= 4 * dK
+    tol_mll = 0.5 * float(g['norm_alpha']) ** 2 * dK + 0.5 * dK * np.sqrt(n) / float(g['evmin_Kxx'])
+    assert abs(mll - float(g['mll'])) <= tol_mll
+    assert tol_mll <= 1e-2 * abs(float(g['mll']))
+
+
 def test_fuse_solve_matches_separate_solve(lgp):
     """ GP(..., fuse_solve=True): pred carries [Kxxs | y] through the factorisation; same posterior as the separate solve """
     rng = np.random.default_rng(11)

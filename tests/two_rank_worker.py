@@ -38,6 +38,24 @@ def main(rank, world, port, n, nb, m, tmpdir):
     carry = (xs, y) if os.environ.get('LGP_TEST_CARRY') == '1' else None
     d = DistributedChol(lgp.ExpQuad(), x, noise=0.01, nb=nb, ctx=ctx, carry=carry)
     mean, cov, mlnd = d.posterior(lgp.ExpQuad(), x, xs, y)
+    if os.environ.get('LGP_TEST_BIG') == '1':
+        # large problem: instead of the factor itself, its action on fixed random vectors, summed / stacked by the parent:
+        # L Z = sum over owned blocks L[:, blk] Z[blk];  (L^T Z)[blk] = L[:, blk]^T Z
+        Z = np.random.default_rng(11).standard_normal((n, 2))
+        LZ = np.zeros((n, 2))
+        LtZ = {}
+        diag = {}
+        for b, blk in d.local_factor().items():
+            c0 = b * nb
+            w = blk.shape[1]
+            LZ[c0:] += blk @ Z[c0:c0 + w]
+            LtZ[b] = blk.T @ Z[c0:]
+            diag[b] = np.diag(blk[:w]).copy()
+        np.savez(os.path.join(tmpdir, f'rank{rank}.npz'), mean=mean, cov=cov, mlnd=mlnd, eps=d.eps, LZ=LZ,
+                 owned=np.array(sorted(LtZ)), **{f'lt{b}': v for b, v in LtZ.items()}, **{f'dg{b}': v for b, v in diag.items()})
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     blocks = {b: blk for b, blk in d.local_factor().items()}
     np.savez(os.path.join(tmpdir, f'rank{rank}.npz'), mean=mean, cov=cov, mlnd=mlnd, eps=d.eps,
              owned=np.array(sorted(blocks)), **{f'b{b}': blk for b, blk in blocks.items()})
