@@ -20,6 +20,7 @@ UNITS = [
     ('gemm.hip', []),
     # accumulators that alternate between MFMA and vector ops stay in VGPRs (no AGPR copies)
     ('potrf.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form=1']),
+    ('potf2m.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form=1']),
     ('elementwise.hip', []),
     # the Gram kernels follow the reference's unfused square-then-add evaluation
     ('gram.hip', ['-ffp-contract=off']),

@@ -53,8 +53,14 @@ int lgp_ctx_create(int device, lgp_ctx **out) {
     return LGP_EINVAL;
   }
   lgp_ctx *c = new lgp_ctx();
+  // any failure below releases what was created so far (lgp_ctx_destroy accepts a partially built context)
+  struct Guard {
+    lgp_ctx *c;
+    ~Guard() { if (c) lgp_ctx_destroy(c); }
+  } guard{c};
   c->device = device;
   c->cus = prop.multiProcessorCount;
+  if (const char *m = getenv("LGP_POTF2")) c->potf2_mode = strcmp(m, "valu") == 0 ? 1 : (strcmp(m, "mfma") == 0 ? 2 : 0);
   // stream2 carries the latency-bound panel factorisation of the look-ahead: highest priority, so that its
   // few workgroups are dispatched ahead of the queued trailing-update workgroups of the main stream
   int prio_lo = 0, prio_hi = 0;
@@ -74,6 +80,7 @@ int lgp_ctx_create(int device, lgp_ctx **out) {
     uint64_t thr = ~0ull;
     (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
   }
+  guard.c = nullptr;
   *out = c;
   return LGP_OK;
 }
@@ -81,17 +88,17 @@ int lgp_ctx_create(int device, lgp_ctx **out) {
 int lgp_ctx_destroy(lgp_ctx *c) {
   if (!c) return LGP_OK;
   DeviceGuard dg(c->device);
-  (void)hipStreamSynchronize(c->stream);
-  (void)hipStreamSynchronize(c->stream2);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   lgp_comm_destroy(c);
-  (void)hipFree(c->d_info);
-  (void)hipFree(c->d_scratch);
-  (void)hipHostFree(c->h_pinned);
-  (void)hipEventDestroy(c->ev_a);
-  (void)hipEventDestroy(c->ev_b);
+  if (c->d_info) (void)hipFree(c->d_info);
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+  if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
-  (void)hipStreamDestroy(c->stream);
-  (void)hipStreamDestroy(c->stream2);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
   return LGP_OK;
 }
@@ -458,6 +465,7 @@ int lgp_comm_init(lgp_ctx *c, int rank, int nranks, const void *hid128) {
   LGP_REQUIRE(c != nullptr && hid128 != nullptr, "null pointer");
   LGP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank");
   LGP_REQUIRE(c->comm == nullptr, "communicator already initialised");
+  LGP_REQUIRE(c->hostfn == nullptr, "a host-staged transport is active on this context (lgp_comm_destroy it first)");
   LGP_CHECK(rccl_load());
   DeviceGuard dg(c->device);
   ncclUniqueId id;
@@ -477,6 +485,8 @@ int lgp_comm_destroy(lgp_ctx *c) {
     (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(c->comm));
   }
   c->comm = nullptr;
+  c->hostfn = nullptr;      // a destroyed host transport must not keep intercepting lgp_bcast / lgp_allreduce_*
+  c->hostuser = nullptr;
   c->rank = 0;
   c->nranks = 1;
   return LGP_OK;
@@ -512,6 +522,7 @@ int lgp_comm_init_host(lgp_ctx *c, int rank, int nranks, int (*fn)(void *, int, 
   LGP_REQUIRE(c != nullptr && fn != nullptr, "null pointer");
   LGP_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank");
   LGP_REQUIRE(c->comm == nullptr, "an RCCL communicator is already initialised");
+  LGP_REQUIRE(c->hostfn == nullptr, "a host-staged transport is already active on this context");
   c->hostfn = fn;
   c->hostuser = user;
   c->rank = rank;

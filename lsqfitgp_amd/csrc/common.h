@@ -25,6 +25,8 @@ struct lgp_ctx {
   int rank = 0, nranks = 1;
   int cus = 256;
   int swapped = 0;                    // lgp_select_stream(1): `stream` and `stream2` exchanged
+  int potf2_mode = 0;                 // diagonal-block kernel: 0 = auto, 1 = VALU, 2 = matrix cores (env LGP_POTF2=valu|mfma)
+  int potf2_small = 1;                // auto mode: the factorisation in progress is small enough for the matrix-core kernel
   // live kernel timing of the dominant kernel (trailing-update syrk) for bench.py: HIP event pairs on the
   // stream the kernel is launched on, enabled by lgp_profile_begin
   int prof_on = 0;
@@ -98,6 +100,7 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
 // ---- factorisation pieces (potrf.hip) ------------------------------------------------------
 template <typename T>
 int lgp_potf2_launch(lgp_ctx *ctx, hipStream_t stream, T *A, size_t lda, int nb, T *dblk, size_t row0);
+int lgp_potf2_mfma_launch(lgp_ctx *ctx, hipStream_t stream, double *A, size_t lda, int nb, double *dblk, size_t row0);   // potf2m.hip
 template <typename T>
 int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t nb, T *P, size_t ldp, T *dblk, size_t row0);
 template <typename T>

@@ -470,8 +470,9 @@ __device__ __forceinline__ T block_sum(T v, T *sh) {
 
 // Gershgorin row sums of |K_ij / s_j / s_i|, one workgroup per row; per-row result to rows[i]
 template <typename T>
-__global__ void __launch_bounds__(256) rowabs_kernel(const T *K, long ldk, int n, const T *s, int unit_scale, T *rows) {
+__global__ void __launch_bounds__(256) rowabs_kernel(const T *K, long ldk, int n, const T *s, const unsigned int *nonunit, T *rows) {
   __shared__ T sh[4];
+  const bool unit_scale = *nonunit == 0;      // all s_i == 1 (device-side flag: no host round trip inside the factorisation)
   const int i = blockIdx.x;
   const T *row = K + (long)i * ldk;
   const T si = s[i];
@@ -525,8 +526,9 @@ __global__ void __launch_bounds__(256) eps_kernel(const T *rows, const T *s, int
 
 // L_ij = K_ij / s_j / s_i (+ eps on the diagonal) for j <= i, 0 above the diagonal
 template <typename T>
-__global__ void __launch_bounds__(256) prep_lower_kernel(const T *K, long ldk, int n, int nbx, const T *s, int unit_scale,
+__global__ void __launch_bounds__(256) prep_lower_kernel(const T *K, long ldk, int n, int nbx, const T *s, const unsigned int *nonunit,
                                                          const T *epsp, T *L, long ldl) {
+  const bool unit_scale = *nonunit == 0;
   // one workgroup per 2048-column segment of a row (grid.x * 256 must stay below 2^32: N = 65536 rows)
   const int i = blockIdx.x / nbx;
   const int jbeg = (blockIdx.x % nbx) * 2048;
@@ -542,7 +544,8 @@ __global__ void __launch_bounds__(256) prep_lower_kernel(const T *K, long ldk, i
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) scale_rows_kernel(T *L, long ldl, int n, int nbx, const T *s) {
+__global__ void __launch_bounds__(256) scale_rows_kernel(T *L, long ldl, int n, int nbx, const T *s, const unsigned int *nonunit) {
+  if (*nonunit == 0) return;
   const int i = blockIdx.x / nbx;
   const int jbeg = (blockIdx.x % nbx) * 2048;
   for (int j = jbeg + threadIdx.x; j < jbeg + 2048 && j <= i && j < n; j += 256) L[(long)i * ldl + j] *= s[i];
@@ -553,10 +556,34 @@ __global__ void __launch_bounds__(256) scale_rows_kernel(T *L, long ldl, int n, 
 // ================================================================================================
 // host drivers
 
+// Factors one diagonal block and leaves the fragment image of the block in its workspace (read by the right-side
+// substitution of the panel).  fp64: the matrix-core kernel; fp32: the VALU kernel + pack_frag_kernel.  The images that
+// the left-side substitutions of the solves read (D, D^T, 1/diag) are extracted from the finished factor afterwards
+// (extract_dblk_kernel), off the dependent chain of the factorisation.
 template <typename T>
 int lgp_potf2_launch(lgp_ctx *ctx, hipStream_t stream, T *A, size_t lda, int nb, T *dblk, size_t row0) {
   LGP_REQUIRE(nb >= 1 && nb <= LGP_DB, "diagonal block size must be in [1,128]");
-  hipLaunchKernelGGL((potf2_kernel<T>), dim3(1), dim3(256), 0, stream, A, (long)lda, nb, dblk, ctx->d_info, (long)row0);
+  // fp64 has two kernels.  The matrix-core kernel (potf2m.hip: one wave, the whole block in its 512 registers) is 5-10 %
+  // faster end to end while the GPU has idle SIMDs (measured: N = 4096 4.24 -> 4.01 ms, N = 8192 10.7 -> 10.3 ms), but a
+  // wave that needs a whole SIMD's register file cannot be placed next to the two resident workgroups per CU of a large
+  // trailing update: in the N = 32768 profile it waited 0.58 ms on average for a SIMD to drain (204 -> 213 ms per step).
+  // ctx->potf2_mode: 0 = by the number of rows below the block, 1 = VALU kernel, 2 = matrix-core kernel (LGP_POTF2).
+  const bool mfma = std::is_same<T, double>::value && (ctx->potf2_mode == 2 || (ctx->potf2_mode == 0 && ctx->potf2_small));
+  if constexpr (std::is_same<T, double>::value) {
+    if (mfma) return lgp_potf2_mfma_launch(ctx, stream, A, lda, nb, dblk, row0);
+  }
+  {
+    hipLaunchKernelGGL((potf2_kernel<T>), dim3(1), dim3(256), 0, stream, A, (long)lda, nb, dblk, ctx->d_info, (long)row0);
+    LGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((pack_frag_kernel<T>), dim3((LGP_NFRAG + 3) / 4), dim3(256), 0, stream, dblk);
+    LGP_LAUNCH_CHECK();
+  }
+  return LGP_OK;
+}
+
+template <typename T>
+int lgp_extract_dblk(lgp_ctx *ctx, hipStream_t stream, const T *L, size_t ldl, size_t n, T *dblk) {
+  hipLaunchKernelGGL((extract_dblk_kernel<T>), dim3((unsigned)((n + LGP_DB - 1) / LGP_DB)), dim3(256), 0, stream, L, (long)ldl, (int)n, dblk);
   LGP_LAUNCH_CHECK();
   return LGP_OK;
 }
@@ -574,8 +601,6 @@ int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t 
     const size_t below = rows - (j0 + jb);
     if (below > 0) {
       T *X = P + (j0 + jb) * ldp + j0;   // below x jb, solved in place: X <- X * L_jj^-T
-      hipLaunchKernelGGL((pack_frag_kernel<T>), dim3((LGP_NFRAG + 3) / 4), dim3(256), 0, stream, w);
-      LGP_LAUNCH_CHECK();
       hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((below + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, stream, w, (int)jb, X,
                          (long)ldp, (long)below);
       LGP_LAUNCH_CHECK();
@@ -595,6 +620,7 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx)
   LGP_REQUIRE(ldl >= n, "ldl < n");
   hipStream_t s0 = ctx->stream, s1 = ctx->stream2;
   const size_t NB = LGP_NB;
+  ctx->potf2_small = n <= 8192;
   // Rows n .. n+nx-1 (optional) ride along: they are "rows below" for every panel, so the right-side substitutions and
   // the trailing updates turn B^T into (L^-1 B)^T -- the forward solve of the posterior done by the MFMA updates of
   // the factorisation instead of a separate latency chain of 2 n / 128 small kernels.
@@ -694,7 +720,8 @@ int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) scale_cols_kernel(T *W, long ldw, int rows, int n, const T *s) {
+__global__ void __launch_bounds__(256) scale_cols_kernel(T *W, long ldw, int rows, int n, const T *s, const unsigned int *nonunit) {
+  if (*nonunit == 0) return;
   // extra rows B^T (rows x n): column j /= s[j], so that they carry (S^-1 B)^T into the factorisation of K/s/s'
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)rows * n; idx += (long)gridDim.x * 256) {
     const long r = idx / n, j = idx % n;
@@ -720,31 +747,26 @@ static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T ep
   const int ni = (int)n;
   hipLaunchKernelGGL((diag_scale_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, K, (long)ldk, ni, s, stats);
   LGP_LAUNCH_CHECK();
-  // is the scaling trivial?  (one small sync; lets the big passes skip two divisions per element)
-  unsigned int nonunit = 0;
-  LGP_HIP(hipMemcpyAsync(&nonunit, reinterpret_cast<unsigned int *>(stats) + 8, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-  LGP_HIP(hipStreamSynchronize(st));
-  const int unit = nonunit == 0 ? 1 : 0;
-  hipLaunchKernelGGL((rowabs_kernel<T>), dim3((unsigned)n), dim3(256), 0, st, K, (long)ldk, ni, s, unit, rows);
+  // is the scaling trivial?  The kernels read the count of s_i != 1 from device memory (all s_i == 1 lets the big passes
+  // skip two divisions per element, with bit-identical results): no host synchronisation until the final read-back
+  const unsigned int *nonunit = reinterpret_cast<const unsigned int *>(stats) + 8;
+  hipLaunchKernelGGL((rowabs_kernel<T>), dim3((unsigned)n), dim3(256), 0, st, K, (long)ldk, ni, s, nonunit, rows);
   LGP_LAUNCH_CHECK();
   hipLaunchKernelGGL((eps_kernel<T>), dim3(1), dim3(256), 0, st, rows, s, ni, epsrel, epsabs, flags, stats);
   LGP_LAUNCH_CHECK();
   const int nbx = (int)((n + 2047) / 2048);
-  hipLaunchKernelGGL((prep_lower_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, st, K, (long)ldk, ni, nbx, s, unit,
+  hipLaunchKernelGGL((prep_lower_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, st, K, (long)ldk, ni, nbx, s, nonunit,
                      stats, L, (long)ldl);
   LGP_LAUNCH_CHECK();
-  if (!unit && nrhs > 0) {
+  if (nrhs > 0) {
     hipLaunchKernelGGL((scale_cols_kernel<T>), dim3((unsigned)((nrhs * n + 255) / 256 < 65536 ? (nrhs * n + 255) / 256 : 65536)), dim3(256), 0, st,
-                       L + n * ldl, (long)ldl, (int)nrhs, ni, s);
+                       L + n * ldl, (long)ldl, (int)nrhs, ni, s, nonunit);
     LGP_LAUNCH_CHECK();
   }
   LGP_CHECK(lgp_potrf_impl<T>(ctx, n, L, ldl, dblk, nrhs));
-  if (!unit) {
-    hipLaunchKernelGGL((scale_rows_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, st, L, (long)ldl, ni, nbx, s);
-    LGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((extract_dblk_kernel<T>), dim3((unsigned)((n + LGP_DB - 1) / LGP_DB)), dim3(256), 0, st, L, (long)ldl, ni, dblk);
-    LGP_LAUNCH_CHECK();
-  }
+  hipLaunchKernelGGL((scale_rows_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, st, L, (long)ldl, ni, nbx, s, nonunit);
+  LGP_LAUNCH_CHECK();
+  LGP_CHECK(lgp_extract_dblk<T>(ctx, st, L, ldl, n, dblk));     // D, D^T, 1/diag of every diagonal block (read by the solves)
   T hstats[3];
   int info = 0;
   LGP_HIP(hipMemcpyAsync(hstats, stats, 3 * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -782,6 +804,7 @@ static int potrf_entry(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk) {
   DeviceGuard dg(ctx->device);
   LGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   LGP_CHECK(lgp_potrf_impl<T>(ctx, n, L, ldl, dblk));
+  LGP_CHECK(lgp_extract_dblk<T>(ctx, ctx->stream, L, ldl, n, dblk));
   int info = 0;
   LGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   LGP_HIP(hipStreamSynchronize(ctx->stream));
@@ -806,7 +829,9 @@ extern "C" int lgp_trsm_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl,
 extern "C" int lgp_panel_factor_f64(lgp_ctx *ctx, size_t rows, size_t nb, double *dP, size_t ldp, double *ddblk, size_t row0) {
   LGP_REQUIRE(ctx != nullptr && dP != nullptr && ddblk != nullptr, "null pointer");
   DeviceGuard dg(ctx->device);
-  return lgp_panel_factor_impl<double>(ctx, ctx->stream, rows, nb, dP, ldp, ddblk, row0);
+  ctx->potf2_small = rows <= 8192;
+  LGP_CHECK(lgp_panel_factor_impl<double>(ctx, ctx->stream, rows, nb, dP, ldp, ddblk, row0));
+  return lgp_extract_dblk<double>(ctx, ctx->stream, dP, ldp, nb, ddblk);
 }
 
 extern "C" int lgp_get_info(lgp_ctx *ctx, int *hinfo) {

@@ -1,14 +1,15 @@
 // Probe: time potf2_kernel / subst kernels alone (1 workgroup) and back-to-back, and read the shader clock.
 #include "../lsqfitgp_amd/csrc/potrf.hip"
+#include "../lsqfitgp_amd/csrc/potf2m.hip"
 #include <vector>
 #include <cmath>
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} }while(0)
 void lgp_set_error(const char *fmt, ...) {}
 int lgp_prof_start(lgp_ctx *, hipStream_t, double) { return 0; }
 int lgp_prof_stop(lgp_ctx *, hipStream_t) { return 0; }
-template <typename T> int lgp_gemm_launch(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, T, const T *, size_t, const T *, size_t, T, T *, size_t, bool, int) { return 0; }
-template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t, const double *, size_t, double, double *, size_t, bool, int);
-template int lgp_gemm_launch<float>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, float, const float *, size_t, const float *, size_t, float, float *, size_t, bool, int);
+template <typename T> int lgp_gemm_launch(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, T, const T *, size_t, const T *, size_t, T, T *, size_t, bool, int, int, int) { return 0; }
+template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t, const double *, size_t, double, double *, size_t, bool, int, int, int);
+template int lgp_gemm_launch<float>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, float, const float *, size_t, const float *, size_t, float, float *, size_t, bool, int, int, int);
 
 __global__ void clock_probe(unsigned long long *out, int iters) {
   unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -38,6 +39,44 @@ int main() {
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("potf2 alone: %.1f us\n", ms * 1e3);
+  }
+  // the matrix-core kernel: same block, compared with the VALU kernel's result, timed alone and back-to-back
+  {
+    std::vector<double> L0(n * n), L1(n * n);
+    CK(hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice));
+    potf2_kernel<double><<<1, 256>>>(dA, n, n, dW, dinfo, 0);
+    CK(hipMemcpy(L0.data(), dA, n * n * 8, hipMemcpyDeviceToHost));
+    std::vector<double> F0(LGP_NFRAG * 64), F1(LGP_NFRAG * 64);
+    pack_frag_kernel<double><<<(LGP_NFRAG + 3) / 4, 256>>>(dW);
+    CK(hipMemcpy(F0.data(), dW + LGP_FRAG0, F0.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemset(dW, 0, LGP_DBLK * 8));
+    for (int rep = 0; rep < 5; ++rep) {
+      CK(hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice));
+      CK(hipEventRecord(e0));
+      potf2_mfma_kernel<<<1, 64>>>(dA, n, n, dW, dinfo, 0);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("potf2_mfma alone: %.1f us\n", ms * 1e3);
+    }
+    CK(hipMemcpy(L1.data(), dA, n * n * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(F1.data(), dW + LGP_FRAG0, F1.size() * 8, hipMemcpyDeviceToHost));
+    double dl = 0, df = 0, nl = 0, nf = 0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { dl = fmax(dl, fabs(L0[i * n + j] - L1[i * n + j])); nl = fmax(nl, fabs(L0[i * n + j])); }
+    for (size_t i = 0; i < F0.size(); ++i) { df = fmax(df, fabs(F0[i] - F1[i])); nf = fmax(nf, fabs(F0[i])); }
+    printf("potf2_mfma vs potf2: max |dL| = %.3e (max |L| %.3e), max |dF| = %.3e (max |F| %.3e)\n", dl, nl, df, nf);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 50; ++i) potf2_mfma_kernel<<<1, 64>>>(dA, n, n, dW, dinfo, 0);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("potf2_mfma x50 back-to-back: %.1f us each\n", ms * 1e3 / 50);
+#ifdef LGP_POTF2_TRACE
+    unsigned long long st[16];
+    CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(lgp_potf2_trace), sizeof(st)));
+    printf("potf2_mfma phases (cycles): ");
+    for (int k = 1; k <= 9; ++k) printf("%llu ", st[k] - st[k - 1]);
+    printf("| hot-loop passes: %llu %llu %llu", st[11] - st[9], st[12] - st[11], st[13] - st[12]);
+    printf("\n");
+#endif
   }
   // 50 back-to-back
   CK(hipEventRecord(e0));
