@@ -140,6 +140,37 @@ int lgp_gram_bart_f64(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const i
                       int nops, const int *hops_code, const double *hops_val,
                       double *dout, size_t ldo);
 
+/* The isotropic Gram matrix together with its derivative with respect to `scale` (dout and ddscale: n x m, ld ldo): the
+ * forward-mode tangent of `(x - loc) / scale` (_Kernel/_ops.py:310-326) through the cores and the output algops -- what
+ * jax.jacfwd of a gpfactory with a `scale` hyperparameter produces in the reference's fit (_fit.py:679-690), here in the
+ * same pass over the pairs as the matrix itself.  scale=None: the derivative at scale = 1. */
+int lgp_gram_isotropic_dscale_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d,
+                                  const double *dx, size_t ldx, size_t n, const double *dy, size_t ldy, size_t m,
+                                  int has_loc, double loc, int has_scale, double scale,
+                                  int nops, const int *hops_code, const double *hops_val,
+                                  double *dout, double *ddscale, size_t ldo);
+int lgp_gram_isotropic_dscale_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int d,
+                                  const float *dx, size_t ldx, size_t n, const float *dy, size_t ldy, size_t m,
+                                  int has_loc, float loc, int has_scale, float scale,
+                                  int nops, const int *hops_code, const float *hops_val,
+                                  float *dout, float *ddscale, size_t ldo);
+/* The BART Gram matrix with ntan <= 2 forward-mode tangents of the splitting probabilities (alpha and beta of
+ * bayestree.bart, bayestree/_bart.py:187-205): arguments as lgp_gram_bart_*, plus hdprobs (HOST, ntan x repeat*size:
+ * d hprobs / d theta_t, laid out like hprobs), hdtan (HOST array of ntan DEVICE n x m outputs, ld ldo: d dout / d theta_t)
+ * and hdgtan (HOST array of ntan DEVICE per-pair tangents of the deeper slice's result, may alias hdtan; NULL = zero). */
+int lgp_gram_bart_jvp_f32(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const int32_t *diy, size_t m,
+                          const int32_t *hnsplits, const float *hweights,
+                          int size, int repeat, const float *hprobs, float gamma, const float *dgamma_mat,
+                          const float *dpsi, size_t npsi, int nops, const int *hops_code, const float *hops_val,
+                          float *dout, size_t ldo, int ntan, const float *hdprobs, float *const *hdtan,
+                          const float *const *hdgtan);
+int lgp_gram_bart_jvp_f64(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const int32_t *diy, size_t m,
+                          const int32_t *hnsplits, const double *hweights,
+                          int size, int repeat, const double *hprobs, double gamma, const double *dgamma_mat,
+                          const double *dpsi, size_t npsi, int nops, const int *hops_code, const double *hops_val,
+                          double *dout, size_t ldo, int ntan, const double *hdprobs, double *const *hdtan,
+                          const double *const *hdgtan);
+
 /* Elementwise ("pairs") forms of the same kernels: out[i] = k(x_i, y_i), i < npairs -- the broadcasting
  * call contract of CrossKernel.__call__ for equally shaped inputs (_Kernel/_crosskernel.py:192-200) and the
  * flat upper-triangle evaluation of `halfmatrix` (_GP/_elements.py:567-573).  Arguments as the Gram forms.
@@ -273,6 +304,20 @@ int lgp_mlnd_value_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, con
                        double *dr, double *hvalue);
 int lgp_mlnd_value_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, const float *ddblk,
                        float *dr, float *hvalue);
+
+/* minus_log_normal_density(r, dK=..., dr=..., value, gradfwd, fisher) (_decomp.py:441-561): the value, its forward-mode
+ * gradient 1/2 tr(K^-1 dK_k) - 1/2 r'K^-1 dK_k K^-1 r + r'K^-1 dr_k and the Fisher matrix 1/2 tr(K^-1 dK_k K^-1 dK_q) +
+ * dr_k' K^-1 dr_q of the p parameters, computed on the device from the factor: K^-1 is formed once (as the reference
+ * does, :470-472), every contraction is an MFMA gemm or a reduction kernel; nothing n x n leaves HBM.
+ * dr (n, device) is overwritten with L^-1 r.  hdK: HOST array of p DEVICE pointers to the n x n matrices dK_k (ld lddk), or
+ * NULL; ddr: n x p device matrix (ld lddr) of dr_k, or NULL.  Outputs (host, each may be NULL): hvalue, hgrad[p],
+ * hfisher[p*p] row-major.  Synchronises. */
+int lgp_mlnd_grad_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *ddblk, double *dr,
+                      size_t p, const double *const *hdK, size_t lddk, const double *ddr, size_t lddr,
+                      double *hvalue, double *hgrad, double *hfisher);
+int lgp_mlnd_grad_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, const float *ddblk, float *dr,
+                      size_t p, const float *const *hdK, size_t lddk, const float *ddr, size_t lddr,
+                      float *hvalue, float *hgrad, float *hfisher);
 
 /* ---- multi-GPU: 1-D block-column-cyclic Cholesky over RCCL (no reference counterpart) -- */
 

@@ -191,6 +191,23 @@ class _Isotropic(Kernel):
                      nops, codes, vals, int(xd is yd), out.ptr, out.ld), 'lgp_gram_isotropic')
         return out
 
+    def gram_dscale(self, xs, ys, *, ctx=None):
+        """ ``(K, dK/dscale)`` as two device matrices from one pass over the pairs (``lgp_gram_isotropic_dscale``): the
+        tangent that ``jax.jacfwd`` of a reference gpfactory produces for a ``scale`` hyperparameter
+        (``_Kernel/_ops.py:310-326`` through the core); with ``scale=None`` the derivative at scale = 1 """
+        xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
+        n, m = xd.shape[1], yd.shape[1]
+        out = DeviceArray.empty((n, m), dtype, ctx)
+        dout = DeviceArray.empty((n, m), dtype, ctx)
+        if n == 0 or m == 0:
+            return out, dout
+        f, F = _lib.fn('lgp_gram_isotropic_dscale', dtype)
+        nops, codes, vals = _ops_arrays(self._outops, F)
+        _lib.check(f(ctx.handle, self._kind, int(self._p), *self._par_args(F), d, xd.ptr, xd.ld, n, yd.ptr, yd.ld, m,
+                     int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
+                     nops, codes, vals, out.ptr, dout.ptr, out.ld), 'lgp_gram_isotropic_dscale')
+        return out, dout
+
     def pairs(self, xs, ys, *, ctx=None):
         xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
         n = xd.shape[1]
@@ -308,6 +325,7 @@ class BART(Kernel):
                 raise ValueError('scale/loc make no sense with indices=True')
         self._splits = self._check_splits(splits, indices)
         self._indices = bool(indices)
+        self._dpnt_ab = None
         # splitting probabilities, _bart.py:373-384
         if pnt is None:
             assert maxd == int(maxd) and maxd >= 0, maxd
@@ -324,6 +342,8 @@ class BART(Kernel):
             assert beta_a >= 0, 'beta must be in [0, inf)'
             d = numpy.arange(int(maxd) + 1)
             pnt = alpha_a.astype(ft) / (1 + d).astype(ft) ** beta_a.astype(ft)
+            # tangents of the probabilities with respect to alpha and beta, for `gram_jvp`
+            self._dpnt_ab = (1 / (1 + d).astype(ft) ** beta_a.astype(ft), -pnt * numpy.log((1 + d).astype(ft)))
         else:
             pnt = numpy.asarray(pnt)
             if pnt.ndim != 1:
@@ -350,6 +370,8 @@ class BART(Kernel):
         if not intercept:                                            # :411-412
             pnt = pnt.copy()
             pnt[0] = 1
+            if self._dpnt_ab is not None:
+                self._dpnt_ab = tuple(numpy.concatenate([[0], t[1:]]) for t in self._dpnt_ab)
         # float type of (pnt, gamma, w): fp32 iff all three are fp32 (:657, tests/kernels/test_bart.py:313-330)
         # JAX promotion lattice: integer arrays and weak Python scalars never widen a float type
         fl = [d for d in ([pnt.dtype, weights.dtype] + ([] if gamma_weak else [gamma.dtype])) if numpy.issubdtype(d, numpy.floating)]
@@ -559,6 +581,57 @@ class BART(Kernel):
         ixd = DeviceArray.from_host(ix, ctx=ctx)
         iyd = ixd if iy is ix else DeviceArray.from_host(iy, ctx=ctx)
         return self._run('lgp_gram_bart', ctx, p, ixd, iyd, n, m, self._splits[0], None, out, out.ld)
+
+    def gram_jvp(self, xs, ys, dpnt=None, *, ctx=None):
+        """
+        The Gram matrix and its forward-mode tangents: ``dpnt`` is a sequence of at most two arrays like ``pnt``
+        (derivatives of the splitting probabilities with respect to a parameter); default: the derivatives with
+        respect to ``alpha`` and ``beta`` of ``pnt_d = alpha / (1 + d)^beta`` (``_bart.py:379-382``).  Returns
+        ``(K, [dK_0, dK_1])`` as device matrices -- what ``jax.jacfwd`` of the reference's ``makegp`` yields for the
+        BART hyperparameters of ``bayestree.bart`` (``bayestree/_bart.py:187-205``), computed in the same pass as K.
+        """
+        ctx = ctx or Context.default()
+        if dpnt is None:
+            if self._dpnt_ab is None:
+                raise ValueError('the kernel was built from `pnt`: pass the derivatives of pnt explicitly')
+            dpnt = self._dpnt_ab
+        dpnt = [numpy.asarray(t, self._flt) for t in dpnt]
+        if not 1 <= len(dpnt) <= 2 or any(t.shape != self._pnt.shape for t in dpnt):
+            raise ValueError(f'one or two tangent arrays of shape {self._pnt.shape} expected')
+        ix = self._to_indices(xs)
+        iy = ix if ys is xs else self._to_indices(ys)
+        n, m, p = ix.shape[0], iy.shape[0], ix.shape[1]
+        out = DeviceArray.empty((n, m), self._flt, ctx)
+        tans = [DeviceArray.zeros((n, m), self._flt, ctx) for _ in dpnt]
+        if n == 0 or m == 0:
+            return out, tans
+        ixd = DeviceArray.from_host(ix, ctx=ctx)
+        iyd = ixd if iy is ix else DeviceArray.from_host(iy, ctx=ctx)
+        f, F = _lib.fn('lgp_gram_bart_jvp', self._flt)
+        nsplits = self._splits[0]
+        nsp = (ctypes.c_int32 * max(p, 1))(*[int(v) for v in nsplits])
+        w = (F * max(p, 1))(*[float(v) for v in self._weights])
+        psi = self._psi_table(int(numpy.max(nsplits)) if p else 0, ctx)
+        ntan = len(dpnt)
+        tptr = (ctypes.c_void_p * ntan)(*[t.ptr for t in tans])
+        first = True
+        for t, b, repeat in reversed(self._brackets):                # :434-455, tangents chained like the values
+            probs = _bart_probs(self._pnt, t, b, repeat)
+            size = len(probs) // repeat
+            dprobs = []
+            for tan in dpnt:
+                # same layout as the probabilities; the entries that `_bart_probs` sets to the constant 1 have zero derivative
+                const = _bart_probs(numpy.full_like(self._pnt, 2), t, b, repeat) == 1
+                dprobs.append(numpy.where(const, 0, _bart_probs(tan, t, b, repeat)))
+            pr = (F * len(probs))(*[float(v) for v in probs])
+            dpr = (F * (ntan * len(probs)))(*[float(v) for dp in dprobs for v in dp])
+            last = (t, b, repeat) == self._brackets[0]
+            nops, codes, vals = _ops_arrays(self._outops if last else (), F)
+            _lib.check(f(ctx.handle, p, ixd.ptr, n, iyd.ptr, m, nsp, w, size, repeat, pr, F(float(self._gamma0)),
+                         None if first else out.ptr, psi.ptr, psi.shape[0], nops, codes, vals, out.ptr, out.ld,
+                         ntan, dpr, tptr, None if first else tptr), 'lgp_gram_bart_jvp')
+            first = False
+        return out, tans
 
     def _pairs_indices(self, ix, iy, npair=None, ctx=None):
         ctx = ctx or Context.default()

@@ -85,6 +85,11 @@ def _signatures():
             'lgp_gram_bart_' + suf: (c_int, [c_void_p, c_int, _P, _S, _P, _S, POINTER(c_int32), POINTER(F),
                                             c_int, c_int, POINTER(F), F, _P, _P, _S,
                                             c_int, POINTER(c_int), POINTER(F), _P, _S]),
+            'lgp_gram_isotropic_dscale_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, _P, _S, _S, _P, _S, _S,
+                                                        c_int, F, c_int, F, c_int, POINTER(c_int), POINTER(F), _P, _P, _S]),
+            'lgp_gram_bart_jvp_' + suf: (c_int, [c_void_p, c_int, _P, _S, _P, _S, POINTER(c_int32), POINTER(F),
+                                                c_int, c_int, POINTER(F), F, _P, _P, _S,
+                                                c_int, POINTER(c_int), POINTER(F), _P, _S, c_int, POINTER(F), POINTER(c_void_p), POINTER(c_void_p)]),
             'lgp_pairs_isotropic_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, _P, _S, _P, _S, _S,
                                                   c_int, F, c_int, F, c_int, POINTER(c_int), POINTER(F), _P]),
             'lgp_pairs_bart_' + suf: (c_int, [c_void_p, c_int, _P, _P, _S, POINTER(c_int32), _P, POINTER(F),
@@ -106,6 +111,7 @@ def _signatures():
             'lgp_posterior_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, _P, _P, _S, _P, _S, _P, _P, _S, POINTER(F)]),
             'lgp_posterior_solved_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, _P, _S, _P, _S, _P, _P, _S, POINTER(F)]),
             'lgp_mlnd_value_' + suf: (c_int, [c_void_p, _S, _P, _S, _P, _P, POINTER(F)]),
+            'lgp_mlnd_grad_' + suf: (c_int, [c_void_p, _S, _P, _S, _P, _P, _S, POINTER(c_void_p), _S, _P, _S, POINTER(F), POINTER(F), POINTER(F)]),
         })
     return sig
 

@@ -100,28 +100,28 @@ class Decomposition(abc.ABC):
 
 def solve_triangular_python(a, b, *, lower=False):
     """
-    Substitution on object arrays (``_decomp.py:280-309``); host Python by
-    nature, used only by `pinv_bilinear_robj`.
+    Triangular solve ``a x = b`` by substitution with plain Python arithmetic,
+    so that ``b`` may hold arbitrary objects (same contract as the reference's
+    helper, ``_decomp.py:280-309``; host code by nature, used only by
+    `pinv_bilinear_robj`).  ``b`` is a vector or a matrix of right-hand sides.
     """
     a = numpy.asarray(a)
-    x = numpy.copy(b)
-    vec = x.ndim < 2
-    if vec:
-        x = x[:, None]
+    b = numpy.asarray(b)
     n = a.shape[-1]
-    assert x.shape[-2] == n
-    if not lower:
-        a = a[..., ::-1, ::-1]
-        x = x[..., ::-1, :]
-    x[..., 0, :] /= a[..., 0, 0, None]
-    for i in range(1, n):
-        x[..., i:, :] -= x[..., None, i - 1, :] * a[..., i:, i - 1, None]
-        x[..., i, :] /= a[..., i, i, None]
-    if not lower:
-        x = x[..., ::-1, :]
-    if vec:
-        x = numpy.squeeze(x, -1)
-    return x
+    if b.shape[0] != n:
+        raise ValueError(f'right-hand side has {b.shape[0]} rows, the matrix has {n}')
+    cols = b.reshape(n, -1)
+    out = numpy.empty(cols.shape, dtype=b.dtype if b.dtype == object else numpy.result_type(a.dtype, b.dtype, float))
+    order = range(n) if lower else range(n - 1, -1, -1)
+    for c in range(cols.shape[1]):
+        done = []                                   # indices already solved, in elimination order
+        for i in order:
+            acc = cols[i, c]
+            for j in done:
+                acc = acc - a[i, j] * out[j, c]
+            out[i, c] = acc / a[i, i]
+            done.append(i)
+    return out.reshape(b.shape)
 
 
 class Chol(Decomposition):
@@ -338,82 +338,127 @@ class Chol(Decomposition):
         self._trsm(B, 0)
         return self._out(B, vec, device)
 
+    def _dK_list(self, dK):
+        """ derivative matrices as a list of (n, n) device matrices: accepts the reference's (n, n, p) array
+        (``∂K_ij/∂p_k``) or a sequence of host / device matrices """
+        if dK is None:
+            return None
+        if isinstance(dK, DeviceArray):
+            mats = [dK]
+        elif isinstance(dK, (list, tuple)):
+            mats = list(dK)
+        else:
+            arr = numpy.asarray(dK)
+            if arr.ndim == 2:
+                arr = arr[:, :, None]
+            if arr.ndim != 3:
+                raise ValueError(f'dK must have shape (n, n, p), found {arr.shape}')
+            mats = [numpy.ascontiguousarray(arr[:, :, k]) for k in range(arr.shape[2])]
+        out = []
+        for m in mats:
+            if not isinstance(m, DeviceArray):
+                m = DeviceArray.from_host(numpy.asarray(m), dtype=self._dtype, ctx=self._ctx)
+            if m.shape != (self.n, self.n) or m.dtype != self._dtype:
+                raise ValueError(f'derivative matrix has shape {m.shape} / dtype {m.dtype}, expected {(self.n, self.n)} / {self._dtype}')
+            out.append(m)
+        return out
+
+    def normal_density_derivs(self, r, dK=None, dr=None, *, fisher=False):
+        """
+        Value, forward-mode gradient and (optionally) Fisher matrix of the minus log density in ONE device call
+        (``lgp_mlnd_grad``; ``_decomp.py:461-561``): ``dK`` as for `_dK_list`, ``dr`` an (n, p) host or device
+        matrix.  Returns ``(value, grad, fisher_or_None)`` as host scalars / arrays.  Nothing n x n is downloaded.
+        """
+        mats = self._dK_list(dK)
+        drd = None
+        if dr is not None:
+            drd = dr.as2d() if isinstance(dr, DeviceArray) else DeviceArray.from_host(numpy.asarray(dr).reshape(self.n, -1), dtype=self._dtype, ctx=self._ctx)
+            if drd.shape[0] != self.n:
+                raise ValueError(f'dr has {drd.shape[0]} rows, the decomposed matrix has {self.n}')
+        p = len(mats) if mats is not None else (drd.shape[1] if drd is not None else 0)
+        if mats is not None and drd is not None and drd.shape[1] != p:
+            raise ValueError(f'dK has {p} parameters, dr has {drd.shape[1]}')
+        rd, _ = self._rhs(r, copy=True)
+        if rd.shape[1] != 1:
+            raise ValueError('r must be a vector')
+        f, F = _lib.fn('lgp_mlnd_grad', self._dtype)
+        val = F()
+        grad = (F * max(p, 1))()
+        fish = (F * max(p * p, 1))()
+        ptrs = None
+        ldk = 0
+        if mats is not None and p:
+            lds = {m.ld for m in mats}
+            if len(lds) != 1:
+                mats = [m.copy() for m in mats]
+            ptrs = (ctypes.c_void_p * p)(*[m.ptr for m in mats])
+            ldk = mats[0].ld
+        _lib.check(f(self._ctx.handle, self.n, self._L.ptr, self._L.ld, self._dblk.ptr, rd.ptr, p, ptrs, ldk,
+                     None if drd is None else drd.ptr, 0 if drd is None else drd.ld,
+                     ctypes.byref(val), grad if p else None, fish if (fisher and p) else None), 'lgp_mlnd_grad')
+        t = self._dtype.type
+        g = numpy.array([t(grad[k]) for k in range(p)], self._dtype)
+        Fm = numpy.array([t(v) for v in fish[:p * p]], self._dtype).reshape(p, p) if fisher else None
+        return t(val.value), g, Fm
+
     def minus_log_normal_density(self, r, *, dr_vjp=None, dK_vjp=None,
         dr_jvp_vec=None, dK_jvp_vec=None, dr=None, dK=None, value=False,
         gradrev=False, gradfwd=False, fisher=False, fishvec=False):
         """
-        ``_decomp.py:441-586``.  The value is one fused device call; the
-        derivative pieces are compositions of the device solves with small host
-        contractions (the derivative inputs are host callables / arrays).
-        """
-        out = {}
-        grad = (
-            (gradrev and (dK_vjp is not None or dr_vjp is not None))
-            or (gradfwd and (dK is not None or dr is not None))
-        )
-        if grad:
-            invKr = self.ginv_linear(r)                                   # :468-469
-        if (gradrev and dK_vjp is not None) or (gradfwd and dK is not None):
-            invK = self.ginv()                                            # :470-472
+        Minus log of a Normal density with covariance K and its derivatives, same arguments and 5-tuple
+        ``(value, gradrev, gradfwd, fisher, fishvec)`` as ``_decomp.py:441-586``.
 
-        if value:                                                         # :474-488
+        Array-valued derivative inputs (``dK``, ``dr``: forward mode, what `empbayes_fit` uses) are contracted on the
+        device by `normal_density_derivs`.  The reverse-mode inputs are *host callables* by contract (``dK_vjp(X)``
+        takes an (n, n) array), so K^-1 is downloaded for them once.
+        """
+        val = rev = fwd = fis = fvec = None
+        have_fwd_in = dK is not None or dr is not None
+
+        if (gradfwd or fisher) and have_fwd_in:
+            v, g, Fm = self.normal_density_derivs(r, dK, dr, fisher=fisher)
+            if value:
+                val = v
+            if gradfwd:
+                fwd = g
+            if fisher:
+                fis = Fm
+        if gradfwd and fwd is None:
+            fwd = 0
+        if fisher and fis is None:
+            fis = 0
+        if value and val is None:
             rd, _ = self._rhs(r, copy=True)
             if rd.shape[1] != 1:
                 raise ValueError('r must be a vector')
             f, F = _lib.fn('lgp_mlnd_value', self._dtype)
-            val = F()
-            _lib.check(f(self._ctx.handle, self.n, self._L.ptr, self._L.ld, self._dblk.ptr, rd.ptr, ctypes.byref(val)), 'lgp_mlnd_value')
-            out['value'] = self._dtype.type(val.value)
-        else:
-            out['value'] = None
+            out = F()
+            _lib.check(f(self._ctx.handle, self.n, self._L.ptr, self._L.ld, self._dblk.ptr, rd.ptr, ctypes.byref(out)), 'lgp_mlnd_value')
+            val = self._dtype.type(out.value)
 
-        if gradrev:                                                       # :492-514
-            out['gradrev'] = 0
-            if dK_vjp is not None:
-                tr_invK_dK = dK_vjp(invK)
-                r_invK_dK_invK_r = dK_vjp(numpy.outer(invKr, invKr))
-                out['gradrev'] += 1/2 * (tr_invK_dK - r_invK_dK_invK_r)
-            if dr_vjp is not None:
-                out['gradrev'] += dr_vjp(invKr)
-        else:
-            out['gradrev'] = None
+        if gradrev:
+            rev = 0
+            if dK_vjp is not None or dr_vjp is not None:
+                invKr = self.ginv_linear(r)
+                if dK_vjp is not None:
+                    invK = self.ginv()
+                    rev = rev + (dK_vjp(invK) - dK_vjp(numpy.outer(invKr, invKr))) / 2
+                if dr_vjp is not None:
+                    rev = rev + dr_vjp(invKr)
 
-        if gradfwd:                                                       # :516-534
-            out['gradfwd'] = 0
-            if dK is not None:
-                dK = numpy.asarray(dK)
-                tr_invK_dK = numpy.einsum('ij,ijk->k', invK, dK)
-                r_invK_dK_invK_r = numpy.einsum('i,ijk,j->k', invKr, dK, invKr)
-                out['gradfwd'] += 1/2 * (tr_invK_dK - r_invK_dK_invK_r)
-            if dr is not None:
-                out['gradfwd'] += invKr @ numpy.asarray(dr)
-        else:
-            out['gradfwd'] = None
+        if fishvec:
+            fvec = 0
+            if dK_jvp_vec is not None or dK_vjp is not None:
+                if dK_jvp_vec is None or dK_vjp is None:
+                    raise ValueError('fishvec needs both dK_jvp_vec and dK_vjp')
+                half = self.ginv_linear(numpy.asarray(dK_jvp_vec))          # K^-1 (dK v)
+                fvec = fvec + dK_vjp(self.ginv_linear(half.T)) / 2          # K^-1 (dK v) K^-1, the matrix being symmetric
+            if dr_jvp_vec is not None or dr_vjp is not None:
+                if dr_jvp_vec is None or dr_vjp is None:
+                    raise ValueError('fishvec needs both dr_jvp_vec and dr_vjp')
+                fvec = fvec + dr_vjp(self.ginv_linear(numpy.asarray(dr_jvp_vec)))
 
-        if fisher:                                                        # :536-561
-            out['fisher'] = 0
-            if dK is not None:
-                dKk = numpy.moveaxis(numpy.asarray(dK), 2, 0)
-                invL_dK = [self.pinv_correlate(m) for m in dKk]           # kim: L⁻¹_il dK_lmk
-                invL_dK_invL = numpy.stack([self.pinv_correlate(m.T) for m in invL_dK])
-                out['fisher'] += 1/2 * numpy.einsum('kij,qij->kq', invL_dK_invL, invL_dK_invL)
-            if dr is not None:
-                out['fisher'] += self.ginv_quad(numpy.asarray(dr))
-        else:
-            out['fisher'] = None
-
-        if fishvec:                                                       # :563-584
-            out['fishvec'] = 0
-            if not (dK_jvp_vec is None and dK_vjp is None):
-                invK_dKv = self.ginv_linear(numpy.asarray(dK_jvp_vec))
-                invK_dKv_invK = self.ginv_linear(invK_dKv.T)
-                out['fishvec'] += 1/2 * dK_vjp(invK_dKv_invK)
-            if not (dr_jvp_vec is None and dr_vjp is None):
-                out['fishvec'] += dr_vjp(self.ginv_linear(numpy.asarray(dr_jvp_vec)))
-        else:
-            out['fishvec'] = None
-
-        return tuple(out.values())
+        return val, rev, fwd, fis, fvec
 
     @property
     def n(self):

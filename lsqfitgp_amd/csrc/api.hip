@@ -21,6 +21,10 @@ template <typename T>
 int lgp_dot_strided_device(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *x, size_t incx, const T *y, size_t incy, T *dout);
 template <typename T>
 int lgp_logdet_device(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t ldl, T *dout);
+template <typename T>
+int lgp_frob_device(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t cols, const T *A, size_t lda, const T *B, size_t ldb, T *dpart, T *dout);
+template <typename T>
+int lgp_set_diag_device(lgp_ctx *ctx, hipStream_t stream, size_t n, T *A, size_t lda, T value);
 
 extern "C" {
 
@@ -373,7 +377,101 @@ static int mlnd_impl(lgp_ctx *c, size_t n, const T *L, size_t ldl, const T *dblk
   return LGP_OK;
 }
 
+// minus_log_normal_density with forward-mode gradient and Fisher matrix (_decomp.py:461-561) on the device.  Like the
+// reference it forms K^-1 = L^-T L^-1 explicitly (:470-472); the Fisher term tr(K^-1 dK_k K^-1 dK_q) is taken as
+// <K^-1 dK_k K^-1, dK_q> (two MFMA gemms per parameter + Frobenius products) instead of the reference's two-sided
+// triangular solves of every dK (:547-553): the same number, gemm-bound instead of latency-bound.
+template <typename T>
+static int mlnd_grad_impl(lgp_ctx *c, size_t n, const T *L, size_t ldl, const T *dblk, T *r, size_t p, const T *const *hdK, size_t lddk,
+                          const T *ddr, size_t lddr, T *hvalue, T *hgrad, T *hfisher) {
+  LGP_REQUIRE(c != nullptr && L != nullptr && dblk != nullptr && r != nullptr, "null pointer");
+  LGP_REQUIRE(n >= 1 && p <= 64, "bad sizes (at most 64 parameters)");
+  LGP_REQUIRE(p == 0 || hdK != nullptr || ddr != nullptr, "no derivative given");
+  LGP_REQUIRE(hdK == nullptr || lddk >= n, "lddk < n");
+  LGP_REQUIRE(ddr == nullptr || lddr >= p, "lddr < p");
+  DeviceGuard dg(c->device);
+  hipStream_t st = c->stream;
+  const bool want_grad = hgrad != nullptr && p > 0, want_fisher = hfisher != nullptr && p > 0;
+  // scalars (device): [0] sum log L_ii, [1] |L^-1 r|^2, [2 + k] <K^-1, dK_k>, [2 + p + k] z' dK_k z, [2 + 2p + k] z' dr_k,
+  // [2 + 3p + k p + q] <K^-1 dK_k K^-1, dK_q>, [2 + 3p + p^2 + k p + q] (L^-1 dr)'(L^-1 dr); partial sums after them
+  const size_t nscal = 2 + 3 * p + 2 * p * p;
+  LGP_REQUIRE((nscal + 1024) * sizeof(T) <= c->scratch_bytes, "scratch too small");
+  T *ds = reinterpret_cast<T *>(c->d_scratch), *dpart = ds + nscal;
+  LGP_HIP(hipMemsetAsync(ds, 0, nscal * sizeof(T), st));
+  LGP_CHECK(lgp_trsm_impl<T>(c, st, n, L, ldl, dblk, 0, r, 1, 1));            // y = L^-1 r, :467
+  LGP_CHECK(lgp_logdet_device<T>(c, st, n, L, ldl, ds));
+  LGP_CHECK(lgp_dot_strided_device<T>(c, st, n, r, 1, r, 1, ds + 1));
+  T *ws = nullptr;
+  if (want_grad || want_fisher) {
+    const bool needK = hdK != nullptr;
+    const size_t nmat = needK ? (want_fisher ? 3 : 2) : 0;
+    LGP_HIP(hipMallocAsync(reinterpret_cast<void **>(&ws), (nmat * n * n + 2 * n + n * (p ? p : 1)) * sizeof(T), st));
+    T *X = ws, *IK = ws + (needK ? n * n : 0), *S = ws + (needK ? 2 * n * n : 0);
+    T *z = ws + nmat * n * n, *w = z + n, *V = w + n;
+    LGP_HIP(hipMemcpyAsync(z, r, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+    LGP_CHECK(lgp_trsm_impl<T>(c, st, n, L, ldl, dblk, 1, z, 1, 1));          // z = K^-1 r, :469
+    if (needK) {
+      // X = L^-1 (forward solve of the identity), K^-1 = X' X                  :470-472
+      LGP_HIP(hipMemsetAsync(X, 0, n * n * sizeof(T), st));
+      LGP_CHECK(lgp_set_diag_device<T>(c, st, n, X, n, T(1)));
+      LGP_CHECK(lgp_trsm_impl<T>(c, st, n, L, ldl, dblk, 0, X, n, n));
+      LGP_CHECK(lgp_gemm_launch<T>(c, st, true, false, n, n, n, T(1), X, n, X, n, T(0), IK, n, false));
+      for (size_t k = 0; k < p; ++k) {
+        LGP_REQUIRE(hdK[k] != nullptr, "null derivative matrix");
+        LGP_CHECK(lgp_frob_device<T>(c, st, n, n, IK, n, hdK[k], lddk, dpart, ds + 2 + k));                  // tr(K^-1 dK_k), :526
+        LGP_CHECK(lgp_gemm_launch<T>(c, st, false, false, n, 1, n, T(1), hdK[k], lddk, z, 1, T(0), w, 1, false));
+        LGP_CHECK(lgp_dot_strided_device<T>(c, st, n, z, 1, w, 1, ds + 2 + p + k));                          // z' dK_k z, :527
+      }
+      if (want_fisher) {
+        for (size_t k = 0; k < p; ++k) {
+          LGP_CHECK(lgp_gemm_launch<T>(c, st, false, false, n, n, n, T(1), hdK[k], lddk, IK, n, T(0), X, n, false));   // dK_k K^-1
+          LGP_CHECK(lgp_gemm_launch<T>(c, st, false, false, n, n, n, T(1), IK, n, X, n, T(0), S, n, false));          // K^-1 dK_k K^-1
+          for (size_t q = k; q < p; ++q)
+            LGP_CHECK(lgp_frob_device<T>(c, st, n, n, S, n, hdK[q], lddk, dpart, ds + 2 + 3 * p + k * p + q));
+        }
+      }
+    }
+    if (ddr != nullptr) {
+      for (size_t k = 0; k < p; ++k) LGP_CHECK(lgp_dot_strided_device<T>(c, st, n, z, 1, ddr + k, lddr, ds + 2 + 2 * p + k));   // z' dr_k, :532
+      if (want_fisher) {
+        LGP_HIP(hipMemcpy2DAsync(V, p * sizeof(T), ddr, lddr * sizeof(T), p * sizeof(T), n, hipMemcpyDeviceToDevice, st));
+        LGP_CHECK(lgp_trsm_impl<T>(c, st, n, L, ldl, dblk, 0, V, p, p));                                     // L^-1 dr, :556
+        LGP_CHECK(lgp_gemm_launch<T>(c, st, true, false, p, p, n, T(1), V, p, V, p, T(0), ds + 2 + 3 * p + p * p, p, false));
+      }
+    }
+  }
+  std::vector<T> h(nscal);
+  LGP_HIP(hipMemcpyAsync(h.data(), ds, nscal * sizeof(T), hipMemcpyDeviceToHost, st));
+  if (ws) LGP_HIP(hipFreeAsync(ws, st));
+  LGP_HIP(hipStreamSynchronize(st));
+  if (hvalue) *hvalue = T(0.5) * (T(n) * T(std::log(2 * M_PI)) + T(2) * h[0] + h[1]);                       // :484-488
+  if (want_grad)
+    for (size_t k = 0; k < p; ++k) {
+      T gk = T(0);
+      if (hdK) gk += T(0.5) * (h[2 + k] - h[2 + p + k]);                                                     // :528
+      if (ddr) gk += h[2 + 2 * p + k];                                                                        // :533
+      hgrad[k] = gk;
+    }
+  if (want_fisher)
+    for (size_t k = 0; k < p; ++k)
+      for (size_t q = 0; q < p; ++q) {
+        T f = T(0);
+        if (hdK) f += T(0.5) * (k <= q ? h[2 + 3 * p + k * p + q] : h[2 + 3 * p + q * p + k]);               // :554
+        if (ddr) f += h[2 + 3 * p + p * p + k * p + q];                                                       // :558
+        hfisher[k * p + q] = f;
+      }
+  return LGP_OK;
+}
+
 extern "C" {
+int lgp_mlnd_grad_f64(lgp_ctx *c, size_t n, const double *L, size_t ldl, const double *dblk, double *r, size_t p, const double *const *hdK,
+                      size_t lddk, const double *ddr, size_t lddr, double *hvalue, double *hgrad, double *hfisher) {
+  return mlnd_grad_impl<double>(c, n, L, ldl, dblk, r, p, hdK, lddk, ddr, lddr, hvalue, hgrad, hfisher);
+}
+int lgp_mlnd_grad_f32(lgp_ctx *c, size_t n, const float *L, size_t ldl, const float *dblk, float *r, size_t p, const float *const *hdK,
+                      size_t lddk, const float *ddr, size_t lddr, float *hvalue, float *hgrad, float *hfisher) {
+  return mlnd_grad_impl<float>(c, n, L, ldl, dblk, r, p, hdK, lddk, ddr, lddr, hvalue, hgrad, hfisher);
+}
 int lgp_posterior_f64(lgp_ctx *c, size_t n, size_t m, const double *L, size_t ldl, const double *dblk, double *W, size_t ldw,
                       const double *K, size_t ldk, double *mean, double *cov, size_t ldc, double *hmlnd) {
   return posterior_impl<double>(c, n, m, L, ldl, dblk, W, ldw, K, ldk, mean, cov, ldc, hmlnd);

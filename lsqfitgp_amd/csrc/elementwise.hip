@@ -180,6 +180,34 @@ __global__ void __launch_bounds__(1024) dot_kernel(size_t n, const T *x, size_t 
   }
 }
 
+// Frobenius inner product sum_ij A_ij B_ij in two deterministic stages: per-workgroup partial sums over row chunks, then one
+// workgroup over the partials (tr(K^-1 dK) = <K^-1, dK> and tr(K^-1 dK K^-1 dK') = <K^-1 dK K^-1, dK'>, _decomp.py:526,553)
+template <typename T>
+__global__ void __launch_bounds__(256) frob_partial_kernel(size_t rows, size_t cols, const T *A, size_t lda, const T *B, size_t ldb, T *part,
+                                                           size_t rows_per_blk) {
+  __shared__ T sh[4];
+  const size_t r0 = (size_t)blockIdx.x * rows_per_blk;
+  const size_t r1 = (r0 + rows_per_blk) < rows ? (r0 + rows_per_blk) : rows;
+  T acc = T(0);
+  for (size_t i = r0; i < r1; ++i)
+    for (size_t j = threadIdx.x; j < cols; j += 256) acc += A[i * lda + j] * B[i * ldb + j];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) sum_partials_kernel(size_t count, const T *part, T *out) {
+  __shared__ T sh[4];
+  T acc = T(0);
+  for (size_t i = threadIdx.x; i < count; i += 256) acc += part[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 inline unsigned grid_for(size_t rows, size_t cols) {
   const size_t nb = rows * ((cols + 255) / 256);
   return (unsigned)(nb < 1048576 ? (nb ? nb : 1) : 1048576);
@@ -398,3 +426,36 @@ int lgp_logdet_diag_f32(lgp_ctx *c, size_t n, const float *L, size_t ldl, float 
 int lgp_dot_f64(lgp_ctx *c, size_t n, const double *x, const double *y, double *h) { return dot_impl<double>(c, n, x, y, h); }
 int lgp_dot_f32(lgp_ctx *c, size_t n, const float *x, const float *y, float *h) { return dot_impl<float>(c, n, x, y, h); }
 }
+
+// dout[0] = sum_ij A_ij B_ij; `dpart` is a device workspace of at least 1024 values
+template <typename T>
+int lgp_frob_device(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t cols, const T *A, size_t lda, const T *B, size_t ldb, T *dpart, T *dout) {
+  (void)ctx;
+  size_t chunks = rows < 1024 ? (rows ? rows : 1) : 1024;
+  const size_t rpb = (rows + chunks - 1) / chunks;
+  chunks = rows ? (rows + rpb - 1) / rpb : 1;
+  hipLaunchKernelGGL((frob_partial_kernel<T>), dim3((unsigned)chunks), dim3(256), 0, stream, rows, cols, A, lda, B, ldb, dpart, rpb ? rpb : 1);
+  LGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL((sum_partials_kernel<T>), dim3(1), dim3(256), 0, stream, chunks, dpart, dout);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+template int lgp_frob_device<double>(lgp_ctx *, hipStream_t, size_t, size_t, const double *, size_t, const double *, size_t, double *, double *);
+template int lgp_frob_device<float>(lgp_ctx *, hipStream_t, size_t, size_t, const float *, size_t, const float *, size_t, float *, float *);
+
+namespace {
+template <typename T>
+__global__ void set_diag_kernel(size_t n, T *A, size_t lda, T value) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[i * lda + i] = value;
+}
+}  // namespace
+template <typename T>
+int lgp_set_diag_device(lgp_ctx *ctx, hipStream_t stream, size_t n, T *A, size_t lda, T value) {
+  (void)ctx;
+  hipLaunchKernelGGL((set_diag_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, A, lda, value);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+template int lgp_set_diag_device<double>(lgp_ctx *, hipStream_t, size_t, double *, size_t, double);
+template int lgp_set_diag_device<float>(lgp_ctx *, hipStream_t, size_t, float *, size_t, float);

@@ -32,6 +32,12 @@ struct OutOps {
     for (int i = 0; i < n; ++i) v = (code[i] == LGP_OP_MUL) ? v * val[i] : v + val[i];
     return v;
   }
+  // derivative of apply(v) with respect to v: the product of the multiplications
+  __device__ __forceinline__ T slope() const {
+    T f = T(1);
+    for (int i = 0; i < n; ++i) f = (code[i] == LGP_OP_MUL) ? f * val[i] : f;
+    return f;
+  }
 };
 
 template <typename T>
@@ -39,6 +45,7 @@ struct IsoArgs {
   const T *x;
   const T *y;
   T *out;
+  T *dsc;          // optional second output: d out / d scale (same shape and leading dimension)
   long ldx, ldy, ldo;
   int n, m, d;
   int kernel, p;
@@ -73,8 +80,44 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2) {
   }
 }
 
+// core value and its derivative with respect to `scale` (the inputs are divided by scale before differencing, so
+// r2 = R2 / scale^2 and d r2 / d scale = -2 r2 / scale): analytic forms of the cores above.  With scale=None the
+// derivative is taken at scale = 1.
+template <typename T>
+__device__ __forceinline__ T iso_core_dscale(const IsoArgs<T> &g, T r2, T &dk) {
+  const T inv_s = g.has_scale ? T(1) / g.scale : T(1);
+  if (g.kernel == LGP_KERNEL_EXPQUAD) {                  // k = exp(-r2/2): dk/dscale = k r2 / scale
+    const T k = exp(T(-0.5) * r2);
+    dk = k * r2 * inv_s;
+    return k;
+  } else if (g.kernel == LGP_KERNEL_GAMMAEXP) {          // k = exp(-r2^(gamma/2)): dk/dscale = k gamma r2^(gamma/2) / scale
+    const T pw = g.flag ? r2 : pow(r2, g.par[1]);
+    const T k = exp(-pw);
+    dk = k * g.par[0] * pw * inv_s;
+    return k;
+  } else if (g.kernel == LGP_KERNEL_CAUCHY) {            // k = (1 + pw/beta)^(-beta/alpha), pw = r2^(alpha/2): dk/dscale = k pw / ((1 + pw/beta) scale)
+    const T pw = g.flag ? r2 : pow(r2, g.par[0]);
+    const T base = T(1) + pw / g.par[1];
+    const T k = pow(base, g.par[2]);
+    dk = k * pw / base * inv_s;
+    return k;
+  } else {                                               // Maternp: k = exp(-x) poly(x), x = sqrt((2p+1) r2 + 1e-30); dx/dscale = -r2s / (x scale)
+    const T r2s = g.twop1 * r2;
+    const T x = sqrt(r2s + T(1e-30));
+    T poly = T(1), dpoly = T(0);
+    for (int k = 0; k < g.p; ++k) {
+      const T c2 = g.coef[k] * T(2);
+      dpoly = dpoly * c2 * x + poly * c2;                // d/dx of (1 + poly c 2 x)
+      poly = T(1) + poly * c2 * x;
+    }
+    const T e = exp(-x);
+    dk = e * (poly - dpoly) * r2s / x * inv_s;           // -(dk/dx) r2s / (x scale)
+    return e * poly;
+  }
+}
+
 // D > 0: compile-time field count (coordinates of the lane's columns live in registers); D == 0: runtime d
-template <typename T, int D>
+template <typename T, int D, bool GRAD = false>
 __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g) {
   constexpr int W = VecOf<T>::W;
   constexpr int GT_COLS = GT_THREADS * W;
@@ -121,8 +164,9 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
   }
   const bool colfull = (col0 + c0 + W <= g.m) && ((g.ldo % W) == 0) && ((reinterpret_cast<uintptr_t>(g.out) % 16) == 0);
   const int rmax = (g.n - row0) < GT_ROWS ? (g.n - row0) : GT_ROWS;
+  const T slope = GRAD ? g.ops.slope() : T(0);
   for (int r = 0; r < rmax; ++r) {
-    T res[W];
+    T res[W], dres[W];
 #pragma unroll
     for (int e = 0; e < W; ++e) {
       T r2 = T(0);
@@ -140,18 +184,33 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
           r2 = (f == 0) ? sq : r2 + sq;
         }
       }
-      res[e] = g.ops.apply(iso_core<T>(g, r2));
+      if (GRAD) {
+        T dk;
+        res[e] = g.ops.apply(iso_core_dscale<T>(g, r2, dk));
+        dres[e] = slope * dk;
+      } else {
+        res[e] = g.ops.apply(iso_core<T>(g, r2));
+      }
     }
     T *po = g.out + (long)(row0 + r) * g.ldo + col0 + c0;
-    if (colfull) {
+    T *pd = GRAD ? g.dsc + (long)(row0 + r) * g.ldo + col0 + c0 : nullptr;
+    if (colfull && (!GRAD || (reinterpret_cast<uintptr_t>(g.dsc) % 16) == 0)) {
       vec_t v;
 #pragma unroll
       for (int e = 0; e < W; ++e) v[e] = res[e];
       *reinterpret_cast<vec_t *>(po) = v;
+      if (GRAD) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[e] = dres[e];
+        *reinterpret_cast<vec_t *>(pd) = v;
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < W; ++e)
-        if (col0 + c0 + e < g.m) po[e] = res[e];
+        if (col0 + c0 + e < g.m) {
+          po[e] = res[e];
+          if (GRAD) pd[e] = dres[e];
+        }
     }
   }
 }
@@ -177,7 +236,7 @@ __global__ void __launch_bounds__(256) gram_iso_pairs_kernel(const IsoArgs<T> g)
 template <typename T>
 int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, int d, const T *dx, size_t ldx, size_t n, const T *dy, size_t ldy, size_t m,
                     int has_loc, T loc, int has_scale, T scale, int nops, const int *hops_code, const T *hops_val, T *dout,
-                    size_t ldo, bool pairs = false) {
+                    size_t ldo, bool pairs = false, T *ddsc = nullptr) {
   LGP_REQUIRE(ctx != nullptr, "null context");
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
@@ -193,7 +252,8 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   LGP_REQUIRE(!has_loc || (loc > T(-INFINITY) && loc < T(INFINITY)), "loc must be finite");                 // _ops.py:306-307
   DeviceGuard dg(ctx->device);
   IsoArgs<T> g;
-  g.x = dx; g.y = dy; g.out = dout;
+  g.x = dx; g.y = dy; g.out = dout; g.dsc = ddsc;
+  LGP_REQUIRE(!(pairs && ddsc), "the scale derivative is available for the Gram form only");
   g.ldx = (long)ldx; g.ldy = (long)ldy; g.ldo = (long)ldo;
   g.n = (int)n; g.m = (int)m; g.d = d;
   g.kernel = kernel; g.p = p;
@@ -236,11 +296,20 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   LGP_REQUIRE(ntr * ntc < (1ull << 31), "gram grid too large");
   const size_t shmem = (size_t)d * (GT_ROWS + GT_COLS) * sizeof(T);
   dim3 gd((unsigned)(ntr * ntc)), bd(GT_THREADS);
-  switch (d) {
-    case 1: hipLaunchKernelGGL((gram_iso_kernel<T, 1>), gd, bd, shmem, ctx->stream, g); break;
-    case 2: hipLaunchKernelGGL((gram_iso_kernel<T, 2>), gd, bd, shmem, ctx->stream, g); break;
-    case 3: hipLaunchKernelGGL((gram_iso_kernel<T, 3>), gd, bd, shmem, ctx->stream, g); break;
-    default: hipLaunchKernelGGL((gram_iso_kernel<T, 0>), gd, bd, shmem, ctx->stream, g); break;
+  if (ddsc) {
+    switch (d) {
+      case 1: hipLaunchKernelGGL((gram_iso_kernel<T, 1, true>), gd, bd, shmem, ctx->stream, g); break;
+      case 2: hipLaunchKernelGGL((gram_iso_kernel<T, 2, true>), gd, bd, shmem, ctx->stream, g); break;
+      case 3: hipLaunchKernelGGL((gram_iso_kernel<T, 3, true>), gd, bd, shmem, ctx->stream, g); break;
+      default: hipLaunchKernelGGL((gram_iso_kernel<T, 0, true>), gd, bd, shmem, ctx->stream, g); break;
+    }
+  } else {
+    switch (d) {
+      case 1: hipLaunchKernelGGL((gram_iso_kernel<T, 1>), gd, bd, shmem, ctx->stream, g); break;
+      case 2: hipLaunchKernelGGL((gram_iso_kernel<T, 2>), gd, bd, shmem, ctx->stream, g); break;
+      case 3: hipLaunchKernelGGL((gram_iso_kernel<T, 3>), gd, bd, shmem, ctx->stream, g); break;
+      default: hipLaunchKernelGGL((gram_iso_kernel<T, 0>), gd, bd, shmem, ctx->stream, g); break;
+    }
   }
   LGP_LAUNCH_CHECK();
   return LGP_OK;
@@ -252,6 +321,8 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
 constexpr int BART_MAX_P = 64;
 constexpr int BART_MAX_ROWS = 24;   // repeat*size <= 24 probabilities
 constexpr int BT_ROWS = 16, BT_COLS = 256;
+
+constexpr int BART_MAX_TAN = 2;    // forward-mode tangents carried beside the value (alpha, beta)
 
 template <typename T>
 struct BartArgs {
@@ -268,46 +339,71 @@ struct BartArgs {
   T w[BART_MAX_P];
   T probs[BART_MAX_ROWS];
   OutOps<T> ops;
+  // pair-independent per-axis constants of the depth-2 closed form, evaluated once on the host in T arithmetic with the
+  // operations and the order of the per-pair code (so the Gram entries do not change): valid when `pre` (global split totals)
+  int pre;
+  T wn[BART_MAX_P];      // [n != 0] w / n
+  T invWm[BART_MAX_P];   // 1 / (Wn - [n != 0] w)
+  T wiW[BART_MAX_P];     // w * (1 / Wn)
+  T Wn, invWn;
+  // forward-mode tangents: d probs / d theta_t laid out like probs; outputs tan[t] (ld ldo), optional per-pair tangents of
+  // gamma from the deeper slice gtan[t] (may alias tan[t])
+  int ntan;
+  T dprobs[BART_MAX_TAN][BART_MAX_ROWS];
+  T *tan[BART_MAX_TAN];
+  const T *gtan[BART_MAX_TAN];
 };
 
-// correlation of one pair; X(a), Y(a), N(a) give the (already weight-masked) indices and split totals of axis a
-template <typename T, typename FX, typename FY, typename FN>
-__device__ __forceinline__ T bart_pair(const BartArgs<T> &g, FX X, FY Y, FN N, T gam) {
+template <typename T> __device__ __forceinline__ T bart_div(T a, T b) { return a / b; }
+// fp32: hardware reciprocal (1 ulp) instead of the ~10-instruction IEEE division sequence; the entries stay within a few
+// ulp of the oracle (the reference's own tolerance for re-orderings of this fp32 evaluation is 16-64 ulp)
+template <> __device__ __forceinline__ float bart_div<float>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
+// geometry of one pair: everything that does not depend on the splitting probabilities
+template <typename T>
+struct BartGeom {
+  bool anyn0;
+  T Wn, inv_Wn, sum_term, S, sumi;
+};
+
+// X(a), Y(a), N(a) give the (already weight-masked) indices and split totals of axis a.  PRE: the per-axis constants of
+// BartArgs are valid (N(a) is the same for every pair)
+template <typename T, bool PRE, typename FX, typename FY, typename FN>
+__device__ __forceinline__ BartGeom<T> bart_geometry(const BartArgs<T> &g, FX X, FY Y, FN N) {
   const int p = g.p;
   const T one = T(1);
-  if (p == 0) return one;                                 // no covariates (:651-652)
-  bool anyn0 = false;
-  for (int a = 0; a < p; ++a) anyn0 |= (X(a) != Y(a));    // reference: 64-bit hash inequality (:674-681)
-  if (g.size == 1) {                                      // :685-691
-    for (int k = 0; k < g.repeat; ++k) gam = anyn0 ? one - (one - gam) * g.probs[k] : one;
-    return gam;
+  BartGeom<T> q;
+  q.anyn0 = false;
+  q.Wn = q.inv_Wn = q.sum_term = q.S = q.sumi = T(0);
+  for (int a = 0; a < p; ++a) q.anyn0 |= (X(a) != Y(a));    // reference: 64-bit hash inequality (:674-681)
+  if (g.size == 1) return q;
+  if (PRE) {
+    q.Wn = g.Wn;
+  } else {
+    T Wn = T(0);                                            // :694
+    for (int a = 0; a < p; ++a)
+      if (N(a)) Wn += g.w[a];
+    q.Wn = Wn;
   }
-  T Wn = T(0);                                            // :694
-  for (int a = 0; a < p; ++a)
-    if (N(a)) Wn += g.w[a];
-  if (g.size == 2) {                                      // :697-708
+  if (g.size == 2) {                                        // :697-708
     T sum_term = T(0);
     for (int a = 0; a < p; ++a) {
       const int na = N(a), x = X(a), y = Y(a);
       const int n0 = x > y ? x - y : y - x;
-      const T wn = na ? g.w[a] / T(na) : T(0);
+      const T wn = PRE ? g.wn[a] : (na ? g.w[a] / T(na) : T(0));
       sum_term += wn * T(n0);
     }
-    for (int k = 0; k < g.repeat; ++k) {
-      const T P0 = g.probs[2 * k], P1 = g.probs[2 * k + 1];
-      const T Q = one - P1 + gam * P1;
-      const T result = one - P0 + Q * (P0 - P0 / Wn * sum_term);
-      gam = anyn0 ? result : one;
-    }
-    return gam;
+    q.sum_term = sum_term;
+    return q;
   }
   // size == 3, :711-757
-  const T inv_Wn = one / Wn;
+  const T inv_Wn = PRE ? g.invWn : one / q.Wn;
+  q.inv_Wn = inv_Wn;
   T S = T(0);
   for (int a = 0; a < p; ++a) {
     const int na = N(a), x = X(a), y = Y(a);
     const int n0 = x > y ? x - y : y - x;
-    const T wn = na ? g.w[a] / T(na) : T(0);
+    const T wn = PRE ? g.wn[a] : (na ? g.w[a] / T(na) : T(0));
     S += wn * T(na - n0);
   }
   T sumi = T(0);
@@ -318,31 +414,80 @@ __device__ __forceinline__ T bart_pair(const BartArgs<T> &g, FX X, FY Y, FN N, T
     const int mn = xlty ? x : y, mx = xlty ? y : x;
     const int n0 = mx - mn;
     const int nminus0 = mx, nplus0 = na - mn, nout = na - n0;
-    const T inv_Wnmod = one / (Wn - (na ? w : T(0)));
+    const T inv_Wnmod = PRE ? g.invWm[a] : one / (q.Wn - (na ? w : T(0)));
     const T inv_Wnminus = nplus0 ? inv_Wn : inv_Wnmod;
     const T inv_Wnplus = nminus0 ? inv_Wn : inv_Wnmod;
-    const T wn = na ? w / T(na) : T(0);
+    const T wn = PRE ? g.wn[a] : (na ? w / T(na) : T(0));
+    const T wiW = PRE ? g.wiW[a] : w * inv_Wn;
     const T t = wn * T(n0);
     const T terms1 = (S + t) * (inv_Wnminus + inv_Wnplus + inv_Wn * T(nout - 2));
-    T terms2 = nplus0 ? w * inv_Wn * T(n0) / T(nplus0) : w * inv_Wnmod;
-    terms2 += nminus0 ? w * inv_Wn * T(n0) / T(nminus0) : w * inv_Wnmod;
-    const T psin = g.psi[na ? na : 1];
+    T terms2 = nplus0 ? (PRE ? bart_div<T>(wiW * T(n0), T(nplus0)) : wiW * T(n0) / T(nplus0)) : w * inv_Wnmod;
+    terms2 += nminus0 ? (PRE ? bart_div<T>(wiW * T(n0), T(nminus0)) : wiW * T(n0) / T(nminus0)) : w * inv_Wnmod;
+    const T psin2 = T(2) * g.psi[na ? na : 1];     // (pair-independent in Gram mode: a uniform load)
     const T psiminus = g.psi[1 + mx];          // where(xlty, psi(1+iy), psi(1+ix)) = psi(1 + max)
     const T psiplus = g.psi[1 + na - mn];      // where(xlty, psi(1+n-ix), psi(1+n-iy)) = psi(1 + n - min)
-    const T terms3 = w * inv_Wn * T(n0) * (T(2) * psin - psiminus - psiplus);
+    const T terms3 = wiW * T(n0) * (psin2 - psiminus - psiplus);
     sumi += wn * (terms1 - terms2 - terms3);
   }
-  for (int k = 0; k < g.repeat; ++k) {
+  q.S = S;
+  q.sumi = sumi;
+  return q;
+}
+
+// the recursion over the `repeat` probability rows; NT tangents ride along (dgam[t] on entry = d gamma / d theta_t)
+template <typename T, int NT>
+__device__ __forceinline__ T bart_iterate(const BartArgs<T> &g, const BartGeom<T> &q, T gam, T (&dgam)[NT > 0 ? NT : 1]) {
+  const T one = T(1);
+  if (g.p == 0) {                                         // no covariates (:651-652)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dgam[t] = T(0);
+    return one;
+  }
+  if (g.size == 1) {                                      // :685-691
+    for (int k = 0; k < g.repeat; ++k) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dgam[t] = q.anyn0 ? dgam[t] * g.probs[k] - (one - gam) * g.dprobs[t][k] : T(0);
+      gam = q.anyn0 ? one - (one - gam) * g.probs[k] : one;
+    }
+    return gam;
+  }
+  if (g.size == 2) {                                      // :697-708
+    for (int k = 0; k < g.repeat; ++k) {
+      const T P0 = g.probs[2 * k], P1 = g.probs[2 * k + 1];
+      const T Q = one - P1 + gam * P1;
+      const T inner = P0 - P0 / q.Wn * q.sum_term;
+      const T result = one - P0 + Q * inner;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const T dP0 = g.dprobs[t][2 * k], dP1 = g.dprobs[t][2 * k + 1];
+        const T dQ = dgam[t] * P1 + (gam - one) * dP1;
+        const T dinner = dP0 - dP0 / q.Wn * q.sum_term;
+        dgam[t] = q.anyn0 ? dQ * inner + Q * dinner - dP0 : T(0);
+      }
+      gam = q.anyn0 ? result : one;
+    }
+    return gam;
+  }
+  for (int k = 0; k < g.repeat; ++k) {                    // :749-756
     const T P0 = g.probs[3 * k], P1 = g.probs[3 * k + 1], P2 = g.probs[3 * k + 2];
     const T Q = one + P2 * (gam - one);
-    const T sump = S + P1 * (Q * sumi - S);
-    const T result = one + P0 * (inv_Wn * sump - one);
-    gam = anyn0 ? result : one;
+    const T core = Q * q.sumi - q.S;
+    const T sump = q.S + P1 * core;
+    const T outer = q.inv_Wn * sump - one;
+    const T result = one + P0 * outer;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const T dP0 = g.dprobs[t][3 * k], dP1 = g.dprobs[t][3 * k + 1], dP2 = g.dprobs[t][3 * k + 2];
+      const T dQ = dP2 * (gam - one) + P2 * dgam[t];
+      const T dsump = dP1 * core + P1 * (dQ * q.sumi);
+      dgam[t] = q.anyn0 ? dP0 * outer + P0 * (q.inv_Wn * dsump) : T(0);
+    }
+    gam = q.anyn0 ? result : one;
   }
   return gam;
 }
 
-template <typename T>
+template <typename T, int NT>
 __global__ void __launch_bounds__(BT_COLS) gram_bart_kernel(const BartArgs<T> g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int32_t *sx = reinterpret_cast<int32_t *>(smem_raw);      // [BT_ROWS][p]
@@ -368,13 +513,21 @@ __global__ void __launch_bounds__(BT_COLS) gram_bart_kernel(const BartArgs<T> g)
   __syncthreads();
   const int col = col0 + tid;
   if (col >= g.m) return;
+  const T slope = NT > 0 ? g.ops.slope() : T(0);
   const int rmax = (g.n - row0) < BT_ROWS ? (g.n - row0) : BT_ROWS;
   for (int r = 0; r < rmax; ++r) {
-    const T gam0 = g.gamma_mat ? g.gamma_mat[(long)(row0 + r) * g.ldo + col] : g.gamma;
-    const T gam = bart_pair<T>(
+    const long o = (long)(row0 + r) * g.ldo + col;
+    const T gam0 = g.gamma_mat ? g.gamma_mat[o] : g.gamma;
+    T dgam[NT > 0 ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dgam[t] = g.gtan[t] ? g.gtan[t][o] : T(0);
+    const BartGeom<T> q = bart_geometry<T, true>(
         g, [&](int a) { return sx[r * p + a]; }, [&](int a) { return sy[a * BT_COLS + tid]; },
-        [&](int a) { return (g.w[a] != T(0)) ? g.nsplits[a] : 0; }, gam0);
-    g.out[(long)(row0 + r) * g.ldo + col] = g.ops.apply(gam);
+        [&](int a) { return (g.w[a] != T(0)) ? g.nsplits[a] : 0; });
+    const T gam = bart_iterate<T, NT>(g, q, gam0, dgam);
+    g.out[o] = g.ops.apply(gam);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) g.tan[t][o] = slope * dgam[t];
   }
 }
 
@@ -387,17 +540,19 @@ __global__ void __launch_bounds__(256) bart_pairs_kernel(const BartArgs<T> g, co
   const int p = g.p;
   const int32_t *x = g.ix + i * p, *y = g.iy + i * p, *nn = npair ? npair + i * p : nullptr;
   const T gam0 = g.gamma_mat ? g.gamma_mat[i] : g.gamma;
-  const T gam = bart_pair<T>(
+  T nodual[1];
+  const BartGeom<T> q = bart_geometry<T, false>(
       g, [&](int a) { return (g.w[a] != T(0)) ? x[a] : 0; }, [&](int a) { return (g.w[a] != T(0)) ? y[a] : 0; },
-      [&](int a) { return (g.w[a] != T(0)) ? (nn ? nn[a] : g.nsplits[a]) : 0; }, gam0);
-  g.out[i] = g.ops.apply(gam);
+      [&](int a) { return (g.w[a] != T(0)) ? (nn ? nn[a] : g.nsplits[a]) : 0; });
+  g.out[i] = g.ops.apply(bart_iterate<T, 0>(g, q, gam0, nodual));
 }
 
 template <typename T>
 int gram_bart_launch(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const int32_t *diy, size_t m, const int32_t *hnsplits,
                      const T *hweights, int size, int repeat, const T *hprobs, T gamma, const T *dgamma_mat, const T *dpsi,
                      size_t npsi, int nops, const int *hops_code, const T *hops_val, T *dout, size_t ldo, bool pairs = false,
-                     const int32_t *dnpair = nullptr) {
+                     const int32_t *dnpair = nullptr, int ntan = 0, const T *hdprobs = nullptr, T *const *hdtan = nullptr,
+                     const T *const *hdgtan = nullptr) {
   LGP_REQUIRE(ctx != nullptr, "null context");
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
@@ -407,6 +562,8 @@ int gram_bart_launch(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const in
   LGP_REQUIRE(dout != nullptr && (p == 0 || (dix != nullptr && diy != nullptr)), "null pointer");
   LGP_REQUIRE(nops >= 0 && nops <= MAX_OPS, "at most 8 output operations");
   LGP_REQUIRE(n < (1u << 30) && m < (1u << 30) && ldo >= m, "bad dimensions");
+  LGP_REQUIRE(ntan >= 0 && ntan <= BART_MAX_TAN && (ntan == 0 || (!pairs && hdprobs != nullptr && hdtan != nullptr)),
+              "at most 2 tangents, Gram form only, with their probability derivatives and outputs");
   DeviceGuard dg(ctx->device);
   BartArgs<T> g;
   memset(&g, 0, sizeof(g));
@@ -426,6 +583,13 @@ int gram_bart_launch(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const in
   // with per-pair totals the caller guarantees npsi >= max total + 2
   if (size == 3) LGP_REQUIRE(dpsi != nullptr && npsi >= (size_t)maxn + 2, "digamma table too short");
   for (int i = 0; i < size * repeat; ++i) g.probs[i] = hprobs[i];
+  g.ntan = ntan;
+  for (int t = 0; t < ntan; ++t) {
+    for (int i = 0; i < size * repeat; ++i) g.dprobs[t][i] = hdprobs[t * size * repeat + i];
+    LGP_REQUIRE(hdtan[t] != nullptr, "null tangent output");
+    g.tan[t] = hdtan[t];
+    g.gtan[t] = hdgtan ? hdgtan[t] : nullptr;
+  }
   g.ops.n = nops;
   for (int i = 0; i < nops; ++i) {
     LGP_REQUIRE(hops_code[i] == LGP_OP_MUL || hops_code[i] == LGP_OP_ADD, "unknown output operation");
@@ -437,10 +601,32 @@ int gram_bart_launch(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const in
     LGP_LAUNCH_CHECK();
     return LGP_OK;
   }
+  // Gram form: the split totals are global, so everything that depends on the axis alone is evaluated here, once, with
+  // the same T-precision operations in the same order as the per-pair code (zero-weight axes count as n = 0, :670-672)
+  {
+    volatile T Wn = T(0);                                   // (volatile: plain T arithmetic, no contraction or widening)
+    for (int a = 0; a < p; ++a)
+      if (g.w[a] != T(0) && g.nsplits[a]) Wn = Wn + g.w[a];
+    g.Wn = Wn;
+    volatile T inv = T(1) / g.Wn;
+    g.invWn = inv;
+    for (int a = 0; a < p; ++a) {
+      const int na = g.w[a] != T(0) ? g.nsplits[a] : 0;
+      volatile T wn = na ? g.w[a] / T(na) : T(0);
+      volatile T den = g.Wn - (na ? g.w[a] : T(0));
+      volatile T im = T(1) / den;
+      volatile T wi = g.w[a] * g.invWn;
+      g.wn[a] = wn; g.invWm[a] = im; g.wiW[a] = wi;
+    }
+    g.pre = 1;
+  }
   const size_t ntr = (n + BT_ROWS - 1) / BT_ROWS, ntc = (m + BT_COLS - 1) / BT_COLS;
   LGP_REQUIRE(ntr * ntc < (1ull << 31), "gram grid too large");
   const size_t shmem = (size_t)(p > 0 ? p : 1) * (BT_ROWS + BT_COLS) * sizeof(int32_t);
-  hipLaunchKernelGGL((gram_bart_kernel<T>), dim3((unsigned)(ntr * ntc)), dim3(BT_COLS), shmem, ctx->stream, g);
+  const dim3 gd((unsigned)(ntr * ntc)), bd(BT_COLS);
+  if (ntan == 0) hipLaunchKernelGGL((gram_bart_kernel<T, 0>), gd, bd, shmem, ctx->stream, g);
+  else if (ntan == 1) hipLaunchKernelGGL((gram_bart_kernel<T, 1>), gd, bd, shmem, ctx->stream, g);
+  else hipLaunchKernelGGL((gram_bart_kernel<T, 2>), gd, bd, shmem, ctx->stream, g);
   LGP_LAUNCH_CHECK();
   return LGP_OK;
 }
@@ -502,4 +688,41 @@ extern "C" int lgp_pairs_bart_f64(lgp_ctx *ctx, int p, const int32_t *dix, const
                                   const double *hops_val, double *dout) {
   return gram_bart_launch<double>(ctx, p, dix, npairs, diy, npairs, hnsplits, hweights, size, repeat, hprobs, gamma, dgamma_vec, dpsi,
                                   npsi, nops, hops_code, hops_val, dout, npairs, true, dnpair);
+}
+
+// ---- Gram matrix together with its derivative with respect to `scale` (forward-mode tangent of _Kernel/_ops.py:310-326
+// through the cores; what jax.jacfwd of the reference's gpfactory yields for a `scale` hyperparameter, _fit.py:679-690) ----
+extern "C" int lgp_gram_isotropic_dscale_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d, const double *dx, size_t ldx,
+                                             size_t n, const double *dy, size_t ldy, size_t m, int has_loc, double loc, int has_scale,
+                                             double scale, int nops, const int *hops_code, const double *hops_val, double *dout,
+                                             double *ddscale, size_t ldo) {
+  LGP_REQUIRE(ddscale != nullptr, "null derivative output");
+  return gram_iso_launch<double>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val,
+                                 dout, ldo, false, ddscale);
+}
+extern "C" int lgp_gram_isotropic_dscale_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int d, const float *dx, size_t ldx,
+                                             size_t n, const float *dy, size_t ldy, size_t m, int has_loc, float loc, int has_scale, float scale,
+                                             int nops, const int *hops_code, const float *hops_val, float *dout, float *ddscale, size_t ldo) {
+  LGP_REQUIRE(ddscale != nullptr, "null derivative output");
+  return gram_iso_launch<float>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val,
+                                dout, ldo, false, ddscale);
+}
+
+// ---- BART Gram matrix with forward-mode tangents of the splitting probabilities: what jax.jacfwd of the reference's
+// gpfactory yields for the alpha / beta hyperparameters of bayestree.bart (bayestree/_bart.py:187-205, _fit.py:679-690).
+// hdprobs: HOST ntan x (repeat*size) derivatives of hprobs; hdtan: HOST array of ntan DEVICE output matrices (n x m, ld ldo);
+// hdgtan: HOST array of ntan DEVICE per-pair tangents of gamma from the deeper slice (may alias hdtan; NULL: zero) ----
+extern "C" int lgp_gram_bart_jvp_f32(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const int32_t *diy, size_t m, const int32_t *hnsplits,
+                                     const float *hweights, int size, int repeat, const float *hprobs, float gamma, const float *dgamma_mat,
+                                     const float *dpsi, size_t npsi, int nops, const int *hops_code, const float *hops_val, float *dout,
+                                     size_t ldo, int ntan, const float *hdprobs, float *const *hdtan, const float *const *hdgtan) {
+  return gram_bart_launch<float>(ctx, p, dix, n, diy, m, hnsplits, hweights, size, repeat, hprobs, gamma, dgamma_mat, dpsi, npsi, nops,
+                                 hops_code, hops_val, dout, ldo, false, nullptr, ntan, hdprobs, hdtan, hdgtan);
+}
+extern "C" int lgp_gram_bart_jvp_f64(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const int32_t *diy, size_t m, const int32_t *hnsplits,
+                                     const double *hweights, int size, int repeat, const double *hprobs, double gamma, const double *dgamma_mat,
+                                     const double *dpsi, size_t npsi, int nops, const int *hops_code, const double *hops_val, double *dout,
+                                     size_t ldo, int ntan, const double *hdprobs, double *const *hdtan, const double *const *hdgtan) {
+  return gram_bart_launch<double>(ctx, p, dix, n, diy, m, hnsplits, hweights, size, repeat, hprobs, gamma, dgamma_mat, dpsi, npsi, nops,
+                                  hops_code, hops_val, dout, ldo, false, nullptr, ntan, hdprobs, hdtan, hdgtan);
 }

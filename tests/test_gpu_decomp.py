@@ -330,3 +330,52 @@ def test_full_size_c4_properties(lgp):
     util.assert_allclose(mlnd_c, mlnd_s, rtol=1e-12)
     # the posterior mean interpolates the smooth signal at in-sample density 16 points per lengthscale
     assert np.sqrt(np.mean((mean_s - np.sin(xs / 4)) ** 2)) < 0.05
+
+
+@pytest.mark.parametrize('n', [40, 300, 1100])
+def test_normal_density_derivs_on_device(lgp, n, rng):
+    """ lgp_mlnd_grad (value + forward-mode gradient + Fisher matrix in one device call, _decomp.py:461-561) on
+    K(theta) = a ExpQuad(scale)(x, x) + s I,  r(theta) = y - mu, with the kernel tangent from lgp_gram_isotropic_dscale:
+    against the oracle's restatement of the reference formulas fed the same derivative arrays, and against central
+    differences of the oracle's value """
+    x = rng.uniform(0, n / 8, n)
+    y = np.sin(x) + 0.3 * rng.standard_normal(n)
+    a, sc, s2, mu = 1.3, 0.8, 0.05, 0.1
+
+    def host_K(a_, sc_, s2_):
+        return a_ * oracle.ExpQuad(scale=sc_)(x[:, None], x[None, :]) + s2_ * np.eye(n)
+
+    E, dE = lgp.ExpQuad(scale=sc).gram_dscale(x, x)
+    Eh, dEh = E.to_host(), dE.to_host()
+    K = a * Eh + s2 * np.eye(n)
+    dK = np.stack([Eh, a * dEh, np.eye(n), np.zeros((n, n))], axis=2)
+    dr = np.zeros((n, 4)); dr[:, 3] = -1
+    r = y - mu
+    d = lgp.Chol(K)
+    o = oracle.Chol(K)
+    val, grad, fish = d.normal_density_derivs(r, dK, dr, fisher=True)
+    vo, _, go, fo, _ = o.minus_log_normal_density(r, dK=dK, dr=dr, value=True, gradfwd=True, fisher=True)
+    util.assert_allclose(val, vo, rtol=1e-11)
+    util.assert_close_matrices(grad, go, rtol=1e-9)
+    util.assert_close_matrices(fish, fo, rtol=1e-9)
+    # the same through the reference-shaped entry point, device-resident derivative matrices
+    dKdev = [lgp.DeviceArray.from_host(np.ascontiguousarray(dK[:, :, k])) for k in range(4)]
+    v2, _, g2, f2, _ = d.minus_log_normal_density(r, dK=dKdev, dr=dr, value=True, gradfwd=True, fisher=True)
+    assert v2 == val
+    np.testing.assert_array_equal(g2, grad)
+    np.testing.assert_array_equal(f2, fish)
+    # only dr / only dK
+    _, _, g3, f3, _ = d.minus_log_normal_density(r, dr=dr, gradfwd=True, fisher=True)
+    _, _, g3o, f3o, _ = o.minus_log_normal_density(r, dr=dr, gradfwd=True, fisher=True)
+    util.assert_close_matrices(g3, g3o, rtol=1e-9)
+    util.assert_close_matrices(f3, f3o, rtol=1e-9, atol=1e-300)
+    # central differences of the oracle's value (epsrel=0: the jitter must not move with the parameters)
+    def value(a_, sc_, s2_, mu_):
+        return oracle.Chol(host_K(a_, sc_, s2_), epsrel=0).minus_log_normal_density(y - mu_, value=True)[0]
+    th = np.array([a, sc, s2, mu])
+    d0 = lgp.Chol(K, epsrel=0)
+    _, g0, _ = d0.normal_density_derivs(r, dK, dr)
+    for k in range(4):
+        e = np.zeros(4); e[k] = 1e-6 * max(1, abs(th[k]))
+        fd = (value(*(th + e)) - value(*(th - e))) / (2 * e[k])
+        assert abs(g0[k] - fd) <= 1e-5 * max(1.0, abs(fd))

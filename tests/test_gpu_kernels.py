@@ -279,3 +279,88 @@ def test_bart_corr_one_cases(lgp, rng):
         np.testing.assert_array_equal(c, 1)
         c = lgp.BART.correlation(n, ix, np.minimum(ix + 1, n), maxd=md, gamma=0.2, weights=np.zeros(p), altinput=True)
         np.testing.assert_array_equal(c, 1)
+
+
+# ---- derivative functors (the tangents jax.jacfwd produces in the reference's fit) -------------------
+
+def _fd(f, h):
+    return (f(+h) - f(-h)) / (2 * h)
+
+
+@pytest.mark.parametrize('make', [
+    lambda lgp_, s: lgp_.ExpQuad(scale=s),
+    lambda lgp_, s: lgp_.Maternp(p=2, scale=s),
+    lambda lgp_, s: lgp_.Maternp(p=0, scale=s),
+    lambda lgp_, s: lgp_.Maternp(p=5, scale=s) * 3.5,
+    lambda lgp_, s: lgp_.GammaExp(gamma=1.3, scale=s),
+    lambda lgp_, s: lgp_.GammaExp(gamma=2, scale=s) * 0.5 + 1.0,
+    lambda lgp_, s: lgp_.Cauchy(alpha=1.5, beta=2.5, scale=s),
+    lambda lgp_, s: lgp_.Cauchy(alpha=2, beta=1, scale=s),
+])
+@pytest.mark.parametrize('d', [1, 3, 5])
+def test_gram_dscale_vs_finite_differences_of_the_oracle(lgp, make, d, rng):
+    """ lgp_gram_isotropic_dscale: K bit-identical to the plain Gram kernel, dK/dscale against central differences of the
+    ORACLE's kernel in the scale (same kernel classes on both sides) """
+    n, m, s0 = 70, 45, 1.7
+    if d == 1:
+        x, y = rng.uniform(-3, 3, n), rng.uniform(-3, 3, m)
+    else:
+        dt = [(f'f{i}', float) for i in range(d)]
+        x, y = np.empty(n, dt), np.empty(m, dt)
+        for nm in x.dtype.names:
+            x[nm] = rng.uniform(-3, 3, n)
+            y[nm] = rng.uniform(-3, 3, m)
+    k = make(lgp, s0)
+    K, dK = k.gram_dscale(x, y)
+    np.testing.assert_array_equal(K.to_host(), k.gram(x, y).to_host())
+    fd = _fd(lambda h: make(oracle, s0 + h)(x[:, None], y[None, :]), 1e-5)
+    got = dK.to_host()
+    assert np.max(np.abs(got - fd)) <= 2e-9 * max(1.0, np.max(np.abs(fd)))
+    # symmetric block: the diagonal of the derivative is zero
+    K2, dK2 = k.gram_dscale(x, x)
+    assert np.all(np.diag(dK2.to_host()) == 0)
+
+
+def test_gram_dscale_float32(lgp, rng):
+    x = rng.uniform(-3, 3, 50).astype(np.float32)
+    k = lgp.Maternp(p=2, scale=np.float32(1.3))
+    K, dK = k.gram_dscale(x, x)
+    assert K.dtype == np.float32 and dK.dtype == np.float32
+    fd = _fd(lambda h: oracle.Maternp(p=2, scale=1.3 + h)(x.astype(float)[:, None], x.astype(float)[None, :]), 1e-5)
+    assert np.max(np.abs(dK.to_host() - fd)) <= 2e-5
+
+
+@pytest.mark.parametrize('flt', [np.float64, np.float32])
+@pytest.mark.parametrize('kw', [dict(maxd=2), dict(maxd=1), dict(maxd=0), dict(maxd=4, reset=2), dict(maxd=10, reset=[2, 4, 6, 8]),
+                                dict(maxd=6, reset=[1, 2, 4]), dict(maxd=2, intercept=False), dict(maxd=3, reset=[1], gamma=0.7)])
+def test_bart_gram_jvp_vs_finite_differences_of_the_oracle(lgp, kw, flt, rng):
+    """ lgp_gram_bart_jvp: value identical to lgp_gram_bart, tangents with respect to alpha and beta against central
+    differences of the oracle's float64 kernel (every recursion-slice layout the device path supports) """
+    n, p = 60, 4
+    X = np.concatenate([rng.integers(0, 2, (n, 1)), rng.integers(0, 25, (n, p - 1))], axis=1).astype(float)
+    splits = oracle.BART.splits_from_coord(X)
+    ix = oracle.BART.indices_from_coord(X, splits).astype(np.int32)
+    pts = np.array([tuple(r) for r in ix], dtype=[(f'f{i}', np.int32) for i in range(p)])
+    a0, b0 = 0.9, 1.6
+    kw = dict(kw)
+    kw.setdefault('gamma', flt(1))
+    if not isinstance(kw['gamma'], np.generic):
+        kw['gamma'] = flt(kw['gamma'])
+
+    def mk(mod, a, b, f):
+        return mod.BART(splits=(splits[0], None), indices=True, alpha=f(a), beta=f(b), weights=np.ones(p, f), **kw) * f(2.5)
+
+    k = mk(lgp, a0, b0, flt)
+    K, (dKa, dKb) = k.gram_jvp(pts, pts)
+    np.testing.assert_array_equal(K.to_host(), k.gram(pts, pts).to_host())
+    kw64 = dict(kw, gamma=np.float64(kw['gamma']))
+
+    def ko(a, b):
+        return oracle.BART(splits=(splits[0], None), indices=True, alpha=np.float64(a), beta=np.float64(b), weights=np.ones(p), **kw64)(pts[:, None], pts[None, :]) * 2.5
+
+    fa = _fd(lambda h: ko(a0 + h, b0), 1e-6)
+    fb = _fd(lambda h: ko(a0, b0 + h), 1e-6)
+    tol = 1e-8 if flt == np.float64 else 2e-5
+    assert np.max(np.abs(dKa.to_host() - fa)) <= tol * max(1.0, np.max(np.abs(fa)))
+    assert np.max(np.abs(dKb.to_host() - fb)) <= tol * max(1.0, np.max(np.abs(fb)))
+    assert np.all(np.diag(dKa.to_host()) == 0) and np.all(np.diag(dKb.to_host()) == 0)      # k(x, x) = const
