@@ -12,6 +12,11 @@ from ._device import Context, DeviceArray, asdevice
 from ._linalg import Decomposition, Chol
 from ._kernels import Kernel, ExpQuad, Maternp, GammaExp, Cauchy, BART
 from ._GP import GP
+from ._fit import empbayes_fit
+from ._fastraniter import raniter, sample
+from ._uncertain import UVal
 from . import _linalg
+from . import copula
+from . import bayestree
 
 __version__ = '0.1.0'

@@ -355,7 +355,12 @@ class Chol(Decomposition):
                 raise ValueError(f'dK must have shape (n, n, p), found {arr.shape}')
             mats = [numpy.ascontiguousarray(arr[:, :, k]) for k in range(arr.shape[2])]
         out = []
+        zero = None
         for m in mats:
+            if m is None:                          # a parameter the matrix does not depend on
+                if zero is None:
+                    zero = DeviceArray.zeros((self.n, self.n), self._dtype, self._ctx)
+                m = zero
             if not isinstance(m, DeviceArray):
                 m = DeviceArray.from_host(numpy.asarray(m), dtype=self._dtype, ctx=self._ctx)
             if m.shape != (self.n, self.n) or m.dtype != self._dtype:
