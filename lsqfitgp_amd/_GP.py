@@ -161,156 +161,151 @@ class GP:
 
     # ---- elements (``_GP/_elements.py``) -------------------------------------
 
+    @staticmethod
+    def _keyed(arg, key, what):
+        """ the ``(arg, key)`` calling convention shared by `addx` and `addcov`: either a dictionary and no key, or one
+        object and its key.  Returns a dictionary, with the reference's error messages (``_elements.py:199-212,463-476``) """
+        if hasattr(arg, 'keys'):
+            if key is not None:
+                raise ValueError(f'can not specify key if {what} is a dictionary')
+            if None in arg:
+                raise ValueError(f'None key in {what} not allowed')
+            return arg, True
+        if key is None:
+            raise ValueError(f'{what} is not dictionary but key is None')
+        return None, False
+
+    def _require_new(self, key):
+        if key in self._elements:
+            raise KeyError(f'key {key!r} already in GP')
+
     def addx(self, x, key=None, *, deriv=0, proc=DefaultProcess):
         """ Add points where the Gaussian process is evaluated (``_elements.py:158-242``) """
         if deriv not in (0, None) and deriv != ():
             raise NotImplementedError('derivative observations are out of scope of the device path')
         if proc != self.DefaultProcess:
             raise KeyError(f'process named {proc!r} not found')
-        self = self._clone()
-        if hasattr(x, 'keys'):
-            if key is not None:
-                raise ValueError('can not specify key if x is a dictionary')
-            if None in x:
-                raise ValueError('None key in x not allowed')
-        else:
-            if key is None:
-                raise ValueError('x is not dictionary but key is None')
-            x = {key: x}
-        for key in x:
-            if key in self._elements:
-                raise KeyError('key {!r} already in GP'.format(key))
-            gx = numpy.asarray(x[key])
-            if self._dtype is not None:
-                try:
-                    self._dtype = numpy.result_type(self._dtype, gx.dtype)
-                except TypeError:
-                    raise TypeError('x[{!r}].dtype = {!r} not compatible with {!r}'.format(key, gx.dtype, self._dtype))
+        points, isdict = self._keyed(x, key, 'x')
+        if not isdict:
+            points = {key: x}
+        new = self._clone()
+        for k, value in points.items():
+            new._require_new(k)
+            arr = numpy.asarray(value)
+            # all the point sets of a GP must share a dtype family (plain or the same structure): the kernel is called on
+            # pairs of them                                                      (_elements.py:222-233)
+            if new._dtype is None:
+                new._dtype = arr.dtype
             else:
-                self._dtype = gx.dtype
-            self._elements[key] = _Points(gx)
-        return self
+                try:
+                    new._dtype = numpy.result_type(new._dtype, arr.dtype)
+                except TypeError:
+                    raise TypeError('x[{!r}].dtype = {!r} not compatible with {!r}'.format(k, arr.dtype, new._dtype))
+            new._elements[k] = _Points(arr)
+        return new
 
     def addtransf(self, tensors, key, *, axes=1):
         """ Apply a linear transformation with fixed coefficients to already
         specified process values (``_elements.py:248-346``) """
-        self = self._clone()
         if key is None:
             raise ValueError('key can not be None')
-        if key in self._elements:
-            raise KeyError(f'key {key!r} already in GP')
-        for k in tensors:
-            if k not in self._elements:
-                raise KeyError(k)
+        self._require_new(key)
+        missing = [k for k in tensors if k not in self._elements]
+        if missing:
+            raise KeyError(missing[0])
         if len(tensors) == 0:
             raise ValueError('empty tensors, undetermined output shape')
-        tens = {}
+        coeffs, outshapes = {}, []
         for k, t in tensors.items():
             t = numpy.asarray(t)
             if self._checkfinite and not numpy.all(numpy.isfinite(t)):
                 raise ValueError(f'tensors[{k!r}] contains infs/nans')
-            rshape = self._elements[k].shape
-            if t.shape and t.shape[t.ndim - axes:] != rshape[:axes]:
-                raise ValueError(f'tensors[{k!r}].shape = {t.shape!r} can not be multiplied with shape {rshape!r} with {axes}-axes contraction')
-            tens[k] = t
-        shapes = [
-            t.shape[:t.ndim - axes] + self._elements[k].shape[axes:] if t.shape else self._elements[k].shape
-            for k, t in tens.items()
-        ]
+            eshape = self._elements[k].shape
+            if t.ndim == 0:
+                outshapes.append(eshape)                       # a scalar multiplies the element as it is
+            else:
+                if t.shape[t.ndim - axes:] != eshape[:axes]:
+                    raise ValueError(f'tensors[{k!r}].shape = {t.shape!r} can not be multiplied with shape {eshape!r} with {axes}-axes contraction')
+                outshapes.append(t.shape[:t.ndim - axes] + eshape[axes:])
+            coeffs[k] = t
         try:
-            shape = numpy.broadcast_shapes(*shapes)
+            shape = numpy.broadcast_shapes(*outshapes)
         except ValueError:
-            msg = 'can not broadcast tensors with shapes ['
-            msg += ', '.join(repr(t.shape) for t in tens.values())
-            msg += '] contracted with arrays with shapes ['
-            msg += ', '.join(repr(self._elements[k].shape) for k in tens) + ']'
-            raise ValueError(msg)
-        self._elements[key] = _LinTransf(tens, list(tens.keys()), tuple(shape), axes)
-        return self
+            left = ', '.join(repr(t.shape) for t in coeffs.values())
+            right = ', '.join(repr(self._elements[k].shape) for k in coeffs)
+            raise ValueError(f'can not broadcast tensors with shapes [{left}] contracted with arrays with shapes [{right}]')
+        new = self._clone()
+        new._elements[key] = _LinTransf(coeffs, list(coeffs), tuple(shape), axes)
+        return new
 
     def addcov(self, covblocks, key=None, *, decomps=None):
         """ Add user-defined prior covariance matrix blocks (``_elements.py:408-552``) """
-        self = self._clone()
-        if hasattr(covblocks, 'keys'):
-            if key is not None:
-                raise ValueError('can not specify key if covblocks is a dictionary')
-            if None in covblocks:
-                raise ValueError('None key in covblocks not allowed')
+        given, isdict = self._keyed(covblocks, key, 'covblocks')
+        if isdict:
             if decomps is not None and not hasattr(decomps, 'keys'):
                 raise TypeError('covblocks is dictionary but decomps is not')
+            decomps = dict(decomps or {})
         else:
-            if key is None:
-                raise ValueError('covblocks is not dictionary but key is None')
-            covblocks = {(key, key): covblocks}
-            if decomps is not None:
-                decomps = {key: decomps}
-        if decomps is None:
-            decomps = {}
-        shapes = {}
-        preblocks = {}
-        for keys, block in covblocks.items():
-            for key in keys:
-                if key in self._elements:
-                    raise KeyError(f'key {key!r} already in GP')
-            xkey, ykey = keys
+            given = {(key, key): covblocks}
+            decomps = {} if decomps is None else {key: decomps}
+
+        # pass 1: the diagonal blocks fix the shape of every new element
+        shapes, raw = {}, {}
+        for pair, block in given.items():
+            for k in pair:
+                self._require_new(k)
             if block is None:
-                raise TypeError(f'block {keys!r} is None')
+                raise TypeError(f'block {pair!r} is None')
             block = numpy.asarray(block)
-            if xkey == ykey:
-                if block.ndim % 2 == 1:
-                    raise ValueError(f'diagonal block {key!r} has odd number of axes')
-                half = block.ndim // 2
-                head = block.shape[:half]
-                tail = block.shape[half:]
+            row, col = pair
+            if row == col:
+                if block.ndim % 2:
+                    raise ValueError(f'diagonal block {row!r} has odd number of axes')
+                head, tail = block.shape[:block.ndim // 2], block.shape[block.ndim // 2:]
                 if head != tail:
-                    raise ValueError(f'shape {block.shape!r} of diagonal block {key!r} is not symmetric')
-                shapes[xkey] = head
+                    raise ValueError(f'shape {block.shape!r} of diagonal block {row!r} is not symmetric')
                 if self._checksym and not numpy.allclose(block, block.T):
-                    raise ValueError(f'diagonal block {key!r} is not symmetric')
-            preblocks[keys] = block
-        for key, dec in decomps.items():
-            if key not in shapes:
-                raise KeyError(f'key {key!r} in decomps not found in diagonal blocks')
+                    raise ValueError(f'diagonal block {row!r} is not symmetric')
+                shapes[row] = head
+            raw[pair] = block
+
+        for k, dec in decomps.items():
+            if k not in shapes:
+                raise KeyError(f'key {k!r} in decomps not found in diagonal blocks')
             if not isinstance(dec, Decomposition):
-                raise TypeError(f'decomps[{key!r}] = {dec!r} is not a decomposition')
-            n = math.prod(shapes[key])
-            if dec.n != n:
-                raise ValueError(f'decomposition matrix size {dec.n} != diagonal block size {n} for key {key!r}')
-        blocks = {}
-        for keys, block in preblocks.items():
+                raise TypeError(f'decomps[{k!r}] = {dec!r} is not a decomposition')
+            size = math.prod(shapes[k])
+            if dec.n != size:
+                raise ValueError(f'decomposition matrix size {dec.n} != diagonal block size {size} for key {k!r}')
+
+        # pass 2: flatten every block to a matrix; an off-diagonal block given once also serves as its transpose
+        flat = {}
+        for pair, block in raw.items():
             if self._checkfinite and not numpy.all(numpy.isfinite(block)):
-                raise ValueError(f'block {keys!r} not finite')
-            xkey, ykey = keys
-            if xkey == ykey:
-                size = math.prod(shapes[xkey])
-                blocks[keys] = block.reshape((size, size))
-            else:
-                for key in keys:
-                    if key not in shapes:
-                        raise KeyError(f'key {key!r} from off-diagonal block {keys!r} not found in diagonal blocks')
-                eshape = shapes[xkey] + shapes[ykey]
-                if block.shape != eshape:
-                    raise ValueError(f'shape {block.shape!r} of block {keys!r} is not {eshape!r} as expected from diagonal blocks')
-                xsize = math.prod(shapes[xkey])
-                ysize = math.prod(shapes[ykey])
-                block = block.reshape((xsize, ysize))
-                blocks[keys] = block
-                revkeys = keys[::-1]
-                if preblocks.get(revkeys) is None:
-                    blocks[revkeys] = block.T
+                raise ValueError(f'block {pair!r} not finite')
+            row, col = pair
+            if row != col:
+                for k in pair:
+                    if k not in shapes:
+                        raise KeyError(f'key {k!r} from off-diagonal block {pair!r} not found in diagonal blocks')
+                expected = shapes[row] + shapes[col]
+                if block.shape != expected:
+                    raise ValueError(f'shape {block.shape!r} of block {pair!r} is not {expected!r} as expected from diagonal blocks')
+            flat[pair] = block.reshape(math.prod(shapes[row]), math.prod(shapes[col]))
+        for (row, col), mat in list(flat.items()):
+            if row != col and raw.get((col, row)) is None:
+                flat[col, row] = mat.T
         if self._checksym:
-            for keys, block in blocks.items():
-                xkey, ykey = keys
-                if xkey != ykey:
-                    blockT = blocks[ykey, xkey]
-                    if not numpy.allclose(block.T, blockT):
-                        raise ValueError(f'block {keys!r} is not the transpose of block {keys[::-1]!r}')
-        for key, shape in shapes.items():
-            self._elements[key] = _Cov(blocks, shape)
-            decomp = decomps.get(key)
-            if decomp is not None:
-                self._decompcache[key,] = decomp
-        return self
+            for (row, col), mat in flat.items():
+                if row != col and not numpy.allclose(mat.T, flat[col, row]):
+                    raise ValueError(f'block {(row, col)!r} is not the transpose of block {(col, row)!r}')
+
+        new = self._clone()
+        for k, shape in shapes.items():
+            new._elements[k] = _Cov(flat, shape)
+            if decomps.get(k) is not None:
+                new._decompcache[k,] = decomps[k]
+        return new
 
     # ---- covariance blocks -----------------------------------------------------
 
@@ -438,19 +433,44 @@ class GP:
             r0 += r[0].shape[0]
         return out
 
+    def _extreme_eigenvalues(self, cov, steps=24):
+        """ estimates of the smallest and largest eigenvalue of a symmetric device matrix.  The reference runs two LOBPCG
+        iterations from one random vector on the host copy (``_elements.py:651-668``); here: exact for small matrices,
+        otherwise `steps` Lanczos iterations with the matrix-vector products on the device (the Krylov basis, n x steps
+        numbers, lives on the host and is fully reorthogonalised).  Like LOBPCG's, the Ritz values bracket from inside:
+        the estimate of the minimum is an upper bound of it. """
+        n = cov.shape[0]
+        if n <= 256:
+            w = numpy.linalg.eigvalsh(cov.to_host().astype(float))
+            return w[0], w[-1]
+        rng = numpy.random.default_rng(0x5eed)
+        q = rng.standard_normal(n)
+        q /= numpy.linalg.norm(q)
+        Q = [q]
+        alpha, beta = [], []
+        for j in range(min(steps, n)):
+            v = _gemm(False, False, cov, DeviceArray.from_host(Q[-1].reshape(n, 1), dtype=cov.dtype, ctx=self.ctx)).to_host()[:, 0].astype(float)
+            alpha.append(float(Q[-1] @ v))
+            for qq in Q:                                   # full reorthogonalisation
+                v -= (qq @ v) * qq
+            nb = float(numpy.linalg.norm(v))
+            if nb <= 1e-14 * max(1., abs(alpha[0])):
+                break
+            beta.append(nb)
+            Q.append(v / nb)
+        k = len(alpha)
+        T = numpy.diag(alpha) + numpy.diag(beta[:k - 1], 1) + numpy.diag(beta[:k - 1], -1)
+        w = numpy.linalg.eigvalsh(T)
+        return w[0], w[-1]
+
     def _checkpos(self, cov):
-        """
-        ``_elements.py:651-668``.  The reference estimates the extreme
-        eigenvalues with two host lobpcg runs and rejects
-        ``mineigv < -n eps maxeigv posepsfac``; here the same threshold is
-        applied by a device factorisation: the matrix shifted by
-        ``n eps posepsfac`` times the Gershgorin bound of its largest
-        eigenvalue must be numerically positive definite.
-        """
-        try:
-            Chol(cov, epsrel=len(cov) * numpy.finfo(cov.dtype).eps * self._posepsfac, epsabs=0)
-        except numpy.linalg.LinAlgError:
-            raise numpy.linalg.LinAlgError('covariance matrix is not positive definite: mineigv < -n * eps * maxeigv * posepsfac')
+        """ ``_elements.py:651-668``: reject ``mineigv < -n eps maxeigv posepsfac`` """
+        mineigv, maxeigv = self._extreme_eigenvalues(cov)
+        assert mineigv <= maxeigv
+        if mineigv < 0:
+            bound = -len(cov) * numpy.finfo(cov.dtype).eps * maxeigv * self._posepsfac
+            if mineigv < bound:
+                raise numpy.linalg.LinAlgError('covariance matrix is not positive definite: mineigv = {:.4g} < {:.4g}'.format(mineigv, bound))
 
     def _checkpos_keys(self, keys):
         """ ``_elements.py:672-680`` """
@@ -519,40 +539,33 @@ class GP:
         return decomp
 
     def _flatgiven(self, given, givencov):
-        """ ``_compute.py:96-136`` """
+        """ ``_compute.py:96-136``: the data as flat vectors in dictionary order, and the matching grid of covariance blocks """
         if not hasattr(given, 'keys'):
             raise TypeError('`given` must be dict')
-        gcblack = givencov is None or isinstance(givencov, Decomposition)
-        if not gcblack and not hasattr(givencov, 'keys'):
+        opaque = givencov is None or isinstance(givencov, Decomposition)
+        if not opaque and not hasattr(givencov, 'keys'):
             raise TypeError('`givenconv` must be None, dict or Decomposition')
-        ylist = []
-        keylist = []
-        for key, l in given.items():
-            if key not in self._elements:
-                raise KeyError(key)
-            l = numpy.asarray(l)
-            shape = self._elements[key].shape
-            if l.shape != shape:
-                raise ValueError('given[{!r}] has shape {!r} different from shape {!r}'.format(key, l.shape, shape))
-            if l.dtype == object:
+        keys, values = [], []
+        for k, v in given.items():
+            if k not in self._elements:
+                raise KeyError(k)
+            v = numpy.asarray(v)
+            want = self._elements[k].shape
+            if v.shape != want:
+                raise ValueError('given[{!r}] has shape {!r} different from shape {!r}'.format(k, v.shape, want))
+            if v.dtype == object:
                 raise NotImplementedError('gvar inputs are out of scope of the device path')
-            if not numpy.issubdtype(l.dtype, numpy.number):
-                raise TypeError('given[{!r}] has non-numerical dtype {!r}'.format(key, l.dtype))
-            ylist.append(l.reshape(-1))
-            keylist.append(key)
-        if gcblack:
+            if not numpy.issubdtype(v.dtype, numpy.number):
+                raise TypeError('given[{!r}] has non-numerical dtype {!r}'.format(k, v.dtype))
+            keys.append(k)
+            values.append(v.reshape(-1))
+        if opaque:
             if givencov is not None:
                 raise NotImplementedError('Decomposition as givencov (Woodbury) is un-implemented in the reference too')
-            covblocks = givencov
-        else:
-            covblocks = [
-                [
-                    numpy.asarray(givencov[keylist[i], keylist[j]]).reshape(ylist[i].shape + ylist[j].shape)
-                    for j in range(len(keylist))
-                ]
-                for i in range(len(keylist))
-            ]
-        return ylist, keylist, covblocks
+            return values, keys, None
+        grid = [[numpy.asarray(givencov[ki, kj]).reshape(vi.shape + vj.shape) for kj, vj in zip(keys, values)]
+                for ki, vi in zip(keys, values)]
+        return values, keys, grid
 
     def _check_ymean(self, ymean):
         """ ``_compute.py:369-372`` """

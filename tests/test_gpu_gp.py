@@ -282,3 +282,33 @@ def test_fuse_solve_matches_separate_solve(lgp):
     assert np.linalg.norm(c1 - c0, 2) <= 1e-12
     np.testing.assert_array_equal(mf0, mf1)
     np.testing.assert_array_equal(cf0, cf1)
+
+
+def test_checkpos_is_the_reference_eigenvalue_test(lgp, rng):
+    """ ``_elements.py:651-668`` with the default ``checkpos=True``: exactly singular priors (duplicated points, linear
+    combinations) are accepted as the reference accepts them, clearly indefinite ones are rejected with its message; both
+    the exact small-matrix branch and the Lanczos branch (n > 256) of the device estimate """
+    for n in (30, 400):
+        x = np.sort(rng.uniform(0, n / 16, n))
+        gp = (lgp.GP(lgp.ExpQuad()).addx(x, 'a').addx(x, 'b')               # 'b' duplicates 'a': rank-deficient joint prior
+              .addtransf({'a': 1., 'b': -1.}, 'c'))                          # 'c' is identically zero
+        go = oracle.GP(oracle.ExpQuad()).addx(x, 'a').addx(x, 'b').addtransf({'a': 1., 'b': -1.}, 'c')
+        cov = gp.prior(raw=True)
+        covo = go.prior(raw=True)
+        for k in cov:
+            util.assert_close_matrices(cov[k], covo[k], rtol=1e-13, atol=1e-13)
+        y = np.sin(x)
+        m, c = gp.predfromdata({'a': y}, 'b', {('a', 'a'): 1e-4 * np.eye(n)}, raw=True)
+        mo, co = go.predfromdata({'a': y}, 'b', {('a', 'a'): 1e-4 * np.eye(n)}, raw=True)
+        util.assert_close_matrices(m, mo, rtol=1e-7)
+        # an indefinite user-supplied block
+        bad = np.eye(n)
+        bad[n // 2, n // 2] = -1e-3
+        with pytest.raises(np.linalg.LinAlgError, match='covariance matrix is not positive definite: mineigv = '):
+            lgp.GP().addcov(bad, 'm').prior('m', raw=True)
+        with pytest.raises(np.linalg.LinAlgError):
+            oracle.GP().addcov(bad, 'm').prior('m', raw=True)
+        # a tiny negative eigenvalue inside the tolerance n eps maxeigv passes
+        ok = np.eye(n)
+        ok[0, 0] = -1e-17
+        lgp.GP().addcov(ok, 'm').prior('m', raw=True)
