@@ -5,22 +5,23 @@ bench.py -- the hot path of BASELINE.json on MI355X: dense GP fit+predict in fp6
 posterior mean / covariance + log marginal likelihood), through the C-ABI of
 liblsqfitgp_hip.so with every buffer resident in HBM when the timed region starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--no-cpu-baseline] [--no-sweep]
 
 One "step" = one full pass of the path over one batch of synthetic input:
     c2  ExpQuad 1-D, N = 8192,  M = 100, y = sin(x/4) + noise, givencov 0.01 I
     c3  Matern-5/2, 3-D covariates, N = 32768, M = 100, noise 0.01 I      (default at --gpus 1)
-    c4  ExpQuad 1-D, N = 65536, M = 100, noise 0.01 I
-    c5  BART p = 10 (fp32 Gram), N = 4096, M = 100, through the GP / BART / Chol host classes
-With --gpus N > 1 (launched by torch.distributed.run, one process per GPU) every rank runs an independent
-replica of the workload on its own GPU ("replicas only" until the block-column distributed factorisation is
-the default) -- no data-path collective; torch.distributed (gloo) is used only for the barrier
-and the max-over-ranks of the timing.
+    c4  ExpQuad 1-D, N = 65536, M = 100, noise 0.01 I                     (default at --gpus N > 1, sharded)
+    c5  BART p = 10 (fp32 Gram) on the first 4096 rows of the reference's bart-data.txt, through the GP / BART / Chol
+        host classes: predict the 81 held-out rows + marginal likelihood
+With --gpus N > 1 (launched by torch.distributed.run, one process per GPU) the step is ONE C4 problem sharded by block
+columns over the ranks (lsqfitgp_amd._dist.DistributedChol: RCCL panel broadcasts over xGMI with look-ahead, "scaling":
+"strong"); N independent C3 replicas are timed afterwards and reported under "replicas" (no data-path collective).
+torch.distributed (gloo) is used only for the rendezvous, the barriers and the max-over-ranks of the timings.
 
 Prints ONE JSON line (rank 0): whole-job throughput in TFLOP/s over the algorithmic flop count
 N^3/3 + N^2 (M+1) + N M^2, the roofline of the dominant kernel (syrk trailing update of the Cholesky,
-timed live with HIP events on the stream it runs on) and a CPU baseline (the numpy/scipy oracle on a
-bounded sample of the same workload, on this box's host cores).
+timed live with HIP events on the stream it runs on) and a CPU baseline (the numpy/scipy oracle on bounded samples of the
+same workloads, on this box's host cores).
 """
 
 import argparse
@@ -153,45 +154,77 @@ class Workload:
         return self.mean.to_host(), self.cov.to_host()
 
 
-def cpu_baseline(cfg, budget_s=25.0):
-    """ the oracle (numpy/scipy restatement of the reference's path) on a bounded sample: the same workload at
-    a reduced N chosen so that the CPU work stays within ~10-30 s """
-    import oracle
+def _cpu_model():
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _oracle_fit_predict(cfg, n):
+    """ one fit+predict pass of the CPU oracle on the first n points of the workload, factoring ONCE (as the GPU step does):
+    Gram build, Chol of Kxx + noise, posterior mean / covariance and log marginal likelihood from the same factor.
+    Returns (seconds by phase, total seconds). """
+    import oracle
     m = cfg['m']
-    n = min(cfg['n'], 8192)
     x, xs, y = synth(cfg, n)
+    if cfg['kernel'] == 'expquad':
+        k = oracle.ExpQuad()
+        a, b = x[0], xs[0]
+    else:
+        k = oracle.Maternp(p=2, scale=1.)
+        dt = [(f'f{i}', float) for i in range(cfg['d'])]
+        a = np.empty(n, dt); b = np.empty(m, dt)
+        for i, f in enumerate(a.dtype.names):
+            a[f] = x[i]; b[f] = xs[i]
+    t0 = time.perf_counter()
+    Kxx = k(a[:, None], a[None, :])
+    Kxx[np.diag_indices(n)] += 0.01
+    Kxs = k(a[:, None], b[None, :])
+    Kss = k(b[:, None], b[None, :])
+    t1 = time.perf_counter()
+    dec = oracle.Chol(Kxx)                                                   # _linalg/_decomp.py:380-393
+    t2 = time.perf_counter()
+    mean = dec.pinv_bilinear(Kxs, y)                                         # _GP/_compute.py:259
+    cov = Kss - dec.ginv_quad(Kxs)                                           # :260
+    mll = -dec.minus_log_normal_density(y, value=True)[0]                    # :420-422
+    t3 = time.perf_counter()
+    assert np.isfinite(mll) and mean.shape == (m,) and cov.shape == (m, m)
+    return dict(gram=t1 - t0, decomposition=t2 - t1, solves=t3 - t2), t3 - t0
 
-    def run(n_):
-        xx, xxs, yy = x[:, :n_], xs, y[:n_]
-        if cfg['kernel'] == 'expquad':
-            k = oracle.ExpQuad()
-            a, b = xx[0], xxs[0]
-        else:
-            k = oracle.Maternp(p=2, scale=1.)
-            dt = [('f0', float), ('f1', float), ('f2', float)]
-            a = np.empty(n_, dt); b = np.empty(m, dt)
-            for i, f in enumerate(('f0', 'f1', 'f2')):
-                a[f] = xx[i]; b[f] = xxs[i]
-        t0 = time.perf_counter()
-        gp = oracle.GP(k, checkpos=False, checksym=False).addx(a, 'data').addx(b, 'test')
-        gc = {('data', 'data'): 0.01 * np.eye(n_)}
-        mean, cov = gp.predfromdata({'data': yy}, 'test', gc, raw=True)
-        mll = gp.marginal_likelihood({'data': yy}, gc)
-        return time.perf_counter() - t0
 
-    t = run(n)
-    while t > budget_s and n > 1024:
-        n //= 2
-        t = run(n)
-    tf = flops_fit_predict(n, m) / t / 1e12
-    return dict(value=tf, unit='TFLOP/s', cores=int(threads), kind='port',
-                sample=f'{cfg["kernel"]} d={cfg["d"]} N={n} M={m} fit+predict with the numpy/scipy oracle (LAPACK potrf/trsm), {t:.2f} s wall, one run',
-                seconds=t, host_cpus=os.cpu_count())
+def cpu_baseline(main_cfg):
+    """ the oracle (numpy/scipy restatement of the reference's path, LAPACK potrf/trsm like JAX-CPU) on bounded samples of
+    the C2 and C3 workloads, on this box's host cores: one warm-up + best of 3, with all BLAS threads and with one
+    (BASELINE.md section 3).  ~30-60 s in all. """
+    from threadpoolctl import threadpool_limits, threadpool_info
+    info = threadpool_info()
+    all_threads = max([p.get('num_threads', 1) for p in info] or [1])
+    out = {}
+
+    def best(cfg, n, threads, reps=3):
+        with threadpool_limits(limits=threads):
+            _oracle_fit_predict(cfg, min(n, 2048))                           # warm-up (imports, thread pools)
+            runs = [_oracle_fit_predict(cfg, n) for _ in range(reps)]
+        ph, t = min(runs, key=lambda r: r[1])
+        return dict(N=n, M=cfg['m'], seconds=t, phases_s=ph, tflops=flops_fit_predict(n, cfg['m']) / t / 1e12,
+                    cholesky_gflops=n ** 3 / 3 / ph['decomposition'] / 1e9, threads=threads)
+
+    for name in ('c2', 'c3'):
+        cfg = CONFIGS[name]
+        out[name] = {'all_cores': best(cfg, 8192, all_threads), 'one_core': best(cfg, 4096, 1)}
+    key = 'c2' if main_cfg['kernel'] == 'expquad' else 'c3'
+    top = out[key]['all_cores']
+    return dict(value=top['tflops'], unit='TFLOP/s', cores=int(all_threads), kind='port',
+                sample=(f"{main_cfg['kernel']} d={main_cfg['d']} N={top['N']} M={top['M']} fit+predict with the numpy/scipy oracle (LAPACK potrf/trsm), "
+                        f"factored once, best of 3 after a warm-up, {top['seconds']:.2f} s"),
+                seconds=top['seconds'], host_cpus=os.cpu_count(), cpu_model=_cpu_model(), blas=[p.get('internal_api') for p in info],
+                one_core={'value': out[key]['one_core']['tflops'], 'N': out[key]['one_core']['N'], 'seconds': out[key]['one_core']['seconds']},
+                by_config=out)
 
 
 def size_sweep(ctx, main_cfg):
@@ -222,47 +255,70 @@ def size_sweep(ctx, main_cfg):
         out.append({'workload': c['name'], 'N': c['n'], 'ms_per_step': dt * 1e3, 'value': flops_fit_predict(c['n'], c['m']) / dt / 1e12,
                     'cholesky_ms': float(ph[1]), 'cholesky_tflops': (c['n'] ** 3 / 3) / (ph[1] * 1e-3) / 1e12})
         del wl
+    try:
+        out.append(c5_step(ctx, steps=3, warmup=1))
+    except Exception as exc:                      # the sweep is informative: never let it take the headline number down
+        out.append({'workload': 'C5', 'error': repr(exc)})
     return out
 
 
-def main_c5(args, ctx):
-    """ configuration C5: the GP that bayestree.bart builds (``bayestree/_bart.py:187-205``) at fixed hyperparameters on
-    synthetic Abalone-like covariates (p = 10, N = 4096 train, M = 100 test), driven through the host classes
-    (``GP`` / ``BART`` / ``Chol``) exactly as a user of the reference would: fp32 BART Gram, fp64 assembly and solve.
-    One step = new GP -> predfromdata(testmean) + marginal_likelihood.  Roofline object: the BART Gram kernel (HBM). """
+def default_path(ctx, cfg_name='c2', reps=3):
+    """ the same fit+predict through the drop-in host classes with their defaults (GP.predfromdata + marginal_likelihood,
+    reference call sequence, dense givencov uploaded by the caller) next to the C-ABI step that `value` is measured on """
     import lsqfitgp_amd as lgp
-    rng = np.random.default_rng(5)
-    n, nt, p = 4096, 100, 10
-    f = np.float32
-    X = np.concatenate([rng.integers(0, 2, (n + nt, 3)), rng.integers(0, 200, (n + nt, 7)) / 200.], axis=1).astype(f)
-    yv = (10 * X[:n, 4] + 3 * X[:n, 0] + rng.standard_normal(n)).astype(f)
-    k_sigma_mu = f((yv.max() - yv.min()) / 2)
-    lam2 = f((k_sigma_mu / f(2)) ** 2)
-    sigma2 = f(np.mean((yv - yv.mean()) ** 2))
-    splits = lgp.BART.splits_from_coord(X[:n])
-    ix = lgp.BART.indices_from_coord(X, splits).astype(np.int32)
-    pts = np.array([tuple(r) for r in ix], dtype=[(f'f{i}', np.int32) for i in range(p)])
-    kern = lgp.BART(splits=(splits[0], None), indices=True, alpha=f(0.95), beta=f(2), gamma=f(1), maxd=10, reset=[2, 4, 6, 8],
-                    weights=np.ones(p, f)) * lam2
-    noise = np.diag(np.full(n, sigma2)).astype(f)
-    given = {'train': yv - f(yv.mean())}
+    cfg = CONFIGS[cfg_name]
+    n, m = cfg['n'], cfg['m']
+    x, xs, y = synth(cfg)
+    kern = lgp.ExpQuad() if cfg['kernel'] == 'expquad' else lgp.Maternp(p=2, scale=1.)
+    if cfg['d'] == 1:
+        a, b = x[0], xs[0]
+    else:
+        dt = [(f'f{i}', float) for i in range(cfg['d'])]
+        a = np.empty(n, dt); b = np.empty(m, dt)
+        for i, f in enumerate(a.dtype.names):
+            a[f] = x[i]; b[f] = xs[i]
+    gc = {('data', 'data'): lgp.diag(np.full(n, 0.01))}
+    out = {}
+    for label, fuse in (('carried_solve_default', True), ('separate_solve', False)):
+        def step():
+            gp = lgp.GP(kern, checkpos=False, checksym=False, fuse_solve=fuse, ctx=ctx).addx(a, 'data').addx(b, 'test')
+            mean, cov = gp.predfromdata({'data': y}, 'test', gc, raw=True)
+            return gp.marginal_likelihood({'data': y}, gc)
+        step(); ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            mll = step()
+        ctx.sync()
+        out[label + '_ms'] = (time.perf_counter() - t0) / reps * 1e3
+    out['workload'] = cfg['name'] + ' via GP.predfromdata + GP.marginal_likelihood (two factorisations: the reference call sequence)'
+    out['log_marginal_likelihood'] = float(mll)
+    return out
+
+
+def c5_step(ctx, steps=3, warmup=1):
+    """ configuration C5 on its real workload: the GP that bayestree.bart builds (``bayestree/_bart.py:187-205``) at the fixed
+    hyperparameters of SURVEY.md 8(d) on the first 4096 rows of the reference's examples/bart-data.txt (p = 10, fp32 kernel,
+    81 held-out rows), driven through the host classes as a user of the reference would: one step = new GP ->
+    predfromdata('testmean') + marginal_likelihood(epsrel=0).  Roofline object: the BART Gram kernel. """
+    import lsqfitgp_amd as lgp
+    from tests.abalone import load_abalone, c5_problem
+    X, y = load_abalone()
+    n = 4096
 
     def step():
-        gp = (lgp.GP(kern, checkpos=False, checksym=False, solver='chol')
-              .addx(pts[:n], 'trainmean').addx(pts[n:], 'testmean')
-              .addcov(noise, 'trainnoise').addcov(np.asarray(k_sigma_mu ** 2, f), 'mean')
-              .addtransf({'trainmean': 1, 'trainnoise': 1, 'mean': 1}, 'train'))
+        gp, given, kern, pts = c5_problem(lgp, X, y, n)
         mean, cov = gp.predfromdata(given, 'testmean', raw=True)
-        return mean, cov, gp.marginal_likelihood(given, epsrel=0)
+        return mean, cov, gp.marginal_likelihood(given, epsrel=0), kern, pts
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     ctx.sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         res = step()
     ctx.sync()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / steps
+    kern, pts = res[3], res[4]
     # the BART Gram kernel alone, N x N fp32, HIP events on the context's stream
     e0, e1 = ctx.event(), ctx.event()
     kern.gram(pts[:n], pts[:n], ctx=ctx)
@@ -272,17 +328,26 @@ def main_c5(args, ctx):
         kern.gram(pts[:n], pts[:n], ctx=ctx)
         ctx.record(e1)
         best = min(best, ctx.elapsed_ms(e0, e1))
-    gbps = 4. * n * n / (best * 1e-3) / 1e9
+    nt = len(pts) - n
+    return {'workload': f'C5 BART kernel p=10 fp32 on bart-data.txt, N={n} train / {nt} held out, via GP/BART/Chol host classes',
+            'N': n, 'M': nt, 'ms_per_step': dt * 1e3, 'value': flops_fit_predict(n, nt) / dt / 1e12,
+            'log_marginal_likelihood': float(res[2]),
+            'bart_gram': {'ms': best, 'gpairs_per_s': n * n / (best * 1e-3) / 1e9, 'bound': 'hbm', 'achieved': 4. * n * n / (best * 1e-3) / 1e9,
+                          'peak': 8000., 'unit': 'GB/s', 'note': 'includes the host-side per-call setup of kernel.gram (index upload, digamma table)'}}
+
+
+def main_c5(args, ctx):
+    r = c5_step(ctx, steps=args.steps, warmup=args.warmup)
+    g = r['bart_gram']
     print(json.dumps({
         'metric': 'GP fit+predict throughput (Gram build + Cholesky + solves; flops N^3/3 + N^2(M+1) + N M^2)',
-        'value': flops_fit_predict(n, nt) / dt / 1e12, 'unit': 'TFLOP/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': dt * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 Gram, f64 assembly and solve (as the reference: zero cross blocks are float64)', 'data': 'synthetic',
-        'config': {'workload': 'C5 BART kernel p=10 N=4096 M=100 via GP/BART/Chol host classes (bayestree.bart GP at fixed hyperparameters)',
-                   'N': n, 'M': nt, 'p': p, 'parallelism': 'single GPU'},
-        'log_marginal_likelihood': float(res[2]),
-        'roofline': {'kernel': 'gram_bart_kernel<float> (N x N, includes the host-side per-call setup of kernel.gram)', 'bound': 'hbm',
-                     'achieved': gbps, 'peak': 8000., 'unit': 'GB/s', 'frac': gbps / 8000., 'traffic': None, 'avg_launch_ms': best},
+        'value': r['value'], 'unit': 'TFLOP/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': r['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 Gram, f64 assembly and solve (as the reference: zero cross blocks are float64)', 'data': 'reference data file (examples/bart-data.txt)',
+        'config': {'workload': r['workload'], 'N': r['N'], 'M': r['M'], 'p': 10, 'parallelism': 'single GPU'},
+        'log_marginal_likelihood': r['log_marginal_likelihood'],
+        'roofline': {'kernel': 'gram_bart_kernel<float> (N x N)', 'bound': 'hbm', 'achieved': g['achieved'], 'peak': 8000., 'unit': 'GB/s',
+                     'frac': g['achieved'] / 8000., 'traffic': None, 'avg_launch_ms': g['ms'], 'gpairs_per_s': g['gpairs_per_s']},
         'cpu_baseline': None}), flush=True)
 
 
@@ -290,7 +355,9 @@ def pmc_traffic(config):
     """ HBM bytes per trailing-update launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
     x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, collected in their own runs of this same
     command); counters cannot be read live from inside the process, so None when no committed pass matches """
-    path = os.path.join(ROOT, 'profiles', f'r01_{config}_pmc_traffic.json')
+    path = os.path.join(ROOT, 'profiles', f'r02_{config}_pmc_traffic.json')
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, 'profiles', f'r01_{config}_pmc_traffic.json')
     try:
         with open(path) as f:
             d = json.load(f)
@@ -299,68 +366,113 @@ def pmc_traffic(config):
         return None
 
 
-def main_dist(args, cfg, ctx, dist, rank, world):
-    """ opt-in: Gram build + regularisation + Cholesky of ONE N x N problem sharded by block columns over the ranks
-    (lsqfitgp_amd/_dist.py); strong scaling, value = N^3/3 flops / time """
+def init_transport(ctx, dist, rank, world):
+    """ RCCL communicator over the ranks (one GPU each), or -- LGP_DIST_TRANSPORT=host -- panels staged through host memory and
+    gloo (lets several ranks rehearse the sharded path on ONE GPU).  Every rank learns whether every rank succeeded, so that a
+    failure can fall back to replicas instead of hanging in a collective.  Returns (ok, message). """
     import torch
     import lsqfitgp_amd as lgp
+    err = ''
+    try:
+        if os.environ.get('LGP_DIST_TRANSPORT') == 'host':
+            def collective(op, arr, root):
+                t = torch.from_numpy(arr)
+                if op == 0:
+                    dist.broadcast(t, src=root)
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 1 else dist.ReduceOp.MAX)
+            ctx.comm_init_host(rank, world, collective)
+        else:
+            # every rank loads librccl first (lgp_comm_unique_id does): a missing library must not leave the others blocked
+            # inside ncclCommInitRank
+            probe = lgp.Context.comm_unique_id()
+            ok = torch.tensor([1.0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            uid = [probe if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(rank, world, uid[0])
+    except Exception as exc:
+        err = repr(exc)
+    flag = torch.tensor([0.0 if err else 1.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag[0] > 0), err
+
+
+def dist_step_factory(cfg, ctx):
+    """ one step of the sharded path: Gram build of the owned block columns + regularisation + look-ahead factorisation with
+    [Kxxs | y] carried through it + posterior mean / covariance / log marginal likelihood (one all-reduce) """
+    import lsqfitgp_amd as lgp
     from lsqfitgp_amd._dist import DistributedChol
-    if os.environ.get('LGP_DIST_TRANSPORT') == 'host':
-        # panels through host memory and gloo (lgp_comm_init_host): lets several ranks share one GPU, e.g. to rehearse the
-        # multi-rank path on a single-GPU box; the default is RCCL over xGMI
-        def collective(op, arr, root):
-            t = torch.from_numpy(arr)
-            if op == 0:
-                dist.broadcast(t, src=root)
-            else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 1 else dist.ReduceOp.MAX)
-        ctx.comm_init_host(rank, world, collective)
-    else:
-        uid = [lgp.Context.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(rank, world, uid[0])
-    lgp.Context._default = ctx
     x, xs, y = synth(cfg)
     kern = lgp.ExpQuad() if cfg['kernel'] == 'expquad' else lgp.Maternp(p=2, scale=1.)
     if cfg['d'] == 1:
-        pts = x[0]
+        pts, tpts = x[0], xs[0]
     else:
-        pts = np.empty(cfg['n'], [(f'f{i}', float) for i in range(cfg['d'])])
-        for i in range(cfg['d']):
-            pts[f'f{i}'] = x[i]
-
-    if cfg['d'] == 1:
-        tpts = xs[0]
-    else:
-        tpts = np.empty(cfg['m'], pts.dtype)
-        for i in range(cfg['d']):
-            tpts[f'f{i}'] = xs[i]
+        dt = [(f'f{i}', float) for i in range(cfg['d'])]
+        pts = np.empty(cfg['n'], dt); tpts = np.empty(cfg['m'], dt)
+        for i, f in enumerate(pts.dtype.names):
+            pts[f] = x[i]; tpts[f] = xs[i]
 
     def step():
-        d = DistributedChol(kern, pts, noise=0.01, nb=1024, ctx=ctx, carry=(tpts, y))   # Gram build + jitter + factorisation, solve carried
-        mean, cov, mlnd = d.posterior(kern, pts, tpts, y)                     # fan-in solve, mean, covariance, likelihood
+        d = DistributedChol(kern, pts, noise=0.01, nb=1024, ctx=ctx, carry=(tpts, y))
+        mean, cov, mlnd = d.posterior(kern, pts, tpts, y)
         return -mlnd
+    return step
 
+
+def timed(step, args, ctx, dist):
+    """ W untimed + exactly K timed steps, bracketed by barrier + device sync on both sides; max over the ranks """
+    import torch
     for _ in range(args.warmup):
         step()
     ctx.sync(); dist.barrier(); ctx.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ld = step()
+        out = step()
     ctx.sync(); dist.barrier(); ctx.sync()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t[0])
-    n = cfg['n']
+    return float(t[0]), out
+
+
+def main_multi(args, ctx, dist, rank, world):
+    """ --gpus N > 1: BASELINE configuration C4 (or --config) as ONE problem sharded by block columns over the N GPUs; then N
+    independent C3 replicas as the extra "replicas" entry """
+    import lsqfitgp_amd as lgp
+    lgp.Context._default = ctx
+    cfg = CONFIGS[args.config if args.config_given else 'c4']
+    ok, err = init_transport(ctx, dist, rank, world)
+    sharded = None
+    if ok:
+        try:
+            elapsed, mll = timed(dist_step_factory(cfg, ctx), args, ctx, dist)
+            sharded = dict(elapsed=elapsed, mll=mll)
+        except Exception as exc:             # (a rank that fails here leaves the others in a collective: reported, not hidden)
+            err = repr(exc)
+    # replicas: every rank runs the single-GPU C3 step on its own GPU, no data-path collective
+    rcfg = CONFIGS['c3']
+    wl = Workload(rcfg, ctx)
+    relapsed, _ = timed(lambda: wl.step(), args, ctx, dist)
+    replicas = {'workload': rcfg['name'], 'scaling': 'weak', 'value': flops_fit_predict(rcfg['n'], rcfg['m']) * args.steps * world / relapsed / 1e12,
+                'unit': 'TFLOP/s', 'ms_per_step': relapsed / args.steps * 1e3, 'parallelism': f'{world} independent replicas, one per GPU (no collective)'}
     if rank == 0:
-        print(json.dumps({
-            'metric': 'GP fit+predict fp64 throughput, one problem sharded over the GPUs (flops N^3/3 + N^2(M+1) + N M^2)',
-            'value': flops_fit_predict(n, cfg['m']) * args.steps / elapsed / 1e12, 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': cfg['name'], 'N': n, 'M': cfg['m'],
-                       'parallelism': f'1-D block-column-cyclic over {world} GPUs, nb=1024, ' + ('host-staged gloo' if os.environ.get('LGP_DIST_TRANSPORT') == 'host' else 'RCCL') + ' panel broadcast with look-ahead'},
-            'log_marginal_likelihood': ld, 'roofline': None, 'cpu_baseline': None}), flush=True)
+        transport = 'host-staged gloo' if os.environ.get('LGP_DIST_TRANSPORT') == 'host' else 'RCCL over xGMI'
+        if sharded is not None:
+            n, m = cfg['n'], cfg['m']
+            out = {'metric': 'GP fit+predict fp64 throughput, one problem sharded over the GPUs (flops N^3/3 + N^2(M+1) + N M^2)',
+                   'value': flops_fit_predict(n, m) * args.steps / sharded['elapsed'] / 1e12, 'unit': 'TFLOP/s', 'n_gpus': world,
+                   'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': sharded['elapsed'] / args.steps * 1e3,
+                   'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                   'config': {'workload': cfg['name'], 'N': n, 'M': m,
+                              'parallelism': f'1-D block-column-cyclic Cholesky over {world} GPUs, nb=1024, {transport} panel broadcast with look-ahead (lgp_chol_factor_dist)'},
+                   'log_marginal_likelihood': sharded['mll'], 'roofline': None, 'cpu_baseline': None, 'replicas': replicas}
+        else:
+            out = {'metric': 'GP fit+predict fp64 throughput (Gram build + Cholesky + solves; flops N^3/3 + N^2(M+1) + N M^2)',
+                   'value': replicas['value'], 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                   'ms_per_step': replicas['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+                   'data': 'synthetic', 'config': {'workload': rcfg['name'], 'N': rcfg['n'], 'M': rcfg['m'], 'parallelism': replicas['parallelism']},
+                   'roofline': None, 'cpu_baseline': None, 'sharded_path_error': err}
+        print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -370,22 +482,26 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', choices=sorted(CONFIGS) + ['c5'], default='c3')
+    ap.add_argument('--config', choices=sorted(CONFIGS) + ['c5'], default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-sweep', action='store_true', help='skip the smaller-N / C2 runs reported under "vs_N"')
+    ap.add_argument('--no-sweep', action='store_true', help='skip the smaller-N / C2 / C4 / C5 runs reported under "vs_N"')
     ap.add_argument('--dist', action='store_true', default=os.environ.get('LGP_BENCH_DIST') == '1',
-                    help='N > 1: one block-column-cyclic factorisation sharded over the ranks (RCCL panel broadcasts) '
-                         'instead of independent replicas')
+                    help='single process: run the sharded code path with one rank (the multi-rank default of --gpus N > 1)')
     args = ap.parse_args()
+    args.config_given = args.config is not None
+    if args.config is None:
+        args.config = 'c3'
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
-    if world > 1:
+    if world > 1 or args.dist:
         import torch                       # plumbing only: rendezvous, barrier, max-over-ranks
         import torch.distributed as dist
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('gloo', rank=rank, world_size=world)       # rendezvous before any GPU call
         os.environ.setdefault('LGP_DEVICE', str(local_rank))
 
     import lsqfitgp_amd as lgp              # fails loudly without the HIP library / a GPU
@@ -393,26 +509,16 @@ def main():
     if args.config == 'c5':
         lgp.Context._default = ctx
         return main_c5(args, ctx)
+    if dist is not None:
+        return main_multi(args, ctx, dist, rank, world)
     cfg = CONFIGS[args.config]
-    if args.dist:
-        if dist is None:                      # single process: still goes through the sharded code path (1 rank)
-            import torch.distributed as dist
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29511')
-            dist.init_process_group('gloo', rank=0, world_size=1)
-        return main_dist(args, cfg, ctx, dist, rank, world)
+    lgp.Context._default = ctx
     wl = Workload(cfg, ctx)
     lib, _lib = wl.lib, wl._lib
 
-    def barrier():
-        ctx.sync()
-        if dist is not None:
-            dist.barrier()
-        ctx.sync()
-
     for _ in range(args.warmup):
         wl.step()
-    barrier()
+    ctx.sync()
 
     # ---- timed region: exactly K steps
     evs = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
@@ -420,68 +526,59 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         wl.step(evs[k])
-    barrier()
+    ctx.sync()
     t1 = time.perf_counter()
     launches = ctypes.c_size_t(); tot_ms = ctypes.c_double(); tot_fl = ctypes.c_double(); max_fl = ctypes.c_double(); max_ms = ctypes.c_double()
     _lib.check(lib.lgp_profile_end(ctx.handle, ctypes.byref(launches), ctypes.byref(tot_ms), ctypes.byref(tot_fl), ctypes.byref(max_fl), ctypes.byref(max_ms)))
     elapsed = t1 - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
 
     n, m = cfg['n'], cfg['m']
     ms_per_step = elapsed / args.steps * 1e3
-    total_flops = flops_fit_predict(n, m) * args.steps * world
+    total_flops = flops_fit_predict(n, m) * args.steps
     phases = np.array([[ctx.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in evs]).mean(axis=0)
-
-    if rank == 0:
-        achieved = tot_fl.value / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else None
-        out = {
-            'metric': 'GP fit+predict fp64 throughput (Gram build + Cholesky + solves; flops N^3/3 + N^2(M+1) + N M^2)',
-            'value': total_flops / elapsed / 1e12,
+    achieved = tot_fl.value / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else None
+    out = {
+        'metric': 'GP fit+predict fp64 throughput (Gram build + Cholesky + solves; flops N^3/3 + N^2(M+1) + N M^2)',
+        'value': total_flops / elapsed / 1e12,
+        'unit': 'TFLOP/s',
+        'n_gpus': 1,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': ms_per_step,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f64',
+        'data': 'synthetic',
+        'config': {'workload': cfg['name'], 'N': n, 'M': m, 'd': cfg['d'], 'parallelism': 'single GPU'},
+        'phases_ms': {'gram': float(phases[0]), 'decomposition': float(phases[1]), 'solves+likelihood': float(phases[2])},
+        'cholesky_tflops': (n ** 3 / 3) / (phases[1] * 1e-3) / 1e12,
+        # Gram build against the HBM roofline: bytes written for Kxx, Kxxs, Kxsxs / time of the phase
+        'gram_build': {'bound': 'hbm', 'achieved': 8. * (n * n + n * m + m * m) / (phases[0] * 1e-3) / 1e9, 'peak': 8000., 'unit': 'GB/s'},
+        'log_marginal_likelihood': wl.results.get('mll'),
+        'roofline': {
+            'kernel': 'gemm_kernel<double,NT> lower (syrk trailing update of the blocked Cholesky, v_mfma_f64_16x16x4_f64)',
+            'bound': 'mfma',
+            'achieved': achieved,
+            'peak': FP64_MFMA_PEAK_TFLOPS,
             'unit': 'TFLOP/s',
-            'n_gpus': world,
-            'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': ms_per_step,
-            'higher_is_better': True,
-            'scaling': 'weak',
-            'vs_baseline': None,
-            'dtype': 'f64',
-            'data': 'synthetic',
-            'config': {'workload': cfg['name'], 'N': n, 'M': m, 'd': cfg['d'],
-                       'parallelism': 'single GPU' if world == 1 else f'{world} independent replicas, one per GPU (no collective)'},
-            'phases_ms': {'gram': float(phases[0]), 'decomposition': float(phases[1]), 'solves+likelihood': float(phases[2])},
-            'cholesky_tflops': (n ** 3 / 3) / (phases[1] * 1e-3) / 1e12,
-            # Gram build against the HBM roofline: bytes written for Kxx, Kxxs, Kxsxs / time of the phase
-            'gram_build': {'bound': 'hbm', 'achieved': 8. * (n * n + n * m + m * m) / (phases[0] * 1e-3) / 1e9, 'peak': 8000., 'unit': 'GB/s'},
-            'log_marginal_likelihood': wl.results.get('mll'),
-            'roofline': {
-                'kernel': 'gemm_kernel<double,NT> lower (syrk trailing update of the blocked Cholesky, v_mfma_f64_16x16x4_f64)',
-                'bound': 'mfma',
-                'achieved': achieved,
-                'peak': FP64_MFMA_PEAK_TFLOPS,
-                'unit': 'TFLOP/s',
-                'frac': achieved / FP64_MFMA_PEAK_TFLOPS if achieved else None,
-                'traffic': pmc_traffic(args.config),
-                'launches': int(launches.value),
-                'avg_launch_ms': tot_ms.value / max(launches.value, 1),
-                'avg_launch_gflop': tot_fl.value / max(launches.value, 1) / 1e9,
-                'largest_launch_tflops': (max_fl.value / (max_ms.value * 1e-3) / 1e12) if max_ms.value > 0 else None,
-            },
-        }
-        if world == 1 and not args.no_sweep:
-            out['vs_N'] = size_sweep(ctx, cfg)
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg)
-        else:
-            out['cpu_baseline'] = None
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            'frac': achieved / FP64_MFMA_PEAK_TFLOPS if achieved else None,
+            'traffic': pmc_traffic(args.config),
+            'launches': int(launches.value),
+            'avg_launch_ms': tot_ms.value / max(launches.value, 1),
+            'avg_launch_gflop': tot_fl.value / max(launches.value, 1) / 1e9,
+            'largest_launch_tflops': (max_fl.value / (max_ms.value * 1e-3) / 1e12) if max_ms.value > 0 else None,
+        },
+    }
+    del wl
+    if not args.no_sweep:
+        out['vs_N'] = size_sweep(ctx, cfg)
+        try:
+            out['default_path'] = default_path(ctx, 'c2')
+        except Exception as exc:
+            out['default_path'] = {'error': repr(exc)}
+    out['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(cfg)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

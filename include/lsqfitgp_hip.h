@@ -360,6 +360,27 @@ int lgp_update_nt_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const do
                       const double *dB, size_t ldb, double *dC, size_t ldc, int lower);
 int lgp_get_info(lgp_ctx *ctx, int *hinfo);    /* read & reset the pivot info word; synchronises */
 
+/* The whole sharded factorisation in one call (no host language between the panels): dLloc holds this rank's block
+ * columns (block b = columns [b nb, (b+1) nb) of the n x n matrix lives on rank b % nranks at local columns
+ * [(b / nranks) nb, ...), all n + nx rows, ld ldl; lower triangle + regularisation already in place; rows n .. n+nx-1 are
+ * right-hand sides carried through the factorisation as in lgp_chol_factor_rhs).  Right-looking with one-panel look-ahead:
+ * the owner factors panel b+1 and ncclBroadcasts it on the auxiliary stream while every rank updates its remaining block
+ * columns with panel b in one staircase MFMA launch.  ddblk: nlocal * lgp_chol_dblk_size(nb) workspace/outputs (packed
+ * diagonal blocks of the owned block columns); dpanels: workspace of 2 (n + nx) ldp doubles, ldp >= nb (pad it: ldp = nb
+ * puts every operand row of the trailing update on one HBM channel).  dsrow (n values, may be NULL): the power-of-two row
+ * scaling s undone on the finished factor, L = L~ s[:, None] (_decomp.py:392).  *hinfo: pivot info of THIS rank's panels
+ * (0 = ok).  Uses the context's communicator (lgp_comm_init / lgp_comm_init_host; none: single rank).  Synchronises. */
+int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_t nx, double *dLloc, size_t ldl, double *ddblk,
+                             double *dpanels, size_t ldp, const double *dsrow, int *hinfo);
+/* dout[0] = max_i dx[i] (NaN if any element is NaN, like jnp.max): the Gershgorin bound over a rank's column sums */
+int lgp_max_f64(lgp_ctx *ctx, size_t n, const double *dx, double *dout);
+/* A_ij <- A_ij / drow_i / dcol_j (divide != 0) or * drow_i * dcol_j: the power-of-two scaling of a locally owned block
+ * column and its undoing on the factor (_decomp.py:385,392); drow / dcol may be NULL */
+int lgp_scale_rows_cols_f64(lgp_ctx *ctx, size_t rows, size_t cols, double *dA, size_t lda,
+                            const double *drow, const double *dcol, int divide);
+/* ds_j = 2^rint(log2(A_jj) / 2), or 1 where A_jj == 0 (_decomp.py:356-361) */
+int lgp_diag_scale_pow2_f64(lgp_ctx *ctx, size_t n, const double *dA, size_t lda, double *ds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,45 @@ class _Cov(_Element):
         self.shape = shape
 
 
+class Diagonal:
+    """
+    A diagonal covariance block given by its diagonal: ``addcov(diag(v), key)`` / ``givencov={(k, k): diag(v)}`` mean the
+    same as the dense ``numpy.diag(v)`` of the reference API, without materialising (and uploading) n^2 zeros on the host:
+    the device matrix is built by a memset and one kernel.  Not in the reference (it takes dense arrays only).
+    """
+
+    def __init__(self, values):
+        self.values = numpy.asarray(values)
+        if self.values.ndim != 1:
+            raise ValueError('the diagonal must be a vector')
+        self.shape = (len(self.values), len(self.values))
+        self.ndim = 2
+        self.dtype = self.values.dtype
+        self.size = len(self.values) ** 2
+
+    @property
+    def T(self):
+        return self
+
+    def dense(self):
+        return numpy.diag(self.values)
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and not isinstance(shape[0], int) else shape
+        if tuple(shape) != self.shape:
+            raise ValueError(f'a diagonal block of shape {self.shape} can not be reshaped to {tuple(shape)}')
+        return self
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.dense()
+        return a if dtype is None else a.astype(dtype)
+
+
+def diag(values):
+    """ ``lsqfitgp_amd.diag(v)``: see `Diagonal` """
+    return Diagonal(values)
+
+
 def _allclose_dev(A, B):
     """ ``jnp.allclose(A, B)`` on device matrices """
     f, F = _lib.fn('lgp_allclose', A.dtype)
@@ -115,14 +154,17 @@ class GP:
     kernel object of this package, ``solver`` must be ``'chol'``, the
     ``check*`` flags and ``posepsfac``/``halfmatrix`` keep their meaning, and
     extra keyword arguments (``epsrel``, ``epsabs``) go to the decomposition.
-    ``fuse_solve=True`` (not in the reference) lets `pred` carry ``[Kxxs | y]`` through the factorisation of
-    ``Kxx + ycov`` (`Chol` ``rhs=``) instead of solving afterwards.
+    ``fuse_solve`` (not in the reference; default True): when `pred` has to factor ``Kxx + ycov`` for this call only (a
+    nonzero ``givencov``: such decompositions are never cached, ``_compute.py:55-58``), ``[Kxxs | y]`` is carried through
+    the factorisation (`Chol` ``rhs=``) instead of being solved afterwards by a latency-bound chain of small kernels.
+    Cached decompositions (no ``givencov``, or one that is exactly zero) always use the separate solve, so that a cache hit
+    reproduces the first call bit for bit.
     """
 
     DefaultProcess = 'default'
 
     def __init__(self, covfun=None, *, solver='chol', checkpos=True, checksym=True,
-        checkfinite=True, checklin=True, posepsfac=1, halfmatrix=False, ctx=None, fuse_solve=False, **kw):
+        checkfinite=True, checklin=True, posepsfac=1, halfmatrix=False, ctx=None, fuse_solve=True, **kw):
         if covfun is not None and not isinstance(covfun, _kernels.Kernel):
             raise TypeError('covariance function must be a lsqfitgp_amd kernel object')
         self._covfun = covfun
@@ -256,7 +298,8 @@ class GP:
                 self._require_new(k)
             if block is None:
                 raise TypeError(f'block {pair!r} is None')
-            block = numpy.asarray(block)
+            if not isinstance(block, Diagonal):
+                block = numpy.asarray(block)
             row, col = pair
             if row == col:
                 if block.ndim % 2:
@@ -264,7 +307,7 @@ class GP:
                 head, tail = block.shape[:block.ndim // 2], block.shape[block.ndim // 2:]
                 if head != tail:
                     raise ValueError(f'shape {block.shape!r} of diagonal block {row!r} is not symmetric')
-                if self._checksym and not numpy.allclose(block, block.T):
+                if self._checksym and not isinstance(block, Diagonal) and not numpy.allclose(block, block.T):
                     raise ValueError(f'diagonal block {row!r} is not symmetric')
                 shapes[row] = head
             raw[pair] = block
@@ -281,7 +324,7 @@ class GP:
         # pass 2: flatten every block to a matrix; an off-diagonal block given once also serves as its transpose
         flat = {}
         for pair, block in raw.items():
-            if self._checkfinite and not numpy.all(numpy.isfinite(block)):
+            if self._checkfinite and not numpy.all(numpy.isfinite(block.values if isinstance(block, Diagonal) else block)):
                 raise ValueError(f'block {pair!r} not finite')
             row, col = pair
             if row != col:
@@ -310,6 +353,14 @@ class GP:
     # ---- covariance blocks -----------------------------------------------------
 
     def _upload_block(self, block):
+        if isinstance(block, Diagonal):
+            dtype = numpy.float32 if block.dtype == numpy.float32 else numpy.float64
+            out = DeviceArray.zeros(block.shape, dtype, self.ctx)
+            if block.shape[0]:
+                vec = DeviceArray.from_host(block.values, dtype=dtype, ctx=self.ctx)
+                f, F = _lib.fn('lgp_add_diag', dtype)
+                _lib.check(f(self.ctx.handle, block.shape[0], out.ptr, out.ld, vec.ptr, F(1)), 'lgp_add_diag')
+            return out
         block = numpy.asarray(block)
         dtype = numpy.float32 if block.dtype == numpy.float32 else numpy.float64
         return DeviceArray.from_host(block, dtype=dtype, ctx=self.ctx)
@@ -563,9 +614,26 @@ class GP:
             if givencov is not None:
                 raise NotImplementedError('Decomposition as givencov (Woodbury) is un-implemented in the reference too')
             return values, keys, None
+        if len(keys) == 1 and isinstance(givencov[keys[0], keys[0]], Diagonal):
+            d = givencov[keys[0], keys[0]]
+            if d.shape[0] != values[0].size:
+                raise ValueError(f'diagonal covariance of size {d.shape[0]} for {values[0].size} values')
+            return values, keys, d                      # stays a diagonal: built on the device, nothing dense on the host
         grid = [[numpy.asarray(givencov[ki, kj]).reshape(vi.shape + vj.shape) for kj, vj in zip(keys, values)]
                 for ki, vi in zip(keys, values)]
         return values, keys, grid
+
+    @staticmethod
+    def _join_ycov(blocks):
+        """ the covariance of the data as one matrix (``_compute.py:225-227``).  A covariance that is exactly zero is the
+        same as none -- the reference pins that identity bit for bit (tests/GP/test_GP.py:652-660) -- and is treated as none,
+        so that the cached decomposition of the prior serves it """
+        if blocks is None:
+            return None
+        if isinstance(blocks, Diagonal):
+            return None if not numpy.any(blocks.values) else blocks
+        ycov = numpy.block(blocks)
+        return None if not numpy.any(ycov) else ycov
 
     def _check_ymean(self, ymean):
         """ ``_compute.py:369-372`` """
@@ -575,6 +643,10 @@ class GP:
     def _check_ycov(self, ycov):
         """ ``_compute.py:374-381`` (ycov is a host array here: it comes from the caller) """
         if ycov is None:
+            return
+        if isinstance(ycov, Diagonal):
+            if self._checkfinite and not numpy.all(numpy.isfinite(ycov.values)):
+                raise ValueError('covariance matrix of `given` is not finite')
             return
         if self._checkfinite and not numpy.all(numpy.isfinite(ycov)):
             raise ValueError('covariance matrix of `given` is not finite')
@@ -611,7 +683,7 @@ class GP:
 
         Kxxs = self._assemblecovblocks(inkeys, outkeys)                   # :230
 
-        ycov = numpy.block(ycovblocks) if ycovblocks is not None else None
+        ycov = self._join_ycov(ycovblocks)
         self._check_ycov(ycov)
         ymean = y
         self._check_ymean(ymean)
@@ -629,10 +701,9 @@ class GP:
             built['W'] = W
             return W
 
-        # fuse_solve=True (extension, off by default): a factorisation that is computed for this call only (ycov
-        # given: never cached, :55-58) carries W through it and the solve is free.  It is opt-in because it rounds
-        # differently from the separate solve, and the reference pins "zero givencov == no givencov" and "cache hit ==
-        # first call" bit for bit (tests/GP/test_GP.py:587-596,652-660).
+        # a factorisation that is computed for this call only (nonzero ycov: never cached, :55-58) carries W through it and
+        # the solve is free.  The reference pins "zero givencov == no givencov" and "cache hit == first call" bit for bit
+        # (tests/GP/test_GP.py:587-596,652-660): a zero ycov has become None above, and cached decompositions never carry.
         carry = build_rhs if (self._fuse_solve and issubclass(self._decomptype, Chol) and fromdata and ycov_dev is not None) else None
         if fromdata:
             solver = self._solver(inkeys, ycov_dev, rhs_builder=carry)   # :255
@@ -692,7 +763,7 @@ class GP:
         self._checkpos_keys(inkeys)
         ymean = y
         self._check_ymean(ymean)
-        ycov = numpy.block(ycovblocks) if ycovblocks is not None else None
+        ycov = self._join_ycov(ycovblocks)
         self._check_ycov(ycov)
         ycov_dev = None if ycov is None else self._upload_block(ycov)
         decomp = self._solver(inkeys, ycov_dev, **kw)

@@ -11,7 +11,7 @@ from ._lib import LibraryError
 from ._device import Context, DeviceArray, asdevice
 from ._linalg import Decomposition, Chol
 from ._kernels import Kernel, ExpQuad, Maternp, GammaExp, Cauchy, BART
-from ._GP import GP
+from ._GP import GP, Diagonal, diag
 from ._fit import empbayes_fit
 from ._fastraniter import raniter, sample
 from ._uncertain import UVal

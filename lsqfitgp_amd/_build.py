@@ -22,6 +22,7 @@ UNITS = [
     ('potrf.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form=1']),
     ('potf2m.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form=1']),
     ('elementwise.hip', []),
+    ('dist.hip', []),
     # the Gram kernels follow the reference's unfused square-then-add evaluation
     ('gram.hip', ['-ffp-contract=off']),
 ]

@@ -14,9 +14,9 @@ so the (N - k) x nb panel message (one ``ncclBroadcast`` per panel, every peer f
 travels while the trailing updates (MFMA) run.  The only other collectives are scalars
 (``max`` for the Gershgorin bound, ``sum`` for the log-determinant).
 
-The schedule (`factor_schedule`) is pure Python over an ``ops`` backend so that it can be exercised with
-world_size > 1 on CPU (gloo + numpy backend in ``tests/test_dist_gloo.py``); `DeviceOps` is the product backend
-(C-ABI kernels + RCCL).
+The product runs the schedule inside the library (``lgp_chol_factor_dist``, ``csrc/dist.hip``); `factor_schedule` below
+states the same schedule over an abstract ``ops`` backend so that ownership, ordering and the panel slots can be exercised
+with world_size > 1 on CPU (gloo + numpy backend in ``tests/test_dist_gloo.py``).
 """
 
 import ctypes
@@ -25,6 +25,16 @@ import numpy
 
 from . import _lib
 from ._device import Context, DeviceArray
+
+
+def kernel_dtype(kernel, x):
+    """ dtype of the kernel's Gram blocks on the points x (float32 kernels evaluate in float32, `_kernels.py`) """
+    return numpy.dtype(kernel._result_dtype(x[:0], x[:0]))
+
+
+def _astype(A, dtype):
+    from ._GP import _astype_dev
+    return _astype_dev(A, dtype)
 
 
 class Layout:
@@ -129,130 +139,39 @@ def forward_solve_schedule(layout, ops):
                 ops.accumulate(b)
 
 
-class DeviceOps:
-    """ product backend: C-ABI kernels on the local GPU, RCCL broadcasts on the auxiliary stream """
-
-    def __init__(self, ctx, layout, Lloc, dblk, nx=0):
-        """ nx: extra rows below the n matrix rows of ``Lloc`` (right-hand sides carried through the factorisation:
-        they are "rows below" for every panel, like in lgp_chol_factor_rhs) """
-        self.ctx, self.layout, self.Lloc, self.dblk, self.nx = ctx, layout, Lloc, dblk, int(nx)
-        self.lib = _lib.load()
-        n, nb = layout.n, layout.nb
-        self.P = [DeviceArray.empty((n + self.nx, nb), numpy.float64, ctx) for _ in range(2)]
-        self.ev = {k: [ctx.event(), ctx.event()] for k in ('ready', 'recv', 'free')}
-        self.dblk_per_block = self.lib.lgp_chol_dblk_size(nb)
-
-    # -- streams
-    def _compute(self):
-        _lib.check(self.lib.lgp_select_stream(self.ctx.handle, 0))
-
-    def _comm(self):
-        _lib.check(self.lib.lgp_select_stream(self.ctx.handle, 1))
-
-    def _mark(self, kind, slot):
-        self.ctx.record(self.ev[kind][slot])
-
-    def _wait(self, kind, slot):
-        _lib.check(self.lib.lgp_stream_wait_event(self.ctx.handle, self.ev[kind][slot]))
-
-    def compute_mark_ready(self, slot):
-        self._compute(); self._mark('ready', slot)
-
-    def comm_wait_ready(self, slot):
-        self._comm(); self._wait('ready', slot); self._compute()
-
-    def comm_mark_received(self, slot):
-        self._comm(); self._mark('recv', slot); self._compute()
-
-    def compute_wait_received(self, slot):
-        self._compute(); self._wait('recv', slot)
-
-    def compute_mark_free(self, slot):
-        self._compute(); self._mark('free', slot)
-
-    def comm_wait_free(self, slot):
-        self._comm(); self._wait('free', slot); self._compute()
-
-    # -- data
-    def _block(self, b):
-        """ device view of the locally owned block column b from its diagonal down: rows(b) x width(b) """
-        L = self.layout
-        lb = L.local_index(b)
-        return self.Lloc.block(L.col0(b), L.n + self.nx, lb * L.nb, lb * L.nb + L.width(b))
-
-    def panel_factor(self, b):
-        L = self.layout
-        blk = self._block(b)
-        w = self.dblk.rows(L.local_index(b) * self.dblk_per_block, (L.local_index(b) + 1) * self.dblk_per_block)
-        _lib.check(self.lib.lgp_panel_factor_f64(self.ctx.handle, L.rows(b) + self.nx, L.width(b), blk.ptr, blk.ld, w.ptr, L.col0(b)), 'lgp_panel_factor')
-
-    def pack_panel(self, b, slot):
-        L = self.layout
-        blk = self._block(b)
-        dst = self.P[slot]
-        _lib.check(self.lib.lgp_copy2d(self.ctx.handle, dst.ptr, L.width(b), blk.ptr, blk.ld, L.rows(b) + self.nx, L.width(b), 8), 'lgp_copy2d')
-
-    def bcast_panel(self, b, slot):
-        L = self.layout
-        self._comm()
-        _lib.check(self.lib.lgp_bcast(self.ctx.handle, self.P[slot].ptr, (L.rows(b) + self.nx) * L.width(b) * 8, L.owner(b)), 'lgp_bcast')
-        self._compute()
-
-    def update(self, c, b, slot):
-        L = self.layout
-        kb = L.width(b)
-        off = L.col0(c) - L.col0(b)                 # first row of block c inside panel b
-        A = self.P[slot].ptr + off * kb * 8
-        blk = self._block(c)
-        _lib.check(self.lib.lgp_update_nt_f64(self.ctx.handle, L.rows(c) + self.nx, L.width(c), kb, A, kb, A, kb, blk.ptr, blk.ld, 1), 'lgp_update_nt')
-
-    def update_rest(self, cols, b, slot):
-        """ every remaining owned block column with panel b in one "staircase" launch (lgp_update_nt_cyclic_f64) """
-        L = self.layout
-        kb = L.width(b)
-        lb0 = L.local_index(cols[0])
-        assert [L.local_index(c) for c in cols] == list(range(lb0, lb0 + len(cols)))
-        g0 = L.col0(cols[0])
-        A = self.P[slot].ptr + (g0 - L.col0(b)) * kb * 8
-        ncols = sum(L.width(c) for c in cols)
-        C = self.Lloc.block(g0, L.n + self.nx, lb0 * L.nb, lb0 * L.nb + ncols)
-        if L.nb % 128:
-            for c in cols:                              # block widths that are not whole tiles: one launch per block column
-                self.update(c, b, slot)
-            return
-        _lib.check(self.lib.lgp_update_nt_cyclic_f64(self.ctx.handle, L.n - g0 + self.nx, ncols, kb, A, kb, C.ptr, C.ld, L.nb, L.nranks), 'lgp_update_nt_cyclic')
-
-    def finish(self):
-        self._compute()
-        self.ctx.sync()
-
-
 class DistributedChol:
     """
-    Regularised Cholesky of a kernel Gram matrix sharded by block columns over the ranks of ``ctx``'s
-    communicator: the distributed counterpart of ``Chol(kernel.gram(x, x) + noise * I)`` for kernels with unit
-    diagonal (ExpQuad, Maternp, BART correlations), i.e. ``diag_scale_pow2`` is the identity
-    (``_linalg/_decomp.py:356-361``); the jitter follows ``_decomp.py:245-255,349-354`` with the Gershgorin
-    bound reduced (max) over the ranks.
+    Regularised Cholesky of a kernel Gram matrix sharded by block columns over the ranks of ``ctx``'s communicator: the
+    distributed counterpart of ``Chol(kernel.gram(x, x) + noise * I)`` (``_linalg/_decomp.py:380-393``) for any kernel
+    object of this package (isotropic or BART, with scalar ``*`` / ``+``).  The power-of-two diagonal scaling, the
+    Gershgorin jitter (bound reduced with a max over the ranks) and the final rescaling follow the reference step by
+    step; the factorisation itself is ONE library call per rank (``lgp_chol_factor_dist``).
     """
+
+    PANEL_PAD = 16          # padding (doubles) of the packed panels' leading dimension, see csrc/dist.hip
 
     def __init__(self, kernel, x, *, noise=0., epsrel='auto', epsabs=0, nb=1024, ctx=None, carry=None):
         """ ``carry=(xs, y)`` (optional): test points and data whose forward solve ``L^-1 [K(x, xs) | y]`` rides through the
         factorisation as extra rows of every rank's block columns (as in ``lgp_chol_factor_rhs``); `posterior` then
         needs no solve and no per-panel all-reduce """
-        from ._kernels import _Isotropic, _leaf_columns
-        if not isinstance(kernel, _Isotropic):
-            raise NotImplementedError('the distributed Gram build covers the isotropic kernels')
-        if kernel._outops:
-            raise NotImplementedError('distributed path: kernels with unit diagonal only (no output algops)')
         self.ctx = ctx or Context.default()
         lib = self.lib = _lib.load()
-        cols = _leaf_columns(numpy.asarray(x).reshape(-1))
-        n = len(cols[0])
+        import os, time
+        timing = os.environ.get('LGP_DIST_TIMING') == '1'
+        self.phases = {}
+
+        def mark(name, t0=[None]):
+            if timing:
+                self.ctx.sync()
+                now = time.perf_counter()
+                if t0[0] is not None:
+                    self.phases[name] = (now - t0[0]) * 1e3
+                t0[0] = now
+        mark('start')
+        x = numpy.asarray(x).reshape(-1)
+        n = len(x)
         self.layout = L = Layout(n, nb, self.ctx.rank, self.ctx.nranks)
         self.n = n
-        xd = DeviceArray.from_host(numpy.stack([numpy.asarray(c, float) for c in cols]), ctx=self.ctx)   # replicated covariates: 8 d N bytes
-        d = len(cols)
         self._carry = None
         nx = 0
         if carry is not None:
@@ -265,61 +184,85 @@ class DistributedChol:
             self._carry = (xs_c, y_c, mq)
         self.nx = nx
         self.Lloc = DeviceArray.zeros((n + nx, L.local_cols), numpy.float64, self.ctx)
-        self.dblk = DeviceArray.empty((max(L.nlocal, 1) * lib.lgp_chol_dblk_size(nb),), numpy.float64, self.ctx)
+        self.dblk_per_block = lib.lgp_chol_dblk_size(nb)
+        self.dblk = DeviceArray.empty((max(L.nlocal, 1) * self.dblk_per_block,), numpy.float64, self.ctx)
         F = ctypes.c_double
-        # ---- Gram build: every rank evaluates its own block columns in place, no communication
+        h = self.ctx.handle
+        # ---- Gram build: every rank evaluates its own block columns in place, no communication; the points (replicated:
+        # 8 d N bytes) go to the device once
+        kdt = kernel_dtype(kernel, x)
+        xdev = kernel.prepare(x, ctx=self.ctx)
+        xsdev = kernel.prepare(self._carry[0], ctx=self.ctx, dtype=xdev.dtype) if self._carry is not None else None
+        ydev = DeviceArray.from_host(self._carry[1].reshape(1, n), ctx=self.ctx) if self._carry is not None else None
         for b in L.owned():
             lb, w, c0 = L.local_index(b), L.width(b), L.col0(b)
             out = self.Lloc.block(0, n, lb * nb, lb * nb + w)
-            yb = xd.block(0, d, c0, c0 + w)
-            _lib.check(lib.lgp_gram_isotropic_f64(self.ctx.handle, kernel._kind, int(kernel._p), *kernel._par_args(F), d, xd.ptr, xd.ld, n, yb.ptr, yb.ld, w,
-                                                  int(kernel._loc is not None), F(kernel._loc or 0), int(kernel._scale is not None), F(kernel._scale or 1),
-                                                  0, None, None, 0, out.ptr, out.ld), 'lgp_gram_isotropic')
+            blk = kernel.gram(xdev, xdev.sub(c0, c0 + w), ctx=self.ctx, out=out if out.dtype == kdt else None)
+            if blk is not out:                           # float32 kernels: promoted into the float64 factor storage
+                out.assign(_astype(blk, numpy.float64))
             if noise:
                 diag = self.Lloc.block(c0, c0 + w, lb * nb, lb * nb + w)
-                _lib.check(lib.lgp_add_diag_f64(self.ctx.handle, w, diag.ptr, diag.ld, None, F(noise)), 'lgp_add_diag')
+                _lib.check(lib.lgp_add_diag_f64(h, w, diag.ptr, diag.ld, None, F(noise)), 'lgp_add_diag')
             if self._carry is not None:                  # K(xs, x[block]) and y[block] below the matrix rows
                 xs_c, y_c, mq = self._carry
-                xsd = DeviceArray.from_host(numpy.stack([numpy.asarray(c_, float) for c_ in _leaf_columns(xs_c)]), ctx=self.ctx)
                 rows_k = self.Lloc.block(n, n + mq - 1, lb * nb, lb * nb + w)
-                _lib.check(lib.lgp_gram_isotropic_f64(self.ctx.handle, kernel._kind, int(kernel._p), *kernel._par_args(F), d, xsd.ptr, xsd.ld, mq - 1,
-                                                      yb.ptr, yb.ld, w, int(kernel._loc is not None), F(kernel._loc or 0),
-                                                      int(kernel._scale is not None), F(kernel._scale or 1), 0, None, None, 0, rows_k.ptr, rows_k.ld),
-                           'lgp_gram_isotropic')
-                self.Lloc.block(n + mq - 1, n + mq, lb * nb, lb * nb + w).assign(DeviceArray.from_host(y_c[c0:c0 + w].reshape(1, w), ctx=self.ctx))
-        if 1 + noise > 2 or 1 + noise < 0.5:
-            raise NotImplementedError('distributed path assumes diag_scale_pow2 == 1 (diagonal in [0.5, 2))')
-        # ---- jitter: eps = epsrel * max_i sum_j |K_ij| + epsabs, column sums of the owned block columns
+                kb = kernel.gram(xsdev, xdev.sub(c0, c0 + w), ctx=self.ctx, out=rows_k if rows_k.dtype == kdt else None)
+                if kb is not rows_k:
+                    rows_k.assign(_astype(kb, numpy.float64))
+                self.Lloc.block(n + mq - 1, n + mq, lb * nb, lb * nb + w).assign(ydev.block(0, 1, c0, c0 + w))
+        mark('gram')
+        # ---- s = diag_scale_pow2(K) (_decomp.py:356-361): own columns, then shared with one all-reduce
+        svec = DeviceArray.zeros((n,), numpy.float64, self.ctx)
+        for b in L.owned():
+            lb, w, c0 = L.local_index(b), L.width(b), L.col0(b)
+            diag = self.Lloc.block(c0, c0 + w, lb * nb, lb * nb + w)
+            _lib.check(lib.lgp_diag_scale_pow2_f64(h, w, diag.ptr, diag.ld, svec.ptr + c0 * 8), 'lgp_diag_scale_pow2')
+        _lib.check(lib.lgp_allreduce_sum_f64(h, svec.ptr, n), 'lgp_allreduce_sum')
+        self.ctx.sync()
+        s_host = svec.to_host()
+        self._unit = bool(numpy.all(s_host == 1))
+        if not self._unit:                               # K~ = K / s / s[:, None] (:385); carried rows: columns / s
+            for b in L.owned():
+                lb, w, c0 = L.local_index(b), L.width(b), L.col0(b)
+                blk = self.Lloc.block(0, n, lb * nb, lb * nb + w)
+                _lib.check(lib.lgp_scale_rows_cols_f64(h, n, w, blk.ptr, blk.ld, svec.ptr, svec.ptr + c0 * 8, 1), 'lgp_scale_rows_cols')
+                if nx:
+                    ext = self.Lloc.block(n, n + nx, lb * nb, lb * nb + w)
+                    _lib.check(lib.lgp_scale_rows_cols_f64(h, nx, w, ext.ptr, ext.ld, None, svec.ptr + c0 * 8, 1), 'lgp_scale_rows_cols')
+        # ---- jitter: eps = epsrel * max_i sum_j |K~_ij| + epsabs (:245-255,349-354); column sums of the owned block columns
+        # (= row sums of the symmetric matrix), maximum on the device, one scalar all-reduce
         meps = numpy.finfo(float).eps
         if isinstance(epsrel, str):
             epsrel = n * meps
         if isinstance(epsabs, str):
             epsabs = meps
         sums = DeviceArray.zeros((L.local_cols,), numpy.float64, self.ctx)
-        gmax = 0.
         for b in L.owned():
             lb, w = L.local_index(b), L.width(b)
             blk = self.Lloc.block(0, n, lb * nb, lb * nb + w)          # matrix rows only (not the carried rows)
-            _lib.check(lib.lgp_colabssum_f64(self.ctx.handle, n, w, blk.ptr, blk.ld, sums.ptr + lb * nb * 8), 'lgp_colabssum')
+            _lib.check(lib.lgp_colabssum_f64(h, n, w, blk.ptr, blk.ld, sums.ptr + lb * nb * 8), 'lgp_colabssum')
+        red = DeviceArray.zeros((1,), numpy.float64, self.ctx)
         if L.nlocal:
-            gmax = float(numpy.max(sums.to_host()[:L.nlocal * nb]))
-        red = DeviceArray.from_host(numpy.array([gmax]), ctx=self.ctx)
-        _lib.check(lib.lgp_allreduce_max_f64(self.ctx.handle, red.ptr, 1), 'lgp_allreduce_max')
+            _lib.check(lib.lgp_max_f64(h, L.nlocal * nb, sums.ptr, red.ptr), 'lgp_max')
+        _lib.check(lib.lgp_allreduce_max_f64(h, red.ptr, 1), 'lgp_allreduce_max')
         self.ctx.sync()
-        self.eps = epsrel * float(red.to_host()[0]) + epsabs
+        eps_scaled = epsrel * float(red.to_host()[0]) + epsabs
+        self.eps = eps_scaled * float(numpy.min(s_host * s_host))     # :393
         for b in L.owned():
             lb, w, c0 = L.local_index(b), L.width(b), L.col0(b)
             diag = self.Lloc.block(c0, c0 + w, lb * nb, lb * nb + w)
-            _lib.check(lib.lgp_add_diag_f64(self.ctx.handle, w, diag.ptr, diag.ld, None, F(self.eps)), 'lgp_add_diag')
-        # ---- factorisation
-        self.ops = DeviceOps(self.ctx, L, self.Lloc, self.dblk, nx)
-        info0 = ctypes.c_int()
-        _lib.check(lib.lgp_get_info(self.ctx.handle, ctypes.byref(info0)))       # reset
-        factor_schedule(L, self.ops)
+            _lib.check(lib.lgp_add_diag_f64(h, w, diag.ptr, diag.ld, None, F(eps_scaled)), 'lgp_add_diag')
+        mark('regularisation')
+        # ---- factorisation: the whole look-ahead schedule inside the library
+        ldp = nb + self.PANEL_PAD
+        self._panels = DeviceArray.empty((2 * (n + nx) * ldp,), numpy.float64, self.ctx)
         info = ctypes.c_int()
-        _lib.check(lib.lgp_get_info(self.ctx.handle, ctypes.byref(info)))
+        _lib.check(lib.lgp_chol_factor_dist_f64(h, n, nb, nx, self.Lloc.ptr, self.Lloc.ld, self.dblk.ptr, self._panels.ptr, ldp,
+                                                None if self._unit else svec.ptr, ctypes.byref(info)), 'lgp_chol_factor_dist')
+        self._panels = None
+        mark('factorisation')
         bad = DeviceArray.from_host(numpy.array([float(info.value != 0)]), ctx=self.ctx)
-        _lib.check(lib.lgp_allreduce_max_f64(self.ctx.handle, bad.ptr, 1))
+        _lib.check(lib.lgp_allreduce_max_f64(h, bad.ptr, 1))
         self.ctx.sync()
         if bad.to_host()[0] != 0:
             raise numpy.linalg.LinAlgError('cholesky decomposition not finite, probably matrix not pos def numerically')
@@ -404,7 +347,7 @@ class DistributedChol:
                 Sb = S.block(c0, c0 + w, 0, k)
                 _lib.check(lib.lgp_axpby_f64(ctx.handle, w, k, ctypes.c_double(1.), Wb.ptr, Wb.ld, ctypes.c_double(-1.), Sb.ptr, Sb.ld, Wb.ptr, Wb.ld))
                 D = dist.Lloc.block(c0, c0 + w, lb * nb, lb * nb + w)
-                wsp = dist.dblk.rows(lb * dist.ops.dblk_per_block, (lb + 1) * dist.ops.dblk_per_block)
+                wsp = dist.dblk.rows(lb * dist.dblk_per_block, (lb + 1) * dist.dblk_per_block)
                 _lib.check(lib.lgp_trsm_f64(ctx.handle, w, D.ptr, D.ld, wsp.ptr, 0, Wb.ptr, Wb.ld, k), 'lgp_trsm')
 
             def accumulate(self, b):

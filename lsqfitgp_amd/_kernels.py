@@ -81,6 +81,23 @@ def _is_outer(xshape, yshape):
     return (xa[0] if xa else None), (ya[0] if ya else None), nd
 
 
+class DevicePoints:
+    """ a point set already resident on the device in the layout a kernel's Gram entry point reads (``kernel.prepare``):
+    columnar coordinates (d x n) for the isotropic kernels, bin indices (n x p) for BART.  ``sub(i0, i1)`` is a view of
+    points i0..i1.  Lets callers that evaluate many blocks over the same points (the sharded Gram build) upload them once. """
+
+    def __init__(self, kind, array, dtype, ctx):
+        self.kind, self.array, self.dtype, self.ctx = kind, array, dtype, ctx
+
+    def __len__(self):
+        return self.array.shape[1] if self.kind == 'coords' else self.array.shape[0]
+
+    def sub(self, i0, i1):
+        if self.kind == 'coords':
+            return DevicePoints(self.kind, self.array.block(0, self.array.shape[0], i0, i1), self.dtype, self.ctx)
+        return DevicePoints(self.kind, self.array.block(i0, i1, 0, self.array.shape[1]), self.dtype, self.ctx)
+
+
 class Kernel:
     """ base class: input transformation, output algops, call contract """
 
@@ -163,7 +180,22 @@ class _Isotropic(Kernel):
     def _result_dtype(self, x, y):
         return _float_dtype_of(_leaf_columns(x.reshape(-1)[:0]) + _leaf_columns(y.reshape(-1)[:0]), self._scale, self._loc)
 
+    def prepare(self, xs, *, ctx=None, dtype=None):
+        """ upload a flat point set once: `DevicePoints` accepted by `gram` in place of the host array """
+        ctx = ctx or Context.default()
+        xc = _leaf_columns(numpy.asarray(xs))
+        dtype = dtype or _float_dtype_of(xc, self._scale, self._loc)
+        return DevicePoints('coords', DeviceArray.from_host(numpy.stack([numpy.asarray(c, dtype) for c in xc]), ctx=ctx), numpy.dtype(dtype), ctx)
+
     def _prepare(self, xs, ys, ctx):
+        if isinstance(xs, DevicePoints) or isinstance(ys, DevicePoints):
+            if not (isinstance(xs, DevicePoints) and isinstance(ys, DevicePoints)):
+                dt = (xs if isinstance(xs, DevicePoints) else ys).dtype
+                xs = xs if isinstance(xs, DevicePoints) else self.prepare(xs, ctx=ctx, dtype=dt)
+                ys = ys if isinstance(ys, DevicePoints) else self.prepare(ys, ctx=ctx, dtype=dt)
+            if xs.dtype != ys.dtype or xs.array.shape[0] != ys.array.shape[0]:
+                raise ValueError('device point sets of different dtype or field count')
+            return xs.array, ys.array, xs.dtype, xs.ctx, xs.array.shape[0]
         xc = _leaf_columns(numpy.asarray(xs))
         yc = _leaf_columns(numpy.asarray(ys))
         if len(xc) != len(yc):
@@ -568,18 +600,26 @@ class BART(Kernel):
             first = False
         return out
 
+    def prepare(self, xs, *, ctx=None, dtype=None):
+        """ bin indices of a flat point set, uploaded once: `DevicePoints` accepted by `gram` """
+        ctx = ctx or Context.default()
+        return DevicePoints('indices', DeviceArray.from_host(self._to_indices(xs), ctx=ctx), self._flt, ctx)
+
     def gram(self, xs, ys, *, ctx=None, out=None):
         ctx = ctx or Context.default()
-        ix = self._to_indices(xs)
-        iy = ix if ys is xs else self._to_indices(ys)
-        n, m, p = ix.shape[0], iy.shape[0], ix.shape[1]
+        same = ys is xs
+        ixd = xs.array if isinstance(xs, DevicePoints) else DeviceArray.from_host(self._to_indices(xs), ctx=ctx)
+        iyd = ixd if same else (ys.array if isinstance(ys, DevicePoints) else DeviceArray.from_host(self._to_indices(ys), ctx=ctx))
+        if not (ixd.contiguous and iyd.contiguous):
+            raise ValueError('index arrays must be contiguous row blocks')
+        n, m, p = ixd.shape[0], iyd.shape[0], ixd.shape[1]
+        if p != len(self._splits[0]):
+            raise ValueError(f'splitting grid is for {len(self._splits[0])} dimensions, found {p}')
         if out is None:
             out = DeviceArray.empty((n, m), self._flt, ctx)
         assert out.shape == (n, m) and out.dtype == self._flt
         if n == 0 or m == 0:
             return out
-        ixd = DeviceArray.from_host(ix, ctx=ctx)
-        iyd = ixd if iy is ix else DeviceArray.from_host(iy, ctx=ctx)
         return self._run('lgp_gram_bart', ctx, p, ixd, iyd, n, m, self._splits[0], None, out, out.ld)
 
     def gram_jvp(self, xs, ys, dpnt=None, *, ctx=None):

@@ -19,7 +19,7 @@ from .. import copula
 from .. import _fastraniter
 from .._device import Context, DeviceArray
 from .._fit import empbayes_fit
-from .._GP import GP
+from .._GP import GP, diag
 from .._kernels import BART
 from .._linalg import Chol
 from .._uncertain import UVal, sqrt as usqrt
@@ -88,7 +88,7 @@ class bart:
         def makegp(hp, *, i_train, weights, splits, **_):
             gp = (GP(makekernel(hp, splits), checkpos=False, checksym=False, solver='chol', ctx=self._ctx)
                   .addx(i_train, 'trainmean')
-                  .addcov(numpy.diag(hp['sigma2'] / weights), 'trainnoise'))
+                  .addcov(diag(hp['sigma2'] / weights), 'trainnoise'))      # (= jnp.diag(...) of the reference, built on the device)
             pieces = {'trainmean': 1, 'trainnoise': 1}
             if 'mean' not in hp:
                 gp = gp.addcov(k_sigma_mu ** 2, 'mean')
@@ -180,7 +180,7 @@ class bart:
                 assert weights.shape == i_test.shape
             else:
                 weights = numpy.ones(i_test.shape)
-            gp = gp.addx(i_test, 'testmean').addcov(numpy.diag(hp['sigma2'] / weights), 'testnoise')
+            gp = gp.addx(i_test, 'testmean').addcov(diag(hp['sigma2'] / weights), 'testnoise')
             pieces = {'testmean': 1, 'testnoise': 1}
             if 'mean' not in hp:
                 pieces.update({'mean': 1})

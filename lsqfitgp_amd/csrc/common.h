@@ -109,6 +109,8 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx 
 template <typename T>
 int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t ldl, const T *dblk, int trans, T *B, size_t ldb, size_t nrhs);
 
+int lgp_extract_dblk_public(lgp_ctx *ctx, hipStream_t stream, const double *L, size_t ldl, size_t n, double *dblk);   // potrf.hip
+
 // ---- reductions (elementwise.hip) -------------------------------------------------------------
 template <typename T>
 int lgp_colsumsq_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t cols, const T *A, size_t lda, T *out);

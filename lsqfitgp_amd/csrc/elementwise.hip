@@ -213,6 +213,7 @@ inline unsigned grid_for(size_t rows, size_t cols) {
   return (unsigned)(nb < 1048576 ? (nb ? nb : 1) : 1048576);
 }
 
+
 template <typename T>
 int axpby_impl(lgp_ctx *ctx, size_t rows, size_t cols, T alpha, const T *A, size_t lda, T beta, const T *B, size_t ldb, T *C, size_t ldc) {
   LGP_REQUIRE(ctx != nullptr, "null context");
@@ -331,6 +332,8 @@ int dot_impl(lgp_ctx *ctx, size_t n, const T *x, const T *y, T *hout) {
 }
 
 }  // namespace
+
+static unsigned grid_for_public(size_t rows, size_t cols) { return grid_for(rows, cols); }
 
 template <typename T>
 int lgp_colsumsq_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t cols, const T *A, size_t lda, T *out) {
@@ -459,3 +462,86 @@ int lgp_set_diag_device(lgp_ctx *ctx, hipStream_t stream, size_t n, T *A, size_t
 }
 template int lgp_set_diag_device<double>(lgp_ctx *, hipStream_t, size_t, double *, size_t, double);
 template int lgp_set_diag_device<float>(lgp_ctx *, hipStream_t, size_t, float *, size_t, float);
+
+// A_ij <- A_ij (/ or *) row_i (/ or *) col_j: the symmetric power-of-two scaling K / s / s[:, None] of a locally owned block column
+// and the final L * s[:, None] of the distributed factorisation (_decomp.py:385,392); drow / dcol may be NULL
+namespace {
+__global__ void __launch_bounds__(256) scale_rc_kernel(size_t rows, size_t cols, double *A, size_t lda, const double *row, const double *col, int divide) {
+  const size_t nbx = (cols + 255) / 256;
+  for (size_t blk = blockIdx.x; blk < rows * nbx; blk += gridDim.x) {
+    const size_t i = blk / nbx, j = (blk % nbx) * 256 + threadIdx.x;
+    if (j < cols) {
+      double v = A[i * lda + j];
+      if (divide) {
+        if (col) v = v / col[j];
+        if (row) v = v / row[i];
+      } else {
+        if (col) v = v * col[j];
+        if (row) v = v * row[i];
+      }
+      A[i * lda + j] = v;
+    }
+  }
+}
+// s_j = 2^rint(log2(d_j) / 2) where d_j != 0 else 1 from the diagonal elements d (_decomp.py:356-361)
+__global__ void diag_pow2_kernel(size_t n, const double *A, size_t lda, double *s) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const double d = A[j * lda + j];
+  s[j] = d != 0.0 ? exp2(rint(0.5 * log2(d))) : 1.0;
+}
+}  // namespace
+
+extern "C" int lgp_scale_rows_cols_f64(lgp_ctx *ctx, size_t rows, size_t cols, double *dA, size_t lda, const double *drow, const double *dcol, int divide) {
+  LGP_REQUIRE(ctx != nullptr && (dA != nullptr || rows * cols == 0), "null pointer");
+  if (rows == 0 || cols == 0) return LGP_OK;
+  LGP_REQUIRE(lda >= cols, "lda < cols");
+  DeviceGuard dg(ctx->device);
+  hipLaunchKernelGGL(scale_rc_kernel, dim3(grid_for_public(rows, cols)), dim3(256), 0, ctx->stream, rows, cols, dA, lda, drow, dcol, divide);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
+extern "C" int lgp_diag_scale_pow2_f64(lgp_ctx *ctx, size_t n, const double *dA, size_t lda, double *ds) {
+  LGP_REQUIRE(ctx != nullptr && dA != nullptr && ds != nullptr, "null pointer");
+  if (n == 0) return LGP_OK;
+  DeviceGuard dg(ctx->device);
+  hipLaunchKernelGGL(diag_pow2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, dA, lda, ds);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
+namespace {
+__global__ void __launch_bounds__(1024) max_kernel(size_t n, const double *x, double *out) {
+  __shared__ double sh[16];
+  __shared__ int shnan[16];
+  double m = -INFINITY;
+  int nan = 0;
+  for (size_t i = threadIdx.x; i < n; i += 1024) {
+    const double v = x[i];
+    nan |= (v != v);
+    m = v > m ? v : m;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(m, off, 64);
+    m = o > m ? o : m;
+    nan |= __shfl_down(nan, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = m; shnan[threadIdx.x >> 6] = nan; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = -INFINITY;
+    int anynan = 0;
+    for (int w = 0; w < 16; ++w) { t = sh[w] > t ? sh[w] : t; anynan |= shnan[w]; }
+    out[0] = anynan ? (double)NAN : t;
+  }
+}
+}  // namespace
+extern "C" int lgp_max_f64(lgp_ctx *ctx, size_t n, const double *dx, double *dout) {
+  LGP_REQUIRE(ctx != nullptr && dout != nullptr && (dx != nullptr || n == 0), "null pointer");
+  DeviceGuard dg(ctx->device);
+  hipLaunchKernelGGL(max_kernel, dim3(1), dim3(1024), 0, ctx->stream, n, dx, dout);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}

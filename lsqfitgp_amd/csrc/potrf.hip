@@ -849,3 +849,7 @@ template int lgp_potrf_impl<double>(lgp_ctx *, size_t, double *, size_t, double 
 template int lgp_potrf_impl<float>(lgp_ctx *, size_t, float *, size_t, float *, size_t);
 template int lgp_trsm_impl<double>(lgp_ctx *, hipStream_t, size_t, const double *, size_t, const double *, int, double *, size_t, size_t);
 template int lgp_trsm_impl<float>(lgp_ctx *, hipStream_t, size_t, const float *, size_t, const float *, int, float *, size_t, size_t);
+
+int lgp_extract_dblk_public(lgp_ctx *ctx, hipStream_t stream, const double *L, size_t ldl, size_t n, double *dblk) {
+  return lgp_extract_dblk<double>(ctx, stream, L, ldl, n, dblk);
+}

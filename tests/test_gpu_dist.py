@@ -119,8 +119,8 @@ def test_distributed_posterior_single_rank(lgp, rng):
     assert abs(-mlnd - lo) <= 1e-8 * abs(lo) + 1e-6
 
 
-@pytest.mark.parametrize('n,nb,world,carry', [(1500, 256, 2, 0), (2600, 1024, 2, 1), (2900, 256, 3, 1)])
-def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry):
+@pytest.mark.parametrize('n,nb,world,carry,amp', [(1500, 256, 2, 0, 1), (2600, 1024, 2, 1, 1), (2900, 256, 3, 1, 1), (1700, 256, 2, 1, 37)])
+def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry, amp):
     """ world size 2 and 3 on the device: real kernels, real stream/event choreography of the panel look-ahead, panels
     exchanged through the host-callback transport; factor, posterior and likelihood against the oracle """
     import os
@@ -133,7 +133,7 @@ def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry):
     m = 37
     # separate interpreters (not torch.multiprocessing: torch must not be loaded into this process next to the library)
     script = os.path.join(os.path.dirname(__file__), 'two_rank_worker.py')
-    env = dict(os.environ, LGP_TEST_CARRY=str(carry))        # carry = 1: [Kxxs | y] rides through the factorisation
+    env = dict(os.environ, LGP_TEST_CARRY=str(carry), LGP_TEST_AMP=str(amp))        # carry = 1: [Kxxs | y] rides through the factorisation
     procs = [subprocess.Popen([sys.executable, script, str(rank), str(world), str(port), str(n), str(nb), str(m), str(tmp_path)],
                               cwd=os.path.dirname(os.path.dirname(__file__)), env=env) for rank in range(world)]
     for p in procs:
@@ -142,10 +142,10 @@ def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry):
     x = rng.uniform(0, n / 16, n)
     xs = rng.uniform(0, n / 16, m)
     y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
-    K = oracle.ExpQuad()(x[:, None], x[None, :]) + 0.01 * np.eye(n)
+    K = amp * (oracle.ExpQuad()(x[:, None], x[None, :]) + 0.01 * np.eye(n))
     o = oracle.Chol(K)
-    Kxs = oracle.ExpQuad()(x[:, None], xs[None, :])
-    Kss = oracle.ExpQuad()(xs[:, None], xs[None, :])
+    Kxs = amp * oracle.ExpQuad()(x[:, None], xs[None, :])
+    Kss = amp * oracle.ExpQuad()(xs[:, None], xs[None, :])
     mean_o = o.pinv_bilinear(Kxs, y)
     cov_o = Kss - o.ginv_quad(Kxs)
     mlnd_o = o.minus_log_normal_density(y, value=True)[0]
@@ -224,3 +224,39 @@ def test_sharded_path_two_ranks_large(lgp, tmp_path):
             util.assert_allclose(r[f'dg{b}'], diag1[b * nb:(b + 1) * nb], rtol=1e-11)
     assert len(seen) == n // nb
     util.assert_close_matrices(LZ, LZ1, rtol=1e-12)
+
+
+@pytest.mark.parametrize('nb', [256, 1024])
+def test_distributed_scaled_kernel_and_bart(lgp, nb, rng):
+    """ the sharded path is not restricted to unit-diagonal isotropic kernels: `kernel * c` (power-of-two diagonal scaling,
+    eps rescaled by min s^2, L = L~ s[:, None]) and the BART kernel, against the oracle's Chol of the same matrix """
+    from lsqfitgp_amd._dist import DistributedChol
+    n = 1500
+    x = rng.uniform(0, n / 16, n)
+    for amp, noise in ((37., 0.3), (0.003, 1e-5)):
+        d = DistributedChol(lgp.ExpQuad() * amp, x, noise=noise, nb=nb)
+        K = amp * oracle.ExpQuad()(x[:, None], x[None, :]) + noise * np.eye(n)
+        o = oracle.Chol(K)
+        util.assert_allclose(d.eps, o.eps, rtol=1e-13)
+        full = np.zeros((n, n))
+        for b, blk in d.local_factor().items():
+            c0 = d.layout.col0(b)
+            full[c0:, c0:c0 + blk.shape[1]] = blk
+        util.assert_close_matrices(full, o._L, rtol=1e-11)
+        util.assert_allclose(d.logdet(), np.sum(np.log(np.diag(o._L))), rtol=1e-10)
+    # BART (float64), unstructured integer-valued covariates
+    p = 4
+    X = rng.integers(0, 30, (700, p)).astype(float)
+    splits = oracle.BART.splits_from_coord(X)
+    from numpy.lib import recfunctions
+    Xs = recfunctions.unstructured_to_structured(X)
+    kd = lgp.BART(splits=splits, maxd=4, reset=2) * 2.5
+    ko = oracle.BART(splits=splits, maxd=4, reset=2) * 2.5
+    d = DistributedChol(kd, Xs, noise=0.1, nb=nb)
+    o = oracle.Chol(ko(Xs[:, None], Xs[None, :]) + 0.1 * np.eye(700))
+    util.assert_allclose(d.eps, o.eps, rtol=1e-12)
+    full = np.zeros((700, 700))
+    for b, blk in d.local_factor().items():
+        c0 = d.layout.col0(b)
+        full[c0:, c0:c0 + blk.shape[1]] = blk
+    util.assert_close_matrices(full, o._L, rtol=1e-10)

@@ -312,3 +312,29 @@ def test_checkpos_is_the_reference_eigenvalue_test(lgp, rng):
         ok = np.eye(n)
         ok[0, 0] = -1e-17
         lgp.GP().addcov(ok, 'm').prior('m', raw=True)
+
+
+def test_diagonal_blocks(lgp, rng):
+    """ ``lsqfitgp_amd.diag(v)`` stands for the dense ``numpy.diag(v)`` in addcov and givencov, bit for bit """
+    n = 300
+    x = rng.uniform(0, 20, n); xs = rng.uniform(0, 20, 17)
+    y = np.sin(x)
+    v = rng.uniform(0.01, 0.1, n)
+    out = []
+    for noise in (np.diag(v), lgp.diag(v)):
+        gp = (lgp.GP(lgp.ExpQuad()).addx(x, 'f').addx(xs, 't').addcov(noise, 'e').addtransf({'f': 1, 'e': 1}, 'y'))
+        m, c = gp.predfromdata({'y': y}, 't', raw=True)
+        out.append((m, c, gp.marginal_likelihood({'y': y})))
+        gp2 = lgp.GP(lgp.ExpQuad(), checkpos=False).addx(x, 'f').addx(xs, 't')
+        m2, c2 = gp2.predfromdata({'f': y}, 't', {('f', 'f'): noise}, raw=True)
+        out[-1] += (m2, c2, gp2.marginal_likelihood({'f': y}, {('f', 'f'): noise}))
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):
+        lgp.GP(lgp.ExpQuad()).addx(x, 'f').predfromdata({'f': y}, 'f', {('f', 'f'): lgp.diag(v[:-1])}, raw=True)
+    # an exactly zero givencov is no givencov (reference tests/GP/test_GP.py:652-660), dense or diagonal
+    g0 = lgp.GP(lgp.ExpQuad()).addx(x[:50], 'f').addx(xs, 't')
+    r0 = g0.predfromdata({'f': y[:50]}, 't', raw=True)
+    for z in (np.zeros((50, 50)), lgp.diag(np.zeros(50))):
+        r1 = g0.predfromdata({'f': y[:50]}, 't', {('f', 'f'): z}, raw=True)
+        np.testing.assert_array_equal(r0[0], r1[0]); np.testing.assert_array_equal(r0[1], r1[1])

@@ -36,8 +36,10 @@ def main(rank, world, port, n, nb, m, tmpdir):
     xs = rng.uniform(0, n / 16, m)
     y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
     carry = (xs, y) if os.environ.get('LGP_TEST_CARRY') == '1' else None
-    d = DistributedChol(lgp.ExpQuad(), x, noise=0.01, nb=nb, ctx=ctx, carry=carry)
-    mean, cov, mlnd = d.posterior(lgp.ExpQuad(), x, xs, y)
+    amp = float(os.environ.get('LGP_TEST_AMP', '1'))          # kernel * amp: exercises the power-of-two diagonal scaling across ranks
+    kern = lgp.ExpQuad() if amp == 1 else lgp.ExpQuad() * amp
+    d = DistributedChol(kern, x, noise=0.01 * amp, nb=nb, ctx=ctx, carry=carry)
+    mean, cov, mlnd = d.posterior(kern, x, xs, y)
     if os.environ.get('LGP_TEST_BIG') == '1':
         # large problem: instead of the factor itself, its action on fixed random vectors, summed / stacked by the parent:
         # L Z = sum over owned blocks L[:, blk] Z[blk];  (L^T Z)[blk] = L[:, blk]^T Z
