@@ -83,5 +83,27 @@ if tf:
 with open(os.path.join(dst, f'{tag}_{cfg}_pmc_traffic.json'), 'w') as f:
     json.dump(res, f, indent=1)
 print(json.dumps(res, indent=1))
+
+# pass 4: matrix-core utilisation of the trailing-update launches (own pass: SQ counters + kernel trace only)
+try:
+    names = ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CU_CYCLES', 'SQ_INSTS_MFMA', 'SQ_INSTS_VALU']
+    sums = {nm: sum(d[2] for d in trailing(counter('mfma', nm))) for nm in names}
+    mtrace = list(csv.DictReader(open(one('mfma/**/*kernel_trace.csv'))))
+    dur_ns = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in mtrace if is_trailing(r['Kernel_Name']))
+    nl = sum(1 for r in mtrace if is_trailing(r['Kernel_Name']))
+    util = {
+        'note': 'rocprofv3 --kernel-trace --pmc ' + ' '.join(names) + ' (1 step of bench.py %s), sums over the trailing-update launches (tag-1 gemm)' % cfg,
+        'launches': nl, 'duration_ms_sum': dur_ns / 1e6, **sums,
+        # an fp64 16x16x4 MFMA occupies its SIMD for 64 cycles (tools/f64_rate_probe.hip); 1024 SIMDs; the counter sums all SEs/XCDs
+        'mfma_pipe_busy_frac_from_insts': sums['SQ_INSTS_MFMA'] * 64 / (dur_ns * 1e-9 * 2.4e9 * 1024) if dur_ns else None,
+        'mfma_busy_cycles_per_mfma_inst': sums['SQ_VALU_MFMA_BUSY_CYCLES'] / sums['SQ_INSTS_MFMA'] if sums['SQ_INSTS_MFMA'] else None,
+        'mfma_busy_over_cu_busy': sums['SQ_VALU_MFMA_BUSY_CYCLES'] / sums['SQ_BUSY_CU_CYCLES'] if sums['SQ_BUSY_CU_CYCLES'] else None,
+        'valu_insts_per_mfma_inst': sums['SQ_INSTS_VALU'] / sums['SQ_INSTS_MFMA'] if sums['SQ_INSTS_MFMA'] else None,
+    }
+    with open(os.path.join(dst, f'{tag}_{cfg}_mfma_util.json'), 'w') as f:
+        json.dump(util, f, indent=1)
+    print(json.dumps(util, indent=1))
+except Exception as exc:
+    print('mfma utilisation pass not summarised:', repr(exc))
 for r in rows[:12]:
     print(r['Name'][:90], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'])
