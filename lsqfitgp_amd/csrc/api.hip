@@ -64,13 +64,14 @@ int lgp_ctx_create(int device, lgp_ctx **out) {
   } guard{c};
   c->device = device;
   c->cus = prop.multiProcessorCount;
-  if (const char *m = getenv("LGP_POTF2")) c->potf2_mode = strcmp(m, "valu") == 0 ? 1 : (strcmp(m, "mfma") == 0 ? 2 : 0);
+  if (const char *m = getenv("LGP_POTF2")) c->potf2_mode = strcmp(m, "valu") == 0 ? 1 : (strcmp(m, "mfma") == 0 ? 2 : (strcmp(m, "mfma1") == 0 ? 3 : 0));
   // stream2 carries the latency-bound panel factorisation of the look-ahead: highest priority, so that its
   // few workgroups are dispatched ahead of the queued trailing-update workgroups of the main stream
   int prio_lo = 0, prio_hi = 0;
   LGP_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   LGP_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo));
   LGP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi));
+  LGP_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi));
   LGP_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
   LGP_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
   LGP_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_info), sizeof(int)));
@@ -101,6 +102,8 @@ int lgp_ctx_destroy(lgp_ctx *c) {
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->panel_events) (void)hipEventDestroy(e);
+  if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
@@ -112,6 +115,7 @@ int lgp_sync(lgp_ctx *c) {
   DeviceGuard dg(c->device);
   LGP_HIP(hipStreamSynchronize(c->stream));
   LGP_HIP(hipStreamSynchronize(c->stream2));
+  LGP_HIP(hipStreamSynchronize(c->stream3));
   return LGP_OK;
 }
 

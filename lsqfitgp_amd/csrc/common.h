@@ -13,6 +13,8 @@ struct lgp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;       // main stream: all public entry points enqueue here
   hipStream_t stream2 = nullptr;      // look-ahead stream of the blocked factorisation
+  hipStream_t stream3 = nullptr;      // bulk stream of the panel factorisation (rows that the next diagonal block does not wait for)
+  std::vector<hipEvent_t> panel_events;   // per 128-block of a panel: potf2 done, look-ahead rows solved, bulk done
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   int *d_info = nullptr;              // pivot info word (0 = ok, else 1-based index), device
   void *d_scratch = nullptr;          // small reductions (>= 64 KiB)

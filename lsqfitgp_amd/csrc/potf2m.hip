@@ -253,10 +253,206 @@ potf2_mfma_kernel(double *A, long lda, int nb, double *dblk, int *info, long row
   LGP_PSTAMP(10);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same algorithm on FOUR waves (one workgroup), so that it fits where the chain runs: beside the trailing update every
+// SIMD holds two 224-register waves and a kernel that needs a whole register file (the one-wave kernel above) waits for a
+// SIMD to drain -- 0.58 ms on average in the N = 32768 profile.  Four waves of ~150 registers and 18 KB of LDS fit the slot
+// of ONE retiring trailing-update workgroup.
+//   * wave w owns block columns w and 7 - w of U (9 tiles): tA[j] = tile (j, w), j <= w; tB[j] = tile (j, 7 - w), j <= 7 - w;
+//   * block step s: the owner of the diagonal tile publishes it in LDS; EVERY wave runs the 16-pivot chain on its copy
+//     (redundantly: no hand-over inside the chain) and eliminates its own (at most two) tiles of block row s beside it;
+//     the eliminated tiles go to LDS; every wave updates its trailing tiles with A operands read from there.
+//   Two barriers per block step, 16 in all.
+constexpr int P4_ROWBUF = 8 * 4 * 64;   // block row s: tile of block column i, register r, lane  (doubles)
+
+template <int S>
+__device__ __forceinline__ void potf2m4_step(acc_t (&tA)[4], acc_t (&tB)[8], double (&rdn)[8], double *rowbuf, double *diagbuf, int w, int lane,
+                                             int n, int g, int nb, int *info, long row0) {
+  constexpr bool DIAG_IN_A = S <= 3;               // the diagonal tile (S, S) is tile S of block column S: column w = S or 7 - w = S
+  const int wd = DIAG_IN_A ? S : 7 - S;            // its owner
+  const bool hasA = S < w;                         // this wave owns a tile of block row S in its column A (right of the diagonal)
+  const bool hasB = S < 7 - w;                     // ... in its column B
+  // ---- 1. publish the diagonal tile
+  if (w == wd) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) diagbuf[r * 64 + lane] = DIAG_IN_A ? tA[S < 4 ? S : 0][r] : tB[S][r];
+  }
+  __syncthreads();
+  acc_t dt;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dt[r] = diagbuf[r * 64 + lane];
+  acc_t ta = hasA ? tA[S < 4 ? S : 0] : acc_t{0, 0, 0, 0};
+  acc_t tb = hasB ? tB[S] : acc_t{0, 0, 0, 0};
+  double dn = 1.0;
+  // ---- 2. the 16 pivots: diagonal tile copy + the wave's own tiles of the block row
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double w0 = dt[r], w1 = ta[r], w2 = tb[r];
+    double dg = 1.0;
+#pragma unroll 1
+    for (int g0 = 0; g0 < 4; ++g0) {
+      const int kk = 4 * r + g0;
+      const double d = readlane_d(w0, g0 * 16 + kk);
+      const int arow = (g0 * 16 + n) * 4, acol = (g0 * 16 + 4 * r + g) * 4;
+      const double cf = MmaD::bpermute(acol, w0);
+      const double rn0 = MmaD::bpermute(arow, w0), rn1 = MmaD::bpermute(arow, w1), rn2 = MmaD::bpermute(arow, w2);
+      const double rc = rcp_chain(d);
+      const double cfm = (g > g0) ? -cf : 0.0;
+      w0 = __builtin_fma(cfm * rn0, rc, w0);
+      const double cfs = cfm * rc;
+      w1 = __builtin_fma(cfs, rn1, w1);
+      w2 = __builtin_fma(cfs, rn2, w2);
+      dg = (g == g0) ? d : dg;
+      dn = (n == kk) ? d : dn;
+    }
+    const bool badv = !(dg > 0.0) || (dg + dg == dg);
+    const unsigned long long badm = __builtin_amdgcn_ballot_w64(badv);
+    if (badm != 0 && w == wd) {
+      const int gb = (__builtin_ctzll(badm) >> 4);
+      if (n == 0 && g == 0 && 16 * S + 4 * r + gb < nb) atomicCAS(info, 0, (int)(row0 + 16 * S + 4 * r + gb + 1));
+    }
+    const double sclv = rsqrt_d(badv ? (double)NAN : dg);
+    w0 *= sclv; w1 *= sclv; w2 *= sclv;
+    dt[r] = w0; ta[r] = w1; tb[r] = w2;
+    // the finished rows of the wave's own tiles -> LDS (A operands of everybody's trailing updates)
+    if (hasA) rowbuf[(w * 4 + r) * 64 + lane] = w1;
+    if (hasB) rowbuf[((7 - w) * 4 + r) * 64 + lane] = w2;
+    if (r < 3) {
+      const double am = (n > 4 * r + 3) ? -w0 : 0.0;
+      dt = MmaD::run(am, w0, dt);
+      ta = MmaD::run(am, w1, ta);
+      tb = MmaD::run(am, w2, tb);
+    }
+  }
+  rdn[S] = rsqrt_d(dn);
+  if (w == wd) {
+    if (DIAG_IN_A) tA[S < 4 ? S : 0] = dt; else tB[S] = dt;
+  }
+  if (hasA) tA[S < 4 ? S : 0] = ta;
+  if (hasB) tB[S] = tb;
+  __syncthreads();
+  // ---- 3. trailing tiles of the wave's two block columns: t(j, i) -= U_sj^T U_si, the A operand from LDS
+#pragma unroll
+  for (int j = S + 1; j < 8; ++j) {
+    const bool doA = hasA && j <= w, doB = hasB && j <= 7 - w;      // wave-uniform
+    if (!(doA || doB)) continue;
+    double neg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) neg[r] = -rowbuf[(j * 4 + r) * 64 + lane];
+    if (j < 4) {
+      if (doA) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tA[j < 4 ? j : 0] = MmaD::run(neg[r], ta[r], tA[j < 4 ? j : 0]);
+      }
+    }
+    if (doB) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tB[j] = MmaD::run(neg[r], tb[r], tB[j]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) potf2_mfma4_kernel(double *A, long lda, int nb, double *dblk, int *info, long row0) {
+  __shared__ double rowbuf[P4_ROWBUF];
+  __shared__ double diagbuf[4 * 64];
+  __builtin_amdgcn_s_setprio(LGP_CHAIN_PRIO);
+  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int cA = w, cB = 7 - w;
+  const __amdgpu_buffer_rsrc_t abuf = __builtin_amdgcn_make_buffer_rsrc(A, 0, 0x7fffff00, 0x00020000);
+  const int lbase = (int)(((long)n * lda + g) * 8), ldstep = (int)(16 * lda * 8);
+  acc_t tA[4], tB[8];
+  // tile (j, i)[r] <- A[16 i + n][16 j + 4 r + g] (lower triangle, transposed; identity padding beyond nb)
+  auto load_tile = [&](int j, int i, bool live) {
+    acc_t t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * i + n, col = 16 * j + 4 * r + g;
+      const bool in = live && row < nb && col <= row;
+      const double v = MmaD::load(abuf, in ? lbase + (16 * j + 4 * r) * 8 : 0x7ffffff0, i * ldstep);
+      t[r] = (!in && row == col) ? 1.0 : v;
+    }
+    return t;
+  };
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tA[j] = load_tile(j, cA, j <= cA);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) tB[j] = load_tile(j, cB, j <= cB);
+  double rdn[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) rdn[c] = 1.0;
+  potf2m4_step<0>(tA, tB, rdn, rowbuf, diagbuf, w, lane, n, g, nb, info, row0);
+  potf2m4_step<1>(tA, tB, rdn, rowbuf, diagbuf, w, lane, n, g, nb, info, row0);
+  potf2m4_step<2>(tA, tB, rdn, rowbuf, diagbuf, w, lane, n, g, nb, info, row0);
+  potf2m4_step<3>(tA, tB, rdn, rowbuf, diagbuf, w, lane, n, g, nb, info, row0);
+  potf2m4_step<4>(tA, tB, rdn, rowbuf, diagbuf, w, lane, n, g, nb, info, row0);
+  potf2m4_step<5>(tA, tB, rdn, rowbuf, diagbuf, w, lane, n, g, nb, info, row0);
+  potf2m4_step<6>(tA, tB, rdn, rowbuf, diagbuf, w, lane, n, g, nb, info, row0);
+  potf2m4_step<7>(tA, tB, rdn, rowbuf, diagbuf, w, lane, n, g, nb, info, row0);
+
+  // ---- outputs of the wave's two block columns c: rows 16 c .. 16 c + 15 of L, and the fragments that carry index c
+  const __amdgpu_buffer_rsrc_t fbuf = __builtin_amdgcn_make_buffer_rsrc(dblk + LGP_FRAG0, 0, LGP_NFRAG * 64 * 8, 0x00020000);
+  const int fl = lane * 8;
+  auto putf = [&](int f, double v) {
+    typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v), fbuf, fl, f * 512, 0);
+  };
+  auto store_tile = [&](const acc_t &t, int j, int c) {          // rows 16 c .. of L, columns 16 j ..
+    const int row = 16 * c + n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = 16 * j + 4 * r + g;
+      if (row < nb && col <= row) A[(long)row * lda + col] = t[r];
+    }
+  };
+  auto off_frags = [&](const acc_t &t, int i, int c, double nrd) {   // off(c, i, s) = -U[16 i + 4 s + g][16 c + n] / L_(16c+n)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) putf((c * (c - 1) / 2 + i) * 4 + s, t[s] * nrd);
+  };
+  auto diag_frags = [&](const acc_t &d, int c, double rdc) {
+    const double nrd = -rdc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double rdg = MmaD::bpermute((4 * r + g) * 4, rdc);     // 1 / L at row 16 c + 4 r + g
+      if (r < 3) putf(112 + 3 * c + r, (n >= 4 * (r + 1)) ? d[r] * nrd : 0.0);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double u = MmaD::bpermute((a * 16 + 4 * r + g) * 4, d[r]);
+        putf(136 + (4 * c + r) * 3 + a, (g > a) ? -(u * rdg) : 0.0);
+      }
+      putf(232 + 4 * c + r, rdg);
+    }
+  };
+  double rdA = 1.0, rdB = 1.0;                                     // 1 / L_(16c+n) of the wave's two block columns
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    rdA = (c == cA) ? rdn[c] : rdA;
+    rdB = (c == cB) ? rdn[c] : rdB;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j <= cA) store_tile(tA[j], j, cA);
+    if (j < cA) off_frags(tA[j], j, cA, -rdA);
+    if (j == cA) diag_frags(tA[j], cA, rdA);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j <= cB) store_tile(tB[j], j, cB);
+    if (j < cB) off_frags(tB[j], j, cB, -rdB);
+    if (j == cB) diag_frags(tB[j], cB, rdB);
+  }
+}
+
 }  // namespace
 
 int lgp_potf2_mfma_launch(lgp_ctx *ctx, hipStream_t stream, double *A, size_t lda, int nb, double *dblk, size_t row0) {
   LGP_REQUIRE(lda < (1u << 20), "leading dimension too large for the 32-bit offsets of the diagonal-block kernel");
+  if (ctx->potf2_mode != 3) {
+    hipLaunchKernelGGL(potf2_mfma4_kernel, dim3(1), dim3(256), 0, stream, A, (long)lda, nb, dblk, ctx->d_info, (long)row0);
+    LGP_LAUNCH_CHECK();
+    return LGP_OK;
+  }
   hipLaunchKernelGGL(potf2_mfma_kernel, dim3(1), dim3(64), 0, stream, A, (long)lda, nb, dblk, ctx->d_info, (long)row0);
   LGP_LAUNCH_CHECK();
   return LGP_OK;

@@ -374,6 +374,9 @@ template <> struct Mma<float> {
 
 constexpr int SUBSTM_ROWS = 64;   // rows per 256-thread workgroup (16 per wave)
 
+#ifdef LGP_SUBST_TRACE
+__device__ unsigned long long lgp_subst_trace[16];
+#endif
 template <typename T>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) subst_right_mfma_kernel(const T *__restrict__ w, int jb, T *X, long ldx, long rows) {
   typedef typename Mma<T>::acc_t acc_t;
@@ -400,23 +403,66 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 #pragma unroll
   for (int a = 0; a < 3; ++a) baddr[a] = (a * 16 + n) * 4;
 
+  // Right-looking over the eight 16-column tiles.  The dependent chain of a tile is its in-tile solve (four slabs of three
+  // broadcast + fma steps and one MFMA) plus the four MFMAs that bring in the tile just finished; everything else -- the
+  // updates of the later tiles with a finished tile, and above all the FRAGMENT LOADS (L2 round trips of several hundred
+  // cycles each) -- is issued a whole tile step ahead of its use: the fragments of step c + 1 are requested at the top of
+  // step c, into registers.
+#ifdef LGP_SUBST_TRACE
+#define LGP_SSTAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0 && blockIdx.x == 0) lgp_subst_trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LGP_SSTAMP(k) do { } while (0)
+#endif
+  LGP_SSTAMP(0);
+  T rdv[8][4];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rdv[c][r] = F(232 + 4 * c + r);
+  T coef[2][4][3], dg[2][3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) coef[0][r][a] = F(136 + r * 3 + a);
+    if (r < 3) dg[0][r] = F(112 + r);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[c][r] *= rdv[c][r];                       // x~ = x / diag, every tile up front
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
+    const int cur = c & 1, nxt = cur ^ 1;
+    // requests for the next step: its in-tile coefficients, and the fragments that apply THIS tile to the later ones
+    T off[7][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) t[c][r] *= F(232 + 4 * c + r);            // x~ = x / diag
+    for (int cc = c + 1; cc < 8; ++cc)
 #pragma unroll
-    for (int i = 0; i < c; ++i)
+      for (int s2 = 0; s2 < 4; ++s2) off[cc - c - 1][s2] = F((cc * (cc - 1) / 2 + c) * 4 + s2);
+    if (c < 7) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) t[c] = Mma<T>::run(F((c * (c - 1) / 2 + i) * 4 + s), t[i][s], t[c]);
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) coef[nxt][r][a] = F(136 + (4 * (c + 1) + r) * 3 + a);
+        if (r < 3) dg[nxt][r] = F(112 + 3 * (c + 1) + r);
+      }
+    }
+    // in-tile solve
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const T yb = Mma<T>::bpermute(baddr[a], t[c][r]);                 // unknown 4r + a of this row, to every lane group
-        t[c][r] = __builtin_fma(F(136 + (4 * c + r) * 3 + a), yb, t[c][r]);   // zero coefficient for groups <= a
+        t[c][r] = __builtin_fma(coef[cur][r][a], yb, t[c][r]);            // zero coefficient for groups <= a
       }
-      if (r < 3) t[c] = Mma<T>::run(F(112 + 3 * c + r), t[c][r], t[c]);    // finished unknowns -> later registers of the tile
+      if (r < 3) t[c] = Mma<T>::run(dg[cur][r], t[c][r], t[c]);           // finished unknowns -> later registers of the tile
     }
+    // the finished tile -> every later tile (nearest first: it is the next one on the chain)
+#pragma unroll
+    for (int cc = c + 1; cc < 8; ++cc)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) t[cc] = Mma<T>::run(off[cc - c - 1][s2], t[c][s2], t[cc]);
+    LGP_SSTAMP(1 + c);
   }
 
   if (rok) {
@@ -428,6 +474,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
         if (col < jb) xrow[col] = t[c][r];
       }
   }
+  LGP_SSTAMP(9);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -563,12 +610,12 @@ __global__ void __launch_bounds__(256) scale_rows_kernel(T *L, long ldl, int n, 
 template <typename T>
 int lgp_potf2_launch(lgp_ctx *ctx, hipStream_t stream, T *A, size_t lda, int nb, T *dblk, size_t row0) {
   LGP_REQUIRE(nb >= 1 && nb <= LGP_DB, "diagonal block size must be in [1,128]");
-  // fp64 has two kernels.  The matrix-core kernel (potf2m.hip: one wave, the whole block in its 512 registers) is 5-10 %
-  // faster end to end while the GPU has idle SIMDs (measured: N = 4096 4.24 -> 4.01 ms, N = 8192 10.7 -> 10.3 ms), but a
-  // wave that needs a whole SIMD's register file cannot be placed next to the two resident workgroups per CU of a large
-  // trailing update: in the N = 32768 profile it waited 0.58 ms on average for a SIMD to drain (204 -> 213 ms per step).
-  // ctx->potf2_mode: 0 = by the number of rows below the block, 1 = VALU kernel, 2 = matrix-core kernel (LGP_POTF2).
-  const bool mfma = std::is_same<T, double>::value && (ctx->potf2_mode == 2 || (ctx->potf2_mode == 0 && ctx->potf2_small));
+  // fp64: the four-wave matrix-core kernel of potf2m.hip (46 us alone against 60 us for the VALU kernel below; end to end
+  // N = 4096 4.24 -> 3.69 ms, N = 8192 10.7 -> 9.7 ms, N = 16384 39.6 -> 37.4 ms, N = 32768 204 -> 200.7 ms).
+  // ctx->potf2_mode (env LGP_POTF2): 0 / 2 = that kernel, 1 = VALU kernel, 3 = the one-wave matrix-core kernel, which needs a
+  // whole SIMD's register file and therefore waits for a SIMD to drain beside a large trailing update (0.58 ms on average
+  // in the N = 32768 profile: 204 -> 213 ms per step).
+  const bool mfma = std::is_same<T, double>::value && ctx->potf2_mode != 1;
   if constexpr (std::is_same<T, double>::value) {
     if (mfma) return lgp_potf2_mfma_launch(ctx, stream, A, lda, nb, dblk, row0);
   }
@@ -590,28 +637,81 @@ int lgp_extract_dblk(lgp_ctx *ctx, hipStream_t stream, const T *L, size_t ldl, s
 
 // Factor a block-column panel: P is rows x nb (ld ldp), top nb x nb block is the diagonal block.
 // dblk receives ceil(nb/128) diagonal-block workspaces.
+//
+// Inside the panel the dependent chain is  potf2(D_j) -> rows of the NEXT diagonal block solved -> D_j+1 updated -> potf2(D_j+1):
+// only those 128 rows and that one 128 x 128 update stay on `stream`.  Everything else a block produces -- the substitution
+// of all the other rows below it and the update of the rest of the panel with them -- goes to the context's bulk stream, which
+// follows one block behind (it needs potf2(D_j) and the look-ahead rows of block j; the chain needs bulk(j - 1) before it
+// solves the look-ahead rows of block j: by then bulk(j - 1) has had a whole potf2 to finish).  Per block the chain is
+// potf2 + one latency-bound substitution of 128 rows + one small product instead of potf2 + substitution of all rows +
+// update of the whole rest of the panel.
 template <typename T>
 int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t nb, T *P, size_t ldp, T *dblk, size_t row0) {
   LGP_REQUIRE(rows >= nb, "panel must have at least nb rows");
-  for (size_t j0 = 0; j0 < nb; j0 += LGP_DB) {
+  const size_t nblk = (nb + LGP_DB - 1) / LGP_DB;
+  hipStream_t bulk = ctx->stream3;
+  // measured: the split costs more in cross-stream event hops (three per block) than it takes off the chain -- N = 4096
+  // 3.64 -> 4.25 ms, N = 8192 9.8 -> 10.7 ms, N = 16384 38.4 -> 40.6 ms -- so it is off unless LGP_PANEL_SPLIT=1
+  static const bool want_split = getenv("LGP_PANEL_SPLIT") != nullptr;
+  const bool split = want_split && bulk != nullptr && bulk != stream && nblk > 1;
+  while (ctx->panel_events.size() < 3 * nblk + 1) {
+    hipEvent_t e;
+    LGP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->panel_events.push_back(e);
+  }
+  auto ev = [&](size_t blk, int which) { return ctx->panel_events[3 * blk + which]; };     // 0: potf2 done, 1: look-ahead rows solved, 2: bulk done
+  if (split) {      // the bulk stream starts from the panel as `stream` has it now
+    hipEvent_t e0 = ctx->panel_events[3 * nblk];
+    LGP_HIP(hipEventRecord(e0, stream));
+    LGP_HIP(hipStreamWaitEvent(bulk, e0, 0));
+  }
+  auto subst = [&](hipStream_t st, const T *w, size_t jb, T *X, size_t nrows) -> int {
+    if (nrows == 0) return LGP_OK;
+    hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((nrows + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, st, w, (int)jb, X,
+                       (long)ldp, (long)nrows);
+    LGP_LAUNCH_CHECK();
+    return LGP_OK;
+  };
+  size_t bi = 0;
+  hipEvent_t last_bulk = nullptr;
+  for (size_t j0 = 0; j0 < nb; j0 += LGP_DB, ++bi) {
     const size_t jb = (nb - j0) < (size_t)LGP_DB ? (nb - j0) : (size_t)LGP_DB;
     T *Dg = P + j0 * ldp + j0;
     T *w = dblk + (j0 / LGP_DB) * (size_t)LGP_DBLK;
     LGP_CHECK(lgp_potf2_launch<T>(ctx, stream, Dg, ldp, (int)jb, w, row0 + j0));
     const size_t below = rows - (j0 + jb);
-    if (below > 0) {
-      T *X = P + (j0 + jb) * ldp + j0;   // below x jb, solved in place: X <- X * L_jj^-T
-      hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((below + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, stream, w, (int)jb, X,
-                         (long)ldp, (long)below);
-      LGP_LAUNCH_CHECK();
-      const size_t wc = nb - (j0 + jb);
-      if (wc > 0) {
-        // remaining panel columns: C (below x wc, C(0,0) on the diagonal) -= X * X[0:wc]^T, lower part
-        T *C = P + (j0 + jb) * ldp + (j0 + jb);
-        LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, false, true, below, wc, jb, T(-1), X, ldp, X, ldp, T(1), C, ldp, true));
-      }
+    if (below == 0) continue;
+    T *X = P + (j0 + jb) * ldp + j0;           // below x jb, solved in place: X <- X * L_jj^-T
+    T *C = P + (j0 + jb) * ldp + (j0 + jb);    // below x wc: the rest of the panel, C(0, 0) on the diagonal
+    const size_t wc = nb - (j0 + jb);
+    if (!split) {
+      LGP_CHECK(subst(stream, w, jb, X, below));
+      if (wc > 0) LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, false, true, below, wc, jb, T(-1), X, ldp, X, ldp, T(1), C, ldp, true));
+      continue;
     }
+    const size_t jn = wc < (size_t)LGP_DB ? wc : (size_t)LGP_DB;      // rows of the next diagonal block (0: this is the last block)
+    LGP_HIP(hipEventRecord(ev(bi, 0), stream));
+    if (jn > 0) {
+      // chain: the look-ahead rows and the next diagonal block
+      if (bi > 0) LGP_HIP(hipStreamWaitEvent(stream, ev(bi - 1, 2), 0));      // they carry the updates of every earlier block
+      LGP_CHECK(subst(stream, w, jb, X, jn));
+      LGP_HIP(hipEventRecord(ev(bi, 1), stream));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, stream, false, true, jn, jn, jb, T(-1), X, ldp, X, ldp, T(1), C, ldp, true));
+    }
+    // bulk: every other row below, then the rest of the panel
+    LGP_HIP(hipStreamWaitEvent(bulk, ev(bi, 0), 0));
+    LGP_CHECK(subst(bulk, w, jb, X + jn * ldp, below - jn));
+    if (jn > 0 && below > jn) {
+      LGP_HIP(hipStreamWaitEvent(bulk, ev(bi, 1), 0));
+      T *Xr = X + jn * ldp, *Cr = C + jn * ldp;
+      // rows [jn, below) x columns [0, jn): full rectangle;  x columns [jn, wc): lower part, diagonal at (jn, jn)
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, bulk, false, true, below - jn, jn, jb, T(-1), Xr, ldp, X, ldp, T(1), Cr, ldp, false));
+      if (wc > jn) LGP_CHECK(lgp_gemm_launch<T>(ctx, bulk, false, true, below - jn, wc - jn, jb, T(-1), Xr, ldp, Xr, ldp, T(1), Cr + jn, ldp, true));
+    }
+    LGP_HIP(hipEventRecord(ev(bi, 2), bulk));
+    last_bulk = ev(bi, 2);
   }
+  if (last_bulk) LGP_HIP(hipStreamWaitEvent(stream, last_bulk, 0));      // the panel is complete on `stream` when the bulk stream is
   return LGP_OK;
 }
 

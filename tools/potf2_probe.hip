@@ -78,6 +78,35 @@ int main() {
     printf("\n");
 #endif
   }
+  // the four-wave matrix-core kernel
+  {
+    std::vector<double> L0(n * n), L1(n * n), F0(LGP_NFRAG * 64), F1(LGP_NFRAG * 64);
+    CK(hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice));
+    potf2_kernel<double><<<1, 256>>>(dA, n, n, dW, dinfo, 0);
+    pack_frag_kernel<double><<<(LGP_NFRAG + 3) / 4, 256>>>(dW);
+    CK(hipMemcpy(L0.data(), dA, n * n * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(F0.data(), dW + LGP_FRAG0, F0.size() * 8, hipMemcpyDeviceToHost));
+    CK(hipMemset(dW, 0, LGP_DBLK * 8));
+    for (int rep = 0; rep < 5; ++rep) {
+      CK(hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice));
+      CK(hipEventRecord(e0));
+      potf2_mfma4_kernel<<<1, 256>>>(dA, n, n, dW, dinfo, 0);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("potf2_mfma4 alone: %.1f us\n", ms * 1e3);
+    }
+    CK(hipMemcpy(L1.data(), dA, n * n * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(F1.data(), dW + LGP_FRAG0, F1.size() * 8, hipMemcpyDeviceToHost));
+    double dl = 0, df = 0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) dl = fmax(dl, fabs(L0[i * n + j] - L1[i * n + j]));
+    for (size_t i = 0; i < F0.size(); ++i) df = fmax(df, fabs(F0[i] - F1[i]));
+    printf("potf2_mfma4 vs potf2: max |dL| = %.3e, max |dF| = %.3e\n", dl, df);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 50; ++i) potf2_mfma4_kernel<<<1, 256>>>(dA, n, n, dW, dinfo, 0);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("potf2_mfma4 x50 back-to-back: %.1f us each\n", ms * 1e3 / 50);
+  }
   // 50 back-to-back
   CK(hipEventRecord(e0));
   for (int i = 0; i < 50; ++i) potf2_kernel<double><<<1, 256>>>(dA, n, n, dW, dinfo, 0);
@@ -94,6 +123,10 @@ int main() {
       CK(hipEventElapsedTime(&ms, e0, e1));
       printf("subst_right rows=%ld: %.1f us\n", rows, ms * 1e3);
     }
+#ifdef LGP_SUBST_TRACE
+    { unsigned long long st[16]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(lgp_subst_trace), sizeof(st)));
+      printf("subst phases (cycles): start->"); for (int k = 1; k <= 9; ++k) printf("%llu ", st[k] - st[k - 1]); printf("\n"); }
+#endif
     CK(hipFree(dX));
   }
   return 0;
