@@ -292,6 +292,24 @@ int lgp_chol_factor_rhs_f64(lgp_ctx *ctx, size_t n, const double *dK, size_t ldk
                             double *dL, size_t ldl, size_t nrhs, double *ddblk, double *heps_out);
 int lgp_chol_factor_rhs_f32(lgp_ctx *ctx, size_t n, const float *dK, size_t ldk, float epsrel, float epsabs, int eps_flags,
                             float *dL, size_t ldl, size_t nrhs, float *ddblk, float *heps_out);
+/* Gram build and Chol.__init__ fused (_GP/_elements.py:575-577 + _GP/_compute.py:85 + _linalg/_decomp.py:380-393): the
+ * factor of K = kernel(x, x) + diag(noise) for an isotropic kernel, K itself never materialised.  One pass over the pairs
+ * writes tril(K / s / s') into dL and leaves the Gershgorin sums (the separate path writes K, re-reads it for the sums and
+ * again for the scaled lower copy); then eps, the blocked factorisation and the rescaling exactly as lgp_chol_factor_rhs_*.
+ * Kernel arguments as lgp_gram_isotropic_* (x against itself); noise: scalar added to the diagonal, or dnoise (n device
+ * values) if not NULL; dL: (n + nrhs) x n, rows n.. hold B^T on entry like for lgp_chol_factor_rhs_*; nrhs may be 0. */
+int lgp_gram_chol_factor_rhs_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d,
+                                 const double *dx, size_t ldx, size_t n,
+                                 int has_loc, double loc, int has_scale, double scale,
+                                 int nops, const int *hops_code, const double *hops_val,
+                                 double noise, const double *dnoise, double epsrel, double epsabs, int eps_flags,
+                                 double *dL, size_t ldl, size_t nrhs, double *ddblk, double *heps_out);
+int lgp_gram_chol_factor_rhs_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int d,
+                                 const float *dx, size_t ldx, size_t n,
+                                 int has_loc, float loc, int has_scale, float scale,
+                                 int nops, const int *hops_code, const float *hops_val,
+                                 float noise, const float *dnoise, float epsrel, float epsabs, int eps_flags,
+                                 float *dL, size_t ldl, size_t nrhs, float *ddblk, float *heps_out);
 /* lgp_posterior for right-hand sides solved that way: dWt = (m+1) x n, rows 0..m-1 = (L^-1 Kxxs)^T, row m = (L^-1 y)^T
  * (typically dL + n * ldl); same outputs as lgp_posterior. */
 int lgp_posterior_solved_f64(lgp_ctx *ctx, size_t n, size_t m, const double *dL, size_t ldl, const double *dWt, size_t ldw,

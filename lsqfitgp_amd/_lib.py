@@ -106,6 +106,8 @@ def _signatures():
             'lgp_check_matrix_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, c_int, F, F, POINTER(c_int)]),
             'lgp_chol_factor_' + suf: (c_int, [c_void_p, _S, _P, _S, F, F, c_int, _P, _S, _P, POINTER(F)]),
             'lgp_chol_factor_rhs_' + suf: (c_int, [c_void_p, _S, _P, _S, F, F, c_int, _P, _S, _S, _P, POINTER(F)]),
+            'lgp_gram_chol_factor_rhs_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, _P, _S, _S, c_int, F, c_int, F,
+                                                       c_int, POINTER(c_int), POINTER(F), F, _P, F, F, c_int, _P, _S, _S, _P, POINTER(F)]),
             'lgp_potrf_' + suf: (c_int, [c_void_p, _S, _P, _S, _P]),
             'lgp_trsm_' + suf: (c_int, [c_void_p, _S, _P, _S, _P, c_int, _P, _S, _S]),
             'lgp_gemm_' + suf: (c_int, [c_void_p, c_int, c_int, _S, _S, _S, F, _P, _S, _P, _S, F, _P, _S]),

@@ -316,6 +316,186 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// Gram build fused with the regularisation passes of Chol.__init__ (_decomp.py:384-387): one pass over the pairs writes
+// tril(K / s / s') straight into the factor's storage (zeros above the diagonal) and leaves the Gershgorin sums, instead of
+// K -> HBM -> row sums (read n^2) -> scaled lower copy (read n^2 / 2, write n^2).  K = kernel(x, x) + diag(noise) is never
+// materialised.  s_i = 2^rint(log2(K_ii) / 2) needs only the diagonal, K_ii = ops(core(0)) + noise_i, so every workgroup
+// derives the scales of its own rows and columns; being powers of two, multiplying by 1 / s is the division.  Each thread
+// owns W columns of a 128 x (256 W) tile and accumulates |K~_ij| down its columns: the column sums of the FULL symmetric
+// matrix are the Gershgorin row sums, and the partial sums of the n / 128 tile rows are added in a fixed order afterwards
+// (deterministic, no atomics).  The upper triangle is evaluated only for those sums.
+constexpr int GR_ROWS = 128;
+
+template <typename T>
+__device__ __forceinline__ T pow2_scale(T d) {      // _decomp.py:356-361
+  return d != T(0) ? exp2(rint(T(0.5) * log2(d))) : T(1);
+}
+
+template <typename T, int D>
+__global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g, T noise, const T *__restrict__ noisev, T *__restrict__ svec,
+                                                              T *__restrict__ part) {
+  constexpr int W = VecOf<T>::W;
+  constexpr int GT_COLS = GT_THREADS * W;
+  typedef typename VecOf<T>::type vec_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *su = reinterpret_cast<T *>(smem_raw);            // [d][GR_ROWS] transformed row coordinates
+  const int d = D > 0 ? D : g.d;
+  T *sv = su + d * GR_ROWS;                            // [d][GT_COLS]
+  T *sinv = sv + d * GT_COLS;                          // [GR_ROWS] 1 / s_i of the rows;  then [GR_ROWS] their noise
+  T *snz = sinv + GR_ROWS;
+  const int n = g.n;
+  const int ntc = (n + GT_COLS - 1) / GT_COLS;
+  const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
+  const int row0 = tr * GR_ROWS, col0 = tc * GT_COLS;
+  const int tid = threadIdx.x;
+  const T k0 = g.ops.apply(iso_core<T>(g, T(0)));     // the kernel on its diagonal: r2 = 0 exactly, as for the pairs (i, i)
+  for (int idx = tid; idx < d * GR_ROWS; idx += GT_THREADS) {
+    const int f = idx / GR_ROWS, r = idx % GR_ROWS;
+    T v = T(0);
+    if (row0 + r < n) {
+      v = g.x[(long)f * g.ldx + row0 + r];
+      if (g.has_loc) v = v - g.loc;
+      if (g.has_scale) v = v / g.scale;
+    }
+    su[idx] = v;
+  }
+  for (int idx = tid; idx < d * GT_COLS; idx += GT_THREADS) {
+    const int f = idx / GT_COLS, c = idx % GT_COLS;
+    T v = T(0);
+    if (col0 + c < n) {
+      v = g.x[(long)f * g.ldx + col0 + c];
+      if (g.has_loc) v = v - g.loc;
+      if (g.has_scale) v = v / g.scale;
+    }
+    sv[idx] = v;
+  }
+  for (int r = tid; r < GR_ROWS; r += GT_THREADS) {
+    const T nz = (row0 + r < n) ? (noisev ? noisev[row0 + r] : noise) : T(0);
+    snz[r] = nz;
+    sinv[r] = T(1) / pow2_scale<T>(k0 + nz);
+  }
+  __syncthreads();
+
+  const int c0 = tid * W;
+  T vreg[D > 0 ? D : 1][W], cinv[W], cnz[W], acc[W];
+#pragma unroll
+  for (int e = 0; e < W; ++e) {
+    const int j = col0 + c0 + e;
+    cnz[e] = (j < n) ? (noisev ? noisev[j] : noise) : T(0);
+    const T sj = pow2_scale<T>(k0 + cnz[e]);
+    cinv[e] = T(1) / sj;
+    acc[e] = T(0);
+    if (tr == 0 && j < n) svec[j] = sj;
+    if (D > 0) {
+#pragma unroll
+      for (int f = 0; f < D; ++f) vreg[f][e] = sv[f * GT_COLS + c0 + e];
+    }
+  }
+  const bool colfull = (col0 + c0 + W <= n) && ((g.ldo % W) == 0) && ((reinterpret_cast<uintptr_t>(g.out) % 16) == 0);
+  const int rmax = (n - row0) < GR_ROWS ? (n - row0) : GR_ROWS;
+  for (int r = 0; r < rmax; ++r) {
+    const int i = row0 + r;
+    const T rinv = sinv[r];
+    T res[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+      const int j = col0 + c0 + e;
+      T r2 = T(0);
+      if (D > 0) {
+#pragma unroll
+        for (int f = 0; f < D; ++f) {
+          const T df = su[f * GR_ROWS + r] - vreg[f][e];
+          const T sq = df * df;
+          r2 = (f == 0) ? sq : r2 + sq;
+        }
+      } else {
+        for (int f = 0; f < d; ++f) {
+          const T df = su[f * GR_ROWS + r] - sv[f * GT_COLS + c0 + e];
+          const T sq = df * df;
+          r2 = (f == 0) ? sq : r2 + sq;
+        }
+      }
+      T v = g.ops.apply(iso_core<T>(g, r2));
+      if (i == j) v = v + cnz[e];                       // Kxx + ycov (_compute.py:85), noise on the diagonal
+      v = v * cinv[e] * rinv;                           // K / s / s[:, None] (:385): exact, s is a power of two
+      if (j < n) acc[e] += fabs(v);
+      res[e] = (j <= i) ? v : T(0);
+    }
+    T *po = g.out + (long)i * g.ldo + col0 + c0;
+    if (colfull) {
+      vec_t v;
+#pragma unroll
+      for (int e = 0; e < W; ++e) v[e] = res[e];
+      *reinterpret_cast<vec_t *>(po) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < W; ++e)
+        if (col0 + c0 + e < n) po[e] = res[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < W; ++e)
+    if (col0 + c0 + e < n) part[(long)tr * n + col0 + c0 + e] = acc[e];
+}
+
+template <typename T>
+int gram_reg_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, int d, const T *dx, size_t ldx, size_t n, int has_loc, T loc,
+                    int has_scale, T scale, int nops, const int *hops_code, const T *hops_val, T noise, const T *dnoise, T *dL, size_t ldl, T *dsvec,
+                    T *dpart, size_t *ntr_out) {
+  LGP_REQUIRE(ctx != nullptr && dx != nullptr && dL != nullptr && dsvec != nullptr && dpart != nullptr, "null pointer");
+  LGP_REQUIRE(kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_MATERNP || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY,
+              "unknown isotropic kernel");
+  LGP_REQUIRE(d >= 1 && d <= 64 && p >= 0 && p <= MAX_P && nops >= 0 && nops <= MAX_OPS, "bad kernel parameters");
+  LGP_REQUIRE(n >= 1 && n < (1u << 30) && ldx >= n && ldl >= n, "bad dimensions");
+  LGP_REQUIRE(!has_scale || (scale > T(0) && scale < T(INFINITY)), "scale must be positive and finite");
+  LGP_REQUIRE(!has_loc || (loc > T(-INFINITY) && loc < T(INFINITY)), "loc must be finite");
+  DeviceGuard dg(ctx->device);
+  IsoArgs<T> g;
+  g.x = dx; g.y = dx; g.out = dL; g.dsc = nullptr;
+  g.ldx = (long)ldx; g.ldy = (long)ldx; g.ldo = (long)ldl;
+  g.n = (int)n; g.m = (int)n; g.d = d;
+  g.kernel = kernel; g.p = p;
+  g.has_loc = has_loc; g.has_scale = has_scale; g.loc = loc; g.scale = scale;
+  for (int i = 0; i < MAX_P; ++i) g.coef[i] = T(0);
+  int pos = 0;
+  for (int k = p - 1; k >= 0; --k) g.coef[pos++] = (T)((double)(p - k) / ((double)(2 * p - k) * (double)(k + 1)));
+  g.twop1 = (T)(2 * p + 1);
+  g.par[0] = g.par[1] = g.par[2] = T(0);
+  g.flag = 0;
+  if (kernel == LGP_KERNEL_GAMMAEXP) {
+    LGP_REQUIRE(npar == 2 && hpar != nullptr && hpar[0] > T(0) && hpar[0] <= T(2), "GammaExp takes {gamma, gamma/2}, gamma in (0, 2]");
+    g.par[0] = hpar[0]; g.par[1] = hpar[1]; g.flag = hpar[0] == T(2);
+  } else if (kernel == LGP_KERNEL_CAUCHY) {
+    LGP_REQUIRE(npar == 3 && hpar != nullptr && hpar[0] > T(0) && hpar[0] <= T(2) && hpar[1] > T(0), "Cauchy takes {alpha, beta, -beta/alpha}");
+    g.par[0] = hpar[0] / T(2); g.par[1] = hpar[1]; g.par[2] = hpar[2]; g.flag = hpar[0] == T(2);
+  } else {
+    LGP_REQUIRE(npar == 0, "this kernel takes no real parameters");
+  }
+  g.ops.n = nops;
+  for (int i = 0; i < MAX_OPS; ++i) { g.ops.code[i] = 0; g.ops.val[i] = T(0); }
+  for (int i = 0; i < nops; ++i) {
+    LGP_REQUIRE(hops_code[i] == LGP_OP_MUL || hops_code[i] == LGP_OP_ADD, "unknown output operation");
+    g.ops.code[i] = hops_code[i];
+    g.ops.val[i] = hops_val[i];
+  }
+  constexpr int W = VecOf<T>::W;
+  constexpr int GT_COLS = GT_THREADS * W;
+  const size_t ntr = (n + GR_ROWS - 1) / GR_ROWS, ntc = (n + GT_COLS - 1) / GT_COLS;
+  LGP_REQUIRE(ntr * ntc < (1ull << 31), "gram grid too large");
+  const size_t shmem = ((size_t)d * (GR_ROWS + GT_COLS) + 2 * GR_ROWS) * sizeof(T);
+  dim3 gd((unsigned)(ntr * ntc)), bd(GT_THREADS);
+  switch (d) {
+    case 1: hipLaunchKernelGGL((gram_reg_kernel<T, 1>), gd, bd, shmem, ctx->stream, g, noise, dnoise, dsvec, dpart); break;
+    case 2: hipLaunchKernelGGL((gram_reg_kernel<T, 2>), gd, bd, shmem, ctx->stream, g, noise, dnoise, dsvec, dpart); break;
+    case 3: hipLaunchKernelGGL((gram_reg_kernel<T, 3>), gd, bd, shmem, ctx->stream, g, noise, dnoise, dsvec, dpart); break;
+    default: hipLaunchKernelGGL((gram_reg_kernel<T, 0>), gd, bd, shmem, ctx->stream, g, noise, dnoise, dsvec, dpart); break;
+  }
+  LGP_LAUNCH_CHECK();
+  *ntr_out = ntr;
+  return LGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // BART
 
 constexpr int BART_MAX_P = 64;
@@ -725,4 +905,43 @@ extern "C" int lgp_gram_bart_jvp_f64(lgp_ctx *ctx, int p, const int32_t *dix, si
                                      size_t ldo, int ntan, const double *hdprobs, double *const *hdtan, const double *const *hdgtan) {
   return gram_bart_launch<double>(ctx, p, dix, n, diy, m, hnsplits, hweights, size, repeat, hprobs, gamma, dgamma_mat, dpsi, npsi, nops,
                                   hops_code, hops_val, dout, ldo, false, nullptr, ntan, hdprobs, hdtan, hdgtan);
+}
+
+// ---- Gram build + Chol.__init__ in one call: the matrix K = kernel(x, x) + diag(noise) goes straight into the factor ----
+template <typename T>
+int lgp_chol_from_prepared(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nrhs, T *ws, size_t ntr, T epsrel, T epsabs, int flags,
+                           T *heps_out);   // potrf.hip
+
+template <typename T>
+static int gram_chol_impl(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, int d, const T *dx, size_t ldx, size_t n, int has_loc, T loc,
+                          int has_scale, T scale, int nops, const int *hops_code, const T *hops_val, T noise, const T *dnoise, T epsrel, T epsabs,
+                          int flags, T *dL, size_t ldl, size_t nrhs, T *ddblk, T *heps_out) {
+  LGP_REQUIRE(ctx != nullptr && ddblk != nullptr, "null pointer");
+  LGP_REQUIRE(n >= 1 && n < (1u << 30), "matrix size out of range");
+  DeviceGuard dg(ctx->device);
+  const size_t ntr = (n + GR_ROWS - 1) / GR_ROWS;
+  // workspace: s (n), Gershgorin sums (n), stats (16), partial column sums (ntr x n)
+  T *ws = nullptr;
+  LGP_HIP(hipMallocAsync(reinterpret_cast<void **>(&ws), (2 * n + 16 + ntr * n) * sizeof(T), ctx->stream));
+  size_t got = 0;
+  int st = gram_reg_launch<T>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, noise, dnoise, dL,
+                              ldl, ws, ws + 2 * n + 16, &got);
+  if (st == LGP_OK) st = lgp_chol_from_prepared<T>(ctx, n, dL, ldl, ddblk, nrhs, ws, ntr, epsrel, epsabs, flags, heps_out);
+  else (void)hipFreeAsync(ws, ctx->stream);
+  return st;
+}
+
+extern "C" int lgp_gram_chol_factor_rhs_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d, const double *dx, size_t ldx, size_t n,
+                                            int has_loc, double loc, int has_scale, double scale, int nops, const int *hops_code,
+                                            const double *hops_val, double noise, const double *dnoise, double epsrel, double epsabs, int eps_flags,
+                                            double *dL, size_t ldl, size_t nrhs, double *ddblk, double *heps_out) {
+  return gram_chol_impl<double>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, noise, dnoise,
+                                epsrel, epsabs, eps_flags, dL, ldl, nrhs, ddblk, heps_out);
+}
+extern "C" int lgp_gram_chol_factor_rhs_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int d, const float *dx, size_t ldx, size_t n,
+                                            int has_loc, float loc, int has_scale, float scale, int nops, const int *hops_code, const float *hops_val,
+                                            float noise, const float *dnoise, float epsrel, float epsabs, int eps_flags, float *dL, size_t ldl,
+                                            size_t nrhs, float *ddblk, float *heps_out) {
+  return gram_chol_impl<float>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, noise, dnoise,
+                               epsrel, epsabs, eps_flags, dL, ldl, nrhs, ddblk, heps_out);
 }

@@ -877,6 +877,62 @@ static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T ep
   return info;
 }
 
+// Tail of Chol.__init__ for a matrix that the fused Gram kernel (gram.hip, gram_reg_kernel) has already scaled and written as
+// a lower triangle: ws = [s (n) | Gershgorin sums (n) | stats (16) | partial column sums (ntr x n)], freed here.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) colpart_reduce_kernel(size_t n, size_t ntr, const T *part, const T *s, T *rows, unsigned int *nonunit) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  T acc = T(0);
+  for (size_t t = 0; t < ntr; ++t) acc += part[t * n + j];      // fixed order: deterministic
+  rows[j] = acc;
+  if (s[j] != T(1)) atomicAdd(nonunit, 1u);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) add_eps_diag_kernel(size_t n, T *L, size_t ldl, const T *epsp) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) L[i * ldl + i] += epsp[0];
+}
+}  // namespace
+
+template <typename T>
+int lgp_chol_from_prepared(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nrhs, T *ws, size_t ntr, T epsrel, T epsabs, int flags,
+                           T *heps_out) {
+  hipStream_t st = ctx->stream;
+  T *s = ws, *rows = ws + n, *stats = ws + 2 * n, *part = ws + 2 * n + 16;
+  const int ni = (int)n;
+  LGP_HIP(hipMemsetAsync(stats, 0, 16 * sizeof(T), st));
+  LGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), st));
+  unsigned int *nonunit = reinterpret_cast<unsigned int *>(stats) + 8;
+  hipLaunchKernelGGL((colpart_reduce_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, ntr, part, s, rows, nonunit);
+  LGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL((eps_kernel<T>), dim3(1), dim3(256), 0, st, rows, s, ni, epsrel, epsabs, flags, stats);
+  LGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL((add_eps_diag_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, L, ldl, stats);
+  LGP_LAUNCH_CHECK();
+  if (nrhs > 0) {
+    hipLaunchKernelGGL((scale_cols_kernel<T>), dim3((unsigned)((nrhs * n + 255) / 256 < 65536 ? (nrhs * n + 255) / 256 : 65536)), dim3(256), 0, st,
+                       L + n * ldl, (long)ldl, (int)nrhs, ni, s, nonunit);
+    LGP_LAUNCH_CHECK();
+  }
+  LGP_CHECK(lgp_potrf_impl<T>(ctx, n, L, ldl, dblk, nrhs));
+  const int nbx = (int)((n + 2047) / 2048);
+  hipLaunchKernelGGL((scale_rows_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, st, L, (long)ldl, ni, nbx, s, nonunit);
+  LGP_LAUNCH_CHECK();
+  LGP_CHECK(lgp_extract_dblk<T>(ctx, st, L, ldl, n, dblk));
+  T hstats[3];
+  int info = 0;
+  LGP_HIP(hipMemcpyAsync(hstats, stats, 3 * sizeof(T), hipMemcpyDeviceToHost, st));
+  LGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+  LGP_HIP(hipFreeAsync(ws, st));
+  LGP_HIP(hipStreamSynchronize(st));
+  if (heps_out) *heps_out = hstats[1];
+  return info;
+}
+template int lgp_chol_from_prepared<double>(lgp_ctx *, size_t, double *, size_t, double *, size_t, double *, size_t, double, double, int, double *);
+template int lgp_chol_from_prepared<float>(lgp_ctx *, size_t, float *, size_t, float *, size_t, float *, size_t, float, float, int, float *);
+
 extern "C" int lgp_chol_factor_rhs_f64(lgp_ctx *ctx, size_t n, const double *dK, size_t ldk, double epsrel, double epsabs, int eps_flags,
                                        double *dL, size_t ldl, size_t nrhs, double *ddblk, double *heps_out) {
   return chol_factor_impl<double>(ctx, n, dK, ldk, epsrel, epsabs, eps_flags, dL, ldl, ddblk, heps_out, nrhs);

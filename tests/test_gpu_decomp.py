@@ -379,3 +379,53 @@ def test_normal_density_derivs_on_device(lgp, n, rng):
         e = np.zeros(4); e[k] = 1e-6 * max(1, abs(th[k]))
         fd = (value(*(th + e)) - value(*(th - e))) / (2 * e[k])
         assert abs(g0[k] - fd) <= 1e-5 * max(1.0, abs(fd))
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('n,d,q', [(1, 1, 0), (130, 1, 3), (700, 3, 0), (1025, 2, 101), (2600, 5, 7)])
+def test_fused_gram_factor(lgp, rng, dtype, n, d, q):
+    """ lgp_gram_chol_factor_rhs: Gram build + regularisation + factorisation without materialising K, against the separate
+    path (lgp_gram_isotropic + add_diag + lgp_chol_factor_rhs) on the same inputs: eps to 1e-14 (the Gershgorin sums are
+    added in a different, fixed order), factor and carried solve to rounding; vector and scalar noise; kernel * c (power-of-two
+    diagonal scaling) """
+    from lsqfitgp_amd import _lib
+    lib = _lib.load()
+    ctx = lgp.Context.default()
+    f64 = dtype == np.float64
+    suf, F = ('f64', ctypes.c_double) if f64 else ('f32', ctypes.c_float)
+    x = rng.uniform(0, max(n, 16) / 16, (d, n)).astype(dtype)
+    xd = lgp.DeviceArray.from_host(x)
+    B = rng.standard_normal((q, n)).astype(dtype)
+    for amp, noise, noisev in ((1., 0.01, None), (37., 0.5, rng.uniform(0.1, 0.9, n).astype(dtype)), (0.004, 1e-4, None)):
+        kern = lgp.Maternp(p=2, scale=dtype(1.3), loc=dtype(0.2)) * dtype(amp)
+        # separate path
+        K = lgp.DeviceArray.empty((n, n), dtype)
+        codes = (ctypes.c_int * 1)(_lib.LGP_OP_MUL); vals = (F * 1)(amp)
+        _lib.check(getattr(lib, 'lgp_gram_isotropic_' + suf)(ctx.handle, _lib.LGP_KERNEL_MATERNP, 2, 0, None, d, xd.ptr, xd.ld, n, xd.ptr, xd.ld, n,
+                                                            1, F(0.2), 1, F(1.3), 1, codes, vals, 1, K.ptr, K.ld))
+        nv = None if noisev is None else lgp.DeviceArray.from_host(noisev)
+        _lib.check(getattr(lib, 'lgp_add_diag_' + suf)(ctx.handle, n, K.ptr, K.ld, None if nv is None else nv.ptr, F(1. if nv is not None else noise)))
+        nx = -(-q // 128) * 128 if q else 0
+        outs = []
+        for fused in (False, True):
+            L = lgp.DeviceArray.zeros((n + nx, n), dtype)
+            if q:
+                L.block(n, n + q, 0, n).assign(lgp.DeviceArray.from_host(B))
+            dblk = lgp.DeviceArray.empty((lib.lgp_chol_dblk_size(n),), dtype)
+            eps = F()
+            if fused:
+                st = getattr(lib, 'lgp_gram_chol_factor_rhs_' + suf)(ctx.handle, _lib.LGP_KERNEL_MATERNP, 2, 0, None, d, xd.ptr, xd.ld, n, 1, F(0.2), 1, F(1.3),
+                                                                      1, codes, vals, F(noise), None if nv is None else nv.ptr, F(0), F(0),
+                                                                      _lib.LGP_EPS_AUTO_REL, L.ptr, L.ld, nx, dblk.ptr, ctypes.byref(eps))
+            else:
+                st = getattr(lib, 'lgp_chol_factor_rhs_' + suf)(ctx.handle, n, K.ptr, K.ld, F(0), F(0), _lib.LGP_EPS_AUTO_REL, L.ptr, L.ld, nx, dblk.ptr,
+                                                                 ctypes.byref(eps))
+            assert _lib.check(st) == 0
+            outs.append((eps.value, L.to_host()))
+        (e0, L0), (e1, L1) = outs
+        tol = 1e-14 if f64 else 1e-6
+        assert abs(e1 - e0) <= tol * abs(e0)
+        assert np.all(np.triu(L1[:n], 1) == 0)
+        util.assert_close_matrices(L1[:n], L0[:n], rtol=1e-12 if f64 else 2e-5)
+        if q:
+            util.assert_close_matrices(L1[n:n + q], L0[n:n + q], rtol=1e-9 if f64 else 2e-2)
