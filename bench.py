@@ -212,6 +212,10 @@ def cpu_baseline(main_cfg):
     from threadpoolctl import threadpool_limits, threadpool_info
     info = threadpool_info()
     all_threads = max([p.get('num_threads', 1) for p in info] or [1])
+    try:                      # the cores this process may actually run on (a 1-GPU share of the host), not the BLAS default
+        all_threads = max(1, min(all_threads, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        pass
     out = {}
 
     def best(cfg, n, threads, reps=3):
@@ -309,12 +313,14 @@ def c5_step(ctx, steps=3, warmup=1):
     81 held-out rows), driven through the host classes as a user of the reference would: one step = new GP ->
     predfromdata('testmean') + marginal_likelihood(epsrel=0).  Roofline object: the BART Gram kernel. """
     import lsqfitgp_amd as lgp
-    from tests.abalone import load_abalone, c5_problem
+    from tests.abalone import load_abalone, c5_prepare, c5_gp
     X, y = load_abalone()
     n = 4096
+    prep = c5_prepare(lgp, X, y, n)                  # data preparation (splits, bin indices): once, like bayestree.bart does
+    given, kern, pts = prep['given'], prep['kern'], prep['pts']
 
     def step():
-        gp, given, kern, pts = c5_problem(lgp, X, y, n)
+        gp = c5_gp(lgp, prep, diag=lgp.diag)         # a new GP per step: every block is rebuilt on the device
         mean, cov = gp.predfromdata(given, 'testmean', raw=True)
         return mean, cov, gp.marginal_likelihood(given, epsrel=0), kern, pts
 

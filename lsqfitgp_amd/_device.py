@@ -134,15 +134,20 @@ class _Graveyard:
     def __init__(self, lib, handle):
         self.lib, self.handle = lib, handle
         self.pending, self.nbytes = [], 0
+        # `bury` runs from weakref finalizers, i.e. from the garbage collector in whatever thread triggers it
+        self._lock = threading.RLock()
 
     def bury(self, ptr, nbytes):
-        self.pending.append(ptr)
-        self.nbytes += nbytes
-        if self.nbytes > self.LIMIT_BYTES or len(self.pending) > self.LIMIT_COUNT:
+        with self._lock:
+            self.pending.append(ptr)
+            self.nbytes += nbytes
+            full = self.nbytes > self.LIMIT_BYTES or len(self.pending) > self.LIMIT_COUNT
+        if full:
             self.flush()
 
     def flush(self):
-        pending, self.pending, self.nbytes = self.pending, [], 0
+        with self._lock:
+            pending, self.pending, self.nbytes = self.pending, [], 0
         for ptr in pending:
             self.lib.lgp_free(self.handle, ctypes.c_void_p(ptr))
 

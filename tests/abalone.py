@@ -25,11 +25,10 @@ def load_abalone():
     return X.astype(np.float32), y.astype(np.float32)
 
 
-def c5_problem(mod, X, y, n):
-    """ the GP that ``bayestree.bart`` builds (``bayestree/_bart.py:163-205``) at the fixed hyperparameters of
-    SURVEY.md 8(d): splits from the n training rows, alpha = 0.95, beta = 2, maxd = 10, reset = [2, 4, 6, 8], gamma = 1,
-    k = 2, sigma2 = mean((y - ybar)^2), unit weights, marginalised mean; test block = the rows after the first n.
-    ``mod`` is the oracle or the device package (same surface).  Returns (gp, given). """
+def c5_prepare(mod, X, y, n):
+    """ the data preparation of ``bayestree.bart`` (``bayestree/_bart.py:152-173``) at the fixed hyperparameters of
+    SURVEY.md 8(d): splits from the n training rows, bin indices of every row, alpha = 0.95, beta = 2, maxd = 10,
+    reset = [2, 4, 6, 8], gamma = 1, k = 2, sigma2 = mean((y - ybar)^2), unit weights; everything float32 / int32 """
     f = np.float32
     p = X.shape[1]
     ytr = y[:n]
@@ -43,10 +42,25 @@ def c5_problem(mod, X, y, n):
     pts = np.array([tuple(r) for r in ix], dtype=[(f'f{i}', np.int32) for i in range(p)])
     kern = mod.BART(splits=(splits[0], None), indices=True, alpha=f(0.95), beta=f(2), gamma=f(1), maxd=10,
                     reset=[2, 4, 6, 8], weights=np.ones(p, f)) * lam2
-    gp = (mod.GP(kern, checkpos=False, checksym=False, solver='chol')
-          .addx(pts[:n], 'trainmean')
-          .addcov(np.diag(np.full(n, sigma2)).astype(f), 'trainnoise')
-          .addcov(np.asarray(k_sigma_mu ** 2, f), 'mean')
-          .addtransf({'trainmean': 1, 'trainnoise': 1, 'mean': 1}, 'train')
-          .addx(pts[n:], 'testmean'))
-    return gp, {'train': ytr - mu_mu}, kern, pts
+    return dict(n=n, pts=pts, kern=kern, sigma2=sigma2, k_sigma_mu=k_sigma_mu, given={'train': ytr - mu_mu})
+
+
+def c5_gp(mod, prep, diag=None):
+    """ the GP that ``bayestree.bart`` builds (``bayestree/_bart.py:175-194``, marginalised mean) plus the held-out rows as
+    'testmean'.  ``diag``: how the noise block is given -- default the dense ``numpy.diag`` of the reference API;
+    ``lsqfitgp_amd.diag`` builds the same block on the device """
+    n, pts, f = prep['n'], prep['pts'], np.float32
+    noise = np.diag(np.full(n, prep['sigma2'])).astype(f) if diag is None else diag(np.full(n, prep['sigma2'], f))
+    return (mod.GP(prep['kern'], checkpos=False, checksym=False, solver='chol')
+            .addx(pts[:n], 'trainmean')
+            .addcov(noise, 'trainnoise')
+            .addcov(np.asarray(prep['k_sigma_mu'] ** 2, f), 'mean')
+            .addtransf({'trainmean': 1, 'trainnoise': 1, 'mean': 1}, 'train')
+            .addx(pts[n:], 'testmean'))
+
+
+def c5_problem(mod, X, y, n):
+    """ ``(gp, given, kernel, points)`` of configuration C5: `c5_prepare` + `c5_gp`; ``mod`` is the oracle or the device
+    package (same surface) """
+    prep = c5_prepare(mod, X, y, n)
+    return c5_gp(mod, prep), prep['given'], prep['kern'], prep['pts']
