@@ -21,8 +21,9 @@ follows; paths relative to the reference checkout):
 * ``gp``      -- ``src/lsqfitgp/_GP/_compute.py:45-136,138-305,336-422,430-516``
   and ``src/lsqfitgp/_GP/_elements.py:158-346,408-649,758-826`` (raw outputs only).
 
-PARITY PINNING STATUS: **parity unpinned against the reference's JAX-CPU
-outputs.**  The reference cannot be imported in the build container
+PARITY PINNING STATUS: **pinned at the fit level by outputs of the reference
+stored in its user guide; otherwise parity unpinned against the reference's
+JAX-CPU outputs** (the reference holds no stored posterior means/covariances).  The reference cannot be imported in the build container
 (``ModuleNotFoundError: No module named 'jax'`` at
 ``src/lsqfitgp/_patch_jax.py:22`` -- an ordinary error, jax/gvar are simply not
 installed and there is no network), and the arithmetic of the path lives in
@@ -30,6 +31,13 @@ the un-vendored dependency jax/jaxlib>=0.4.35 (``pyproject.toml:42-43``) whose
 CPU lowering is LAPACK ``potrf``/``trsm`` + BLAS ``gemm``; scipy calls the same
 LAPACK family here.  What *is* pinned, in ``tests/test_oracle_*.py``:
 
+* outputs printed by the reference itself: the hyperparameter fits of
+  ``docs/userguide/hyper.rst:49-70,124-156,252-257`` (``2.16(17)``,
+  ``log(sdev) 0.89(33)``, ``log(scale) 1.051(77)``, ``sdev 2.44(81)``,
+  ``scale 2.86(22)``), which put the ExpQuad Gram build, the jittered Cholesky
+  and the Normal log-density of this restatement on the line through the
+  argmax and curvature of the marginal likelihood
+  (``tests/test_fit_host.py``);
 * the reference's only stored known-answer table on this path, the
   ``fasthash64``/``fasthash32`` vectors of ``tests/test_jax.py:112-186``
   (copied as data into ``tests/golden/fasthash_kat.json``);
