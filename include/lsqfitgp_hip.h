@@ -367,6 +367,15 @@ int lgp_colabssum_f64(lgp_ctx *ctx, size_t rows, size_t cols, const double *dA, 
  * diagonal block; on exit dP holds the L panel and ddblk its packed diagonal blocks (lgp_chol_dblk_size(nb)).
  * info offset `row0` is added to pivot indices. */
 int lgp_panel_factor_f64(lgp_ctx *ctx, size_t rows, size_t nb, double *dP, size_t ldp, double *ddblk, size_t row0);
+/* The order in which the resident workers of the factorisation execute the diagonal squares of all 1024-column panels
+ * of an n x n matrix (n a multiple of 128): two words per task, word 0 = type | j << 8 | c << 16 | k << 24 with k the
+ * panel, type (low 7 bits; bit 7 set: the task is on the dependent chain, which has workers of its own) 0: diagonal
+ * block j of the panel factored, 1: the 64 rows of unit r of the square solved against block
+ * j, 2: the 64 x 64 tile at row unit r, column unit c of the square updated with block j; word 1 = r.  Writes at most
+ * `capacity` tasks and returns their total number (negative: error).  Host only, no device needed: the parity tests
+ * check that every task comes after the tasks it waits for and that executing the list factors the matrix.  No
+ * counterpart in the reference (LAPACK potrf inside jlinalg.cholesky, _linalg/_decomp.py:388, orders its own blocks). */
+long lgp_chain_schedule(size_t n, unsigned int *tasks, size_t capacity);
 /* The same update for ALL block columns a rank owns in a 1-D block-column-cyclic layout, in one launch: dC is the
  * rank's local storage from its first not yet finished block column on (rows x cols, local block q of width nb =
  * global block (q0 + q) * nranks + rank), dP the panel rows from the global row of C(0,0) on (rows x k).  Element (i, j)

@@ -47,7 +47,7 @@ def _stale(target, deps):
 def build_library(force=False, verbose=False):
     """ compile and link; returns the library path """
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'lsqfitgp_hip.h')]
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + [os.path.join(HERE, "..", "include", "lsqfitgp_hip.h")]
     objdir = os.path.join(CSRC, 'build')
     os.makedirs(objdir, exist_ok=True)
     objs = []

@@ -65,13 +65,46 @@ int lgp_ctx_create(int device, lgp_ctx **out) {
   c->device = device;
   c->cus = prop.multiProcessorCount;
   if (const char *m = getenv("LGP_POTF2")) c->potf2_mode = strcmp(m, "valu") == 0 ? 1 : (strcmp(m, "mfma") == 0 ? 2 : (strcmp(m, "mfma1") == 0 ? 3 : 0));
+  if (const char *m = getenv("LGP_CHAIN")) c->chain_mode = strcmp(m, "0") == 0 ? 1 : 0;
+  if (const char *m = getenv("LGP_CHAIN_MAX_N")) c->chain_max_n = (size_t)strtoull(m, nullptr, 10);
+  if (const char *m = getenv("LGP_CHAIN_WORKERS")) {
+    const int wk = atoi(m);
+    if (wk >= 1 && wk <= 256) c->chain_workers = wk;
+  }
+  if (const char *m = getenv("LGP_CHAIN_GROUPS")) {
+    const int g = atoi(m);
+    if (g >= 1 && g <= 4) c->chain_groups = g;
+  }
+  if (const char *m = getenv("LGP_CHAIN_LDS_KB")) {
+    const int kb = atoi(m);
+    if (kb >= 0 && kb <= 140) c->chain_lds_kb = kb;
+  }
   // stream2 carries the latency-bound panel factorisation of the look-ahead: highest priority, so that its
   // few workgroups are dispatched ahead of the queued trailing-update workgroups of the main stream
   int prio_lo = 0, prio_hi = 0;
   LGP_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  c->prio_hi = prio_hi;
   LGP_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo));
   LGP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_hi));
   LGP_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi));
+  if (const char *m = getenv("LGP_RESERVE")) {
+    int rc = 0, rf = 0;
+    if (sscanf(m, "%d,%d", &rc, &rf) == 2 && rc >= 0 && rf >= 0 && rc + rf < c->cus) {
+      c->reserve_chain = rc;
+      c->reserve_far = rf;
+    }
+  }
+  if (const char *m = getenv("LGP_RESERVE_MAX_N")) c->reserve_max_n = (size_t)strtoull(m, nullptr, 10);
+  if (c->reserve_max_n > 0 && c->reserve_chain + c->reserve_far > 0 && c->cus > 64) {
+    const int words = (c->cus + 31) / 32;
+    std::vector<uint32_t> mg((size_t)words, 0u), mf((size_t)words, 0u);
+    for (int i = 0; i < c->cus; ++i) {
+      if (i >= c->reserve_chain + c->reserve_far) mg[(size_t)(i / 32)] |= 1u << (i % 32);
+      if (i >= c->reserve_chain) mf[(size_t)(i / 32)] |= 1u << (i % 32);
+    }
+    LGP_HIP(hipExtStreamCreateWithCUMask(&c->stream_gm, (uint32_t)words, mg.data()));
+    LGP_HIP(hipExtStreamCreateWithCUMask(&c->stream_fm, (uint32_t)words, mf.data()));
+  }
   LGP_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
   LGP_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
   LGP_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_info), sizeof(int)));
@@ -97,6 +130,25 @@ int lgp_ctx_destroy(lgp_ctx *c) {
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   lgp_comm_destroy(c);
   if (c->d_info) (void)hipFree(c->d_info);
+  if (c->chain_trace) {
+    if (const char *path = getenv("LGP_CHAIN_TRACE")) {
+      std::vector<unsigned long long> tr(c->chain_trace_tasks * 4);
+      std::vector<unsigned int> sc(c->chain_trace_tasks * 2);
+      if (hipMemcpy(tr.data(), c->chain_trace, tr.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+          hipMemcpy(sc.data(), c->chain_trace_sched, sc.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (FILE *f = fopen(path, "w")) {
+          fprintf(f, "# task type k j r c worker taken ready done (10 ns ticks)\n");
+          for (size_t t = 0; t < c->chain_trace_tasks; ++t)
+            fprintf(f, "%zu %u %u %u %u %u %llu %llu %llu %llu\n", t, sc[2 * t] & 255u, sc[2 * t] >> 24, (sc[2 * t] >> 8) & 255u, sc[2 * t + 1],
+                    (sc[2 * t] >> 16) & 255u, tr[4 * t], tr[4 * t + 1], tr[4 * t + 2], tr[4 * t + 3]);
+          fclose(f);
+        }
+      }
+    }
+    (void)hipFree(c->chain_trace);
+  }
+  if (c->chain_state) (void)hipFree(c->chain_state);
+  for (const auto &e : c->chain_sched) (void)hipFree(e.tasks);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
@@ -104,6 +156,10 @@ int lgp_ctx_destroy(lgp_ctx *c) {
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->panel_events) (void)hipEventDestroy(e);
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+  for (hipStream_t s : c->far_streams)
+    if (s != c->stream3) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+  if (c->stream_gm) { (void)hipStreamSynchronize(c->stream_gm); (void)hipStreamDestroy(c->stream_gm); }
+  if (c->stream_fm) { (void)hipStreamSynchronize(c->stream_fm); (void)hipStreamDestroy(c->stream_fm); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   delete c;
@@ -116,6 +172,9 @@ int lgp_sync(lgp_ctx *c) {
   LGP_HIP(hipStreamSynchronize(c->stream));
   LGP_HIP(hipStreamSynchronize(c->stream2));
   LGP_HIP(hipStreamSynchronize(c->stream3));
+  for (hipStream_t s : c->far_streams) LGP_HIP(hipStreamSynchronize(s));
+  if (c->stream_gm) LGP_HIP(hipStreamSynchronize(c->stream_gm));
+  if (c->stream_fm) LGP_HIP(hipStreamSynchronize(c->stream_fm));
   return LGP_OK;
 }
 

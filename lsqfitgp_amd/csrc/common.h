@@ -13,7 +13,15 @@ struct lgp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;       // main stream: all public entry points enqueue here
   hipStream_t stream2 = nullptr;      // look-ahead stream of the blocked factorisation
-  hipStream_t stream3 = nullptr;      // bulk stream of the panel factorisation (rows that the next diagonal block does not wait for)
+  hipStream_t stream3 = nullptr;      // far-row stream of the factorisation (rows below a panel's diagonal square)
+  std::vector<hipStream_t> far_streams;   // one per row group below the square (potrf_chain), high priority
+  int prio_hi = 0;
+  int chain_groups = 1;               // row groups = streams for the rows below a square (env LGP_CHAIN_GROUPS, 1..4)
+  // CU-masked twins for chain-bound sizes (potrf.hip, potrf_split): the trailing updates keep off `reserve_chain +
+  // reserve_far` CUs, the far rows off the first `reserve_chain`, so that the dependent chain always finds idle CUs
+  hipStream_t stream_gm = nullptr, stream_fm = nullptr;
+  int reserve_chain = 8, reserve_far = 8;      // env LGP_RESERVE="chain,far" (CUs; mask bit i is a CU of XCD i mod 8)
+  size_t reserve_max_n = 0;                    // env LGP_RESERVE_MAX_N: largest matrix that reserves CUs (0: never, the default: measured slower)
   std::vector<hipEvent_t> panel_events;   // per 128-block of a panel: potf2 done, look-ahead rows solved, bulk done
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   int *d_info = nullptr;              // pivot info word (0 = ok, else 1-based index), device
@@ -29,6 +37,21 @@ struct lgp_ctx {
   int swapped = 0;                    // lgp_select_stream(1): `stream` and `stream2` exchanged
   int potf2_mode = 0;                 // diagonal-block kernel: 0 = auto, 1 = VALU, 2 = matrix cores (env LGP_POTF2=valu|mfma)
   int potf2_small = 1;                // auto mode: the factorisation in progress is small enough for the matrix-core kernel
+  // the dependent chain of the factorisation as one launch of resident workers (potf2m.hip): schedules per matrix size,
+  // flag/counter words (LGP_CH_* layout)
+  struct ChainSched { unsigned long long key; void *tasks; int ntasks, nchain; };
+  std::vector<ChainSched> chain_sched;
+  void *chain_state = nullptr;
+  size_t chain_state_bytes = 0;
+  void *chain_trace = nullptr;        // LGP_CHAIN_TRACE=<file>: per-task times of the last launch
+  size_t chain_trace_tasks = 0;
+  const void *chain_trace_sched = nullptr;
+  int chain_mode = 0;                 // 0 = used where it applies, 1 = off (env LGP_CHAIN=0)
+  size_t chain_max_n = 16384;         // largest matrix factored this way (env LGP_CHAIN_MAX_N); beyond, the trailing update bounds the
+                                      // factorisation and the workers' CUs are worth more to it (N = 32768: 186 ms split driver, 204 ms chain)
+  size_t chain_hog_max_n = 8192;      // ... and largest matrix for which the workers keep other workgroups off their CUs
+  int chain_workers = 16;             // resident worker workgroups = CUs taken from the trailing update (env LGP_CHAIN_WORKERS)
+  int chain_lds_kb = 100;             // untouched dynamic LDS per worker that keeps other workgroups off its CU (env LGP_CHAIN_LDS_KB)
   // live kernel timing of the dominant kernel (trailing-update syrk) for bench.py: HIP event pairs on the
   // stream the kernel is launched on, enabled by lgp_profile_begin
   int prof_on = 0;
@@ -103,6 +126,24 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
 template <typename T>
 int lgp_potf2_launch(lgp_ctx *ctx, hipStream_t stream, T *A, size_t lda, int nb, T *dblk, size_t row0);
 int lgp_potf2_mfma_launch(lgp_ctx *ctx, hipStream_t stream, double *A, size_t lda, int nb, double *dblk, size_t row0);   // potf2m.hip
+// the chain kernel (potf2m.hip): the diagonal squares of all panels, factored by resident workers
+bool lgp_chain_usable(const lgp_ctx *ctx, size_t n, size_t ldl);
+size_t lgp_chain_state_bytes(size_t n);
+int lgp_chain_state(lgp_ctx *ctx, size_t n, unsigned **out);        // device words, LGP_CH_* layout; the caller zeroes them
+int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk);
+// layout of the state words: a header, then LGP_CH_PANEL words per panel
+constexpr int LGP_CH_NEXT = 0, LGP_CH_ABORT = 1, LGP_CH_NEXT_BULK = 2, LGP_CH_HEADER = 16, LGP_CH_PANEL = 512;
+constexpr int LGP_CH_U1 = 0;      // stream -> kernel: the panel's square has the updates of all earlier panels
+constexpr int LGP_CH_U2 = 1;      // stream -> stream: the block column below the NEXT panel's square updated with this panel
+constexpr int LGP_CH_U3 = 2;      // stream -> stream: everything right of the next panel updated with this panel
+constexpr int LGP_CH_GRP = 4;     // [4] stream -> stream: row group g of this panel's rows below its square is final
+constexpr int LGP_CH_READY = 8;   // [8] kernel -> stream: 1 (block j factored) + the square's row units solved against it
+constexpr int LGP_CH_FLAGP = 16;  // [8]
+constexpr int LGP_CH_FLAGS = 32;  // [16][8] row unit r solved against block j
+constexpr int LGP_CH_CNT = 160;   // [16][16] steps applied to tile (r, c)
+// info word written when the workers of the chain kernel gave up waiting (a stall, not a pivot): reported as an error
+constexpr int LGP_INFO_STALLED = 0x7fffffff;
+int lgp_info_result(int info);      // info, or LGP_EHIP with the error text set for LGP_INFO_STALLED (potrf.hip)
 template <typename T>
 int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t nb, T *P, size_t ldp, T *dblk, size_t row0);
 template <typename T>

@@ -573,7 +573,8 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   // operand) rely on one tile covering the aliased dimension, which the callers guarantee for 128 only.
   const size_t t128 = ((m + 127) / 128) * ((n + 127) / 128);
   const bool aliased = (static_cast<const void *>(A) == static_cast<const void *>(C)) || (static_cast<const void *>(B) == static_cast<const void *>(C));
-  if (!aliased && ((t128 <= 64 && k <= 2048) || (t128 <= 512 && k <= 256)))
+  static const size_t t64max = getenv("LGP_GEMM_T64_MAX") ? (size_t)atol(getenv("LGP_GEMM_T64_MAX")) : 512;
+  if (!aliased && ((t128 <= 64 && k <= 2048) || (t128 <= t64max && k <= 256)))
     return gemm_launch_ts<T, 64, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, 0, cyc_nb, cyc_g1);
   // (a 512-thread variant, 4 x 2 waves of 32 x 64 at 4 waves per SIMD, was measured equal: 61.3 vs 61.7 TFLOP/s)
   return gemm_launch_ts<T, 128, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, tag, cyc_nb, cyc_g1);

@@ -17,12 +17,14 @@
 //   finish    : L <- L * s[:,None], diagonal-block workspace re-extracted, eps_out = eps * min(s^2).
 // A non-positive or non-finite pivot is recorded in ctx->d_info (first one wins) and the factor goes
 // NaN from there on, like LAPACK-in-jax; the host turns info != 0 into the reference's LinAlgError.
-#include "common.h"
+#include "chain.h"
 #include <cstdlib>
 
-#ifndef LGP_CHAIN_PRIO
-#define LGP_CHAIN_PRIO 3
-#endif
+int lgp_info_result(int info) {
+  if (info != LGP_INFO_STALLED) return info;
+  lgp_set_error("the panel task graph stalled (a worker waited longer than 2 s for its inputs); the factor is incomplete");
+  return LGP_EHIP;
+}
 
 namespace {
 
@@ -347,134 +349,10 @@ __global__ void __launch_bounds__(256) pack_frag_kernel(T *dblk) {
   F[f * 64 + l] = live ? -(Dl[u * D + v] * rd[u]) : T(0);
 }
 
-template <typename T> struct Mma;
-template <> struct Mma<double> {
-  typedef double acc_t __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-    typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(double, (u2_t)__builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
-  }
-  static __device__ __forceinline__ double bpermute(int addr, double v) {
-    const long long bits = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)bits), hi = __builtin_amdgcn_ds_bpermute(addr, (int)(bits >> 32));
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-  }
-};
-template <> struct Mma<float> {
-  typedef float acc_t __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-    return __builtin_bit_cast(float, (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
-  }
-  static __device__ __forceinline__ float bpermute(int addr, float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
-  }
-};
-
-constexpr int SUBSTM_ROWS = 64;   // rows per 256-thread workgroup (16 per wave)
-
-#ifdef LGP_SUBST_TRACE
-__device__ unsigned long long lgp_subst_trace[16];
-#endif
 template <typename T>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) subst_right_mfma_kernel(const T *__restrict__ w, int jb, T *X, long ldx, long rows) {
-  typedef typename Mma<T>::acc_t acc_t;
-  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-  const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
-  if (r0 >= rows) return;     // wave-uniform
   __builtin_amdgcn_s_setprio(LGP_CHAIN_PRIO);
-  const long row = r0 + n;
-  const bool rok = row < rows;
-  T *xrow = X + (rok ? row : r0) * ldx;     // clamped: out-of-range lanes read a valid row and never store
-  const __amdgpu_buffer_rsrc_t frag = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(w + LGP_FRAG0), 0, LGP_NFRAG * 64 * (int)sizeof(T), 0x00020000);
-  const int voff = lane * (int)sizeof(T);
-  auto F = [&](int id) -> T { return Mma<T>::load(frag, voff, id * 64 * (int)sizeof(T)); };
-
-  acc_t t[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int col = 16 * c + 4 * r + g;
-      t[c][r] = (col < jb) ? xrow[col] : T(0);
-    }
-  int baddr[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) baddr[a] = (a * 16 + n) * 4;
-
-  // Right-looking over the eight 16-column tiles.  The dependent chain of a tile is its in-tile solve (four slabs of three
-  // broadcast + fma steps and one MFMA) plus the four MFMAs that bring in the tile just finished; everything else -- the
-  // updates of the later tiles with a finished tile, and above all the FRAGMENT LOADS (L2 round trips of several hundred
-  // cycles each) -- is issued a whole tile step ahead of its use: the fragments of step c + 1 are requested at the top of
-  // step c, into registers.
-#ifdef LGP_SUBST_TRACE
-#define LGP_SSTAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0 && blockIdx.x == 0) lgp_subst_trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define LGP_SSTAMP(k) do { } while (0)
-#endif
-  LGP_SSTAMP(0);
-  T rdv[8][4];
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rdv[c][r] = F(232 + 4 * c + r);
-  T coef[2][4][3], dg[2][3];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) coef[0][r][a] = F(136 + r * 3 + a);
-    if (r < 3) dg[0][r] = F(112 + r);
-  }
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t[c][r] *= rdv[c][r];                       // x~ = x / diag, every tile up front
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const int cur = c & 1, nxt = cur ^ 1;
-    // requests for the next step: its in-tile coefficients, and the fragments that apply THIS tile to the later ones
-    T off[7][4];
-#pragma unroll
-    for (int cc = c + 1; cc < 8; ++cc)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) off[cc - c - 1][s2] = F((cc * (cc - 1) / 2 + c) * 4 + s2);
-    if (c < 7) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) coef[nxt][r][a] = F(136 + (4 * (c + 1) + r) * 3 + a);
-        if (r < 3) dg[nxt][r] = F(112 + 3 * (c + 1) + r);
-      }
-    }
-    // in-tile solve
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const T yb = Mma<T>::bpermute(baddr[a], t[c][r]);                 // unknown 4r + a of this row, to every lane group
-        t[c][r] = __builtin_fma(coef[cur][r][a], yb, t[c][r]);            // zero coefficient for groups <= a
-      }
-      if (r < 3) t[c] = Mma<T>::run(dg[cur][r], t[c][r], t[c]);           // finished unknowns -> later registers of the tile
-    }
-    // the finished tile -> every later tile (nearest first: it is the next one on the chain)
-#pragma unroll
-    for (int cc = c + 1; cc < 8; ++cc)
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) t[cc] = Mma<T>::run(off[cc - c - 1][s2], t[c][s2], t[cc]);
-    LGP_SSTAMP(1 + c);
-  }
-
-  if (rok) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = 16 * c + 4 * r + g;
-        if (col < jb) xrow[col] = t[c][r];
-      }
-  }
-  LGP_SSTAMP(9);
+  subst_right_wave<T>(w, jb, X, ldx, rows, ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -716,7 +594,7 @@ int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t 
 }
 
 template <typename T>
-int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx) {
+static int potrf_lookahead_v1(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx) {
   LGP_REQUIRE(ldl >= n, "ldl < n");
   hipStream_t s0 = ctx->stream, s1 = ctx->stream2;
   const size_t NB = LGP_NB;
@@ -765,6 +643,255 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx)
     LGP_HIP(hipStreamWaitEvent(s0, ctx->ev_b, 0));
   }
   return LGP_OK;
+}
+
+// The driver.  Three streams:
+//   s1 (chain, high priority)  per panel k: U1(k-1) = the K = 1024 update of the panel's own diagonal SQUARE, then the square
+//                              factored block by block (potf2 -> substitution of the square's rows below -> K = 128 update of
+//                              the rest of the square): everything the next diagonal block waits for, and nothing else;
+//   s3 (far rows)              the rows below the square (and the carried right-hand sides) follow one block behind: for each
+//                              block an event of s1 ("rows of the square solved"), their substitution and their K = 128 update.
+//                              s3 waits for s1, NEVER the other way round inside a panel, so no event latency lands on the chain;
+//   s0 (main)                  U2(k) = rest of block column k+1, U3(k) = everything right of it (the N^3/3 flops).
+// Against the round-1 driver (whole panel, all rows, on the chain stream; kept as potrf_lookahead_v1, LGP_POTRF=v1) the chain
+// loses the substitution and the update of up to N rows per block and the part of the block-column update below the square.
+template <typename T>
+static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx) {
+  // chain-bound sizes: the trailing updates (sg) and the far rows (s3) run on CU-masked streams that leave a few CUs to the chain
+  const bool reserve = ctx->stream_gm != nullptr && ctx->stream_fm != nullptr && n <= ctx->reserve_max_n;
+  hipStream_t s0 = ctx->stream, s1 = ctx->stream2, s3 = reserve ? ctx->stream_fm : ctx->stream3, sg = reserve ? ctx->stream_gm : s0;
+  const size_t NB = LGP_NB;
+  enum { EV_BLK = 0, EV_SQ = 8, EV_FAR = 9, EV_U2 = 10, EV_U3 = 11, EV_START = 12, EV_COUNT = 13 };
+  while (ctx->panel_events.size() < (size_t)EV_COUNT) {
+    hipEvent_t e;
+    LGP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->panel_events.push_back(e);
+  }
+  auto E = [&](int i) { return ctx->panel_events[(size_t)i]; };
+  auto subst = [&](hipStream_t st, const T *w, size_t jb, T *X, size_t nrows) -> int {
+    if (nrows == 0) return LGP_OK;
+    hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((nrows + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, st, w, (int)jb, X,
+                       (long)ldl, (long)nrows);
+    LGP_LAUNCH_CHECK();
+    return LGP_OK;
+  };
+  LGP_HIP(hipEventRecord(E(EV_START), s0));             // the matrix as the caller's stream has it
+  LGP_HIP(hipStreamWaitEvent(s1, E(EV_START), 0));
+  LGP_HIP(hipStreamWaitEvent(s3, E(EV_START), 0));
+  if (sg != s0) LGP_HIP(hipStreamWaitEvent(sg, E(EV_START), 0));
+  bool have_u3 = false, have_far = false;
+  for (size_t k0 = 0; k0 < n; k0 += NB) {
+    const size_t kb = (n - k0) < NB ? (n - k0) : NB;
+    T *P = L + k0 * ldl + k0;
+    T *Yk = dblk + (k0 / LGP_DB) * (size_t)LGP_DBLK;
+    const size_t far = n + nx - (k0 + kb);              // rows below the square, carried rows included
+    T *Pfar = P + kb * ldl;
+    // ---- the square on s1, the far rows one block behind on s3
+    int bi = 0;
+    for (size_t j0 = 0; j0 < kb; j0 += LGP_DB, ++bi) {
+      const size_t jb = (kb - j0) < (size_t)LGP_DB ? (kb - j0) : (size_t)LGP_DB;
+      T *w = Yk + (j0 / LGP_DB) * (size_t)LGP_DBLK;
+      LGP_CHECK(lgp_potf2_launch<T>(ctx, s1, P + j0 * ldl + j0, ldl, (int)jb, w, k0 + j0));
+      const size_t below = kb - (j0 + jb), wc = below;  // rows of the square below the block = columns right of it
+      T *Xsq = P + (j0 + jb) * ldl + j0;
+      LGP_CHECK(subst(s1, w, jb, Xsq, below));
+      if (far > 0) {
+        LGP_HIP(hipEventRecord(E(EV_BLK + bi), s1));
+        LGP_HIP(hipStreamWaitEvent(s3, E(EV_BLK + bi), 0));
+        LGP_CHECK(subst(s3, w, jb, Pfar + j0, far));
+        if (wc > 0) LGP_CHECK(lgp_gemm_launch<T>(ctx, s3, false, true, far, wc, jb, T(-1), Pfar + j0, ldl, Xsq, ldl, T(1), Pfar + (j0 + jb), ldl, false));
+      }
+      if (wc > 0) LGP_CHECK(lgp_gemm_launch<T>(ctx, s1, false, true, below, wc, jb, T(-1), Xsq, ldl, Xsq, ldl, T(1), P + (j0 + jb) * ldl + (j0 + jb), ldl, true));
+    }
+    LGP_HIP(hipEventRecord(E(EV_SQ), s1));
+    have_far = far > 0;
+    if (have_far) LGP_HIP(hipEventRecord(E(EV_FAR), s3));
+    const size_t t0 = k0 + kb;
+    if (t0 >= n) break;
+    const size_t rows_t = n - t0;
+    const T *Pt = L + t0 * ldl + k0;                    // (rows_t + nx) x kb: the panel below its square
+    const size_t nb1 = rows_t < NB ? rows_t : NB;       // width of the next panel
+    T *C1 = L + t0 * ldl + t0;
+    // ---- s1: U1, the next panel's square (it has every earlier update once U3 of the previous step is done)
+    LGP_HIP(hipStreamWaitEvent(s1, E(EV_FAR), 0));
+    if (have_u3) LGP_HIP(hipStreamWaitEvent(s1, E(EV_U3), 0));
+    LGP_CHECK(lgp_gemm_launch<T>(ctx, s1, false, true, nb1, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
+    // ---- sg: U2, the block column below that square; then s3 may touch it
+    LGP_HIP(hipStreamWaitEvent(sg, E(EV_SQ), 0));
+    LGP_HIP(hipStreamWaitEvent(sg, E(EV_FAR), 0));
+    const size_t rows_r = rows_t - nb1;
+    if (rows_r + nx > 0)
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false));
+    LGP_HIP(hipEventRecord(E(EV_U2), sg));
+    LGP_HIP(hipStreamWaitEvent(s3, E(EV_U2), 0));
+    // ---- sg: U3, everything right of the next panel: the N^3/3 flops, one launch
+    if (rows_r > 0) {
+      const T *Pa = Pt + nb1 * ldl;                     // (rows_r + nx) x kb
+      T *Cc = L + (t0 + nb1) * ldl + (t0 + nb1);
+      // algorithmic flops of this launch: 2 k per produced entry of the lower trapezoid
+      const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0) + (double)nx * (double)rows_r;
+      // (timed for bench.py when it is the 128-tile instantiation that profilers list as gemm_kernel<..., 128, 256, 1>;
+      // the last, <= 64-tile update of a factorisation goes to the 64-tile kernel and is left out of both)
+      const bool timed = ((rows_r + nx + 127) / 128) * ((rows_r + 127) / 128) > 64;   // lgp_gemm_launch's 128-tile criterion at K = 1024
+      if (timed) LGP_CHECK(lgp_prof_start(ctx, sg, 2.0 * (double)kb * entries));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 1));
+      if (timed) LGP_CHECK(lgp_prof_stop(ctx, sg));
+    }
+    LGP_HIP(hipEventRecord(E(EV_U3), sg));
+    have_u3 = true;
+  }
+  // the factor is complete on the caller's stream when the chain and the far rows are
+  LGP_HIP(hipStreamWaitEvent(s0, E(EV_SQ), 0));
+  if (have_far) LGP_HIP(hipStreamWaitEvent(s0, E(EV_FAR), 0));
+  if (sg != s0 && have_u3) LGP_HIP(hipStreamWaitEvent(s0, E(EV_U3), 0));
+  return LGP_OK;
+}
+
+// The driver for fp64 matrices whose order is a multiple of 128: the chain kernel (potf2m.hip) factors the diagonal squares of
+// all panels on CUs of its own, from one launch on s1; the rest is enqueued around it, ordered by flag words that the command
+// processor polls (hipStreamWaitValue32) or writes (hipStreamWriteValue32) -- no kernel of the dependent chain is ever
+// launched, waited for through an event, or run beside a trailing update.  The rows below a panel's square are cut into row
+// groups with a stream each: group 0 = the rows of the NEXT diagonal square (the only ones the chain needs back), the others
+// share the rest.  Per panel k:
+//   group stream g   wait u2[k-1];  per block j:  wait ready[k][j]  ->  substitution and K = 128 update of the group's rows;  grp[k][g] := 1
+//   group 0 then     wait u3[k-1],  U1(k) = the K = 1024 update of the next square,  u1[k+1] := 1  (the chain kernel goes on)
+//   s0 (main)        wait grp[k][*]  ->  U2(k) (block column k+1 below its square),  u2[k] := 1,  U3(k) (everything right of it),  u3[k] := 1
+// One stream for all the rows below was measured first: its 16 dependent launches per panel (8 x (37 + 52) us at N = 8192) were
+// slower than the chain (8 x 72 us) and the next square waited ~400 us for them; per group they overlap.
+static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *dblk, size_t nx) {
+  typedef double T;
+  hipStream_t s0 = ctx->stream, s1 = ctx->stream2;
+  const size_t NB = LGP_NB;
+  // row groups (flag words LGP_CH_GRP .. + 3).  Two, so that the factorisation runs on four streams in all: the runtime
+  // maps streams onto four hardware queues (GPU_MAX_HW_QUEUES), and with more streams than that a stream can end up behind
+  // another stream's polling wait in the same queue (measured with four groups: 2 ms per panel hand-over instead of 0.1)
+  const int MAXG = ctx->chain_groups;
+  if (ctx->far_streams.empty()) ctx->far_streams.push_back(ctx->stream3);        // (the context's third stream is the first of them)
+  while (ctx->far_streams.size() < (size_t)MAXG) {
+    hipStream_t s;
+    LGP_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, ctx->prio_hi));
+    ctx->far_streams.push_back(s);
+  }
+  enum { EV_SQ = 8, EV_START = 12, EV_GRP = 13, EV_COUNT = 13 + 4 };
+  while (ctx->panel_events.size() < (size_t)EV_COUNT) {
+    hipEvent_t e;
+    LGP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->panel_events.push_back(e);
+  }
+  auto E = [&](int i) { return ctx->panel_events[(size_t)i]; };
+  unsigned *st = nullptr;
+  LGP_CHECK(lgp_chain_state(ctx, n, &st));
+  auto word = [&](size_t k, int which) { return st + LGP_CH_HEADER + LGP_CH_PANEL * k + which; };
+  auto wait_ge = [&](hipStream_t s, unsigned *p, unsigned v) { return hipStreamWaitValue32(s, p, v, hipStreamWaitValueGte, 0xffffffffu); };
+  auto subst = [&](hipStream_t s, const T *w, T *X, size_t nrows) -> int {
+    if (nrows == 0) return LGP_OK;
+    hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((nrows + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, s, w, (int)LGP_DB, X,
+                       (long)ldl, (long)nrows);
+    LGP_LAUNCH_CHECK();
+    return LGP_OK;
+  };
+  // the flag words are zeroed before any stream can look at them: every stream starts behind this point of s0
+  LGP_HIP(hipMemsetAsync(st, 0, lgp_chain_state_bytes(n), s0));
+  LGP_HIP(hipEventRecord(E(EV_START), s0));
+  LGP_HIP(hipStreamWaitEvent(s1, E(EV_START), 0));
+  for (int g = 0; g < MAXG; ++g) LGP_HIP(hipStreamWaitEvent(ctx->far_streams[(size_t)g], E(EV_START), 0));
+  LGP_CHECK(lgp_chain_launch(ctx, s1, n, L, ldl, dblk));
+  LGP_HIP(hipEventRecord(E(EV_SQ), s1));
+  const size_t npanels = (n + NB - 1) / NB;
+  for (size_t k = 0; k < npanels; ++k) {
+    const size_t k0 = k * NB, kb = (n - k0) < NB ? (n - k0) : NB, nq = kb / LGP_DB;
+    T *P = L + k0 * ldl + k0;
+    T *Yk = dblk + (k0 / LGP_DB) * (size_t)LGP_DBLK;
+    const size_t t0 = k0 + kb, rows_t = n - t0;         // matrix rows below the square
+    const size_t below = rows_t + nx;                   // ... and the carried rows
+    const size_t nb1 = rows_t < NB ? rows_t : NB;       // width of the next panel = rows of group 0
+    // row groups: [g0[g], g0[g+1]) relative to the first row below the square
+    size_t g0[4 + 1];
+    int ng = 0;
+    g0[0] = 0;
+    if (below > 0 && MAXG == 1) {
+      g0[++ng] = below;                                 // one group: every row below the square
+    } else if (below > 0) {
+      const size_t rest = below - nb1;                  // (nb1 = 0 on the last panel: the carried rows are the only group)
+      if (nb1 > 0) g0[++ng] = nb1;
+      if (rest > 0 && ng == MAXG) g0[ng] = below;
+      else if (rest > 0) {
+        const size_t want = (rest + 2047) / 2048, parts = want < (size_t)(MAXG - ng) ? want : (size_t)(MAXG - ng);
+        const size_t per = ((rest + parts - 1) / parts + 63) / 64 * 64;
+        for (size_t q = 0; q < parts && g0[ng] < below; ++q) {
+          const size_t end = g0[ng] + per < below ? g0[ng] + per : below;
+          g0[++ng] = end;
+        }
+        g0[ng] = below;
+      }
+    }
+    for (int g = 0; g < ng; ++g) {
+      hipStream_t sg = ctx->far_streams[(size_t)g];
+      const size_t rows_g = g0[g + 1] - g0[g];
+      T *Pg = P + (kb + g0[g]) * ldl;                   // the group's rows of the panel
+      if (k >= 1) LGP_HIP(wait_ge(sg, word(k - 1, LGP_CH_U2), 1));     // its rows of this block column have panel k-1's update
+      for (size_t j = 0; j < nq; ++j) {
+        const size_t j0 = j * LGP_DB, wc = kb - (j0 + LGP_DB);
+        LGP_HIP(wait_ge(sg, word(k, LGP_CH_READY) + j, (unsigned)(1 + 2 * nq - 2 * j - 2)));
+        LGP_CHECK(subst(sg, Yk + j * (size_t)LGP_DBLK, Pg + j0, rows_g));
+        if (wc > 0)
+          LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_g, wc, LGP_DB, T(-1), Pg + j0, ldl, P + (j0 + LGP_DB) * ldl + j0, ldl, T(1),
+                                       Pg + (j0 + LGP_DB), ldl, false));
+      }
+      LGP_HIP(hipStreamWriteValue32(sg, word(k, LGP_CH_GRP + g), 1, 0));
+    }
+    if (t0 >= n) {
+      if (ng == 0) {      // nothing below the last square: the caller's stream still has to see it finished
+        LGP_HIP(wait_ge(ctx->far_streams[0], word(k, LGP_CH_READY) + (nq - 1), 1));
+      }
+      break;
+    }
+    const T *Pt = L + t0 * ldl + k0;                    // (rows_t + nx) x kb: the panel below its square
+    T *C1 = L + t0 * ldl + t0;
+    // ---- group 0's stream: U1, the next panel's square; it has every earlier update once U3 of the previous step is done
+    {
+      hipStream_t sg = ctx->far_streams[0];
+      if (k >= 1) LGP_HIP(wait_ge(sg, word(k - 1, LGP_CH_U3), 1));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, nb1, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
+      LGP_HIP(hipStreamWriteValue32(sg, word(k + 1, LGP_CH_U1), 1, 0));
+    }
+    // ---- s0: U2, the block column below that square
+    for (int g = 0; g < ng; ++g) LGP_HIP(wait_ge(s0, word(k, LGP_CH_GRP + g), 1));
+    const size_t rows_r = rows_t - nb1;
+    if (rows_r + nx > 0)
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false));
+    LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U2), 1, 0));
+    // ---- s0: U3, everything right of the next panel: the N^3/3 flops, one launch
+    if (rows_r > 0) {
+      const T *Pa = Pt + nb1 * ldl;                     // (rows_r + nx) x kb
+      T *Cc = L + (t0 + nb1) * ldl + (t0 + nb1);
+      const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0) + (double)nx * (double)rows_r;
+      // (timed for bench.py when it is the 128-tile instantiation that profilers list as gemm_kernel<..., 128, 256, 1>)
+      const bool timed = ((rows_r + nx + 127) / 128) * ((rows_r + 127) / 128) > 64;
+      if (timed) LGP_CHECK(lgp_prof_start(ctx, s0, 2.0 * (double)kb * entries));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 1));
+      if (timed) LGP_CHECK(lgp_prof_stop(ctx, s0));
+    }
+    LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U3), 1, 0));
+  }
+  // the factor is complete on the caller's stream when the chain kernel has left and every row group is done
+  LGP_HIP(hipStreamWaitEvent(s0, E(EV_SQ), 0));
+  for (int g = 0; g < MAXG; ++g) {
+    LGP_HIP(hipEventRecord(E(EV_GRP + g), ctx->far_streams[(size_t)g]));
+    LGP_HIP(hipStreamWaitEvent(s0, E(EV_GRP + g), 0));
+  }
+  return LGP_OK;
+}
+
+template <typename T>
+int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx) {
+  LGP_REQUIRE(ldl >= n, "ldl < n");
+  static const bool v1 = getenv("LGP_POTRF") != nullptr && strcmp(getenv("LGP_POTRF"), "v1") == 0;
+  if (v1 || ctx->stream3 == nullptr) return potrf_lookahead_v1<T>(ctx, n, L, ldl, dblk, nx);
+  if constexpr (std::is_same<T, double>::value) {
+    if (lgp_chain_usable(ctx, n, ldl) && n <= ctx->chain_max_n) return potrf_chain(ctx, n, L, ldl, dblk, nx);
+  }
+  return potrf_split<T>(ctx, n, L, ldl, dblk, nx);
 }
 
 template <typename T>
@@ -874,7 +1001,7 @@ static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T ep
   LGP_HIP(hipFreeAsync(ws, st));
   LGP_HIP(hipStreamSynchronize(st));
   if (heps_out) *heps_out = hstats[1];
-  return info;
+  return lgp_info_result(info);
 }
 
 // Tail of Chol.__init__ for a matrix that the fused Gram kernel (gram.hip, gram_reg_kernel) has already scaled and written as
@@ -928,7 +1055,7 @@ int lgp_chol_from_prepared(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, si
   LGP_HIP(hipFreeAsync(ws, st));
   LGP_HIP(hipStreamSynchronize(st));
   if (heps_out) *heps_out = hstats[1];
-  return info;
+  return lgp_info_result(info);
 }
 template int lgp_chol_from_prepared<double>(lgp_ctx *, size_t, double *, size_t, double *, size_t, double *, size_t, double, double, int, double *);
 template int lgp_chol_from_prepared<float>(lgp_ctx *, size_t, float *, size_t, float *, size_t, float *, size_t, float, float, int, float *);
@@ -964,7 +1091,7 @@ static int potrf_entry(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk) {
   int info = 0;
   LGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   LGP_HIP(hipStreamSynchronize(ctx->stream));
-  return info;
+  return lgp_info_result(info);
 }
 extern "C" int lgp_potrf_f64(lgp_ctx *ctx, size_t n, double *dL, size_t ldl, double *ddblk) { return potrf_entry<double>(ctx, n, dL, ldl, ddblk); }
 extern "C" int lgp_potrf_f32(lgp_ctx *ctx, size_t n, float *dL, size_t ldl, float *ddblk) { return potrf_entry<float>(ctx, n, dL, ldl, ddblk); }
@@ -996,7 +1123,7 @@ extern "C" int lgp_get_info(lgp_ctx *ctx, int *hinfo) {
   LGP_HIP(hipMemcpyAsync(hinfo, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   LGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   LGP_HIP(hipStreamSynchronize(ctx->stream));
-  return LGP_OK;
+  return lgp_info_result(*hinfo) < 0 ? LGP_EHIP : LGP_OK;
 }
 
 template int lgp_panel_factor_impl<double>(lgp_ctx *, hipStream_t, size_t, size_t, double *, size_t, double *, size_t);

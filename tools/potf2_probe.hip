@@ -106,6 +106,20 @@ int main() {
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("potf2_mfma4 x50 back-to-back: %.1f us each\n", ms * 1e3 / 50);
+#ifdef LGP_POTF2_TRACE
+    {
+      CK(hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice));
+      potf2_mfma4_kernel<<<1, 256>>>(dA, n, n, dW, dinfo, 0);
+      CK(hipDeviceSynchronize());
+      unsigned long long st[64];
+      CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(lgp_p4_trace), sizeof(st)));
+      printf("potf2_mfma4 wave 0 (cycles): loads %llu |", st[1] - st[0]);
+      for (int s2 = 0; s2 < 8; ++s2)
+        printf(" step %d: publish %llu pivots %llu barrier %llu trailing %llu |", s2, st[2 + 4 * s2] - (s2 ? st[1 + 4 * s2] : st[1]), st[3 + 4 * s2] - st[2 + 4 * s2],
+               st[4 + 4 * s2] - st[3 + 4 * s2], st[5 + 4 * s2] - st[4 + 4 * s2]);
+      printf(" stores %llu; total %llu\n", st[34] - st[33], st[34] - st[0]);
+    }
+#endif
   }
   // 50 back-to-back
   CK(hipEventRecord(e0));
