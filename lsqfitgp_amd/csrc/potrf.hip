@@ -809,20 +809,14 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     size_t g0[4 + 1];
     int ng = 0;
     g0[0] = 0;
-    if (below > 0 && MAXG == 1) {
-      g0[++ng] = below;                                 // one group: every row below the square
-    } else if (below > 0) {
-      const size_t rest = below - nb1;                  // (nb1 = 0 on the last panel: the carried rows are the only group)
-      if (nb1 > 0) g0[++ng] = nb1;
-      if (rest > 0 && ng == MAXG) g0[ng] = below;
-      else if (rest > 0) {
-        const size_t want = (rest + 2047) / 2048, parts = want < (size_t)(MAXG - ng) ? want : (size_t)(MAXG - ng);
-        const size_t per = ((rest + parts - 1) / parts + 63) / 64 * 64;
-        for (size_t q = 0; q < parts && g0[ng] < below; ++q) {
-          const size_t end = g0[ng] + per < below ? g0[ng] + per : below;
-          g0[++ng] = end;
-        }
-        g0[ng] = below;
+    if (below > 0) {
+      // equal shares (multiples of 64 rows), at least 1024 rows each: the groups advance side by side, one block behind the chain
+      size_t parts = below / 1024;
+      parts = parts < 1 ? 1 : (parts > (size_t)MAXG ? (size_t)MAXG : parts);
+      const size_t per = ((below + parts - 1) / parts + 63) / 64 * 64;
+      while (g0[ng] < below) {
+        const size_t end = g0[ng] + per < below ? g0[ng] + per : below;
+        g0[++ng] = end;
       }
     }
     for (int g = 0; g < ng; ++g) {
@@ -851,6 +845,7 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     // ---- group 0's stream: U1, the next panel's square; it has every earlier update once U3 of the previous step is done
     {
       hipStream_t sg = ctx->far_streams[0];
+      for (int g = 1; g < ng; ++g) LGP_HIP(wait_ge(sg, word(k, LGP_CH_GRP + g), 1));      // (the rows of the next square may sit in any group)
       if (k >= 1) LGP_HIP(wait_ge(sg, word(k - 1, LGP_CH_U3), 1));
       LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, nb1, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
       LGP_HIP(hipStreamWriteValue32(sg, word(k + 1, LGP_CH_U1), 1, 0));
