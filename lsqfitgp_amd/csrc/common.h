@@ -119,6 +119,9 @@ template <typename T>
 int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
                     const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag = 0, int cyc_nb = 0,
                     int cyc_g1 = 0);
+// tag & 2: an update of the factorisation that shares the GPU with latency-bound kernels: 64 x 64 tiles up to lgp_gemm_t64_trailing_max()
+// tiles of 128 x 128 (the tag & 1 label then only applies to the launches that still get 128 x 128 tiles)
+size_t lgp_gemm_t64_trailing_max();
 // cyc_nb > 0: block-column-cyclic lower update (see GemmArgs in gemm.hip); only for the NT lower form with A == B rows
 // tag = 1 launches the separately named instantiation used for the Cholesky trailing update (profiling label only)
 

@@ -557,6 +557,11 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
   return LGP_OK;
 }
 
+size_t lgp_gemm_t64_trailing_max() {
+  static const size_t v = getenv("LGP_GEMM_T64_TRAILING_MAX") ? (size_t)atol(getenv("LGP_GEMM_T64_TRAILING_MAX")) : 10000;
+  return v;
+}
+
 template <typename T>
 int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
                     const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag, int cyc_nb, int cyc_g1) {
@@ -573,11 +578,14 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   // operand) rely on one tile covering the aliased dimension, which the callers guarantee for 128 only.
   const size_t t128 = ((m + 127) / 128) * ((n + 127) / 128);
   const bool aliased = (static_cast<const void *>(A) == static_cast<const void *>(C)) || (static_cast<const void *>(B) == static_cast<const void *>(C));
-  static const size_t t64max = getenv("LGP_GEMM_T64_MAX") ? (size_t)atol(getenv("LGP_GEMM_T64_MAX")) : 512;
-  if (!aliased && ((t128 <= 64 && k <= 2048) || (t128 <= t64max && k <= 256)))
+  // tag & 2 (the updates of the factorisation, K = 1024): 64 x 64 tiles up to 10000 tiles of 128 as well.  Their workgroups
+  // live 27 us instead of 200, so the latency-bound kernels of the other streams find CUs and are not squeezed for as long:
+  // N = 8192 7.2 -> 6.8 ms, N = 16384 32.2 -> 30.4 ms, N = 32768 185.7 -> 183.7 ms (all 64-tile: 187.8 ms).
+  const size_t t64big = (tag & 2) ? lgp_gemm_t64_trailing_max() : 64;
+  if (!aliased && ((t128 <= t64big && k <= 2048) || (t128 <= 512 && k <= 256)))
     return gemm_launch_ts<T, 64, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, 0, cyc_nb, cyc_g1);
   // (a 512-thread variant, 4 x 2 waves of 32 x 64 at 4 waves per SIMD, was measured equal: 61.3 vs 61.7 TFLOP/s)
-  return gemm_launch_ts<T, 128, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, tag, cyc_nb, cyc_g1);
+  return gemm_launch_ts<T, 128, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, tag & 1, cyc_nb, cyc_g1);
 }
 
 template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t,

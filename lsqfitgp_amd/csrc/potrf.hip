@@ -634,10 +634,10 @@ static int potrf_lookahead_v1(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk,
       // algorithmic flops of this launch: 2 k per produced entry of the lower trapezoid
       const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0) + (double)nx * (double)rows_r;
       // (timed for bench.py when it is the 128-tile instantiation that profilers list as gemm_kernel<..., 128, 256, 1>;
-      // the last, <= 64-tile update of a factorisation goes to the 64-tile kernel and is left out of both)
-      const bool timed = ((rows_r + nx + 127) / 128) * ((rows_r + 127) / 128) > 64;   // lgp_gemm_launch's 128-tile criterion at K = 1024
+      // the updates of up to lgp_gemm_t64_trailing_max() tiles go to the 64-tile kernel and are left out of both)
+      const bool timed = ((rows_r + nx + 127) / 128) * ((rows_r + 127) / 128) > lgp_gemm_t64_trailing_max();   // lgp_gemm_launch's 128-tile criterion
       if (timed) LGP_CHECK(lgp_prof_start(ctx, s0, 2.0 * (double)kb * entries));
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 1));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 3));
       if (timed) LGP_CHECK(lgp_prof_stop(ctx, s0));
     }
     LGP_HIP(hipStreamWaitEvent(s0, ctx->ev_b, 0));
@@ -721,7 +721,7 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
     LGP_HIP(hipStreamWaitEvent(sg, E(EV_FAR), 0));
     const size_t rows_r = rows_t - nb1;
     if (rows_r + nx > 0)
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false, 2));
     LGP_HIP(hipEventRecord(E(EV_U2), sg));
     LGP_HIP(hipStreamWaitEvent(s3, E(EV_U2), 0));
     // ---- sg: U3, everything right of the next panel: the N^3/3 flops, one launch
@@ -731,10 +731,10 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
       // algorithmic flops of this launch: 2 k per produced entry of the lower trapezoid
       const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0) + (double)nx * (double)rows_r;
       // (timed for bench.py when it is the 128-tile instantiation that profilers list as gemm_kernel<..., 128, 256, 1>;
-      // the last, <= 64-tile update of a factorisation goes to the 64-tile kernel and is left out of both)
-      const bool timed = ((rows_r + nx + 127) / 128) * ((rows_r + 127) / 128) > 64;   // lgp_gemm_launch's 128-tile criterion at K = 1024
+      // the updates of up to lgp_gemm_t64_trailing_max() tiles go to the 64-tile kernel and are left out of both)
+      const bool timed = ((rows_r + nx + 127) / 128) * ((rows_r + 127) / 128) > lgp_gemm_t64_trailing_max();   // lgp_gemm_launch's 128-tile criterion
       if (timed) LGP_CHECK(lgp_prof_start(ctx, sg, 2.0 * (double)kb * entries));
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 1));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 3));
       if (timed) LGP_CHECK(lgp_prof_stop(ctx, sg));
     }
     LGP_HIP(hipEventRecord(E(EV_U3), sg));
@@ -854,7 +854,7 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     for (int g = 0; g < ng; ++g) LGP_HIP(wait_ge(s0, word(k, LGP_CH_GRP + g), 1));
     const size_t rows_r = rows_t - nb1;
     if (rows_r + nx > 0)
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false, 2));
     LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U2), 1, 0));
     // ---- s0: U3, everything right of the next panel: the N^3/3 flops, one launch
     if (rows_r > 0) {
@@ -862,9 +862,9 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
       T *Cc = L + (t0 + nb1) * ldl + (t0 + nb1);
       const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0) + (double)nx * (double)rows_r;
       // (timed for bench.py when it is the 128-tile instantiation that profilers list as gemm_kernel<..., 128, 256, 1>)
-      const bool timed = ((rows_r + nx + 127) / 128) * ((rows_r + 127) / 128) > 64;
+      const bool timed = ((rows_r + nx + 127) / 128) * ((rows_r + 127) / 128) > lgp_gemm_t64_trailing_max();   // lgp_gemm_launch's 128-tile criterion
       if (timed) LGP_CHECK(lgp_prof_start(ctx, s0, 2.0 * (double)kb * entries));
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 1));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 3));
       if (timed) LGP_CHECK(lgp_prof_stop(ctx, s0));
     }
     LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U3), 1, 0));
