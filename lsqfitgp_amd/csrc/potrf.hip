@@ -824,13 +824,21 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
       const size_t rows_g = g0[g + 1] - g0[g];
       T *Pg = P + (kb + g0[g]) * ldl;                   // the group's rows of the panel
       if (k >= 1) LGP_HIP(wait_ge(sg, word(k - 1, LGP_CH_U2), 1));     // its rows of this block column have panel k-1's update
+      // LEFT-looking over the blocks of the square: column block j of the group's rows first receives the update of all
+      // earlier blocks in one product (K = 128 j; it needs the square's rows of block j final = every substitution of step
+      // j - 1 done, and runs WHILE the chain kernel factors block j), then is solved as soon as block j is factored.  After the
+      // last block only a substitution stands between the chain kernel and U1: 75-180 us from the end of a square to the start
+      // of the next in the late panels of N = 8192, where right-looking rows (every block followed by a K = 128 update of all
+      // the remaining columns: 37 + 52 us per step against the chain's 68) fell 20 us further behind per block (~390 us).
+      // (The early panels wait for the previous panel's updates instead: their far rows cannot start before U2.)
       for (size_t j = 0; j < nq; ++j) {
-        const size_t j0 = j * LGP_DB, wc = kb - (j0 + LGP_DB);
-        LGP_HIP(wait_ge(sg, word(k, LGP_CH_READY) + j, (unsigned)(1 + 2 * nq - 2 * j - 2)));
+        const size_t j0 = j * LGP_DB;
+        if (j >= 1) {
+          LGP_HIP(wait_ge(sg, word(k, LGP_CH_READY) + (j - 1), (unsigned)(1 + 2 * nq - 2 * (j - 1) - 2)));
+          LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_g, LGP_DB, j0, T(-1), Pg, ldl, P + j0 * ldl, ldl, T(1), Pg + j0, ldl, false, 2));
+        }
+        LGP_HIP(wait_ge(sg, word(k, LGP_CH_FLAGP) + j, 1));
         LGP_CHECK(subst(sg, Yk + j * (size_t)LGP_DBLK, Pg + j0, rows_g));
-        if (wc > 0)
-          LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_g, wc, LGP_DB, T(-1), Pg + j0, ldl, P + (j0 + LGP_DB) * ldl + j0, ldl, T(1),
-                                       Pg + (j0 + LGP_DB), ldl, false));
       }
       LGP_HIP(hipStreamWriteValue32(sg, word(k, LGP_CH_GRP + g), 1, 0));
     }
