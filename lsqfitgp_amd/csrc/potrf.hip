@@ -675,6 +675,7 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
     LGP_LAUNCH_CHECK();
     return LGP_OK;
   };
+  static const bool right_looking = getenv("LGP_FAR_RIGHT") != nullptr;
   LGP_HIP(hipEventRecord(E(EV_START), s0));             // the matrix as the caller's stream has it
   LGP_HIP(hipStreamWaitEvent(s1, E(EV_START), 0));
   LGP_HIP(hipStreamWaitEvent(s3, E(EV_START), 0));
@@ -698,8 +699,13 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
       if (far > 0) {
         LGP_HIP(hipEventRecord(E(EV_BLK + bi), s1));
         LGP_HIP(hipStreamWaitEvent(s3, E(EV_BLK + bi), 0));
+        // left-looking: column block j of the far rows receives the update of all earlier blocks in one product (K = j0: half the
+        // memory traffic of eight K = 128 updates of all the remaining columns), then is solved
+        if (j0 > 0 && !right_looking)
+          LGP_CHECK(lgp_gemm_launch<T>(ctx, s3, false, true, far, jb, j0, T(-1), Pfar, ldl, P + j0 * ldl, ldl, T(1), Pfar + j0, ldl, false, 2));
         LGP_CHECK(subst(s3, w, jb, Pfar + j0, far));
-        if (wc > 0) LGP_CHECK(lgp_gemm_launch<T>(ctx, s3, false, true, far, wc, jb, T(-1), Pfar + j0, ldl, Xsq, ldl, T(1), Pfar + (j0 + jb), ldl, false));
+        if (wc > 0 && right_looking)
+          LGP_CHECK(lgp_gemm_launch<T>(ctx, s3, false, true, far, wc, jb, T(-1), Pfar + j0, ldl, Xsq, ldl, T(1), Pfar + (j0 + jb), ldl, false));
       }
       if (wc > 0) LGP_CHECK(lgp_gemm_launch<T>(ctx, s1, false, true, below, wc, jb, T(-1), Xsq, ldl, Xsq, ldl, T(1), P + (j0 + jb) * ldl + (j0 + jb), ldl, true));
     }
