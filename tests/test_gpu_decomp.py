@@ -429,3 +429,42 @@ def test_fused_gram_factor(lgp, rng, dtype, n, d, q):
         util.assert_close_matrices(L1[:n], L0[:n], rtol=1e-12 if f64 else 2e-5)
         if q:
             util.assert_close_matrices(L1[n:n + q], L0[n:n + q], rtol=1e-9 if f64 else 2e-2)
+
+
+@pytest.mark.parametrize('n,q', [(256, 0), (1152, 7), (2048, 0), (3200, 3), (4096 + 384, 5)])
+def test_chain_kernel_against_launch_per_operation_driver(lgp, rng, monkeypatch, n, q):
+    """ the two drivers of the blocked factorisation (csrc/potrf.hip: the chain kernel whose resident workers factor the
+    diagonal squares, default up to N = 16384, and the launch-per-operation driver, LGP_CHAIN=0) on the same matrix: the
+    same factor to rounding (the order of the additions differs), both satisfying L L^T = K + eps, and the same carried
+    solve.  LAPACK potrf in the reference (_linalg/_decomp.py:388) is the third opinion (the oracle). """
+    K = randpd(rng, n) * 37.0
+    B = rng.standard_normal((n, q)) if q else None
+    monkeypatch.setenv('LGP_CHAIN', '0')
+    ctx_launch = lgp.Context(0)
+    monkeypatch.delenv('LGP_CHAIN')
+    ctx_chain = lgp.Context(0)
+    a = lgp.Chol(K, ctx=ctx_launch, rhs=B)
+    b = lgp.Chol(K, ctx=ctx_chain, rhs=B)
+    o = oracle.Chol(K)
+    La, Lb = a.factor().to_host(), b.factor().to_host()
+    assert a.eps == b.eps == pytest.approx(o.eps, rel=1e-14)
+    util.assert_close_matrices(La, o._L, rtol=1e-13)
+    util.assert_close_matrices(Lb, o._L, rtol=1e-13)
+    util.assert_close_matrices(Lb, La, rtol=1e-13)
+    assert np.all(np.triu(Lb, 1) == 0)
+    Keps = K + b.eps * np.eye(n)
+    assert np.linalg.norm(Lb @ Lb.T - Keps) <= 1e-13 * n * np.linalg.norm(Keps)
+    if q:
+        util.assert_close_matrices(b.solved(), a.solved(), rtol=1e-10)
+        util.assert_close_matrices(b.solved(), o.pinv_correlate(B), rtol=1e-10)
+
+
+def test_chain_kernel_reports_a_bad_pivot(lgp, rng):
+    """ a matrix that is not positive definite: the worker that meets the pivot records it and the factorisation goes on to
+    its end (no worker is left waiting); the host raises the reference's error (_linalg/_decomp.py:389-391) """
+    n = 1536
+    K = randpd(rng, n)
+    K[700, 700] = -1.0
+    with pytest.raises(np.linalg.LinAlgError):
+        lgp.Chol(K, epsrel=0)
+    lgp.Chol(randpd(rng, n))          # and the context is usable afterwards
