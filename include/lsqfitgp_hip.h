@@ -215,6 +215,13 @@ int lgp_check_matrix_f64(lgp_ctx *ctx, size_t rows, size_t cols, const double *d
                          int check_sym, double rtol, double atol, int *hflags);
 int lgp_check_matrix_f32(lgp_ctx *ctx, size_t rows, size_t cols, const float *dA, size_t lda,
                          int check_sym, float rtol, float atol, int *hflags);
+/* The same two checks without the read-back: the flags are OR-ed into two int words in DEVICE memory that the
+ * caller has zeroed, so that a caller assembling a matrix from many blocks (_GP/_elements.py:642-649) reads all
+ * the verdicts at once.  Does not synchronise. */
+int lgp_check_matrix_dev_f64(lgp_ctx *ctx, size_t rows, size_t cols, const double *dA, size_t lda,
+                             int check_sym, double rtol, double atol, int *dflags);
+int lgp_check_matrix_dev_f32(lgp_ctx *ctx, size_t rows, size_t cols, const float *dA, size_t lda,
+                             int check_sym, float rtol, float atol, int *dflags);
 
 /* *hclose = 1 iff |A - B| <= atol + rtol*|B| everywhere (jnp.allclose(A, B), the off-diagonal symmetry
  * check `allclose(block.T, blockT)` of _GP/_elements.py:631-636).  Synchronises. */

@@ -440,12 +440,44 @@ class GP:
         else:
             cov = DeviceArray.zeros((x.size, y.size), numpy.float64, self.ctx)
         if (self._checkfinite or (self._checksym and xkey == ykey)) and cov.size:
-            nonfinite, asym = _check_dev(cov, self._checksym and xkey == ykey)
-            if self._checkfinite and nonfinite:
-                raise RuntimeError(f'covariance block {(xkey, ykey)!r} is not finite')
-            if self._checksym and xkey == ykey and asym:
-                raise RuntimeError(f'covariance block {(xkey, ykey)!r} is not symmetric')
+            self._enqueue_check(cov, (xkey, ykey))
         return cov
+
+    # The finite / symmetric verdicts of the blocks (``_elements.py:618-622``) are collected on the device and read once per
+    # assembled matrix instead of once per block: every read-back is a device synchronisation (0.12 ms each, 15 per step of
+    # the BART workload).  The error is the reference's, raised before the assembled matrix is used.
+    _CHECK_SLOTS = 64
+
+    def _enqueue_check(self, cov, key):
+        if getattr(self, '_checkflags', None) is None:
+            self._checkflags = DeviceArray.zeros((2 * self._CHECK_SLOTS,), numpy.int32, self.ctx)
+            self._checkkeys = []
+        if len(self._checkkeys) == self._CHECK_SLOTS:
+            self._resolve_checks()
+        slot = len(self._checkkeys)
+        f, F = _lib.fn('lgp_check_matrix_dev', cov.dtype)
+        sym = bool(self._checksym and key[0] == key[1])
+        _lib.check(f(cov.ctx.handle, cov.shape[0], cov.shape[1], cov.ptr, cov.ld, int(sym), F(1e-5), F(1e-8), self._checkflags.ptr + 8 * slot),
+                   'lgp_check_matrix_dev')
+        self._checkkeys.append((key, sym))
+
+    def _resolve_checks(self):
+        keys = getattr(self, '_checkkeys', None)
+        if not keys:
+            return
+        flags = self._checkflags.to_host()
+        self._checkkeys = []
+        if flags.any():
+            self._checkflags.fill_zero()
+            bad = [(key, sym, slot) for slot, (key, sym) in enumerate(keys)
+                   if (self._checkfinite and flags[2 * slot]) or (sym and flags[2 * slot + 1])]
+            for key, _, _ in bad:                       # a block that failed is not kept (the reference raises before it caches)
+                self._covblocks.pop(key, None)
+                self._covblocks.pop(key[::-1], None)
+            for key, sym, slot in bad:
+                if self._checkfinite and flags[2 * slot]:
+                    raise RuntimeError(f'covariance block {key!r} is not finite')
+                raise RuntimeError(f'covariance block {key!r} is not symmetric')
 
     def _covblock(self, row, col):
         """ ``_elements.py:626-640``: block cache, transposed block stored too """
@@ -469,6 +501,7 @@ class GP:
         if colkeys is None:
             colkeys = rowkeys
         blocks = [[self._covblock(row, col) for col in colkeys] for row in rowkeys]
+        self._resolve_checks()
         if len(blocks) == 1 and len(blocks[0]) == 1:
             return blocks[0][0]
         dtype = numpy.result_type(*[b.dtype for r in blocks for b in r])
@@ -548,11 +581,12 @@ class GP:
             outkeys = None
         self._checkpos_keys([key] if outkeys is None else outkeys)
         if outkeys is not None:
-            return {
-                (row, col): self._covblock(row, col).to_host().reshape(self._elements[row].shape + self._elements[col].shape)
-                for row in outkeys for col in outkeys
-            }
-        return self._covblock(key, key).to_host().reshape(2 * self._elements[key].shape)
+            blocks = {(row, col): self._covblock(row, col) for row in outkeys for col in outkeys}
+            self._resolve_checks()
+            return {rc: b.to_host().reshape(self._elements[rc[0]].shape + self._elements[rc[1]].shape) for rc, b in blocks.items()}
+        block = self._covblock(key, key)
+        self._resolve_checks()
+        return block.to_host().reshape(2 * self._elements[key].shape)
 
     def _slices(self, keylist):
         """ ``_elements.py:819-826`` """

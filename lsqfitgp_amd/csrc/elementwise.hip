@@ -289,6 +289,20 @@ int check_impl(lgp_ctx *ctx, size_t rows, size_t cols, const T *A, size_t lda, i
   return LGP_OK;
 }
 
+// the same check without the read-back: the two flags are OR-ed into caller-owned device words (zeroed by the caller), so
+// that a caller with many blocks to check reads them all at once
+template <typename T>
+int check_dev_impl(lgp_ctx *ctx, size_t rows, size_t cols, const T *A, size_t lda, int check_sym, T rtol, T atol, int *dflags) {
+  LGP_REQUIRE(ctx != nullptr && dflags != nullptr, "null pointer");
+  if (rows == 0 || cols == 0) return LGP_OK;
+  LGP_REQUIRE(A != nullptr && lda >= cols, "bad matrix");
+  LGP_REQUIRE(!check_sym || rows == cols, "symmetry check needs a square matrix");
+  DeviceGuard dg(ctx->device);
+  hipLaunchKernelGGL((check_kernel<T>), dim3(grid_for(rows, cols)), dim3(256), 0, ctx->stream, rows, cols, A, lda, check_sym, rtol, atol, dflags);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
 template <typename T>
 int allclose_impl(lgp_ctx *ctx, size_t rows, size_t cols, const T *A, size_t lda, const T *B, size_t ldb, T rtol, T atol, int *hflag) {
   LGP_REQUIRE(ctx != nullptr && hflag != nullptr, "null pointer");
@@ -412,6 +426,8 @@ int lgp_transpose_f64(lgp_ctx *c, double *d, size_t ldd, const double *s, size_t
 int lgp_transpose_f32(lgp_ctx *c, float *d, size_t ldd, const float *s, size_t lds, size_t r, size_t n) { return transpose_impl<float>(c, d, ldd, s, lds, r, n); }
 int lgp_check_matrix_f64(lgp_ctx *c, size_t r, size_t n, const double *A, size_t lda, int sym, double rtol, double atol, int *f) { return check_impl<double>(c, r, n, A, lda, sym, rtol, atol, f); }
 int lgp_check_matrix_f32(lgp_ctx *c, size_t r, size_t n, const float *A, size_t lda, int sym, float rtol, float atol, int *f) { return check_impl<float>(c, r, n, A, lda, sym, rtol, atol, f); }
+int lgp_check_matrix_dev_f64(lgp_ctx *c, size_t r, size_t n, const double *A, size_t lda, int sym, double rtol, double atol, int *df) { return check_dev_impl<double>(c, r, n, A, lda, sym, rtol, atol, df); }
+int lgp_check_matrix_dev_f32(lgp_ctx *c, size_t r, size_t n, const float *A, size_t lda, int sym, float rtol, float atol, int *df) { return check_dev_impl<float>(c, r, n, A, lda, sym, rtol, atol, df); }
 int lgp_allclose_f64(lgp_ctx *c, size_t r, size_t n, const double *A, size_t lda, const double *B, size_t ldb, double rtol, double atol, int *f) { return allclose_impl<double>(c, r, n, A, lda, B, ldb, rtol, atol, f); }
 int lgp_allclose_f32(lgp_ctx *c, size_t r, size_t n, const float *A, size_t lda, const float *B, size_t ldb, float rtol, float atol, int *f) { return allclose_impl<float>(c, r, n, A, lda, B, ldb, rtol, atol, f); }
 int lgp_colsumsq_f64(lgp_ctx *c, size_t r, size_t n, const double *A, size_t lda, double *o) {
