@@ -333,13 +333,16 @@ def c5_step(ctx, steps=3, warmup=1):
     ctx.sync()
     dt = (time.perf_counter() - t0) / steps
     kern, pts = res[3], res[4]
-    # the BART Gram kernel alone, N x N fp32, HIP events on the context's stream
+    # the BART Gram kernel alone, N x N fp32, HIP events on the context's stream: bin indices uploaded once (kernel.prepare, what
+    # the callers that rebuild the matrix per hyperparameter step do), output preallocated
     e0, e1 = ctx.event(), ctx.event()
-    kern.gram(pts[:n], pts[:n], ctx=ctx)
+    dp = kern.prepare(pts[:n], ctx=ctx)
+    gout = lgp.DeviceArray.empty((n, n), np.float32, ctx)
+    kern.gram(dp, dp, ctx=ctx, out=gout)
     best = 1e9
     for _ in range(5):
         ctx.record(e0)
-        kern.gram(pts[:n], pts[:n], ctx=ctx)
+        kern.gram(dp, dp, ctx=ctx, out=gout)
         ctx.record(e1)
         best = min(best, ctx.elapsed_ms(e0, e1))
     nt = len(pts) - n
@@ -347,7 +350,7 @@ def c5_step(ctx, steps=3, warmup=1):
             'N': n, 'M': nt, 'ms_per_step': dt * 1e3, 'value': flops_fit_predict(n, nt) / dt / 1e12,
             'log_marginal_likelihood': float(res[2]),
             'bart_gram': {'ms': best, 'gpairs_per_s': n * n / (best * 1e-3) / 1e9, 'bound': 'hbm', 'achieved': 4. * n * n / (best * 1e-3) / 1e9,
-                          'peak': 8000., 'unit': 'GB/s', 'note': 'includes the host-side per-call setup of kernel.gram (index upload, digamma table)'}}
+                          'peak': 8000., 'unit': 'GB/s', 'note': 'bin indices uploaded once (kernel.prepare), output preallocated; includes the per-call upload of the per-axis constants'}}
 
 
 def main_c5(args, ctx):
