@@ -603,7 +603,16 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
       const long lda = p.ldl, row0 = (long)LGP_NB * k + 128 * j;
       constexpr int nb = 128;
       int *const info = p.info;
+      // the block is published as soon as its fragment image is out: the substitutions read nothing else
+#define P4_FRAGMENTS_OUT                                                                                              \
+      __syncthreads();                                                                                                \
+      if (threadIdx.x == 0) {                                                                                         \
+        __hip_atomic_store(flagP + j, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);                                \
+        __hip_atomic_fetch_add(pst + LGP_CH_READY + j, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);              \
+        if (p.trace) p.trace[4 * t + 3] = wall_clock64();                                                             \
+      }
 #include "potf2m4_block.inc"
+#undef P4_FRAGMENTS_OUT
     } else if (type == CH_TYPE_S) {
       subst_right_wave<double>(pdblk + (size_t)j * LGP_DBLK, 128, P + 128 * j, p.ldl, (long)kb, 64L * r + 16 * (threadIdx.x >> 6));
     } else {
@@ -611,10 +620,10 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
     }
     // ---- publish: the workgroup's stores, then the flag; ready[k][j] counts P(k, j) and the S(k, ., j) for the far-row stream
     __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned *f = type == CH_TYPE_P ? flagP + j : (type == CH_TYPE_S ? flagS + 8 * r + j : cnt + 16 * r + c);
+    if (threadIdx.x == 0 && type != CH_TYPE_P) {         // (P published itself above)
+      unsigned *f = type == CH_TYPE_S ? flagS + 8 * r + j : cnt + 16 * r + c;
       __hip_atomic_store(f, type == CH_TYPE_G ? (unsigned)(j + 1) : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      if (type != CH_TYPE_G) __hip_atomic_fetch_add(pst + LGP_CH_READY + j, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (type == CH_TYPE_S) __hip_atomic_fetch_add(pst + LGP_CH_READY + j, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       if (p.trace) p.trace[4 * t + 3] = wall_clock64();
     }
   }

@@ -6,6 +6,7 @@
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} }while(0)
 void lgp_set_error(const char *fmt, ...) {}
 int lgp_prof_start(lgp_ctx *, hipStream_t, double) { return 0; }
+size_t lgp_gemm_t64_trailing_max() { return 10000; }
 int lgp_prof_stop(lgp_ctx *, hipStream_t) { return 0; }
 template <typename T> int lgp_gemm_launch(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, T, const T *, size_t, const T *, size_t, T, T *, size_t, bool, int, int, int) { return 0; }
 template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t, const double *, size_t, double, double *, size_t, bool, int, int, int);
