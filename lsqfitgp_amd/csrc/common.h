@@ -46,7 +46,7 @@ struct lgp_ctx {
   void *chain_trace = nullptr;        // LGP_CHAIN_TRACE=<file>: per-task times of the last launch
   size_t chain_trace_tasks = 0;
   const void *chain_trace_sched = nullptr;
-  int chain_mode = 0;                 // 0 = used where it applies, 1 = off (env LGP_CHAIN=0)
+  int chain_mode = 0;                 // 0 = not yet checked, 1 = off (env LGP_CHAIN=0, or the self-test failed), 2 = available
   size_t chain_max_n = 16384;         // largest matrix factored this way (env LGP_CHAIN_MAX_N); beyond, the trailing update bounds the
                                       // factorisation and the workers' CUs are worth more to it (N = 32768: 186 ms split driver, 204 ms chain)
   size_t chain_hog_max_n = 8192;      // ... and largest matrix for which the workers keep other workgroups off their CUs
@@ -130,7 +130,7 @@ template <typename T>
 int lgp_potf2_launch(lgp_ctx *ctx, hipStream_t stream, T *A, size_t lda, int nb, T *dblk, size_t row0);
 int lgp_potf2_mfma_launch(lgp_ctx *ctx, hipStream_t stream, double *A, size_t lda, int nb, double *dblk, size_t row0);   // potf2m.hip
 // the chain kernel (potf2m.hip): the diagonal squares of all panels, factored by resident workers
-bool lgp_chain_usable(const lgp_ctx *ctx, size_t n, size_t ldl);
+bool lgp_chain_usable(lgp_ctx *ctx, size_t n, size_t ldl);
 size_t lgp_chain_state_bytes(size_t n);
 int lgp_chain_state(lgp_ctx *ctx, size_t n, unsigned **out);        // device words, LGP_CH_* layout; the caller zeroes them
 int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk);

@@ -635,6 +635,18 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
   }
 }
 
+// self-test of the two mechanisms the chain kernel lives on: a running kernel sees a value written by a stream
+// (hipStreamWriteValue32) and a stream waiting on a value (hipStreamWaitValue32) sees a store of a running kernel.  Bounded:
+// after 20 ms the kernel gives up, but still stores the word the stream waits for, so that nothing is left waiting.
+__global__ void chain_selftest_kernel(unsigned *words) {       // [0] stream -> kernel, [1] kernel -> stream, [2] verdict
+  const unsigned long long t0 = wall_clock64();
+  bool seen = false;
+  while (!(seen = ch_peek(words) >= 1u) && wall_clock64() - t0 < 2000000ull) __builtin_amdgcn_s_sleep(4);
+  words[2] = seen ? 1u : 0u;
+  __hip_atomic_store(words + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void chain_selftest_mark(unsigned *words) { words[3] = 1u; }
+
 }  // namespace
 
 int lgp_potf2_mfma_launch(lgp_ctx *ctx, hipStream_t stream, double *A, size_t lda, int nb, double *dblk, size_t row0) {
@@ -709,8 +721,39 @@ extern "C" long lgp_chain_schedule(size_t n, unsigned int *tasks, size_t capacit
   return (long)sched.size();
 }
 
-bool lgp_chain_usable(const lgp_ctx *ctx, size_t n, size_t ldl) {
-  return ctx->chain_mode != 1 && n >= 256 && n % 128 == 0 && n <= (size_t)LGP_NB * 255 && ldl < (1u << 20);
+// Kernels that wait for kernels of other streams need an environment that really runs streams side by side and implements
+// the stream memory operations.  Under a counter-collecting profiler, for one, kernels are serialised: the chain kernel would
+// wait until its time-out.  Checked once per context with a 20 ms bounded handshake; on failure the launch-per-operation driver
+// is used instead.
+static bool chain_selftest(lgp_ctx *ctx) {
+  unsigned *words = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&words), 4 * sizeof(unsigned)) != hipSuccess) return false;
+  bool ok = hipMemset(words, 0, 4 * sizeof(unsigned)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(chain_selftest_kernel, dim3(1), dim3(1), 0, ctx->stream2, words);
+    ok = hipGetLastError() == hipSuccess;
+    // (whatever happens from here on, the kernel ends by itself and releases the stream wait)
+    ok = ok && hipStreamWriteValue32(ctx->stream3, words, 1, 0) == hipSuccess;
+    ok = ok && hipStreamWaitValue32(ctx->stream3, words + 1, 1, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(chain_selftest_mark, dim3(1), dim3(1), 0, ctx->stream3, words);
+      ok = hipGetLastError() == hipSuccess;
+    }
+    (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipStreamSynchronize(ctx->stream3);
+    unsigned h[4] = {0, 0, 0, 0};
+    ok = ok && hipMemcpy(h, words, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[2] == 1u && h[3] == 1u;
+  }
+  (void)hipFree(words);
+  (void)hipGetLastError();
+  return ok;
+}
+
+bool lgp_chain_usable(lgp_ctx *ctx, size_t n, size_t ldl) {
+  if (ctx->chain_mode == 0 && n >= 256 && n % 128 == 0 && ctx->stream2 != nullptr && ctx->stream3 != nullptr) {
+    ctx->chain_mode = chain_selftest(ctx) ? 2 : 1;      // 2: checked and available, 1: off
+  }
+  return ctx->chain_mode == 2 && n >= 256 && n % 128 == 0 && n <= (size_t)LGP_NB * 255 && ldl < (1u << 20);
 }
 
 size_t lgp_chain_state_bytes(size_t n) {
