@@ -530,7 +530,7 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
   const size_t tiles = (size_t)g.tm * g.tn;
   if (!lower && tiles * 4 <= (size_t)ctx->cus && k >= 2048) {
     size_t ns = (2 * (size_t)ctx->cus) / tiles;
-    const size_t maxs = (k + 511) / 512;
+    const size_t maxs = (k + 255) / 256;
     if (ns > maxs) ns = maxs;
     if (ns > 1) {
       size_t kc = (k + ns - 1) / ns;
@@ -582,7 +582,9 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   // live 27 us instead of 200, so the latency-bound kernels of the other streams find CUs and are not squeezed for as long:
   // N = 8192 7.2 -> 6.8 ms, N = 16384 32.2 -> 30.4 ms, N = 32768 185.7 -> 183.7 ms (all 64-tile: 187.8 ms).
   const size_t t64big = (tag & 2) ? lgp_gemm_t64_trailing_max() : 64;
-  if (!aliased && ((t128 <= t64big && k <= 2048) || (t128 <= 512 && k <= 256)))
+  // ... and for outputs of at most four 128-tiles whatever K (X^T X of the posterior: 101 x 101 over N rows): with split-K below
+  // they become ~100 short workgroups instead of 8 long ones (N = 4096: 90 -> 15 us per product)
+  if (!aliased && ((t128 <= t64big && k <= 2048) || (t128 <= 512 && k <= 256) || t128 <= 4))
     return gemm_launch_ts<T, 64, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, 0, cyc_nb, cyc_g1);
   // (a 512-thread variant, 4 x 2 waves of 32 x 64 at 4 waves per SIMD, was measured equal: 61.3 vs 61.7 TFLOP/s)
   return gemm_launch_ts<T, 128, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, tag & 1, cyc_nb, cyc_g1);
