@@ -36,6 +36,7 @@ struct lgp_ctx {
   int cus = 256;
   int swapped = 0;                    // lgp_select_stream(1): `stream` and `stream2` exchanged
   int potf2_mode = 0;                 // diagonal-block kernel: 0 = auto, 1 = VALU, 2 = matrix cores (env LGP_POTF2=valu|mfma)
+  size_t gemm_thin_lds = 0;           // bytes of untouched dynamic LDS added to NT gemm launches (set around the trailing updates)
   int potf2_small = 1;                // auto mode: the factorisation in progress is small enough for the matrix-core kernel
   // the dependent chain of the factorisation as one launch of resident workers (potf2m.hip): schedules per matrix size,
   // flag/counter words (LGP_CH_* layout)

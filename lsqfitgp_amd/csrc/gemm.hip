@@ -541,8 +541,10 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
     }
   }
   dim3 gd((unsigned)grid, (unsigned)g.nsplit), bd(NTHREADS);
-  if (!ta && tb && tag == 1) hipLaunchKernelGGL((gemm_kernel<T, false, true, TS, NTHREADS, 1>), gd, bd, 0, stream, g);
-  else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, TS, NTHREADS>), gd, bd, 0, stream, g);
+  // untouched dynamic LDS that thins out the workgroups of a trailing update per CU (experiment, see potrf_chain)
+  const size_t thin = (!ta && tb) ? ctx->gemm_thin_lds : 0;
+  if (!ta && tb && tag == 1) hipLaunchKernelGGL((gemm_kernel<T, false, true, TS, NTHREADS, 1>), gd, bd, thin, stream, g);
+  else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<T, false, true, TS, NTHREADS>), gd, bd, thin, stream, g);
   else if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, false, false, TS, NTHREADS>), gd, bd, 0, stream, g);
   else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<T, true, false, TS, NTHREADS>), gd, bd, 0, stream, g);
   else hipLaunchKernelGGL((gemm_kernel<T, true, true, TS, NTHREADS>), gd, bd, 0, stream, g);

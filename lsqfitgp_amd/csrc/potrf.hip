@@ -726,6 +726,9 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
     LGP_HIP(hipStreamWaitEvent(sg, E(EV_SQ), 0));
     LGP_HIP(hipStreamWaitEvent(sg, E(EV_FAR), 0));
     const size_t rows_r = rows_t - nb1;
+    // (the last panels are bound by the chain: their updates leave room on every CU, see potrf_chain)
+    static const long thin_env = getenv("LGP_THIN_LDS_KB") ? atol(getenv("LGP_THIN_LDS_KB")) : -1;
+    ctx->gemm_thin_lds = thin_env >= 0 ? (size_t)thin_env * 1024 : (rows_t <= 6144 ? (size_t)70 * 1024 : (rows_t <= 12288 ? (size_t)20 * 1024 : 0));
     if (rows_r + nx > 0)
       LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false, 2));
     LGP_HIP(hipEventRecord(E(EV_U2), sg));
@@ -743,6 +746,7 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
       LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 3));
       if (timed) LGP_CHECK(lgp_prof_stop(ctx, sg));
     }
+    ctx->gemm_thin_lds = 0;
     LGP_HIP(hipEventRecord(E(EV_U3), sg));
     have_u3 = true;
   }
@@ -867,6 +871,12 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     // ---- s0: U2, the block column below that square
     for (int g = 0; g < ng; ++g) LGP_HIP(wait_ge(s0, word(k, LGP_CH_GRP + g), 1));
     const size_t rows_r = rows_t - nb1;
+    // The updates with this panel leave room on every CU when the chain is what bounds the rest of the factorisation: untouched
+    // dynamic LDS thins their workgroups out (one 64-tile workgroup per CU below 6144 remaining rows, three below 12288), so
+    // that the far-row kernels of the next panel are dispatched at once and not squeezed (N = 4096 2.58 -> 2.48 ms, N = 8192
+    // 6.92 -> 6.55 ms; thinning the large updates of N = 16384 as well: 30.4 -> 31.4 ms, so they are left alone).
+    static const long thin_env = getenv("LGP_THIN_LDS_KB") ? atol(getenv("LGP_THIN_LDS_KB")) : -1;
+    ctx->gemm_thin_lds = thin_env >= 0 ? (size_t)thin_env * 1024 : (rows_t <= 6144 ? (size_t)70 * 1024 : (rows_t <= 12288 ? (size_t)20 * 1024 : 0));
     if (rows_r + nx > 0)
       LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false, 2));
     LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U2), 1, 0));
@@ -881,6 +891,7 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
       LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 3));
       if (timed) LGP_CHECK(lgp_prof_stop(ctx, s0));
     }
+    ctx->gemm_thin_lds = 0;
     LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U3), 1, 0));
   }
   // the factor is complete on the caller's stream when the chain kernel has left and every row group is done
