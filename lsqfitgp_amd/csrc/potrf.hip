@@ -28,6 +28,13 @@ int lgp_info_result(int info) {
 
 namespace {
 
+// restores ctx->gemm_thin_lds (the thinning of the factorisation's updates) on every way out of a driver
+struct ThinGuard {
+  lgp_ctx *c;
+  explicit ThinGuard(lgp_ctx *ctx) : c(ctx) { c->gemm_thin_lds = 0; }
+  ~ThinGuard() { c->gemm_thin_lds = 0; }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Diagonal-block workspace ("dblk"): for every 128x128 diagonal block of L, LGP_DBLK elements:
 //   [0, 128*128)          D   = the strictly lower part of the block, row-major (zero diagonal and above)
@@ -657,6 +664,7 @@ static int potrf_lookahead_v1(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk,
 // loses the substitution and the update of up to N rows per block and the part of the block-column update below the square.
 template <typename T>
 static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx) {
+  ThinGuard thin_guard(ctx);
   // chain-bound sizes: the trailing updates (sg) and the far rows (s3) run on CU-masked streams that leave a few CUs to the chain
   const bool reserve = ctx->stream_gm != nullptr && ctx->stream_fm != nullptr && n <= ctx->reserve_max_n;
   hipStream_t s0 = ctx->stream, s1 = ctx->stream2, s3 = reserve ? ctx->stream_fm : ctx->stream3, sg = reserve ? ctx->stream_gm : s0;
@@ -770,6 +778,7 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
 // slower than the chain (8 x 72 us) and the next square waited ~400 us for them; per group they overlap.
 static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *dblk, size_t nx) {
   typedef double T;
+  ThinGuard thin_guard(ctx);
   hipStream_t s0 = ctx->stream, s1 = ctx->stream2;
   const size_t NB = LGP_NB;
   // row groups (flag words LGP_CH_GRP .. + 3).  Two, so that the factorisation runs on four streams in all: the runtime
