@@ -431,18 +431,32 @@ def test_fused_gram_factor(lgp, rng, dtype, n, d, q):
             util.assert_close_matrices(L1[n:n + q], L0[n:n + q], rtol=1e-9 if f64 else 2e-2)
 
 
-@pytest.mark.parametrize('n,q', [(256, 0), (1152, 7), (2048, 0), (3200, 3), (4096 + 384, 5)])
-def test_chain_kernel_against_launch_per_operation_driver(lgp, rng, monkeypatch, n, q):
+@pytest.fixture(scope='module')
+def driver_contexts(lgp):
+    """ two contexts on the same GPU: the launch-per-operation driver of the factorisation (LGP_CHAIN=0 when the context is
+    created) and the default (chain kernel up to N = 16384) """
+    import os
+    old = os.environ.get('LGP_CHAIN')
+    os.environ['LGP_CHAIN'] = '0'
+    try:
+        launch = lgp.Context(0)
+    finally:
+        if old is None:
+            del os.environ['LGP_CHAIN']
+        else:
+            os.environ['LGP_CHAIN'] = old
+    return launch, lgp.Context(0)
+
+
+@pytest.mark.parametrize('n,q', [(256, 0), (1152, 7), (2048, 0), (3200, 3)])
+def test_chain_kernel_against_launch_per_operation_driver(lgp, rng, driver_contexts, n, q):
     """ the two drivers of the blocked factorisation (csrc/potrf.hip: the chain kernel whose resident workers factor the
     diagonal squares, default up to N = 16384, and the launch-per-operation driver, LGP_CHAIN=0) on the same matrix: the
     same factor to rounding (the order of the additions differs), both satisfying L L^T = K + eps, and the same carried
     solve.  LAPACK potrf in the reference (_linalg/_decomp.py:388) is the third opinion (the oracle). """
     K = randpd(rng, n) * 37.0
     B = rng.standard_normal((n, q)) if q else None
-    monkeypatch.setenv('LGP_CHAIN', '0')
-    ctx_launch = lgp.Context(0)
-    monkeypatch.delenv('LGP_CHAIN')
-    ctx_chain = lgp.Context(0)
+    ctx_launch, ctx_chain = driver_contexts
     a = lgp.Chol(K, ctx=ctx_launch, rhs=B)
     b = lgp.Chol(K, ctx=ctx_chain, rhs=B)
     o = oracle.Chol(K)
