@@ -86,7 +86,7 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   // block column c -= P_b[rows of c] P_b[block rows of c]'
   auto update_one = [&](size_t c, size_t b, int slot) -> int {
     const double *A = P[slot] + (c - b) * nb * ldp;
-    return lgp_gemm_launch<double>(ctx, sc, false, true, rowsof(c), width(c), width(b), -1.0, A, ldp, A, ldp, 1.0, block(c), ldl, true);
+    return lgp_gemm_launch<double>(ctx, sc, false, true, rowsof(c), width(c), width(b), -1.0, A, ldp, A, ldp, 1.0, block(c), ldl, true, 2);
   };
   // every remaining owned block column (consecutive local blocks from c0 on) in one staircase launch
   auto update_rest = [&](size_t c0, size_t b, int slot) -> int {
@@ -97,7 +97,7 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
       return LGP_OK;
     }
     const double *A = P[slot] + (c0 - b) * nb * ldp;
-    return lgp_gemm_launch<double>(ctx, sc, false, true, rowsof(c0), ncols, width(b), -1.0, A, ldp, A, ldp, 1.0, block(c0), ldl, true, 1, (int)nb,
+    return lgp_gemm_launch<double>(ctx, sc, false, true, rowsof(c0), ncols, width(b), -1.0, A, ldp, A, ldp, 1.0, block(c0), ldl, true, 3, (int)nb,
                                    (int)(G - 1));
   };
 
