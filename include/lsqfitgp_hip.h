@@ -92,6 +92,9 @@ int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *to
 #define LGP_KERNEL_MATERNP 1   /* _kernels/_matern.py:29-49 + _special/_bessel.py:101-110 (p)  */
 #define LGP_KERNEL_GAMMAEXP 2  /* _kernels/_basic.py:94-115   exp(-r2^(gamma/2)); hpar = {gamma, gamma/2}                              */
 #define LGP_KERNEL_CAUCHY 3    /* _kernels/_basic.py:315-344  (1 + r2^(alpha/2)/beta)^(-beta/alpha); hpar = {alpha, beta, -beta/alpha}  */
+#define LGP_KERNEL_EXPQUAD_DIFF 4 /* _Kernel/_ops.py:115-211 (`diff`) on ExpQuad, one-dimensional points (d = 1): p = a + b <= 4 the total
+                                   * order of d^a/dx^a d^b/dy^b; the core is He_p(u) exp(-u^2/2), u = (x - y)/scale; the factor
+                                   * (-1)^a / scale^p of the chain rule is an output operation of the caller                      */
 #define LGP_OP_MUL 0           /* kernel * c  (_Kernel/_alg.py:58-82)  */
 #define LGP_OP_ADD 1           /* kernel + c  (_Kernel/_alg.py:32-56)  */
 

@@ -31,9 +31,11 @@ class _Element:
 
 
 class _Points(_Element):
-    """ Points where the process is evaluated (``_elements.py:104-117``) """
-    def __init__(self, x):
+    """ Points where the process is evaluated (``_elements.py:104-117``); `deriv`: order of the derivative of the process taken
+    there (implicit variable) """
+    def __init__(self, x, deriv=0):
         self.x = x
+        self.deriv = deriv
     @property
     def shape(self):
         return self.x.shape
@@ -223,8 +225,15 @@ class GP:
 
     def addx(self, x, key=None, *, deriv=0, proc=DefaultProcess):
         """ Add points where the Gaussian process is evaluated (``_elements.py:158-242``) """
-        if deriv not in (0, None) and deriv != ():
-            raise NotImplementedError('derivative observations are out of scope of the device path')
+        # derivative of the process along the (single, implicit) variable: Deriv(int) of the reference (_Deriv.py:24-60); named
+        # variables of structured points are not available on the device path
+        if deriv is None or deriv == ():
+            deriv = 0
+        if isinstance(deriv, bool) or not isinstance(deriv, (int, numpy.integer)):
+            raise NotImplementedError('derivatives along named fields are out of scope of the device path: use an integer order')
+        if deriv < 0:
+            raise ValueError(f'negative derivative order {deriv}')
+        deriv = int(deriv)
         if proc != self.DefaultProcess:
             raise KeyError(f'process named {proc!r} not found')
         points, isdict = self._keyed(x, key, 'x')
@@ -243,7 +252,9 @@ class GP:
                     new._dtype = numpy.result_type(new._dtype, arr.dtype)
                 except TypeError:
                     raise TypeError('x[{!r}].dtype = {!r} not compatible with {!r}'.format(k, arr.dtype, new._dtype))
-            new._elements[k] = _Points(arr)
+            if deriv and arr.dtype.names is not None:
+                raise NotImplementedError('derivatives of structured points are out of scope of the device path')
+            new._elements[k] = _Points(arr, deriv)
         return new
 
     def addtransf(self, tensors, key, *, axes=1):
@@ -373,12 +384,13 @@ class GP:
         if kernel is None:
             raise ValueError('no covariance function: GP(covfun) is required to add points')
         xf = x.x.reshape(-1)
+        kw = {'deriv': (x.deriv, y.deriv)} if (x.deriv or y.deriv) else {}       # kernel.linop('diff', x.deriv, y.deriv), :565
         if x is y and not self._checksym and self._halfmatrix:
             # the reference evaluates the upper triangle as a flat vector and gathers (:567-573);
             # the device Gram kernels are exactly symmetric, so the full tile evaluation gives the same matrix
-            return kernel.gram(xf, xf, ctx=self.ctx)
+            return kernel.gram(xf, xf, ctx=self.ctx, **kw)
         yf = xf if y is x else y.x.reshape(-1)
-        return kernel.gram(xf, yf, ctx=self.ctx)
+        return kernel.gram(xf, yf, ctx=self.ctx, **kw)
 
     def _makecovblock_lintransf_any(self, xkey, ykey):
         """ ``_elements.py:581-601`` for the tensordot transformation of `addtransf` (``:332-344``) """

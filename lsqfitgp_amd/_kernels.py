@@ -207,17 +207,45 @@ class _Isotropic(Kernel):
         yd = xd if same else DeviceArray.from_host(numpy.stack([numpy.asarray(c, dtype) for c in yc]), ctx=ctx)
         return xd, yd, dtype, ctx, len(xc)
 
-    def gram(self, xs, ys, *, ctx=None, out=None):
-        """ device Gram matrix of two flat point sets """
+    def _diff_call(self, deriv, d):
+        """ (kernel id, order, output operations) of the derived kernel ``kernel.linop('diff', a, b)`` (``_Kernel/_ops.py:115-211``,
+        implicit variable: the points are plain one-dimensional arrays), available in closed form for `ExpQuad`:
+        d^a/dx^a d^b/dy^b exp(-u²/2), u = (x - y)/scale, is (-1)^a / scale^(a+b) He_{a+b}(u) exp(-u²/2).  Scalar factors of
+        the kernel multiply the derivative, added constants drop out of it. """
+        a, b = (int(v) for v in deriv)
+        if a < 0 or b < 0:
+            raise ValueError(f'negative derivative order {deriv!r}')
+        if a == 0 and b == 0:
+            return self._kind, int(self._p), self._outops
+        if self._kind != _lib.LGP_KERNEL_EXPQUAD:
+            raise NotImplementedError('derivatives of the kernel are available in closed form for ExpQuad only')
+        if d != 1:
+            raise NotImplementedError('derivatives are taken along the one variable of one-dimensional points')
+        if a + b > 4:
+            raise NotImplementedError('total derivative order above 4')
+        factor = (-1.) ** a / float(self._scale if self._scale is not None else 1.) ** (a + b)
+        for op, c in self._outops:
+            if op == 'mul':
+                factor = factor * c
+        return _lib.LGP_KERNEL_EXPQUAD_DIFF, a + b, (('mul', factor),)
+
+    def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
+        """ device Gram matrix of two flat point sets; ``deriv=(a, b)``: of the kernel derived a times in x, b times in y """
         xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
         n, m = xd.shape[1], yd.shape[1]
         if out is None:
             out = DeviceArray.empty((n, m), dtype, ctx)
         assert out.shape == (n, m) and out.dtype == dtype
+        kind, order, outops = self._diff_call(deriv, d)
         if n == 0 or m == 0:
             return out
         f, F = _lib.fn('lgp_gram_isotropic', dtype)
-        nops, codes, vals = _ops_arrays(self._outops, F)
+        nops, codes, vals = _ops_arrays(outops, F)
+        if kind != self._kind:
+            _lib.check(f(ctx.handle, kind, order, 0, None, d, xd.ptr, xd.ld, n, yd.ptr, yd.ld, m,
+                         int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
+                         nops, codes, vals, 0, out.ptr, out.ld), 'lgp_gram_isotropic')
+            return out
         _lib.check(f(ctx.handle, self._kind, int(self._p), *self._par_args(F), d, xd.ptr, xd.ld, n, yd.ptr, yd.ld, m,
                      int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
                      nops, codes, vals, int(xd is yd), out.ptr, out.ld), 'lgp_gram_isotropic')

@@ -62,10 +62,22 @@ template <typename T> struct VecOf;
 template <> struct VecOf<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int W = 2; };
 template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int W = 4; };
 
+// d0: the signed difference of the (transformed) first coordinates, used by the derivative kernel only
 template <typename T>
-__device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2) {
+__device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
   if (g.kernel == LGP_KERNEL_EXPQUAD) {
     return exp(T(-0.5) * r2);
+  } else if (g.kernel == LGP_KERNEL_EXPQUAD_DIFF) {
+    // mixed derivative of order p = a + b of exp(-u^2 / 2) in one dimension, u = d0: d^a/dx^a d^b/dy^b = (-1)^a He_p(u) exp(-u^2/2)
+    // (probabilists' Hermite polynomial; the sign and the 1 / scale^p of the chain rule are an output operation of the caller).
+    // What jax's elementwise_grad of the core gives for _Kernel/_ops.py:115-211 (`diff`) on ExpQuad, _kernels/_basic.py:75.
+    const T u = d0, u2 = u * u;
+    T he = T(1);
+    if (g.p == 1) he = u;
+    else if (g.p == 2) he = u2 - T(1);
+    else if (g.p == 3) he = u * (u2 - T(3));
+    else if (g.p == 4) he = u2 * (u2 - T(6)) + T(3);
+    return he * exp(T(-0.5) * r2);
   } else if (g.kernel == LGP_KERNEL_GAMMAEXP) {          // _kernels/_basic.py:111-113
     return g.flag ? exp(-r2) : exp(-pow(r2, g.par[1]));
   } else if (g.kernel == LGP_KERNEL_CAUCHY) {            // _kernels/_basic.py:340-344
@@ -169,19 +181,21 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
     T res[W], dres[W];
 #pragma unroll
     for (int e = 0; e < W; ++e) {
-      T r2 = T(0);
+      T r2 = T(0), d0 = T(0);
       if (D > 0) {
 #pragma unroll
         for (int f = 0; f < D; ++f) {
           const T df = su[f * GT_ROWS + r] - vreg[f][e];
           const T sq = df * df;
           r2 = (f == 0) ? sq : r2 + sq;
+          if (f == 0) d0 = df;
         }
       } else {
         for (int f = 0; f < d; ++f) {
           const T df = su[f * GT_ROWS + r] - sv[f * GT_COLS + c0 + e];
           const T sq = df * df;
           r2 = (f == 0) ? sq : r2 + sq;
+          if (f == 0) d0 = df;
         }
       }
       if (GRAD) {
@@ -189,7 +203,7 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
         res[e] = g.ops.apply(iso_core_dscale<T>(g, r2, dk));
         dres[e] = slope * dk;
       } else {
-        res[e] = g.ops.apply(iso_core<T>(g, r2));
+        res[e] = g.ops.apply(iso_core<T>(g, r2, d0));
       }
     }
     T *po = g.out + (long)(row0 + r) * g.ldo + col0 + c0;
@@ -221,7 +235,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) gram_iso_pairs_kernel(const IsoArgs<T> g) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= g.n) return;
-  T r2 = T(0);
+  T r2 = T(0), d0 = T(0);
   for (int f = 0; f < g.d; ++f) {
     T u = g.x[(long)f * g.ldx + i], v = g.y[(long)f * g.ldy + i];
     if (g.has_loc) { u = u - g.loc; v = v - g.loc; }
@@ -229,8 +243,9 @@ __global__ void __launch_bounds__(256) gram_iso_pairs_kernel(const IsoArgs<T> g)
     const T df = u - v;
     const T sq = df * df;
     r2 = (f == 0) ? sq : r2 + sq;
+    if (f == 0) d0 = df;
   }
-  g.out[i] = g.ops.apply(iso_core<T>(g, r2));
+  g.out[i] = g.ops.apply(iso_core<T>(g, r2, d0));
 }
 
 template <typename T>
@@ -241,10 +256,13 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_MATERNP || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY,
+  LGP_REQUIRE(kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_MATERNP || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY ||
+                  kernel == LGP_KERNEL_EXPQUAD_DIFF,
               "unknown isotropic kernel");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
   LGP_REQUIRE(p >= 0 && p <= MAX_P, "Maternp order must be in [0,16]");
+  LGP_REQUIRE(kernel != LGP_KERNEL_EXPQUAD_DIFF || (d == 1 && p <= 4 && ddsc == nullptr),
+              "the derivative kernel is for one-dimensional points, total order at most 4, without the scale tangent");
   LGP_REQUIRE(nops >= 0 && nops <= MAX_OPS, "at most 8 output operations");
   LGP_REQUIRE(n < (1u << 30) && m < (1u << 30), "too many points");
   LGP_REQUIRE(ldx >= n && ldy >= m && ldo >= m, "leading dimension too small");

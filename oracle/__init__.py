@@ -18,6 +18,7 @@ follows; paths relative to the reference checkout):
   ``_kernels/_basic.py:61-75``, ``_kernels/_matern.py:29-49``,
   ``_special/_bessel.py:101-110``, ``_kernels/_bart.py`` (BART correlation,
   splits, indices) and ``_jaxext/_fasthash.py:56-102`` (fasthash64/32).
+* ``kernels.Kernel.diff`` -- ``src/lsqfitgp/_Kernel/_ops.py:115-211`` for ExpQuad, in closed form.
 * ``gp``      -- ``src/lsqfitgp/_GP/_compute.py:45-136,138-305,336-422,430-516``
   and ``src/lsqfitgp/_GP/_elements.py:158-346,408-649,758-826`` (raw outputs only).
 
@@ -38,6 +39,10 @@ LAPACK family here.  What *is* pinned, in ``tests/test_oracle_*.py``:
   and the Normal log-density of this restatement on the line through the
   argmax and curvature of the marginal likelihood
   (``tests/test_fit_host.py``);
+* a posterior printed by the reference: the worked example of
+  ``docs/userguide/integrals.rst:34-82`` (derivative observations of an ExpQuad
+  process, ``-1.9157(27)`` and ``0.0022(27)``), reproduced digit for digit
+  (``tests/test_deriv_known_answer.py``);
 * the reference's only stored known-answer table on this path, the
   ``fasthash64``/``fasthash32`` vectors of ``tests/test_jax.py:112-186``
   (copied as data into ``tests/golden/fasthash_kat.json``);

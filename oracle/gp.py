@@ -19,8 +19,9 @@ from . import decomp as _decomp
 
 
 class _Points:
-    def __init__(self, x):
+    def __init__(self, x, deriv=0):
         self.x = x
+        self.deriv = deriv
     @property
     def shape(self):
         return self.x.shape
@@ -80,8 +81,9 @@ class GP:
 
     # ---- elements ------------------------------------------------------
 
-    def addx(self, x, key=None):
-        """ ``_elements.py:158-242`` (deriv=0, default process only) """
+    def addx(self, x, key=None, *, deriv=0):
+        """ ``_elements.py:158-242`` (default process only; `deriv`: integer order along the implicit variable) """
+        deriv = 0 if deriv is None else int(deriv)
         self = self._clone()
         if hasattr(x, 'keys'):
             if key is not None:
@@ -95,7 +97,7 @@ class GP:
         for key in x:
             if key in self._elements:
                 raise KeyError('key {!r} already in GP'.format(key))
-            self._elements[key] = _Points(numpy.asarray(x[key]))
+            self._elements[key] = _Points(numpy.asarray(x[key]), deriv)
         return self
 
     def addtransf(self, tensors, key, *, axes=1):
@@ -201,6 +203,8 @@ class GP:
         x = self._elements[xkey]
         y = self._elements[ykey]
         kernel = self._covfun
+        if x.deriv or y.deriv:
+            kernel = kernel.diff(x.deriv, y.deriv)          # :565
         if x is y and not self._checksym and self._halfmatrix:
             n = x.size
             ix, iy = numpy.triu_indices(n)

@@ -98,6 +98,34 @@ class Kernel:
         assert result.shape == shape, (result.shape, shape)
         return result
 
+    def diff(self, xderiv, yderiv):
+        """ ``_Kernel/_ops.py:115-211`` (`diff`, implicit variable: plain one-dimensional points).  The reference
+        differentiates the transformed core with jax (``elementwise_grad``); here the derivative is written out, for the one
+        core that has a closed form at every order, ExpQuad (``_kernels/_basic.py:75``):
+        d^a/dx^a d^b/dy^b exp(-u²/2), u = (x - y)/scale, is (-1)^a / scale^(a+b) He_{a+b}(u) exp(-u²/2) with the
+        probabilists' Hermite polynomials; scalar factors of the kernel multiply it, added constants drop out. """
+        a, b = int(xderiv), int(yderiv)
+        assert a >= 0 and b >= 0
+        if a == 0 and b == 0:
+            return self
+        if getattr(self._core, 'hermite', None) is None:
+            raise NotImplementedError('derivatives in closed form for ExpQuad only')
+        scale = 1. if self._scale is None else self._scale
+        factor = (-1.) ** a / scale ** (a + b)
+        for op, c in self._outops:
+            if op == 'mul':
+                factor = factor * c
+        order = a + b
+
+        def core(x, y):
+            x = numpy.asarray(x, float)
+            y = numpy.asarray(y, float)
+            assert x.dtype.names is None and y.dtype.names is None, 'derivative along the implicit variable of plain arrays'
+            u = x - y
+            he = numpy.polynomial.hermite_e.hermeval(u, [0] * order + [1])
+            return he * numpy.exp(-1/2 * numpy.square(u))
+        return Kernel(core, scale=self._scale, loc=self._loc, outops=(('mul', factor),))
+
     def _with(self, op, c):
         if not isinstance(c, numbers.Number) and numpy.ndim(c) != 0:
             return NotImplemented
@@ -161,7 +189,9 @@ def cauchy_core(r2, alpha=2, beta=2):
 
 
 def ExpQuad(*, scale=None, loc=None):
-    return Kernel(_isotropic(expquad_core), scale=scale, loc=loc)
+    core = _isotropic(expquad_core)
+    core.hermite = True          # Kernel.diff has its derivatives in closed form
+    return Kernel(core, scale=scale, loc=loc)
 
 
 def GammaExp(*, gamma=1, scale=None, loc=None):
