@@ -29,7 +29,21 @@ def integral_example(mod, **kw):
     return area, sdev, true_area
 
 
+def integral_by_transformation(mod):
+    """ the "not obvious way" of integrals.rst:84-91: the difference between the ends as a linear transformation of the process
+    values (there `addlintransf(lambda x: x[-1] - x[0], ...)`; here the same functional as the coefficient tensor of `addtransf`) """
+    x = np.linspace(-5, 5, 11)
+    xplot = np.linspace(-5, 5, 200)
+    coeff = np.zeros(200)
+    coeff[-1], coeff[0] = 1, -1
+    gp = (mod.GP(mod.ExpQuad(scale=2)).addx(xplot, 'primitive').addx(x, 'cosine', deriv=1)
+          .addtransf({'primitive': coeff}, 'integral'))
+    mean, cov = gp.predfromdata({'cosine': np.cos(x)}, 'integral', raw=True)
+    return float(np.reshape(mean, ())), float(np.sqrt(np.reshape(cov, ())))
+
+
 def test_reference_user_guide_integral_on_the_oracle():
+    assert str(UVal(*integral_by_transformation(oracle))) == '-1.9157(27)'      # integrals.rst:91
     area, sdev, true_area = integral_example(oracle)
     assert str(UVal(area, sdev)) == '-1.9157(27)'                     # integrals.rst:76
     assert repr(float(true_area)) == '-1.917848549326277'             # integrals.rst:82

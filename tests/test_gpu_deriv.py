@@ -10,7 +10,7 @@ import pytest
 
 import oracle
 from . import util
-from .test_deriv_known_answer import integral_example
+from .test_deriv_known_answer import integral_example, integral_by_transformation
 
 pytestmark = pytest.mark.gpu
 
@@ -42,6 +42,7 @@ def test_reference_user_guide_integral_on_the_device(lgp):
     area, sdev, true_area = integral_example(lgp)
     assert str(lgp.UVal(area, sdev)) == '-1.9157(27)'                  # integrals.rst:76
     assert str(lgp.UVal(area - true_area, sdev)) == '0.0022(27)'       # integrals.rst:82
+    assert str(lgp.UVal(*integral_by_transformation(lgp))) == '-1.9157(27)'      # integrals.rst:91
     ao, so, _ = integral_example(oracle)
     assert abs(area - ao) <= 1e-9 and abs(sdev - so) <= 1e-9 * so + 1e-12
 
