@@ -196,7 +196,11 @@ class GP:
 
     def _clone(self):
         """ ``_GP/_base.py:86-104`` clone-on-write """
+        # deferred block checks are settled first: the flag words and the list of pending keys belong to ONE object
+        self._resolve_checks()
         new = copy.copy(self)
+        new._checkflags = None
+        new._checkkeys = []
         new._elements = self._elements.copy()
         new._covblocks = self._covblocks.copy()
         new._decompcache = self._decompcache.copy()

@@ -335,23 +335,27 @@ class Cauchy(_Isotropic):
 # BART
 
 def _bart_brackets(npnt, reset, altinput=True, debug=False):
-    """ ``_kernels/_bart.py:415-431``: recursion slices (top, bottom, repeat) """
-    if reset is None:
-        reset = []
-    if not hasattr(reset, '__len__'):
-        reset = [reset]
-    reset = [0] + list(reset) + [npnt - 1]
-    for i, j in zip(reset, reset[1:]):
-        assert int(j) == j and i <= j, (i, j)
-    brackets_norep = list(zip(reset, reset[1:]))
-    brackets = [brackets_norep[0] + (1,)]
-    for t, b in brackets_norep[1:]:
-        lt, lb, lr = brackets[-1]
-        if altinput and not debug and lr * (b - t) == lb - lt and b - t <= 2:
-            brackets[-1] = lt, b, lr + 1
-        else:
-            brackets.append((t, b, 1))
-    return brackets
+    """
+    Cut the depth range [0, npnt - 1] at the `reset` depths into recursion slices ``(top, bottom, repeat)``
+    (``_kernels/_bart.py:415-431``).  On the closed-form path (``altinput`` and not ``debug``) a slice at most two levels
+    deep that is as deep as each of the ``repeat`` pieces of the slice before it is folded into that slice, which is then
+    iterated once more.
+    """
+    inner = [] if reset is None else [int(v) if int(v) == v else v for v in numpy.atleast_1d(reset).tolist()]
+    cuts = [0, *inner, npnt - 1]
+    for above, below in zip(cuts, cuts[1:]):
+        assert int(below) == below and above <= below, (above, below)
+    foldable = altinput and not debug
+    slices = []
+    for top, bottom in zip(cuts, cuts[1:]):
+        depth = bottom - top
+        if slices and foldable and depth <= 2:
+            first, last, repeat = slices[-1]
+            if last - first == repeat * depth:
+                slices[-1] = (first, bottom, repeat + 1)
+                continue
+        slices.append((top, bottom, 1))
+    return slices
 
 
 def _bart_probs(pnt, t, b, repeat):

@@ -75,6 +75,11 @@ int lgp_ctx_create(int device, lgp_ctx **out) {
     const int g = atoi(m);
     if (g >= 1 && g <= 4) c->chain_groups = g;
   }
+  if (const char *m = getenv("LGP_CHAIN_TIMEOUT_MS")) {
+    const long ms = atol(m);
+    if (ms >= 1 && ms <= 600000) c->chain_timeout = (unsigned long long)ms * 100000ull;
+  }
+  if (const char *m = getenv("LGP_CHAIN_TEST_STALL")) c->chain_test_stall = atoi(m) != 0;
   if (const char *m = getenv("LGP_CHAIN_LDS_KB")) {
     const int kb = atoi(m);
     if (kb >= 0 && kb <= 140) c->chain_lds_kb = kb;

@@ -53,6 +53,9 @@ struct lgp_ctx {
   size_t chain_hog_max_n = 8192;      // ... and largest matrix for which the workers keep other workgroups off their CUs
   int chain_workers = 16;             // resident worker workgroups = CUs taken from the trailing update (env LGP_CHAIN_WORKERS)
   int chain_lds_kb = 100;             // untouched dynamic LDS per worker that keeps other workgroups off its CU (env LGP_CHAIN_LDS_KB)
+  unsigned long long chain_timeout = 1000000000ull;   // wall_clock64 ticks (100 MHz) a worker waits for one input: 10 s (env LGP_CHAIN_TIMEOUT_MS)
+  bool chain_attr_set = false;        // the chain kernel's dynamic-LDS limit has been raised on this context's device
+  int chain_test_stall = 0;           // env LGP_CHAIN_TEST_STALL=1 (tests): the driver withholds u1[1], so that the workers time out
   // live kernel timing of the dominant kernel (trailing-update syrk) for bench.py: HIP event pairs on the
   // stream the kernel is launched on, enabled by lgp_profile_begin
   int prof_on = 0;
@@ -147,7 +150,7 @@ constexpr int LGP_CH_FLAGS = 32;  // [16][8] row unit r solved against block j
 constexpr int LGP_CH_CNT = 160;   // [16][16] steps applied to tile (r, c)
 // info word written when the workers of the chain kernel gave up waiting (a stall, not a pivot): reported as an error
 constexpr int LGP_INFO_STALLED = 0x7fffffff;
-int lgp_info_result(int info);      // info, or LGP_EHIP with the error text set for LGP_INFO_STALLED (potrf.hip)
+int lgp_info_result(lgp_ctx *ctx, int info);      // info, or LGP_EHIP with the error text set for LGP_INFO_STALLED (potrf.hip)
 template <typename T>
 int lgp_panel_factor_impl(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t nb, T *P, size_t ldp, T *dblk, size_t row0);
 template <typename T>

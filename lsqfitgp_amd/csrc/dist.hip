@@ -148,5 +148,5 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   LGP_HIP(hipStreamSynchronize(sm));
   LGP_HIP(hipStreamSynchronize(sc));
   if (hinfo) *hinfo = info;
-  return lgp_info_result(info) < 0 ? LGP_EHIP : LGP_OK;
+  return lgp_info_result(ctx, info) < 0 ? LGP_EHIP : LGP_OK;
 }

@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) potf2_mfma4_kernel(double *A, long lda, i
 // Every wait in the kernel is bounded: after CH_TIMEOUT a worker raises the abort flag, releases every ready[] word so that
 // no stream is left waiting, everybody leaves, and the host reports LGP_INFO_STALLED instead of hanging.
 constexpr unsigned CH_TYPE_P = 0, CH_TYPE_S = 1, CH_TYPE_G = 2;
-constexpr unsigned long long CH_TIMEOUT = 1000000000ull;      // wall_clock64 ticks (100 MHz): 10 s per wait
+constexpr unsigned long long CH_TIMEOUT = 1000000000ull;      // wall_clock64 ticks (100 MHz): 10 s per wait (env LGP_CHAIN_TIMEOUT_MS)
 
 struct ChainArgs {
   double *L;              // the matrix (lower triangle of K/s/s' on entry, the factor on exit)
@@ -435,12 +435,13 @@ struct ChainArgs {
   int chainw;
   unsigned *state;        // LGP_CH_* layout (common.h), zeroed by the driver
   unsigned long long *trace;   // optional (LGP_CHAIN_TRACE): per task  worker, taken, inputs ready, done  (wall_clock64)
+  unsigned long long timeout;  // wall_clock64 ticks a worker waits for one input before it abandons the launch
 };
 
 __device__ __forceinline__ unsigned ch_peek(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // thread 0 of the workgroup: spin until *p >= need; false = the launch is being abandoned
-__device__ __forceinline__ bool ch_wait(unsigned *p, unsigned need, unsigned *state) {
+__device__ __forceinline__ bool ch_wait(unsigned *p, unsigned need, unsigned *state, unsigned long long timeout) {
   unsigned spins = 0;
   unsigned long long t0 = 0;
   while (ch_peek(p) < need) {
@@ -449,7 +450,7 @@ __device__ __forceinline__ bool ch_wait(unsigned *p, unsigned need, unsigned *st
       if (ch_peek(state + LGP_CH_ABORT) != 0) return false;
       const unsigned long long now = wall_clock64();
       if (t0 == 0) t0 = now;
-      if (now - t0 > CH_TIMEOUT) {
+      if (now - t0 > timeout) {
         __hip_atomic_store(state + LGP_CH_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return false;
       }
@@ -577,16 +578,16 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
       bool ok = true;
       if (type == CH_TYPE_P) {
         if (j == 0) {
-          if (k > 0) ok = ch_wait(pst + LGP_CH_U1, 1, st);
+          if (k > 0) ok = ch_wait(pst + LGP_CH_U1, 1, st, p.timeout);
         } else {
-          ok = ch_wait(cnt + 16 * (2 * j) + 2 * j, j, st) && ch_wait(cnt + 16 * (2 * j + 1) + 2 * j, j, st) && ch_wait(cnt + 16 * (2 * j + 1) + 2 * j + 1, j, st);
+          ok = ch_wait(cnt + 16 * (2 * j) + 2 * j, j, st, p.timeout) && ch_wait(cnt + 16 * (2 * j + 1) + 2 * j, j, st, p.timeout) && ch_wait(cnt + 16 * (2 * j + 1) + 2 * j + 1, j, st, p.timeout);
         }
       } else if (type == CH_TYPE_S) {
-        ok = ch_wait(flagP + j, 1, st);
-        if (j > 0) ok = ok && ch_wait(cnt + 16 * r + 2 * j, j, st) && ch_wait(cnt + 16 * r + 2 * j + 1, j, st);
+        ok = ch_wait(flagP + j, 1, st, p.timeout);
+        if (j > 0) ok = ok && ch_wait(cnt + 16 * r + 2 * j, j, st, p.timeout) && ch_wait(cnt + 16 * r + 2 * j + 1, j, st, p.timeout);
       } else {
-        ok = ch_wait(flagS + 8 * r + j, 1, st) && ch_wait(flagS + 8 * c + j, 1, st);
-        if (j > 0) ok = ok && ch_wait(cnt + 16 * r + c, j, st);
+        ok = ch_wait(flagS + 8 * r + j, 1, st, p.timeout) && ch_wait(flagS + 8 * c + j, 1, st, p.timeout);
+        if (j > 0) ok = ok && ch_wait(cnt + 16 * r + c, j, st, p.timeout);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       s_task = ok ? 0 : -1;
@@ -629,8 +630,13 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
   }
   if (threadIdx.x == 0 && ch_peek(st + LGP_CH_ABORT) != 0) {
     // nobody may be left waiting for this launch: release every stream-side wait, then report
+    // (ready[k][j] and flagP[k][j] are the two families of words the far-row streams poll, potrf.hip potrf_chain; the
+    // u2 / u3 / grp words are written by the streams themselves once these waits are through)
     for (int k = 0; k < npanels; ++k)
-      for (int j = 0; j < 8; ++j) __hip_atomic_store(st + LGP_CH_HEADER + LGP_CH_PANEL * k + LGP_CH_READY + j, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      for (int j = 0; j < 8; ++j) {
+        __hip_atomic_store(st + LGP_CH_HEADER + LGP_CH_PANEL * k + LGP_CH_READY + j, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(st + LGP_CH_HEADER + LGP_CH_PANEL * k + LGP_CH_FLAGP + j, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     atomicExch(p.info, LGP_INFO_STALLED);
   }
 }
@@ -725,25 +731,39 @@ extern "C" long lgp_chain_schedule(size_t n, unsigned int *tasks, size_t capacit
 // the stream memory operations.  Under a counter-collecting profiler, for one, kernels are serialised: the chain kernel would
 // wait until its time-out.  Checked once per context with a 20 ms bounded handshake; on failure the launch-per-operation driver
 // is used instead.
+static bool chain_selftest_pair(hipStream_t kernel_stream, hipStream_t other, unsigned *words) {
+  bool ok = hipMemset(words, 0, 4 * sizeof(unsigned)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  if (!ok) return false;
+  hipLaunchKernelGGL(chain_selftest_kernel, dim3(1), dim3(1), 0, kernel_stream, words);
+  ok = hipGetLastError() == hipSuccess;
+  // (whatever happens from here on, the kernel ends by itself and releases the stream wait)
+  ok = ok && hipStreamWriteValue32(other, words, 1, 0) == hipSuccess;
+  ok = ok && hipStreamWaitValue32(other, words + 1, 1, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(chain_selftest_mark, dim3(1), dim3(1), 0, other, words);
+    ok = hipGetLastError() == hipSuccess;
+  }
+  (void)hipStreamSynchronize(kernel_stream);
+  (void)hipStreamSynchronize(other);
+  unsigned h[4] = {0, 0, 0, 0};
+  return ok && hipMemcpy(h, words, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[2] == 1u && h[3] == 1u;
+}
+
+// The chain kernel runs on stream2 and trades flag words with EVERY other stream of the driver (potrf_chain: the caller's
+// stream for u2 / u3, the far-row streams for ready / flagP / u1): each of them is paired with stream2 in turn.  A stream that
+// the runtime mapped onto stream2's hardware queue (more streams in the process than queues) fails its pairing -- its packets
+// sit behind the resident kernel -- and the context falls back to the launch-per-operation driver instead of stalling.
 static bool chain_selftest(lgp_ctx *ctx) {
+  if (ctx->far_streams.empty()) ctx->far_streams.push_back(ctx->stream3);        // (the context's third stream is the first of them)
+  while (ctx->far_streams.size() < (size_t)ctx->chain_groups) {
+    hipStream_t s;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, ctx->prio_hi) != hipSuccess) return false;
+    ctx->far_streams.push_back(s);
+  }
   unsigned *words = nullptr;
   if (hipMalloc(reinterpret_cast<void **>(&words), 4 * sizeof(unsigned)) != hipSuccess) return false;
-  bool ok = hipMemset(words, 0, 4 * sizeof(unsigned)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-  if (ok) {
-    hipLaunchKernelGGL(chain_selftest_kernel, dim3(1), dim3(1), 0, ctx->stream2, words);
-    ok = hipGetLastError() == hipSuccess;
-    // (whatever happens from here on, the kernel ends by itself and releases the stream wait)
-    ok = ok && hipStreamWriteValue32(ctx->stream3, words, 1, 0) == hipSuccess;
-    ok = ok && hipStreamWaitValue32(ctx->stream3, words + 1, 1, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess;
-    if (ok) {
-      hipLaunchKernelGGL(chain_selftest_mark, dim3(1), dim3(1), 0, ctx->stream3, words);
-      ok = hipGetLastError() == hipSuccess;
-    }
-    (void)hipStreamSynchronize(ctx->stream2);
-    (void)hipStreamSynchronize(ctx->stream3);
-    unsigned h[4] = {0, 0, 0, 0};
-    ok = ok && hipMemcpy(h, words, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[2] == 1u && h[3] == 1u;
-  }
+  bool ok = chain_selftest_pair(ctx->stream2, ctx->stream, words);
+  for (size_t g = 0; ok && g < ctx->far_streams.size(); ++g) ok = chain_selftest_pair(ctx->stream2, ctx->far_streams[g], words);
   (void)hipFree(words);
   (void)hipGetLastError();
   return ok;
@@ -814,14 +834,17 @@ int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size
     LGP_HIP(hipMemsetAsync(ctx->chain_trace, 0, (size_t)ntasks * 4 * sizeof(unsigned long long), stream));
     a.trace = static_cast<unsigned long long *>(ctx->chain_trace);
   }
-  const int workers = ntasks < ctx->chain_workers ? ntasks : ctx->chain_workers;
+  // at least one worker beside the chain's own: tasks of the chain list wait for tasks of the bulk list (S(4, 1) for the tiles
+  // of step 0), which only a worker that is not holding a chain task can run
+  const int want = ctx->chain_workers < 2 ? 2 : ctx->chain_workers;
+  const int workers = ntasks < want ? (ntasks < 2 ? 2 : ntasks) : want;
+  a.timeout = ctx->chain_timeout;
   a.chainw = workers >= 4 ? 3 : 1;      // the chain offers three tasks at a time at most: S(2j+2), S(2j+3) / the three tiles of the next block
   // dynamic LDS that is never touched: with it no trailing-update workgroup (64 KB of LDS) fits on a worker's CU
   const size_t hog = n <= ctx->chain_hog_max_n ? (size_t)ctx->chain_lds_kb * 1024 : 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!ctx->chain_attr_set) {      // per context (= per device; a context is used by one host thread at a time)
     LGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-    attr_set = true;
+    ctx->chain_attr_set = true;
   }
   hipLaunchKernelGGL(chain_kernel, dim3((unsigned)workers), dim3(256), hog, stream, a);
   LGP_LAUNCH_CHECK();

@@ -20,9 +20,13 @@
 #include "chain.h"
 #include <cstdlib>
 
-int lgp_info_result(int info) {
+int lgp_info_result(lgp_ctx *ctx, int info) {
   if (info != LGP_INFO_STALLED) return info;
-  lgp_set_error("the panel task graph stalled (a worker waited longer than 2 s for its inputs); the factor is incomplete");
+  // a stall means that this process does not run the context's streams side by side the way the self-test saw them
+  // (a stream added since then shares a hardware queue with the chain kernel's): later calls use the launch-per-operation driver
+  ctx->chain_mode = 1;
+  lgp_set_error("the panel task graph stalled (a worker waited longer than %.1f s for its inputs); the factor is incomplete; "
+                "this context now uses the launch-per-operation driver", (double)ctx->chain_timeout / 1e8);
   return LGP_EHIP;
 }
 
@@ -785,12 +789,8 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
   // maps streams onto four hardware queues (GPU_MAX_HW_QUEUES), and with more streams than that a stream can end up behind
   // another stream's polling wait in the same queue (measured with four groups: 2 ms per panel hand-over instead of 0.1)
   const int MAXG = ctx->chain_groups;
-  if (ctx->far_streams.empty()) ctx->far_streams.push_back(ctx->stream3);        // (the context's third stream is the first of them)
-  while (ctx->far_streams.size() < (size_t)MAXG) {
-    hipStream_t s;
-    LGP_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, ctx->prio_hi));
-    ctx->far_streams.push_back(s);
-  }
+  // (the far-row streams were created, and each paired with s1, by the self-test behind lgp_chain_usable)
+  LGP_REQUIRE(ctx->far_streams.size() >= (size_t)MAXG, "far-row streams missing: lgp_chain_usable not called");
   enum { EV_SQ = 8, EV_START = 12, EV_GRP = 13, EV_COUNT = 13 + 4 };
   while (ctx->panel_events.size() < (size_t)EV_COUNT) {
     hipEvent_t e;
@@ -875,7 +875,7 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
       for (int g = 1; g < ng; ++g) LGP_HIP(wait_ge(sg, word(k, LGP_CH_GRP + g), 1));      // (the rows of the next square may sit in any group)
       if (k >= 1) LGP_HIP(wait_ge(sg, word(k - 1, LGP_CH_U3), 1));
       LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, nb1, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
-      LGP_HIP(hipStreamWriteValue32(sg, word(k + 1, LGP_CH_U1), 1, 0));
+      if (!(ctx->chain_test_stall && k == 0)) LGP_HIP(hipStreamWriteValue32(sg, word(k + 1, LGP_CH_U1), 1, 0));
     }
     // ---- s0: U2, the block column below that square
     for (int g = 0; g < ng; ++g) LGP_HIP(wait_ge(s0, word(k, LGP_CH_GRP + g), 1));
@@ -1030,7 +1030,7 @@ static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T ep
   LGP_HIP(hipFreeAsync(ws, st));
   LGP_HIP(hipStreamSynchronize(st));
   if (heps_out) *heps_out = hstats[1];
-  return lgp_info_result(info);
+  return lgp_info_result(ctx, info);
 }
 
 // Tail of Chol.__init__ for a matrix that the fused Gram kernel (gram.hip, gram_reg_kernel) has already scaled and written as
@@ -1084,7 +1084,7 @@ int lgp_chol_from_prepared(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, si
   LGP_HIP(hipFreeAsync(ws, st));
   LGP_HIP(hipStreamSynchronize(st));
   if (heps_out) *heps_out = hstats[1];
-  return lgp_info_result(info);
+  return lgp_info_result(ctx, info);
 }
 template int lgp_chol_from_prepared<double>(lgp_ctx *, size_t, double *, size_t, double *, size_t, double *, size_t, double, double, int, double *);
 template int lgp_chol_from_prepared<float>(lgp_ctx *, size_t, float *, size_t, float *, size_t, float *, size_t, float, float, int, float *);
@@ -1120,7 +1120,7 @@ static int potrf_entry(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk) {
   int info = 0;
   LGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   LGP_HIP(hipStreamSynchronize(ctx->stream));
-  return lgp_info_result(info);
+  return lgp_info_result(ctx, info);
 }
 extern "C" int lgp_potrf_f64(lgp_ctx *ctx, size_t n, double *dL, size_t ldl, double *ddblk) { return potrf_entry<double>(ctx, n, dL, ldl, ddblk); }
 extern "C" int lgp_potrf_f32(lgp_ctx *ctx, size_t n, float *dL, size_t ldl, float *ddblk) { return potrf_entry<float>(ctx, n, dL, ldl, ddblk); }
@@ -1152,7 +1152,7 @@ extern "C" int lgp_get_info(lgp_ctx *ctx, int *hinfo) {
   LGP_HIP(hipMemcpyAsync(hinfo, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   LGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   LGP_HIP(hipStreamSynchronize(ctx->stream));
-  return lgp_info_result(*hinfo) < 0 ? LGP_EHIP : LGP_OK;
+  return lgp_info_result(ctx, *hinfo) < 0 ? LGP_EHIP : LGP_OK;
 }
 
 template int lgp_panel_factor_impl<double>(lgp_ctx *, hipStream_t, size_t, size_t, double *, size_t, double *, size_t);

@@ -88,7 +88,7 @@ def c5small():
     np.savez_compressed(os.path.join(HERE, 'c5_bart_n256.npz'), X=X, nsplits=splits[0], ix=ix, **out)
 
 
-from tests.abalone import load_abalone, c5_problem  # noqa: E402
+from workloads import load_abalone, c5_problem  # noqa: E402
 
 
 C5_GRAM_ROWS = [0, 1, 2, 3, 500, 1777, 3000, 4095]

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 import oracle
-from .abalone import load_abalone, c5_problem, HERE
+from workloads import load_abalone, c5_problem, HERE
 
 REFERENCE_SHA256 = 'de37cdcdcaaa50c309d514f248f7c2302a5f1f88c168905eba23fe2fbc78449f'     # sha256 of examples/bart-data.txt in the reference checkout
 

@@ -482,3 +482,42 @@ def test_chain_kernel_reports_a_bad_pivot(lgp, rng):
     with pytest.raises(np.linalg.LinAlgError):
         lgp.Chol(K, epsrel=0)
     lgp.Chol(randpd(rng, n))          # and the context is usable afterwards
+
+
+def _context_with_env(lgp, **env):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return lgp.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_chain_kernel_stall_is_reported_not_hung(lgp, rng):
+    """ a worker of the chain kernel that never gets an input (here: the driver withholds the flag word u1 of the second
+    panel, LGP_CHAIN_TEST_STALL) gives up after the time-out, every stream-side wait on the kernel's flag words (ready[] and
+    flagP[]) is released, and the call returns an error instead of hanging; the context then switches to the
+    launch-per-operation driver and stays usable """
+    import time
+    ctx = _context_with_env(lgp, LGP_CHAIN_TEST_STALL=1, LGP_CHAIN_TIMEOUT_MS=300)
+    n = 2304                     # three panels: far rows of panels 0 and 1 wait on flagP / ready words of squares that never run
+    K = randpd(rng, n)
+    t0 = time.perf_counter()
+    with pytest.raises(lgp.LibraryError, match='stalled'):
+        lgp.Chol(K, ctx=ctx)
+    assert time.perf_counter() - t0 < 20
+    c = lgp.Chol(K, ctx=ctx)     # launch-per-operation driver from here on
+    util.assert_close_matrices(c.factor().to_host(), oracle.Chol(K)._L, rtol=1e-13)
+
+
+def test_chain_kernel_single_worker_setting(lgp, rng):
+    """ LGP_CHAIN_WORKERS=1 would leave no worker for the tasks the chain's own tasks wait for: the launch takes two """
+    ctx = _context_with_env(lgp, LGP_CHAIN_WORKERS=1, LGP_CHAIN_TIMEOUT_MS=2000)
+    K = randpd(rng, 640)
+    c = lgp.Chol(K, ctx=ctx)
+    util.assert_close_matrices(c.factor().to_host(), oracle.Chol(K)._L, rtol=1e-13)

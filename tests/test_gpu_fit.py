@@ -261,7 +261,7 @@ def test_bart_interface(lgp, rng):
 def test_bart_on_the_c5_data(lgp):
     """ bayestree.bart on the reference's examples/bart-data.txt (first 500 rows, like examples/bart.py:57): the fit runs to
     convergence on the device and predicts held-out rings better than the training mean """
-    from .abalone import load_abalone
+    from workloads import load_abalone
     X, y = load_abalone()
     X = X.astype(float); y = y.astype(float)
     b = lgp.bayestree.bart(X[:500], y[:500], fitkw=dict(verbosity=0))
@@ -272,3 +272,53 @@ def test_bart_on_the_c5_data(lgp):
     rmse = np.sqrt(np.mean((m - y[500:700]) ** 2))
     assert rmse < 0.8 * np.std(y[500:700])
     assert np.all(np.diag(c) > 0)
+
+
+def test_bart_fit_at_c5_size(lgp):
+    """ BASELINE configuration 5 as the caller runs it: ``bayestree.bart`` on the first 4096 rows of the reference's
+    examples/bart-data.txt (float64, the reference's default), the whole L-BFGS fit on the device (every iteration: BART Gram
+    matrix with its alpha / beta tangents, factorisation, likelihood gradient), then the posterior at the 81 held-out rows
+    against the ORACLE's GP built at the device's MAP hyperparameters (north-star tolerances), and the objective of the fit
+    at the MAP against the oracle's """
+    import time
+    from numpy.lib import recfunctions
+    from workloads import load_abalone
+    X, y = load_abalone()
+    X = X.astype(float); y = y.astype(float)
+    n = 4096
+    t0 = time.perf_counter()
+    b = lgp.bayestree.bart(X[:n], y[:n], fitkw=dict(verbosity=0))
+    fit_s = time.perf_counter() - t0
+    hp = dict(b.fit.pmean)
+    calls = b.fit._calls['grad']
+    print(f'bart fit N={n}: {fit_s:.2f} s, {b.fit.minresult.nit} iterations, {calls} objective+gradient evaluations, '
+          f'alpha={hp["alpha"]:.4f} beta={hp["beta"]:.4f} k={hp["k"]:.4f} sigma2={hp["sigma2"]:.4f}')
+    assert 0 < hp['alpha'] < 1 and hp['beta'] > 0 and hp['sigma2'] > 0 and b.fit.minresult.nit >= 3
+    # the fit moved to a better point than the prior mean, and its gradient there is small against the one it started with
+    z0 = np.zeros(4)
+    f0, g0 = b.fit._fun_and_jac(z0)
+    f1, g1 = b.fit._fun_and_jac(b.fit.zmean)
+    assert f1 < f0 and np.linalg.norm(g1) < 0.05 * np.linalg.norm(g0)
+    m, c = b.pred(x_test=X[n:])
+    me, ce = b.pred(x_test=X[n:], error=True)
+    rmse = np.sqrt(np.mean((me - y[n:]) ** 2))
+    assert rmse < 0.8 * np.std(y[n:])
+    # the oracle's GP at the same hyperparameters (numpy/scipy restatement of the reference's path; ~30 s of host time)
+    ymin, ymax = y[:n].min(), y[:n].max()
+    centre, half = (ymax + ymin) / 2, (ymax - ymin) / 2
+    Xs, Xt = recfunctions.unstructured_to_structured(X[:n]), recfunctions.unstructured_to_structured(X[n:])
+    kern = oracle.BART(splits=oracle.BART.splits_from_coord(X[:n]), alpha=hp['alpha'], beta=hp['beta'], maxd=10, reset=[2, 4, 6, 8]) * (half / hp['k']) ** 2
+    gpo = (oracle.GP(kern, checkpos=False, checksym=False)
+           .addx(Xs, 'trainmean').addcov(np.diag(np.full(n, hp['sigma2'])), 'trainnoise').addcov(half ** 2, 'mean')
+           .addtransf({'trainmean': 1, 'trainnoise': 1, 'mean': 1}, 'train').addx(Xt, 'testmean'))
+    given = {'train': y[:n] - centre}
+    mo, co = gpo.predfromdata(given, 'testmean', raw=True)
+    assert np.linalg.norm(m - centre - mo) <= 1e-8 * np.linalg.norm(mo)
+    kss = np.linalg.norm(np.asarray(gpo.prior('testmean', raw=True)), 2)
+    assert np.linalg.norm(c - co, 2) <= 1e-8 * kss
+    lo = gpo.marginal_likelihood(given, epsrel=0)
+    ld = b.gp().marginal_likelihood(b.data(), epsrel=0)
+    assert abs(ld - lo) <= 1e-8 * abs(lo) + 1e-6
+    # the objective the minimiser saw at the MAP: minus log likelihood + the standard-normal prior of z
+    z = b.fit.zmean
+    assert f1 == pytest.approx(-lo + 0.5 * (len(z) * np.log(2 * np.pi) + z @ z), rel=1e-9)

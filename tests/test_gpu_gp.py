@@ -214,7 +214,7 @@ def test_config_c5_abalone_full(lgp):
         ``Ktt <= K`` in the positive-definite order; ``|dK|_2 <= |dK|_F <= delta |Ktt|_F``), with ``|Ktt|_F`` and
         ``|alpha| = |K^-1 r|`` stored in the fixture.  For the likelihood ``|dv| <= 1/2 |alpha|^2 |dK|_F + 1/2
         |K^-1|_2 |dK|_F sqrt(n)`` (quadratic form + log-determinant). """
-    from .abalone import load_abalone, c5_problem
+    from workloads import load_abalone, c5_problem
     g = np.load(os.path.join(HERE, 'golden', 'c5_abalone_n4096.npz'))
     X, y = load_abalone()
     n = 4096

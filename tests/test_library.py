@@ -77,6 +77,15 @@ def test_host_bracket_folding():
     assert _bart_brackets(5, 2) == [(0, 4, 2)]
     assert _bart_brackets(3, None) == [(0, 2, 1)]
     assert _bart_brackets(4, [1]) == [(0, 1, 1), (1, 3, 1)]
+    assert _bart_brackets(7, [1, 3]) == [(0, 1, 1), (1, 3, 1), (3, 6, 1)]
+    assert _bart_brackets(7, [3]) == [(0, 3, 1), (3, 6, 1)]            # three levels deep: never folded
+    assert _bart_brackets(7, [2, 4], altinput=False) == [(0, 2, 1), (2, 4, 1), (4, 6, 1)]
+    assert _bart_brackets(7, [2, 4], debug=True) == [(0, 2, 1), (2, 4, 1), (4, 6, 1)]
+    assert _bart_brackets(6, [2, 4]) == [(0, 4, 2), (4, 5, 1)]
+    assert _bart_brackets(4, [1, 2]) == [(0, 3, 3)]
+    assert _bart_brackets(1, None) == [(0, 0, 1)]
+    with pytest.raises(AssertionError):
+        _bart_brackets(5, [3, 2])
     pnt = 0.95 / (1 + np.arange(11)) ** 2.
     probs = _bart_probs(pnt, 0, 10, 5)
     expected = np.array([1, pnt[9], pnt[10], 1, pnt[7], pnt[8], 1, pnt[5], pnt[6], 1, pnt[3], pnt[4], pnt[0], pnt[1], pnt[2]])

@@ -1,13 +1,13 @@
 """
-Configuration C5 on its real workload (shared by tests/golden/make_golden.py, the GPU parity test and bench.py's
-parity self-check): the reference's data file and the GP that ``bayestree.bart`` builds from it.
+Configuration C5 on its real workload (shared by bench.py, tests/golden/make_golden.py and the GPU parity tests):
+the reference's data file and the GP that ``bayestree.bart`` builds from it.
 """
 
 import os
 
 import numpy as np
 
-HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden')      # the data file is a test fixture
 
 
 def load_abalone():
