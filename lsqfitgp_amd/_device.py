@@ -200,6 +200,7 @@ class _Buffer:
         self._finalizer = weakref.finalize(self, ctx._graveyard.bury, ptr.value, int(nbytes))
 
 
+_POISON = os.environ.get('LGP_POISON', '0') not in ('', '0')
 _ALLOWED = (numpy.dtype(numpy.float64), numpy.dtype(numpy.float32), numpy.dtype(numpy.int32))
 
 
@@ -231,6 +232,8 @@ class DeviceArray:
         assert 1 <= len(shape) <= 2, shape
         n = math.prod(shape)
         buf = _Buffer(ctx, max(n, 1) * dtype.itemsize)
+        if _POISON:        # debugging aid (LGP_POISON=1): fresh blocks read as NaN / -1, so that a read of unwritten memory shows
+            _lib.check(ctx._lib.lgp_memset(ctx.handle, buf.ptr, 0xff, buf.nbytes))
         return cls(buf, buf.ptr, shape, dtype, shape[-1] if len(shape) == 2 else 1)
 
     @classmethod

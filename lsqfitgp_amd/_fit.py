@@ -303,12 +303,17 @@ class empbayes_fit:
         return 0.5 * (len(z) * numpy.log(2 * numpy.pi) + z @ z)
 
     def _fun(self, z):
-        """ minus log marginal posterior of the hyperparameters (not normalised), ``_fit.py:676-683`` """
+        """ minus log marginal posterior of the hyperparameters (not normalised), ``_fit.py:676-683``.  A covariance matrix
+        that cannot be factored gives nan, as the reference's traced function does (its Cholesky raises only outside a trace,
+        ``_linalg/_decomp.py:389-391``), so that the minimiser backs off instead of the fit dying """
         self._calls['fun'] += 1
         z = numpy.asarray(z, float)
         hp = self._space.unflat(z)
-        gp = self.gpfactory(hp, **self.gpfactorykw)
-        decomp, r = gp._prior_decomp(*self._args(hp), **self._mlkw)
+        try:
+            gp = self.gpfactory(hp, **self.gpfactorykw)
+            decomp, r = gp._prior_decomp(*self._args(hp), **self._mlkw)
+        except numpy.linalg.LinAlgError:
+            return numpy.nan
         value = decomp.minus_log_normal_density(numpy.asarray(r, float), value=True)[0]
         loss = 0. if self._additional_loss is None else float(self._additional_loss(hp))
         return float(value) + self._prior_value(z) + loss
@@ -341,7 +346,10 @@ class empbayes_fit:
         z = numpy.asarray(z, float)
         self._calls['grad'] += 1
         if self.gradfactory is not None:
-            value, g, _ = self._derivs(z, False)
+            try:
+                value, g, _ = self._derivs(z, False)
+            except numpy.linalg.LinAlgError:
+                return numpy.nan, numpy.full(len(z), numpy.nan)
             loss = 0. if self._additional_loss is None else float(self._additional_loss(self._space.unflat(z)))
             return value + self._prior_value(z) + loss, g + z + self._loss_grad(z)
         f0 = self._fun(z)

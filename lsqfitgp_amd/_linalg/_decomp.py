@@ -185,7 +185,9 @@ class Chol(Decomposition):
             self._solved = Lfull.block(n, n + q, 0, n)                 # (q, n) = (L^-1 rhs)^T
             self._solved_for = rhs
         if info != 0:                                                  # :389-391
-            raise numpy.linalg.LinAlgError('cholesky decomposition not finite, probably matrix not pos def numerically')
+            err = numpy.linalg.LinAlgError('cholesky decomposition not finite, probably matrix not pos def numerically')
+            err.info = int(info)                                       # LAPACK-style: 1-based index of the first bad pivot
+            raise err
         self._L = L
         self._dblk = dblk
         self._eps = self._dtype.type(eps.value)                        # :393

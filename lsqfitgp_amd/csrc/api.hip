@@ -26,6 +26,75 @@ int lgp_frob_device(lgp_ctx *ctx, hipStream_t stream, size_t rows, size_t cols, 
 template <typename T>
 int lgp_set_diag_device(lgp_ctx *ctx, hipStream_t stream, size_t n, T *A, size_t lda, T value);
 
+// ---- workspaces -----------------------------------------------------------------------------------------------------
+static void ws_trim(lgp_ctx *c, size_t keep) {
+  // idle blocks, largest first, until the idle total fits (hipFree waits for the device: nothing can still be using them)
+  for (;;) {
+    size_t idle = 0, big = (size_t)-1;
+    for (size_t i = 0; i < c->ws_blocks.size(); ++i)
+      if (!c->ws_blocks[i].busy) {
+        idle += c->ws_blocks[i].bytes;
+        if (big == (size_t)-1 || c->ws_blocks[i].bytes > c->ws_blocks[big].bytes) big = i;
+      }
+    if (idle <= keep || big == (size_t)-1) return;
+    (void)hipFree(c->ws_blocks[big].ptr);
+    if (c->ws_blocks[big].ev) (void)hipEventDestroy(c->ws_blocks[big].ev);
+    c->ws_blocks.erase(c->ws_blocks.begin() + (long)big);
+  }
+}
+
+int lgp_ws_alloc(lgp_ctx *c, hipStream_t stream, size_t bytes, void **out) {
+  *out = nullptr;
+  if (bytes == 0) bytes = 256;
+  bytes = (bytes + 255) / 256 * 256;
+  size_t best = (size_t)-1;
+  for (size_t i = 0; i < c->ws_blocks.size(); ++i) {
+    const auto &b = c->ws_blocks[i];
+    if (!b.busy && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 && (best == (size_t)-1 || b.bytes < c->ws_blocks[best].bytes)) best = i;
+  }
+  if (best == (size_t)-1) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {          // give back what is idle and try once more
+      (void)hipGetLastError();
+      ws_trim(c, 0);
+      e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      lgp_set_error("hipMalloc of a %zu-byte workspace failed: %s", bytes, hipGetErrorString(e));
+      return LGP_ENOMEM;
+    }
+    hipEvent_t ev = nullptr;
+    LGP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->ws_blocks.push_back({p, bytes, nullptr, ev, false});
+    best = c->ws_blocks.size() - 1;
+  }
+  auto &b = c->ws_blocks[best];
+  if (b.last != nullptr && b.last != stream) LGP_HIP(hipStreamWaitEvent(stream, b.ev, 0));
+  b.busy = true;
+  *out = b.ptr;
+  return LGP_OK;
+}
+
+int lgp_ws_free(lgp_ctx *c, hipStream_t stream, void *ptr) {
+  if (ptr == nullptr) return LGP_OK;
+  for (auto &b : c->ws_blocks)
+    if (b.ptr == ptr) {
+      b.busy = false;
+      b.last = stream;
+      hipError_t e = hipEventRecord(b.ev, stream);
+      ws_trim(c, c->ws_keep_bytes);
+      if (e != hipSuccess) {
+        lgp_set_error("hipEventRecord failed: %s", hipGetErrorString(e));
+        return LGP_EHIP;
+      }
+      return LGP_OK;
+    }
+  lgp_set_error("lgp_ws_free: not a workspace block");
+  return LGP_EINVAL;
+}
+
 extern "C" {
 
 int lgp_version(void) { return 1; }
@@ -117,12 +186,7 @@ int lgp_ctx_create(int device, lgp_ctx **out) {
   c->scratch_bytes = 1 << 20;
   LGP_HIP(hipMalloc(&c->d_scratch, c->scratch_bytes));
   LGP_HIP(hipHostMalloc(&c->h_pinned, 4096, hipHostMallocDefault));
-  // keep stream-ordered allocations cached instead of returning them to the OS at every sync
-  hipMemPool_t pool;
-  if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-    uint64_t thr = ~0ull;
-    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-  }
+  if (const char *m = getenv("LGP_WS_KEEP_MB")) c->ws_keep_bytes = (size_t)strtoull(m, nullptr, 10) << 20;
   guard.c = nullptr;
   *out = c;
   return LGP_OK;
@@ -133,6 +197,8 @@ int lgp_ctx_destroy(lgp_ctx *c) {
   DeviceGuard dg(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  for (auto &b : c->ws_blocks) b.busy = false;
+  ws_trim(c, 0);
   lgp_comm_destroy(c);
   if (c->d_info) (void)hipFree(c->d_info);
   if (c->chain_trace) {
@@ -470,10 +536,12 @@ static int mlnd_grad_impl(lgp_ctx *c, size_t n, const T *L, size_t ldl, const T 
   LGP_CHECK(lgp_logdet_device<T>(c, st, n, L, ldl, ds));
   LGP_CHECK(lgp_dot_strided_device<T>(c, st, n, r, 1, r, 1, ds + 1));
   T *ws = nullptr;
+  WsGuard wsg(c, st, nullptr);
   if (want_grad || want_fisher) {
     const bool needK = hdK != nullptr;
     const size_t nmat = needK ? (want_fisher ? 3 : 2) : 0;
-    LGP_HIP(hipMallocAsync(reinterpret_cast<void **>(&ws), (nmat * n * n + 2 * n + n * (p ? p : 1)) * sizeof(T), st));
+    LGP_CHECK(lgp_ws_alloc(c, st, (nmat * n * n + 2 * n + n * (p ? p : 1)) * sizeof(T), reinterpret_cast<void **>(&ws)));
+    wsg.p = ws;
     T *X = ws, *IK = ws + (needK ? n * n : 0), *S = ws + (needK ? 2 * n * n : 0);
     T *z = ws + nmat * n * n, *w = z + n, *V = w + n;
     LGP_HIP(hipMemcpyAsync(z, r, n * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -510,7 +578,6 @@ static int mlnd_grad_impl(lgp_ctx *c, size_t n, const T *L, size_t ldl, const T 
   }
   std::vector<T> h(nscal);
   LGP_HIP(hipMemcpyAsync(h.data(), ds, nscal * sizeof(T), hipMemcpyDeviceToHost, st));
-  if (ws) LGP_HIP(hipFreeAsync(ws, st));
   LGP_HIP(hipStreamSynchronize(st));
   if (hvalue) *hvalue = T(0.5) * (T(n) * T(std::log(2 * M_PI)) + T(2) * h[0] + h[1]);                       // :484-488
   if (want_grad)

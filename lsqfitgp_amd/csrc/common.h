@@ -56,6 +56,11 @@ struct lgp_ctx {
   unsigned long long chain_timeout = 1000000000ull;   // wall_clock64 ticks (100 MHz) a worker waits for one input: 10 s (env LGP_CHAIN_TIMEOUT_MS)
   bool chain_attr_set = false;        // the chain kernel's dynamic-LDS limit has been raised on this context's device
   int chain_test_stall = 0;           // env LGP_CHAIN_TEST_STALL=1 (tests): the driver withholds u1[1], so that the workers time out
+  // workspace blocks of the library's own (lgp_ws_alloc / lgp_ws_free): plain hipMalloc blocks kept for reuse, each tagged
+  // with the stream that used it last and an event recorded there when it was given back
+  struct WsBlock { void *ptr; size_t bytes; hipStream_t last; hipEvent_t ev; bool busy; };
+  std::vector<WsBlock> ws_blocks;
+  size_t ws_keep_bytes = (size_t)1 << 30;   // idle blocks beyond this total are returned to the device (env LGP_WS_KEEP_MB)
   // live kernel timing of the dominant kernel (trailing-update syrk) for bench.py: HIP event pairs on the
   // stream the kernel is launched on, enabled by lgp_profile_begin
   int prof_on = 0;
@@ -68,6 +73,21 @@ int lgp_prof_start(lgp_ctx *ctx, hipStream_t stream, double flops);
 int lgp_prof_stop(lgp_ctx *ctx, hipStream_t stream);
 
 void lgp_set_error(const char *fmt, ...);
+
+// Workspaces of the library (api.hip).  NOT hipMallocAsync: with the stream-ordered pool of this ROCm release a workspace of
+// a few hundred MB that was freed and allocated again by the next call gave wrong results every other call (measured on
+// lgp_mlnd_grad at n = 4096, round 3; the same code on hipMalloc blocks, zeroed or poisoned, is exact).  A block handed out for
+// `stream` after it was last used on another stream makes `stream` wait for the event recorded when it was given back.
+int lgp_ws_alloc(lgp_ctx *ctx, hipStream_t stream, size_t bytes, void **out);
+int lgp_ws_free(lgp_ctx *ctx, hipStream_t stream, void *ptr);
+// gives the block back when the scope is left on any path
+struct WsGuard {
+  lgp_ctx *c; hipStream_t s; void *p;
+  WsGuard(lgp_ctx *ctx, hipStream_t stream, void *ptr) : c(ctx), s(stream), p(ptr) {}
+  ~WsGuard() { if (p) (void)lgp_ws_free(c, s, p); }
+  WsGuard(const WsGuard &) = delete;
+  WsGuard &operator=(const WsGuard &) = delete;
+};
 
 #define LGP_HIP(expr)                                                                       \
   do {                                                                                      \

@@ -404,12 +404,12 @@ extern "C" int lgp_colabssum_f64(lgp_ctx *c, size_t rows, size_t cols, const dou
   const size_t rpb = (rows + chunks - 1) / chunks;
   chunks = (rows + rpb - 1) / rpb;
   double *part = nullptr;
-  LGP_HIP(hipMallocAsync(reinterpret_cast<void **>(&part), chunks * cols * sizeof(double), c->stream));
+  LGP_CHECK(lgp_ws_alloc(c, c->stream, chunks * cols * sizeof(double), reinterpret_cast<void **>(&part)));
+  WsGuard part_guard(c, c->stream, part);
   hipLaunchKernelGGL((colabssum_kernel<double>), dim3((unsigned)(nbx * chunks)), dim3(256), 0, c->stream, rows, cols, A, lda, part, rpb);
   LGP_LAUNCH_CHECK();
   hipLaunchKernelGGL((colabssum_reduce_kernel<double>), dim3((unsigned)nbx), dim3(256), 0, c->stream, cols, chunks, part, out);
   LGP_LAUNCH_CHECK();
-  LGP_HIP(hipFreeAsync(part, c->stream));
   return LGP_OK;
 }
 

@@ -537,9 +537,10 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
       kc = ((kc + BK - 1) / BK) * BK;
       ns = (k + kc - 1) / kc;
       g.nsplit = (int)ns; g.kchunk = (int)kc;
-      LGP_HIP(hipMallocAsync(reinterpret_cast<void **>(&g.Cpart), ns * m * n * sizeof(T), stream));
+      LGP_CHECK(lgp_ws_alloc(ctx, stream, ns * m * n * sizeof(T), reinterpret_cast<void **>(&g.Cpart)));
     }
   }
+  WsGuard cpart_guard(ctx, stream, g.Cpart);
   dim3 gd((unsigned)grid, (unsigned)g.nsplit), bd(NTHREADS);
   // untouched dynamic LDS that thins out the workgroups of a trailing update per CU (experiment, see potrf_chain)
   const size_t thin = (!ta && tb) ? ctx->gemm_thin_lds : 0;
@@ -554,7 +555,6 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, stream, g.Cpart, g.nsplit, mn, (int)n,
                        alpha, beta, C, (long)ldc);
     LGP_LAUNCH_CHECK();
-    LGP_HIP(hipFreeAsync(g.Cpart, stream));
   }
   return LGP_OK;
 }

@@ -940,12 +940,12 @@ static int gram_chol_impl(lgp_ctx *ctx, int kernel, int p, int npar, const T *hp
   const size_t ntr = (n + GR_ROWS - 1) / GR_ROWS;
   // workspace: s (n), Gershgorin sums (n), stats (16), partial column sums (ntr x n)
   T *ws = nullptr;
-  LGP_HIP(hipMallocAsync(reinterpret_cast<void **>(&ws), (2 * n + 16 + ntr * n) * sizeof(T), ctx->stream));
+  LGP_CHECK(lgp_ws_alloc(ctx, ctx->stream, (2 * n + 16 + ntr * n) * sizeof(T), reinterpret_cast<void **>(&ws)));
+  WsGuard ws_guard(ctx, ctx->stream, ws);      // (the calls below end with a stream synchronisation: nothing is using it by then)
   size_t got = 0;
   int st = gram_reg_launch<T>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, noise, dnoise, dL,
                               ldl, ws, ws + 2 * n + 16, &got);
   if (st == LGP_OK) st = lgp_chol_from_prepared<T>(ctx, n, dL, ldl, ddblk, nrhs, ws, ntr, epsrel, epsabs, flags, heps_out);
-  else (void)hipFreeAsync(ws, ctx->stream);
   return st;
 }
 

@@ -996,7 +996,8 @@ static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T ep
   hipStream_t st = ctx->stream;
   // workspace: s (n), rows (n), stats (16)
   T *ws = nullptr;
-  LGP_HIP(hipMallocAsync(reinterpret_cast<void **>(&ws), (2 * n + 16) * sizeof(T), st));
+  LGP_CHECK(lgp_ws_alloc(ctx, st, (2 * n + 16) * sizeof(T), reinterpret_cast<void **>(&ws)));
+  WsGuard ws_guard(ctx, st, ws);
   T *s = ws, *rows = ws + n, *stats = ws + 2 * n;
   LGP_HIP(hipMemsetAsync(stats, 0, 16 * sizeof(T), st));
   LGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), st));
@@ -1027,14 +1028,13 @@ static int chol_factor_impl(lgp_ctx *ctx, size_t n, const T *K, size_t ldk, T ep
   int info = 0;
   LGP_HIP(hipMemcpyAsync(hstats, stats, 3 * sizeof(T), hipMemcpyDeviceToHost, st));
   LGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
-  LGP_HIP(hipFreeAsync(ws, st));
   LGP_HIP(hipStreamSynchronize(st));
   if (heps_out) *heps_out = hstats[1];
   return lgp_info_result(ctx, info);
 }
 
 // Tail of Chol.__init__ for a matrix that the fused Gram kernel (gram.hip, gram_reg_kernel) has already scaled and written as
-// a lower triangle: ws = [s (n) | Gershgorin sums (n) | stats (16) | partial column sums (ntr x n)], freed here.
+// a lower triangle: ws = [s (n) | Gershgorin sums (n) | stats (16) | partial column sums (ntr x n)], owned by the caller.
 namespace {
 template <typename T>
 __global__ void __launch_bounds__(256) colpart_reduce_kernel(size_t n, size_t ntr, const T *part, const T *s, T *rows, unsigned int *nonunit) {
@@ -1081,7 +1081,6 @@ int lgp_chol_from_prepared(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, si
   int info = 0;
   LGP_HIP(hipMemcpyAsync(hstats, stats, 3 * sizeof(T), hipMemcpyDeviceToHost, st));
   LGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
-  LGP_HIP(hipFreeAsync(ws, st));
   LGP_HIP(hipStreamSynchronize(st));
   if (heps_out) *heps_out = hstats[1];
   return lgp_info_result(ctx, info);

@@ -521,3 +521,29 @@ def test_chain_kernel_single_worker_setting(lgp, rng):
     K = randpd(rng, 640)
     c = lgp.Chol(K, ctx=ctx)
     util.assert_close_matrices(c.factor().to_host(), oracle.Chol(K)._L, rtol=1e-13)
+
+
+def test_gradient_large_and_repeatable(lgp, rng):
+    """ `normal_density_derivs` at n = 4096 (K^-1 formed in a 2 n^2 workspace of the library), four times in a row on the same
+    inputs: the same numbers every time, equal to the direct formulas 1/2 (tr(K^-1 dK) - z' dK z), z = K^-1 r
+    (_linalg/_decomp.py:526-528).  Regression test of round 3: with the workspace taken from the stream-ordered pool
+    (hipMallocAsync) every other call returned a wrong gradient at this size; the workspaces are now blocks of the library's own
+    (csrc/api.hip, lgp_ws_alloc) """
+    n = 4096
+    A = rng.standard_normal((n, n))
+    K = A @ A.T / n + np.eye(n)
+    r = rng.standard_normal(n)
+    dKh = []
+    for _ in range(2):
+        d = rng.standard_normal((n, n))
+        dKh.append(d + d.T)
+    dec = lgp.Chol(K)
+    dK = [lgp.DeviceArray.from_host(d) for d in dKh]
+    Kinv = np.linalg.inv(K + dec.eps * np.eye(n))
+    z = Kinv @ r
+    gref = np.array([0.5 * (np.sum(Kinv * d) - z @ d @ z) for d in dKh])
+    outs = [dec.normal_density_derivs(r, dK, None) for _ in range(4)]
+    for v, g, _ in outs:
+        assert v == outs[0][0]
+        np.testing.assert_array_equal(np.asarray(g), np.asarray(outs[0][1]))
+    np.testing.assert_allclose(np.asarray(outs[0][1]), gref, rtol=1e-9)
