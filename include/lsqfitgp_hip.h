@@ -400,15 +400,32 @@ int lgp_get_info(lgp_ctx *ctx, int *hinfo);    /* read & reset the pivot info wo
 /* The whole sharded factorisation in one call (no host language between the panels): dLloc holds this rank's block
  * columns (block b = columns [b nb, (b+1) nb) of the n x n matrix lives on rank b % nranks at local columns
  * [(b / nranks) nb, ...), all n + nx rows, ld ldl; lower triangle + regularisation already in place; rows n .. n+nx-1 are
- * right-hand sides carried through the factorisation as in lgp_chol_factor_rhs).  Right-looking with one-panel look-ahead:
- * the owner factors panel b+1 and ncclBroadcasts it on the auxiliary stream while every rank updates its remaining block
- * columns with panel b in one staircase MFMA launch.  ddblk: nlocal * lgp_chol_dblk_size(nb) workspace/outputs (packed
- * diagonal blocks of the owned block columns); dpanels: workspace of 2 (n + nx) ldp doubles, ldp >= nb (pad it: ldp = nb
+ * right-hand sides carried through the factorisation as in lgp_chol_factor_rhs).  Right-looking; the panels are factored,
+ * broadcast (ncclBroadcast on a stream of its own) and consumed in row PIECES -- the diagonal square, then slabs of rows --
+ * that every stream of every rank takes in one common wavefront order (lgp_chol_dist_plan), so that the dependent chain is that
+ * of one slab and the slabs below it follow as a pipeline; each rank updates its remaining block columns with a piece in one
+ * staircase MFMA launch.  ddblk: nlocal * lgp_chol_dblk_size(nb) workspace/outputs (packed diagonal blocks of the owned block
+ * columns); dpanels: workspace of nslots (n + nx) ldp doubles, nslots from lgp_chol_dist_plan, ldp >= nb (pad it: ldp = nb
  * puts every operand row of the trailing update on one HBM channel).  dsrow (n values, may be NULL): the power-of-two row
  * scaling s undone on the finished factor, L = L~ s[:, None] (_decomp.py:392).  *hinfo: pivot info of THIS rank's panels
- * (0 = ok).  Uses the context's communicator (lgp_comm_init / lgp_comm_init_host; none: single rank).  Synchronises. */
+ * (0 = ok).  Uses the context's communicator (lgp_comm_init / lgp_comm_init_host; none: single rank).  Synchronises.  A
+ * failure on one rank still issues the rest of that rank's broadcasts, so that its peers are not left inside a collective.
+ * No counterpart in the reference (LAPACK potrf on one host, _linalg/_decomp.py:388). */
 int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_t nx, double *dLloc, size_t ldl, double *ddblk,
-                             double *dpanels, size_t ldp, const double *dsrow, int *hinfo);
+                             double *dpanels, size_t ldp, size_t nslots, const double *dsrow, int *hinfo);
+/* The plan of that factorisation (host only, no device needed): the pieces in the order in which every stream of every rank
+ * takes them, four values each -- panel b, piece index i (0 = the diagonal square, which stays on its owner), first row,
+ * end row -- at most `capacity` of them written to `pieces` (may be NULL); returns their number (negative: error).  slab:
+ * rows per slab below the squares (rounded up to a multiple of nb), 0 = one piece with all the rows below, (size_t)-1 = the
+ * library's default for `nranks` (what lgp_chol_factor_dist uses: none for one rank, 8 nb otherwise, env LGP_DIST_SLAB).
+ * *nslots: panel slots the factorisation needs; *slab_out: the slab height used.  The CPU tests execute this list over
+ * numpy + gloo (tests/test_dist_gloo.py). */
+long lgp_chol_dist_plan(size_t n, size_t nb, size_t nx, size_t nranks, size_t slab, unsigned long long *pieces, size_t capacity,
+                        size_t *nslots, size_t *slab_out);
+/* One horizontal slab of the staircase update above: rows [roff, roff + rows) below the diagonal of the first block column
+ * of dC (which points at the slab's first row, as dA does; dB points at the panel row of that diagonal). */
+int lgp_update_nt_slab_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dA, size_t lda, const double *dB, size_t ldb,
+                           double *dC, size_t ldc, size_t nb, size_t nranks, size_t roff);
 /* dout[0] = max_i dx[i] (NaN if any element is NaN, like jnp.max): the Gershgorin bound over a rank's column sums */
 int lgp_max_f64(lgp_ctx *ctx, size_t n, const double *dx, double *dout);
 /* A_ij <- A_ij / drow_i / dcol_j (divide != 0) or * drow_i * dcol_j: the power-of-two scaling of a locally owned block

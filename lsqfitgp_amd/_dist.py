@@ -3,20 +3,26 @@
 distributed code, so this has no counterpart there and is judged on parity with the single-GPU factor).
 
 One process per GPU.  Block column ``b`` (columns ``[b*nb, (b+1)*nb)``) lives on rank ``b % G`` with all its
-rows.  Right-looking with one-panel look-ahead:
+rows.  Right-looking; the panels are factored, broadcast and consumed in row PIECES (``csrc/dist.hip``): piece 0 of
+panel b is its diagonal square (it stays on its owner: the trailing updates only read rows below a panel's diagonal
+block), pieces 1.. are slabs of the rows below.  Rows r of panel b+1 depend on rows r of panel b and on the two squares
+only, so a slab moves from panel to panel (update of block column b+1 with the slab's rows of panel b, substitution
+against square b+1, broadcast) independently of the slabs below it: the dependent chain of the factorisation is that of
+one slab, the others follow as a pipeline.  Every stream of every rank takes the pieces in ONE common order (key
+``2 b + i``), a topological order of all the dependencies:
 
-    step b:   every rank has panel b (rows b*nb.., nb columns) in panel slot b%2
-              owner(b+1):  update block column b+1 with panel b, factor it, pack it        [compute stream]
-              all ranks:   broadcast panel b+1 from owner(b+1) into slot (b+1)%2            [comm stream, RCCL]
-              all ranks:   update their other owned block columns c > b with panel b        [compute stream]
+    owner(b), piece 0       update the square with panel b-1, factor it                                  [look-ahead stream 1]
+    owner(b), piece i > 0   update the piece's rows of block column b with panel b-1, solve them
+                            against the square, pack them                                                [look-ahead stream 2]
+    every rank              broadcast piece (b, i) from owner(b)                                         [comm stream, RCCL]
+    every rank              update its block columns c >= b+2, rows of the piece, in one staircase launch  [compute stream]
 
-so the (N - k) x nb panel message (one ``ncclBroadcast`` per panel, every peer fed over its own xGMI link)
-travels while the trailing updates (MFMA) run.  The only other collectives are scalars
-(``max`` for the Gershgorin bound, ``sum`` for the log-determinant).
+The only other collectives are scalars (``max`` for the Gershgorin bound, ``sum`` for the log-determinant).
 
-The product runs the schedule inside the library (``lgp_chol_factor_dist``, ``csrc/dist.hip``); `factor_schedule` below
-states the same schedule over an abstract ``ops`` backend so that ownership, ordering and the panel slots can be exercised
-with world_size > 1 on CPU (gloo + numpy backend in ``tests/test_dist_gloo.py``).
+The product runs the schedule inside the library (``lgp_chol_factor_dist``); the list of pieces is the library's
+(``lgp_chol_dist_plan``, host only) and `factor_schedule` below executes that same list over an abstract ``ops`` backend,
+so that ownership, ordering, the dependencies and the panel slots are exercised with world_size > 1 on CPU (gloo + numpy
+backend in ``tests/test_dist_gloo.py``).
 """
 
 import ctypes
@@ -74,52 +80,120 @@ class Layout:
         return max(self.nlocal, 1) * self.nb
 
 
-def factor_schedule(layout, ops):
-    """
-    The look-ahead schedule described in the module docstring.  ``ops`` provides
+def dist_plan(n, nb, nx=0, nranks=1, slab=None):
+    """ the library's plan of the sharded factorisation: ``(pieces, nslots, slab)`` with ``pieces`` a list of
+    ``(b, i, r0, r1)`` in the order in which every stream of every rank takes them.  ``slab=None``: the library's default
+    for ``nranks`` (what `lgp_chol_factor_dist` uses).  Host only. """
+    lib = _lib.load()
+    slab_arg = ctypes.c_size_t(-1).value if slab is None else int(slab)
+    ns, so = ctypes.c_size_t(), ctypes.c_size_t()
+    count = lib.lgp_chol_dist_plan(n, nb, nx, nranks, slab_arg, None, 0, ctypes.byref(ns), ctypes.byref(so))
+    if count < 0:
+        raise _lib.LibraryError('lgp_chol_dist_plan: ' + _lib.last_error())
+    buf = (ctypes.c_ulonglong * (4 * count))()
+    lib.lgp_chol_dist_plan(n, nb, nx, nranks, slab_arg, buf, count, ctypes.byref(ns), ctypes.byref(so))
+    pieces = [tuple(int(buf[4 * t + k]) for k in range(4)) for t in range(count)]
+    return pieces, int(ns.value), int(so.value)
 
-        panel_factor(b), pack_panel(b, slot)                      compute stream, owner(b) only
-        update(c, b, slot)                                        compute stream, owner(c) only:
-                                                                  block column c -= P_b[rows of c] P_b[block rows of c]'
-        update_rest(cols, b, slot)   (optional)                   the same for a run of consecutive owned block columns
-        bcast_panel(b, slot)                                      comm stream, every rank
-        compute_mark_ready(slot) / comm_wait_ready(slot)          owner: panel packed before it is sent
-        comm_mark_received(slot) / compute_wait_received(slot)    panel arrived before it is used
-        compute_mark_free(slot) / comm_wait_free(slot)            slot no longer read before it is overwritten
+
+class Task:
+    """ one enqueued operation of the sharded factorisation: ``kind`` on ``stream`` for piece ``piece = (b, i, r0, r1)``;
+    it starts after the operations enqueued before it on its stream and after the records ``waits`` (ids of earlier
+    tasks whose completion was recorded as an event), like a kernel behind ``hipStreamWaitEvent`` calls """
+    __slots__ = ('index', 'stream', 'kind', 'piece', 'waits', 'extra')
+
+    def __init__(self, index, stream, kind, piece, waits, extra=None):
+        self.index, self.stream, self.kind, self.piece, self.waits, self.extra = index, stream, kind, piece, waits, extra
+
+    def __repr__(self):
+        return f'Task({self.index}, {self.stream}, {self.kind}, {self.piece}, waits={self.waits})'
+
+
+def factor_tasks(layout, plan=None, nx=0):
+    """
+    What ``lgp_chol_factor_dist`` (``csrc/dist.hip``) enqueues on this rank, operation by operation, in the same order and
+    with the same event waits: a list of `Task`.  Streams: ``'s1'`` (squares), ``'s3'`` (rows below them), ``'sx'``
+    (broadcasts), ``'sc'`` (bulk updates).  Kinds, for a piece ``(b, i, r0, r1)``:
+
+        'U'      owner(b): rows of the piece of block column b -= P(b-1)[rows] P(b-1)[rows of block b]'  (lower part for i = 0)
+        'SQ'     owner(b), i = 0: the diagonal square factored
+        'SOLVE'  owner(b), i > 0: the rows solved against the square
+        'PACK'   owner(b), i > 0: the rows copied into panel slot b % nslots
+        'BCAST'  every rank, i > 0: the piece broadcast from owner(b) (a collective: same order on every rank)
+        'BULK'   every rank, i > 0: block columns ``extra`` (owned, >= b + 2) restricted to the rows of the piece
     """
     L, me = layout, layout.rank
-    if L.owner(0) == me:
-        ops.panel_factor(0)
-        ops.pack_panel(0, 0)
-        ops.compute_mark_ready(0)
-        ops.comm_wait_ready(0)
-    ops.bcast_panel(0, 0)
-    ops.comm_mark_received(0)
+    if plan is None:
+        plan = dist_plan(L.n, L.nb, nx, L.nranks)
+    pieces, nslots, _ = plan
+    by_panel = {}
+    for p in pieces:
+        by_panel.setdefault(p[0], []).append(p)
+    for v in by_panel.values():
+        v.sort(key=lambda p: p[1])
+
+    def cover(b, r):
+        for p in by_panel[b]:
+            if p[2] <= r < p[3]:
+                return p[1]
+        return by_panel[b][-1][1]
+
+    tasks = []
+    rec = {}                     # event name -> id of the task whose completion it last recorded (hipEventRecord)
+
+    def push(stream, kind, piece, wait_names, extra=None):
+        waits = sorted({rec[w] for w in wait_names if w in rec})        # (waiting on an event never recorded is a no-op)
+        tasks.append(Task(len(tasks), stream, kind, piece, waits, extra))
+        return tasks[-1].index
+
+    def slot_events(b):
+        if b < nslots:
+            return []
+        s = b % nslots
+        return [('free_sc', s), ('free_l1', s), ('free_l3', s)]
+
     mine = L.owned()
-    for b in range(L.nblocks):
-        slot, nslot = b % 2, (b + 1) % 2
-        ops.compute_wait_received(slot)
-        nxt = b + 1
-        if nxt < L.nblocks:
-            if L.owner(nxt) == me:
-                ops.update(nxt, b, slot)
-                ops.panel_factor(nxt)
-                ops.pack_panel(nxt, nslot)
-                ops.compute_mark_ready(nslot)
-                ops.comm_wait_ready(nslot)
+    for p in pieces:
+        b, i, r0, r1 = p
+        last = i == by_panel[b][-1][1]
+        if L.owner(b) == me:
+            st = 's1' if i == 0 else 's3'
             if b >= 1:
-                ops.comm_wait_free(nslot)
-            ops.bcast_panel(nxt, nslot)
-            ops.comm_mark_received(nslot)
-        rest = [c for c in mine if c > b and c != nxt]
-        if rest:
-            if hasattr(ops, 'update_rest'):
-                ops.update_rest(rest, b, slot)          # all of them in one launch
+                w = [('recv', b - 1, cover(b - 1, r0)), ('recv', b - 1, cover(b - 1, b * L.nb))]
+                if b >= 2:
+                    w.append(('bulk', b - 2, cover(b - 2, r0)))
+                t = push(st, 'U', p, w)
+            if i == 0:
+                t = push(st, 'SQ', p, [])
+                rec['sq', b] = t
+                if b >= 1:
+                    rec['free_l1', (b - 1) % nslots] = t
             else:
-                for c in rest:
-                    ops.update(c, b, slot)
-        ops.compute_mark_free(slot)
-    ops.finish()
+                t = push(st, 'SOLVE', p, [('sq', b)])
+                if b >= 1 and last:
+                    rec['free_l3', (b - 1) % nslots] = t
+                rec['ready', b, i] = push(st, 'PACK', p, slot_events(b))
+        if i == 0:
+            continue
+        rec['recv', b, i] = push('sx', 'BCAST', p, [('ready', b, i)] if L.owner(b) == me else slot_events(b))
+        cols = [c for c in mine if c >= b + 2 and c * L.nb < r1]
+        w = [('recv', b, i)]
+        if cols:
+            w.append(('recv', b, cover(b, cols[0] * L.nb)))
+        t = push('sc', 'BULK', p, w, cols)
+        rec['bulk', b, i] = t
+        if last:
+            rec['free_sc', b % nslots] = t
+    return tasks, nslots
+
+
+def factor_schedule(layout, ops, plan=None, nx=0):
+    """ `factor_tasks` executed eagerly, in enqueue order, on ``ops`` (methods named after the task kinds in lower case,
+    called with the piece, the panel slot and, for the bulk update, the block columns) """
+    tasks, nslots = factor_tasks(layout, plan, nx)
+    for t in tasks:
+        getattr(ops, t.kind.lower())(t.piece, t.piece[0] % nslots, *([t.extra] if t.kind == 'BULK' else []))
+    return tasks
 
 
 def forward_solve_schedule(layout, ops):
@@ -255,9 +329,10 @@ class DistributedChol:
         mark('regularisation')
         # ---- factorisation: the whole look-ahead schedule inside the library
         ldp = nb + self.PANEL_PAD
-        self._panels = DeviceArray.empty((2 * (n + nx) * ldp,), numpy.float64, self.ctx)
+        _, nslots, self.slab = dist_plan(n, nb, nx, L.nranks)
+        self._panels = DeviceArray.empty((nslots * (n + nx) * ldp,), numpy.float64, self.ctx)
         info = ctypes.c_int()
-        _lib.check(lib.lgp_chol_factor_dist_f64(h, n, nb, nx, self.Lloc.ptr, self.Lloc.ld, self.dblk.ptr, self._panels.ptr, ldp,
+        _lib.check(lib.lgp_chol_factor_dist_f64(h, n, nb, nx, self.Lloc.ptr, self.Lloc.ld, self.dblk.ptr, self._panels.ptr, ldp, nslots,
                                                 None if self._unit else svec.ptr, ctypes.byref(info)), 'lgp_chol_factor_dist')
         self._panels = None
         mark('factorisation')

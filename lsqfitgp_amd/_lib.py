@@ -78,7 +78,9 @@ def _signatures():
         'lgp_select_stream': (c_int, [c_void_p, c_int]),
         'lgp_stream_wait_event': (c_int, [c_void_p, c_void_p]),
         'lgp_colabssum_f64': (c_int, [c_void_p, _S, _S, _P, _S, _P]),
-        'lgp_chol_factor_dist_f64': (c_int, [c_void_p, _S, _S, _S, _P, _S, _P, _P, _S, _P, POINTER(c_int)]),
+        'lgp_chol_factor_dist_f64': (c_int, [c_void_p, _S, _S, _S, _P, _S, _P, _P, _S, _S, _P, POINTER(c_int)]),
+        'lgp_chol_dist_plan': (ctypes.c_long, [_S, _S, _S, _S, _S, _P, _S, POINTER(c_size_t), POINTER(c_size_t)]),
+        'lgp_update_nt_slab_f64': (c_int, [c_void_p, _S, _S, _S, _P, _S, _P, _S, _P, _S, _S, _S, _S]),
         'lgp_max_f64': (c_int, [c_void_p, _S, _P, _P]),
         'lgp_scale_rows_cols_f64': (c_int, [c_void_p, _S, _S, _P, _S, _P, _P, c_int]),
         'lgp_diag_scale_pow2_f64': (c_int, [c_void_p, _S, _P, _S, _P]),

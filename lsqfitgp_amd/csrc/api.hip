@@ -229,6 +229,7 @@ int lgp_ctx_destroy(lgp_ctx *c) {
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   for (hipStream_t s : c->far_streams)
     if (s != c->stream3) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+  if (c->stream_comm) { (void)hipStreamSynchronize(c->stream_comm); (void)hipStreamDestroy(c->stream_comm); }
   if (c->stream_gm) { (void)hipStreamSynchronize(c->stream_gm); (void)hipStreamDestroy(c->stream_gm); }
   if (c->stream_fm) { (void)hipStreamSynchronize(c->stream_fm); (void)hipStreamDestroy(c->stream_fm); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -244,6 +245,7 @@ int lgp_sync(lgp_ctx *c) {
   LGP_HIP(hipStreamSynchronize(c->stream2));
   LGP_HIP(hipStreamSynchronize(c->stream3));
   for (hipStream_t s : c->far_streams) LGP_HIP(hipStreamSynchronize(s));
+  if (c->stream_comm) LGP_HIP(hipStreamSynchronize(c->stream_comm));
   if (c->stream_gm) LGP_HIP(hipStreamSynchronize(c->stream_gm));
   if (c->stream_fm) LGP_HIP(hipStreamSynchronize(c->stream_fm));
   return LGP_OK;

@@ -14,6 +14,7 @@ struct lgp_ctx {
   hipStream_t stream = nullptr;       // main stream: all public entry points enqueue here
   hipStream_t stream2 = nullptr;      // look-ahead stream of the blocked factorisation
   hipStream_t stream3 = nullptr;      // far-row stream of the factorisation (rows below a panel's diagonal square)
+  hipStream_t stream_comm = nullptr;  // the broadcasts of the sharded factorisation (dist.hip), created on first use
   std::vector<hipStream_t> far_streams;   // one per row group below the square (potrf_chain), high priority
   int prio_hi = 0;
   int chain_groups = 1;               // row groups = streams for the rows below a square (env LGP_CHAIN_GROUPS, 1..4)
@@ -142,7 +143,8 @@ constexpr int LGP_DBLK = LGP_FRAG0 + LGP_NFRAG * 64;   // per-diagonal-block wor
 template <typename T>
 int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
                     const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag = 0, int cyc_nb = 0,
-                    int cyc_g1 = 0);
+                    int cyc_g1 = 0, int roff = 0);
+// roff > 0 (lower only): the launch is the horizontal slab of a lower update that starts roff rows below its diagonal
 // tag & 2: an update of the factorisation that shares the GPU with latency-bound kernels: 64 x 64 tiles up to lgp_gemm_t64_trailing_max()
 // tiles of 128 x 128 (the tag & 1 label then only applies to the launches that still get 128 x 128 tiles)
 size_t lgp_gemm_t64_trailing_max();
@@ -157,7 +159,7 @@ int lgp_potf2_mfma_launch(lgp_ctx *ctx, hipStream_t stream, double *A, size_t ld
 bool lgp_chain_usable(lgp_ctx *ctx, size_t n, size_t ldl);
 size_t lgp_chain_state_bytes(size_t n);
 int lgp_chain_state(lgp_ctx *ctx, size_t n, unsigned **out);        // device words, LGP_CH_* layout; the caller zeroes them
-int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk);
+int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk, size_t row0 = 0);
 // layout of the state words: a header, then LGP_CH_PANEL words per panel
 constexpr int LGP_CH_NEXT = 0, LGP_CH_ABORT = 1, LGP_CH_NEXT_BULK = 2, LGP_CH_HEADER = 16, LGP_CH_PANEL = 512;
 constexpr int LGP_CH_U1 = 0;      // stream -> kernel: the panel's square has the updates of all earlier panels

@@ -1,50 +1,138 @@
 // dist.hip -- the 1-D block-column-cyclic Cholesky across the GPUs of one node, driven from the library: no host language
 // between the panels (the reference has no distributed code).  One process per GPU; block column b
-// (columns [b nb, (b+1) nb), all rows) lives on rank b % G.  Right-looking with one-panel look-ahead:
+// (columns [b nb, (b+1) nb), all rows) lives on rank b % G.
 //
-//     step b:   every rank has panel b (rows b nb .., nb columns) in panel slot b % 2
-//               owner(b+1):  update block column b+1 with panel b, factor it, pack it           [compute stream]
-//               all ranks:   broadcast panel b+1 from owner(b+1) into slot (b+1) % 2           [comm stream: RCCL / host transport]
-//               all ranks:   update ALL their other owned block columns c > b with panel b     [compute stream, one staircase launch]
+// Round 3: the panels travel and are consumed in PIECES.  Panel b is cut by rows into
+//     piece 0        its diagonal square, rows [b nb, (b+1) nb)
+//     piece 1, 2 ..  the rows below in slabs that end at absolute multiples of `slab` rows (the carried right-hand sides
+//                    ride with the last one);  one rank: a single piece with all the rows below
+// because everything in a right-looking Cholesky depends on earlier columns only ROW-WISE: rows r of panel b+1 need rows r of
+// panel b and the two squares, nothing else.  A slab therefore moves from panel to panel -- update of block column b+1 with
+// the slab's rows of panel b, substitution against square b+1, broadcast -- independently of the slabs below it, and the
+// dependent chain of the factorisation is no longer  "factor a whole (N - b nb) x nb panel, broadcast all of it, update a whole
+// block column"  per panel but that of one slab; the slabs below follow as a pipeline (a wavefront over (panel, slab)).
+// With whole panels and one panel of look-ahead (rounds 1-2) the chain was, for C4 on 8 GPUs, ~2.3 ms (block-column update)
+// + ~3.5 ms (panel) + 3-11 ms (545 MB broadcast) at the first panel, falling only linearly with b, against 9 ms of trailing
+// update per rank that fall quadratically: chain-bound after the first third of the panels.
 //
-// so the (N - k) x nb panel message travels while the trailing updates (MFMA) run.  Panels are packed with a PADDED leading
-// dimension (ldp = nb + 16 doubles by default): with ld = nb = 1024 every row of the A operand of the trailing update
-// starts on the same HBM channel (8 KiB stride), which was measured at 62 instead of 68.7 TFLOP/s.
+// Every piece (b, i) is one unit of work for three kinds of stream, and ALL streams of ALL ranks take the pieces in the same
+// order, by the key 2 b + i (then b) -- a topological order of the dependencies below, so nothing can wait on something
+// that is queued behind it, on any stream, whatever the transport (the host-staged transport of the tests blocks the host):
+//     owner(b), piece 0     [s1]  U:  square(b) -= P(b-1)[rows of b] P(b-1)[rows of b]'   needs recv(b-1, 1), bulk(b-2, .)
+//                                 factor the square (chain kernel: resident workers, potf2m.hip); it is NOT sent: the updates
+//                                 of the other block columns only read rows below a panel's diagonal block
+//     owner(b), piece i>0   [s3]  U:  rows of the piece of block column b -= P(b-1)[rows] P(b-1)[rows of b]'
+//                                     needs recv(b-1, piece with those rows), bulk(b-2, .)
+//                                 substitution against square b (left-looking over its 128-column blocks), pack, ready(b, i)
+//     every rank            [comm] broadcast piece (b, i) from owner(b) into panel slot b % nslots; recv(b, i)
+//     every rank            [sc]  its block columns c >= b + 2, rows of the piece: one staircase MFMA launch (row offset =
+//                                 the piece's first row below the diagonal of the first of them); bulk(b, i)
+// (block column b + 1 is the look-ahead column: its owner updates it on s1 / s3 as the first step of ITS pieces).
+// The panel slots hold (rows x ldp) with a PADDED leading dimension (ldp = nb + 16: with ld = nb = 1024 every operand row of
+// the update starts on one HBM channel, 62 instead of 68.7 TFLOP/s); a slot is reused for panel b + nslots once this rank's
+// updates with panel b are through (free events of sc and of the look-ahead streams).
 #include "common.h"
+#include <algorithm>
+
+template <typename T>
+int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *Pfar, size_t ldl, const T *Psq, const T *Yk);   // potrf.hip
+int lgp_square_factor_f64(lgp_ctx *ctx, hipStream_t st, size_t kb, double *P, size_t ldl, double *Yk, size_t row0);                // potrf.hip
 
 namespace {
 
-struct Events {
-  hipEvent_t ready[2] = {nullptr, nullptr}, recv[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr};
-  int create() {
-    for (int s = 0; s < 2; ++s) {
-      LGP_HIP(hipEventCreateWithFlags(&ready[s], hipEventDisableTiming));
-      LGP_HIP(hipEventCreateWithFlags(&recv[s], hipEventDisableTiming));
-      LGP_HIP(hipEventCreateWithFlags(&freed[s], hipEventDisableTiming));
-    }
-    return LGP_OK;
+struct Piece { size_t b, i, r0, r1; };
+
+// default slab height (rows): one rank needs none; several: 8 panels' worth (env LGP_DIST_SLAB overrides)
+size_t default_slab(size_t nb, size_t nranks) {
+  if (const char *e = getenv("LGP_DIST_SLAB")) {
+    const size_t v = (size_t)strtoull(e, nullptr, 10);
+    return v == 0 ? 0 : ((v + nb - 1) / nb) * nb;
   }
-  ~Events() {
-    for (int s = 0; s < 2; ++s) {
-      if (ready[s]) (void)hipEventDestroy(ready[s]);
-      if (recv[s]) (void)hipEventDestroy(recv[s]);
-      if (freed[s]) (void)hipEventDestroy(freed[s]);
+  return nranks <= 1 ? 0 : 8 * nb;
+}
+
+// the pieces of panel b in row order
+void panel_pieces(size_t n, size_t nb, size_t nx, size_t slab, size_t b, std::vector<Piece> &out) {
+  out.clear();
+  const size_t top = b * nb, sq_end = std::min(top + nb, n), end = n + nx;
+  out.push_back({b, 0, top, sq_end});
+  size_t r = sq_end;
+  while (r < end) {
+    size_t r1 = end;
+    if (slab > 0) {
+      const size_t cut = (r / slab + 1) * slab;          // next absolute multiple of the slab height
+      if (cut < n) r1 = cut;                             // (the last slab takes the ragged end and the carried rows)
     }
+    out.push_back({b, out.size(), r, r1});
+    r = r1;
+  }
+}
+
+void build_plan(size_t n, size_t nb, size_t nx, size_t slab, std::vector<Piece> &plan, size_t &maxpieces) {
+  const size_t nblocks = (n + nb - 1) / nb;
+  plan.clear();
+  maxpieces = 0;
+  std::vector<Piece> tmp;
+  for (size_t b = 0; b < nblocks; ++b) {
+    panel_pieces(n, nb, nx, slab, b, tmp);
+    maxpieces = std::max(maxpieces, tmp.size());
+    plan.insert(plan.end(), tmp.begin(), tmp.end());
+  }
+  std::stable_sort(plan.begin(), plan.end(), [](const Piece &x, const Piece &y) {
+    const size_t kx = 2 * x.b + x.i, ky = 2 * y.b + y.i;
+    return kx != ky ? kx < ky : x.b < y.b;
+  });
+}
+
+size_t plan_slots(size_t maxpieces) { return maxpieces / 2 + 2; }
+
+struct EventPool {
+  std::vector<hipEvent_t> ev;
+  hipEvent_t get() {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    ev.push_back(e);
+    return e;
+  }
+  ~EventPool() {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
   }
 };
 
-// the context's entry points enqueue on ctx->stream; the broadcasts go on the auxiliary stream by swapping the two for the
-// duration of the call (RAII: always swapped back)
-struct OnCommStream {
+// the context's collectives enqueue on ctx->stream: they go on the communication stream by swapping it in for the call
+struct OnStream {
   lgp_ctx *c;
-  explicit OnCommStream(lgp_ctx *ctx) : c(ctx) { std::swap(c->stream, c->stream2); }
-  ~OnCommStream() { std::swap(c->stream, c->stream2); }
+  hipStream_t saved;
+  OnStream(lgp_ctx *ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { c->stream = s; }
+  ~OnStream() { c->stream = saved; }
 };
 
 }  // namespace
 
+// The plan of the sharded factorisation, for callers that allocate its panel slots and for the CPU restatement of the
+// schedule (tests/test_dist_gloo.py executes this very list over numpy + gloo).  Host only.
+extern "C" long lgp_chol_dist_plan(size_t n, size_t nb, size_t nx, size_t nranks, size_t slab, unsigned long long *pieces, size_t capacity,
+                                   size_t *nslots, size_t *slab_out) {
+  if (n == 0 || nb == 0 || nranks == 0) {
+    lgp_set_error("invalid argument: empty problem");
+    return LGP_EINVAL;
+  }
+  if (slab == (size_t)-1) slab = default_slab(nb, nranks);
+  else if (slab > 0) slab = ((slab + nb - 1) / nb) * nb;
+  std::vector<Piece> plan;
+  size_t maxp = 0;
+  build_plan(n, nb, nx, slab, plan, maxp);
+  if (pieces != nullptr)
+    for (size_t t = 0; t < plan.size() && t < capacity; ++t) {
+      pieces[4 * t] = plan[t].b; pieces[4 * t + 1] = plan[t].i; pieces[4 * t + 2] = plan[t].r0; pieces[4 * t + 3] = plan[t].r1;
+    }
+  if (nslots) *nslots = plan_slots(maxp);
+  if (slab_out) *slab_out = slab;
+  return (long)plan.size();
+}
+
 extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_t nx, double *dLloc, size_t ldl, double *ddblk,
-                                        double *dpanels, size_t ldp, const double *dsrow, int *hinfo) {
+                                        double *dpanels, size_t ldp, size_t nslots, const double *dsrow, int *hinfo) {
   LGP_REQUIRE(ctx != nullptr && dLloc != nullptr && ddblk != nullptr && dpanels != nullptr, "null pointer");
   LGP_REQUIRE(n >= 1 && nb >= 1 && nb <= n + nb, "bad sizes");
   LGP_REQUIRE(ldp >= nb, "ldp < nb");
@@ -53,100 +141,186 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   const size_t nlocal = (nblocks + G - 1 - me) / G;                   // blocks b with b % G == me
   LGP_REQUIRE(nlocal == 0 || ldl >= nlocal * nb, "ldl smaller than the local block columns");
   DeviceGuard dg(ctx->device);
-  hipStream_t sc = ctx->stream, sm = ctx->stream2;                    // compute, communication
-  Events ev;
-  LGP_CHECK(ev.create());
+  const size_t slab = default_slab(nb, G);
+  std::vector<Piece> plan;
+  size_t maxp = 0;
+  build_plan(n, nb, nx, slab, plan, maxp);
+  LGP_REQUIRE(nslots >= plan_slots(maxp), "too few panel slots: ask lgp_chol_dist_plan");
+  LGP_REQUIRE(ctx->stream2 != nullptr && ctx->stream3 != nullptr, "context without auxiliary streams");
+  if (ctx->stream_comm == nullptr) LGP_HIP(hipStreamCreateWithPriority(&ctx->stream_comm, hipStreamNonBlocking, ctx->prio_hi));
+  hipStream_t sc = ctx->stream, s1 = ctx->stream2, s3 = ctx->stream3, sx = ctx->stream_comm;
   const size_t rows_all = n + nx;
-  double *P[2] = {dpanels, dpanels + rows_all * ldp};
   const size_t dblk_per_block = lgp_chol_dblk_size(nb);
-  LGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sc));
   ctx->potf2_small = n <= 8192;
 
   auto owner = [&](size_t b) { return b % G; };
   auto width = [&](size_t b) { return (n - b * nb) < nb ? (n - b * nb) : nb; };
-  auto rowsof = [&](size_t b) { return n - b * nb + nx; };            // panel rows: from the diagonal of block b down, plus carried rows
   auto block = [&](size_t b) { return dLloc + (b * nb) * ldl + (b / G) * nb; };   // local block column b from its diagonal down
+  auto dblk = [&](size_t b) { return ddblk + (b / G) * dblk_per_block; };
+  auto slot_of = [&](size_t b) { return dpanels + (b % nslots) * rows_all * ldp; };
+  auto panel_rows = [&](size_t b, size_t r) { return slot_of(b) + (r - b * nb) * ldp; };      // row r (absolute) of panel b in its slot
 
-  // the latency-bound panel factorisation and the packing run on the auxiliary (high priority) stream, in front of the
-  // broadcast of the same panel: the owner's trailing update of the other block columns proceeds beside them on the
-  // compute stream, as the look-ahead of the single-GPU driver does
-  auto panel_factor = [&](size_t b, hipStream_t st) -> int {
-    LGP_CHECK(lgp_panel_factor_impl<double>(ctx, st, rowsof(b), width(b), block(b), ldl, ddblk + (b / G) * dblk_per_block, b * nb));
-    return lgp_extract_dblk_public(ctx, st, block(b), ldl, width(b), ddblk + (b / G) * dblk_per_block);
+  // piece tables: events per piece, the pieces of every panel in row order
+  std::vector<std::vector<Piece>> pieces(nblocks);
+  for (size_t b = 0; b < nblocks; ++b) panel_pieces(n, nb, nx, slab, b, pieces[b]);
+  auto cover = [&](size_t b, size_t r) -> size_t {      // the piece of panel b that holds row r
+    const auto &v = pieces[b];
+    for (size_t i = 0; i < v.size(); ++i)
+      if (r >= v[i].r0 && r < v[i].r1) return i;
+    return v.size() - 1;
   };
-  auto pack = [&](size_t b, int slot, hipStream_t st) -> int {
-    LGP_HIP(hipMemcpy2DAsync(P[slot], ldp * sizeof(double), block(b), ldl * sizeof(double), width(b) * sizeof(double), rowsof(b),
-                             hipMemcpyDeviceToDevice, st));
+  EventPool pool;
+  std::vector<std::vector<hipEvent_t>> ev_recv(nblocks), ev_ready(nblocks), ev_bulk(nblocks);
+  std::vector<hipEvent_t> ev_sq(nblocks, nullptr), ev_free_sc(nslots, nullptr), ev_free_l1(nslots, nullptr), ev_free_l3(nslots, nullptr);
+  bool ok = true;
+  auto make = [&](hipEvent_t &e) { e = pool.get(); ok = ok && e != nullptr; };
+  for (size_t b = 0; b < nblocks; ++b) {
+    const size_t np = pieces[b].size();
+    ev_recv[b].resize(np); ev_bulk[b].resize(np);
+    for (size_t i = 0; i < np; ++i) { make(ev_recv[b][i]); make(ev_bulk[b][i]); }
+    if (owner(b) == me) {
+      ev_ready[b].resize(np);
+      for (size_t i = 0; i < np; ++i) make(ev_ready[b][i]);
+      make(ev_sq[b]);
+    }
+  }
+  for (size_t s = 0; s < nslots; ++s) { make(ev_free_sc[s]); make(ev_free_l1[s]); make(ev_free_l3[s]); }
+  hipEvent_t ev_start = nullptr, ev_end1 = nullptr, ev_end3 = nullptr, ev_endx = nullptr;
+  make(ev_start); make(ev_end1); make(ev_end3); make(ev_endx);
+  if (!ok) {
+    lgp_set_error("hipEventCreate failed");
+    return LGP_EHIP;
+  }
+
+  LGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sc));
+  LGP_HIP(hipEventRecord(ev_start, sc));                                 // (everything the caller enqueued on the compute stream)
+  LGP_HIP(hipStreamWaitEvent(s1, ev_start, 0));
+  LGP_HIP(hipStreamWaitEvent(s3, ev_start, 0));
+  LGP_HIP(hipStreamWaitEvent(sx, ev_start, 0));
+
+  // a slot is written by the owner's pack (s1 / s3) or by the arriving broadcast (comm stream): both behind its last readers
+  auto wait_slot_free = [&](size_t b, hipStream_t st) -> int {
+    if (b < nslots) return LGP_OK;
+    const size_t s = b % nslots;
+    LGP_HIP(hipStreamWaitEvent(st, ev_free_sc[s], 0));
+    LGP_HIP(hipStreamWaitEvent(st, ev_free_l1[s], 0));
+    LGP_HIP(hipStreamWaitEvent(st, ev_free_l3[s], 0));
     return LGP_OK;
   };
-  auto bcast = [&](size_t b, int slot) -> int {
-    OnCommStream on(ctx);
-    return lgp_bcast(ctx, P[slot], rowsof(b) * ldp * sizeof(double), (int)owner(b));
-  };
-  // block column c -= P_b[rows of c] P_b[block rows of c]'
-  auto update_one = [&](size_t c, size_t b, int slot) -> int {
-    const double *A = P[slot] + (c - b) * nb * ldp;
-    return lgp_gemm_launch<double>(ctx, sc, false, true, rowsof(c), width(c), width(b), -1.0, A, ldp, A, ldp, 1.0, block(c), ldl, true, 2);
-  };
-  // every remaining owned block column (consecutive local blocks from c0 on) in one staircase launch
-  auto update_rest = [&](size_t c0, size_t b, int slot) -> int {
-    size_t ncols = 0;
-    for (size_t c = c0; c < nblocks; c += G) ncols += width(c);
-    if (nb % 128 != 0) {
-      for (size_t c = c0; c < nblocks; c += G) LGP_CHECK(update_one(c, b, slot));
-      return LGP_OK;
+
+  // ---- owner(b): update its piece of block column b with panel b - 1, factor / solve it, pack it
+  auto lane = [&](const Piece &p) -> int {
+    const size_t b = p.b, kb = width(b);
+    hipStream_t st = p.i == 0 ? s1 : s3;
+    double *C = block(b) + (p.r0 - b * nb) * ldl;
+    if (b >= 1) {
+      LGP_HIP(hipStreamWaitEvent(st, ev_recv[b - 1][cover(b - 1, p.r0)], 0));
+      LGP_HIP(hipStreamWaitEvent(st, ev_recv[b - 1][cover(b - 1, b * nb)], 0));           // the rows of block b: the B operand
+      if (b >= 2) LGP_HIP(hipStreamWaitEvent(st, ev_bulk[b - 2][cover(b - 2, p.r0)], 0));   // column b has every earlier update there
+      const double *A = panel_rows(b - 1, p.r0), *B = panel_rows(b - 1, b * nb);
+      const size_t K = width(b - 1);
+      if (p.i == 0) LGP_CHECK(lgp_gemm_launch<double>(ctx, st, false, true, kb, kb, K, -1.0, A, ldp, B, ldp, 1.0, C, ldl, true));
+      else LGP_CHECK(lgp_gemm_launch<double>(ctx, st, false, true, p.r1 - p.r0, kb, K, -1.0, A, ldp, B, ldp, 1.0, C, ldl, false, 2));
     }
-    const double *A = P[slot] + (c0 - b) * nb * ldp;
-    return lgp_gemm_launch<double>(ctx, sc, false, true, rowsof(c0), ncols, width(b), -1.0, A, ldp, A, ldp, 1.0, block(c0), ldl, true, 3, (int)nb,
-                                   (int)(G - 1));
+    if (p.i == 0) {
+      LGP_CHECK(lgp_square_factor_f64(ctx, st, kb, block(b), ldl, dblk(b), b * nb));
+      LGP_HIP(hipEventRecord(ev_sq[b], st));
+    } else {
+      LGP_HIP(hipStreamWaitEvent(st, ev_sq[b], 0));
+      LGP_CHECK(lgp_far_rows_impl<double>(ctx, st, p.r1 - p.r0, kb, C, ldl, block(b), dblk(b)));
+    }
+    // the look-ahead streams are through with panel b - 1 once the square (s1) and the last piece below it (s3) have used it
+    if (b >= 1 && p.i == 0) LGP_HIP(hipEventRecord(ev_free_l1[(b - 1) % nslots], st));
+    if (b >= 1 && p.i >= 1 && p.i + 1 == pieces[b].size()) LGP_HIP(hipEventRecord(ev_free_l3[(b - 1) % nslots], st));
+    // the square itself stays at home: the trailing updates only read rows BELOW a panel's diagonal block
+    if (p.i == 0) return LGP_OK;
+    LGP_CHECK(wait_slot_free(b, st));
+    LGP_HIP(hipMemcpy2DAsync(panel_rows(b, p.r0), ldp * sizeof(double), C, ldl * sizeof(double), kb * sizeof(double), p.r1 - p.r0,
+                             hipMemcpyDeviceToDevice, st));
+    LGP_HIP(hipEventRecord(ev_ready[b][p.i], st));
+    return LGP_OK;
+  };
+  // ---- every rank: the piece travels
+  auto comm = [&](const Piece &p) -> int {
+    if (owner(p.b) == me) LGP_HIP(hipStreamWaitEvent(sx, ev_ready[p.b][p.i], 0));
+    else LGP_CHECK(wait_slot_free(p.b, sx));
+    {
+      OnStream on(ctx, sx);
+      LGP_CHECK(lgp_bcast(ctx, panel_rows(p.b, p.r0), (p.r1 - p.r0) * ldp * sizeof(double), (int)owner(p.b)));
+    }
+    LGP_HIP(hipEventRecord(ev_recv[p.b][p.i], sx));
+    return LGP_OK;
+  };
+  // ---- every rank: its block columns c >= b + 2, rows of the piece, in one staircase launch
+  auto bulk = [&](const Piece &p) -> int {
+    const size_t b = p.b;
+    LGP_HIP(hipStreamWaitEvent(sc, ev_recv[b][p.i], 0));
+    size_t c0 = b + 2;
+    while (c0 < nblocks && owner(c0) != me) ++c0;
+    if (c0 < nblocks) {
+      const size_t rs = std::max(p.r0, c0 * nb);
+      if (rs < p.r1) {
+        LGP_HIP(hipStreamWaitEvent(sc, ev_recv[b][cover(b, c0 * nb)], 0));                  // (arrived earlier: same stream order; explicit)
+        size_t ncols = 0;
+        for (size_t c = c0; c < nblocks; c += G) ncols += width(c);
+        const double *A = panel_rows(b, rs), *B = panel_rows(b, c0 * nb);
+        double *C = block(c0) + (rs - c0 * nb) * ldl;
+        if (nb % 128 == 0) {
+          LGP_CHECK(lgp_gemm_launch<double>(ctx, sc, false, true, p.r1 - rs, ncols, width(b), -1.0, A, ldp, B, ldp, 1.0, C, ldl, true, 3, (int)nb,
+                                            (int)(G - 1), (int)(rs - c0 * nb)));
+        } else {
+          // block widths that are not whole tiles: one launch per block column
+          for (size_t c = c0; c < nblocks; c += G) {
+            const size_t rc = std::max(p.r0, c * nb);
+            if (rc >= p.r1) continue;
+            LGP_CHECK(lgp_gemm_launch<double>(ctx, sc, false, true, p.r1 - rc, width(c), width(b), -1.0, panel_rows(b, rc), ldp, panel_rows(b, c * nb), ldp,
+                                              1.0, block(c) + (rc - c * nb) * ldl, ldl, true, 2, 0, 0, (int)(rc - c * nb)));
+          }
+        }
+      }
+    }
+    LGP_HIP(hipEventRecord(ev_bulk[b][p.i], sc));
+    if (p.i + 1 == pieces[b].size()) LGP_HIP(hipEventRecord(ev_free_sc[b % nslots], sc));
+    return LGP_OK;
   };
 
-  LGP_HIP(hipEventRecord(ev.ready[0], sc));                              // (everything the caller enqueued on the compute stream)
-  LGP_HIP(hipStreamWaitEvent(sm, ev.ready[0], 0));
-  if (owner(0) == me) {
-    LGP_CHECK(panel_factor(0, sm));
-    LGP_CHECK(pack(0, 0, sm));
+  // A failure in the middle must not leave the peers inside a collective: the broadcasts of the rest of the plan are still
+  // issued (their contents no longer matter), every stream is drained, then the error is reported.
+  int failed = LGP_OK;
+  for (const Piece &p : plan) {
+    if (failed == LGP_OK && owner(p.b) == me) failed = lane(p);
+    if (p.i == 0) continue;                                // (squares are not sent, see `lane`)
+    int st = comm(p);
+    if (failed == LGP_OK) failed = st;
+    if (failed == LGP_OK) failed = bulk(p);
   }
-  LGP_CHECK(bcast(0, 0));
-  LGP_HIP(hipEventRecord(ev.recv[0], sm));
-  for (size_t b = 0; b < nblocks; ++b) {
-    const int slot = (int)(b % 2), nslot = (int)((b + 1) % 2);
-    LGP_HIP(hipStreamWaitEvent(sc, ev.recv[slot], 0));
-    const size_t nxt = b + 1;
-    const bool mine = nxt < nblocks && owner(nxt) == me;
-    // compute stream: the look-ahead block column first, then every other owned block column in one staircase launch
-    if (mine) {
-      LGP_CHECK(update_one(nxt, b, slot));
-      LGP_HIP(hipEventRecord(ev.ready[nslot], sc));
-    }
-    size_t c0 = b + 1;
-    while (c0 < nblocks && (owner(c0) != me || c0 == nxt)) ++c0;
-    if (c0 < nblocks) LGP_CHECK(update_rest(c0, b, slot));
-    LGP_HIP(hipEventRecord(ev.freed[slot], sc));
-    // auxiliary stream: factor + pack (owner) and broadcast panel b + 1.  (Enqueued after the trailing update so that a
-    // transport that blocks the host -- the host-staged one of the tests -- does not hold the update back.)
-    if (nxt < nblocks) {
-      if (b >= 1) LGP_HIP(hipStreamWaitEvent(sm, ev.freed[nslot], 0));      // the slot's previous panel is no longer read
-      if (mine) {
-        LGP_HIP(hipStreamWaitEvent(sm, ev.ready[nslot], 0));
-        LGP_CHECK(panel_factor(nxt, sm));
-        LGP_CHECK(pack(nxt, nslot, sm));
-      }
-      LGP_CHECK(bcast(nxt, nslot));
-      LGP_HIP(hipEventRecord(ev.recv[nslot], sm));
+  if (failed == LGP_OK) {
+    hipError_t e = hipEventRecord(ev_end1, s1);
+    if (e == hipSuccess) e = hipEventRecord(ev_end3, s3);
+    if (e == hipSuccess) e = hipEventRecord(ev_endx, sx);
+    if (e == hipSuccess) e = hipStreamWaitEvent(sc, ev_end1, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(sc, ev_end3, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(sc, ev_endx, 0);
+    if (e != hipSuccess) {
+      lgp_set_error("joining the streams of the sharded factorisation: %s", hipGetErrorString(e));
+      failed = LGP_EHIP;
     }
   }
-  if (dsrow != nullptr && nlocal > 0) {
+  if (failed == LGP_OK && dsrow != nullptr && nlocal > 0) {
     // L = L~ * s[:, None] (_decomp.py:392) on the matrix rows of every owned block column, then the packed diagonal blocks
     // again from the scaled factor
-    LGP_CHECK(lgp_scale_rows_cols_f64(ctx, n, nlocal * nb, dLloc, ldl, dsrow, nullptr, 0));
-    for (size_t b = me; b < nblocks; b += G)
-      LGP_CHECK(lgp_extract_dblk_public(ctx, sc, block(b), ldl, width(b), ddblk + (b / G) * dblk_per_block));
+    failed = lgp_scale_rows_cols_f64(ctx, n, nlocal * nb, dLloc, ldl, dsrow, nullptr, 0);
+    for (size_t b = me; b < nblocks && failed == LGP_OK; b += G)
+      failed = lgp_extract_dblk_public(ctx, sc, block(b), ldl, width(b), dblk(b));
   }
   int info = 0;
-  LGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sc));
-  LGP_HIP(hipStreamSynchronize(sm));
-  LGP_HIP(hipStreamSynchronize(sc));
+  if (failed == LGP_OK && hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sc) != hipSuccess) failed = LGP_EHIP;
+  // drain everything before the events go away, on every path
+  (void)hipStreamSynchronize(s1);
+  (void)hipStreamSynchronize(s3);
+  (void)hipStreamSynchronize(sx);
+  (void)hipStreamSynchronize(sc);
+  if (failed != LGP_OK) return failed;
   if (hinfo) *hinfo = info;
   return lgp_info_result(ctx, info) < 0 ? LGP_EHIP : LGP_OK;
 }

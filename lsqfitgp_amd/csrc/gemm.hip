@@ -67,6 +67,10 @@ struct GemmArgs {
   // block (q0 + q) * G + rank, i.e. global column = local column + cyc_nb * cyc_g1 * (local column / cyc_nb), cyc_g1 = G - 1;
   // the B operand rows and the lower mask follow the global column (0, 0: plain lower)
   int cyc_nb, cyc_g1;
+  // row offset of the lower mask (lower != 0): row i of this launch is row i + roff of the trapezoid, i.e. the launch produces
+  // a horizontal slab of a larger lower update (the sharded factorisation updates its block columns slab by slab as the
+  // pieces of a panel arrive, csrc/dist.hip); the operand pointers are the slab's own
+  int roff;
   int tm, tn;          // tile counts
   int nsm, nsn;        // super-tile counts (0: direct mapping)
   int nbulk;           // super-tiles mapped XCD-wise (a multiple of 8); the rest is dealt out slot by slot
@@ -265,10 +269,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
 
   int ti, tj;
   LGP_STAMP(0);
-  if (!map_tile(g.tm, g.tn, g.nsm, g.nsn, g.nbulk, g.lower, ti, tj)) return;
+  if (!map_tile(g.tm, g.tn, g.nsm, g.nsn, g.nbulk, g.lower && g.roff == 0, ti, tj)) return;
   const int row0 = ti * BM, col0 = tj * BN;
   const int cshift = g.cyc_nb ? g.cyc_nb * g.cyc_g1 * (col0 / g.cyc_nb) : 0;   // global column - local column of this tile
-  if (g.lower && row0 + BM - 1 < col0 + cshift) return;                        // entirely above the (global) diagonal
+  const int mshift = cshift - g.roff;                                          // ... as the lower mask sees it (row offset folded in)
+  if (g.lower && row0 + BM - 1 < col0 + mshift) return;                        // entirely above the (global) diagonal
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * WTM, wn = (wave & 1) * WTN;
@@ -278,7 +283,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   // loaded straight into the accumulators while the first operand tiles are in flight, so the epilogue is stores
   // only.  (A read-modify-write epilogue on the same pointer serialises into 64 dependent global round trips per
   // lane.)  alpha = -1 costs nothing in the loop: the accumulators start at -C and the epilogue stores -acc.
-  const bool interior = (row0 + BM <= g.m) && (col0 + BN <= g.n) && !(g.lower && row0 < col0 + cshift + BN - 1);
+  const bool interior = (row0 + BM <= g.m) && (col0 + BN <= g.n) && !(g.lower && row0 < col0 + mshift + BN - 1);
   const bool accinit = g.nsplit <= 1 && g.beta == T(1) && (g.alpha == T(1) || g.alpha == T(-1));
   const bool negC = accinit && g.alpha == T(-1);
 
@@ -341,7 +346,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
 #pragma unroll
           for (int j = 0; j < NFN; ++j) {
             const int col = col0 + wn + j * 16 + fr;
-            const bool ok = row < g.m && col < g.n && !(g.lower && col + cshift > row);
+            const bool ok = row < g.m && col < g.n && !(g.lower && col + mshift > row);
             const T v = g.C[ok ? row * g.ldc + col : 0];   // clamped address instead of a branch around the load
             acc[i][j][r] = ok ? v : T(0);
           }
@@ -451,7 +456,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
 #pragma unroll
         for (int j = 0; j < NFN; ++j) {
           const int col = col0 + wn + j * 16 + fr;
-          const bool ok = interior || (row < g.m && col < g.n && !(g.lower && col + cshift > row));
+          const bool ok = interior || (row < g.m && col < g.n && !(g.lower && col + mshift > row));
           cv[r][j] = Cbase[ok ? row * ldc + col : 0];   // clamped address instead of a branch around the load
         }
       }
@@ -462,7 +467,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
 #pragma unroll
       for (int j = 0; j < NFN; ++j) {
         const int col = col0 + wn + j * 16 + fr;
-        if (interior || (row < g.m && col < g.n && !(g.lower && col + cshift > row))) {
+        if (interior || (row < g.m && col < g.n && !(g.lower && col + mshift > row))) {
           T v = alpha * acc[i][j][r];
           if (beta != T(0)) v += beta * cv[r][j];
           Cbase[row * ldc + col] = v;
@@ -489,7 +494,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const T *part, int n
 
 template <typename T, int TS, int NTHREADS>
 static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha, const T *A, size_t lda,
-                          const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag, int cyc_nb, int cyc_g1) {
+                          const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag, int cyc_nb, int cyc_g1, int roff) {
   constexpr size_t VEC = 16 / sizeof(T);
   GemmArgs<T> g;
   g.A = A; g.B = B; g.C = C;
@@ -499,6 +504,7 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
   g.lower = lower ? 1 : 0;
   g.cyc_nb = cyc_nb;
   g.cyc_g1 = cyc_g1;
+  g.roff = roff;
   g.tm = (int)((m + TS - 1) / TS);
   g.tn = (int)((n + TS - 1) / TS);
   g.alignedA = ((reinterpret_cast<uintptr_t>(A) % 16) == 0 && (lda % VEC) == 0) ? 1 : 0;
@@ -514,7 +520,7 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
     g.nsm = (g.tm + 7) / 8;
     g.nsn = (g.tn + 7) / 8;
     size_t nsuper;
-    if (!lower) {
+    if (!lower || roff != 0) {
       nsuper = (size_t)g.nsm * g.nsn;
     } else {
       const int jmax = g.nsn < g.nsm ? g.nsn : g.nsm;
@@ -566,8 +572,9 @@ size_t lgp_gemm_t64_trailing_max() {
 
 template <typename T>
 int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m, size_t n, size_t k, T alpha,
-                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag, int cyc_nb, int cyc_g1) {
+                    const T *A, size_t lda, const T *B, size_t ldb, T beta, T *C, size_t ldc, bool lower, int tag, int cyc_nb, int cyc_g1, int roff) {
   if (m == 0 || n == 0) return LGP_OK;
+  LGP_REQUIRE(roff == 0 || (lower && roff > 0), "row offset: lower updates only");
   LGP_REQUIRE(cyc_nb == 0 || (lower && cyc_nb % 128 == 0 && cyc_g1 >= 0 && !ta && tb), "cyclic mode: lower NT update, block width a multiple of 128");
   LGP_REQUIRE(m < (1u << 30) && n < (1u << 30) && k < (1u << 30), "gemm dimension too large");
   LGP_REQUIRE(C != nullptr && (k == 0 || (A != nullptr && B != nullptr)), "null matrix pointer");
@@ -587,15 +594,15 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   // ... and for outputs of at most four 128-tiles whatever K (X^T X of the posterior: 101 x 101 over N rows): with split-K below
   // they become ~100 short workgroups instead of 8 long ones (N = 4096: 90 -> 15 us per product)
   if (!aliased && ((t128 <= t64big && k <= 2048) || (t128 <= 512 && k <= 256) || t128 <= 4))
-    return gemm_launch_ts<T, 64, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, 0, cyc_nb, cyc_g1);
+    return gemm_launch_ts<T, 64, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, 0, cyc_nb, cyc_g1, roff);
   // (a 512-thread variant, 4 x 2 waves of 32 x 64 at 4 waves per SIMD, was measured equal: 61.3 vs 61.7 TFLOP/s)
-  return gemm_launch_ts<T, 128, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, tag & 1, cyc_nb, cyc_g1);
+  return gemm_launch_ts<T, 128, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, tag & 1, cyc_nb, cyc_g1, roff);
 }
 
 template int lgp_gemm_launch<double>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, double, const double *, size_t,
-                                     const double *, size_t, double, double *, size_t, bool, int, int, int);
+                                     const double *, size_t, double, double *, size_t, bool, int, int, int, int);
 template int lgp_gemm_launch<float>(lgp_ctx *, hipStream_t, bool, bool, size_t, size_t, size_t, float, const float *, size_t,
-                                    const float *, size_t, float, float *, size_t, bool, int, int, int);
+                                    const float *, size_t, float, float *, size_t, bool, int, int, int, int);
 
 extern "C" int lgp_gemm_f64(lgp_ctx *ctx, int ta, int tb, size_t m, size_t n, size_t k, double alpha, const double *dA,
                             size_t lda, const double *dB, size_t ldb, double beta, double *dC, size_t ldc) {
@@ -618,6 +625,15 @@ extern "C" int lgp_update_nt_cyclic_f64(lgp_ctx *ctx, size_t rows, size_t cols, 
   DeviceGuard dg(ctx->device);
   return lgp_gemm_launch<double>(ctx, ctx->stream, false, true, rows, cols, k, -1.0, dP, ldp, dP, ldp, 1.0, dC, ldc, true, 0, (int)nb,
                                  (int)(nranks - 1));
+}
+
+extern "C" int lgp_update_nt_slab_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dA, size_t lda, const double *dB, size_t ldb,
+                                      double *dC, size_t ldc, size_t nb, size_t nranks, size_t roff) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  LGP_REQUIRE(nb >= 128 && nb % 128 == 0 && nranks >= 1 && nb < (1u << 24) && nranks < 4096 && roff < (1u << 30), "bad block layout");
+  DeviceGuard dg(ctx->device);
+  return lgp_gemm_launch<double>(ctx, ctx->stream, false, true, rows, cols, k, -1.0, dA, lda, dB, ldb, 1.0, dC, ldc, true, 0, (int)nb,
+                                 (int)(nranks - 1), (int)roff);
 }
 
 extern "C" int lgp_update_nt_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dA, size_t lda,

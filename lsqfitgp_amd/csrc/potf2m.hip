@@ -436,6 +436,7 @@ struct ChainArgs {
   unsigned *state;        // LGP_CH_* layout (common.h), zeroed by the driver
   unsigned long long *trace;   // optional (LGP_CHAIN_TRACE): per task  worker, taken, inputs ready, done  (wall_clock64)
   unsigned long long timeout;  // wall_clock64 ticks a worker waits for one input before it abandons the launch
+  long row0;                   // global index of the matrix's first row (pivot indices of the info word)
 };
 
 __device__ __forceinline__ unsigned ch_peek(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -601,7 +602,7 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
     const int kb = (p.n - LGP_NB * k) < LGP_NB ? (p.n - LGP_NB * k) : LGP_NB;
     if (type == CH_TYPE_P) {
       double *const A = P + (128L * j) * p.ldl + 128 * j, *const dblk = pdblk + (size_t)j * LGP_DBLK;
-      const long lda = p.ldl, row0 = (long)LGP_NB * k + 128 * j;
+      const long lda = p.ldl, row0 = p.row0 + (long)LGP_NB * k + 128 * j;
       constexpr int nb = 128;
       int *const info = p.info;
       // the block is published as soon as its fragment image is out: the substitutions read nothing else
@@ -795,7 +796,7 @@ int lgp_chain_state(lgp_ctx *ctx, size_t n, unsigned **out) {
   return LGP_OK;
 }
 
-int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk) {
+int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk, size_t row0) {
   LGP_REQUIRE(lgp_chain_usable(ctx, n, ldl), "matrix not covered by the chain kernel");
   LGP_REQUIRE(ctx->chain_state != nullptr && ctx->chain_state_bytes >= lgp_chain_state_bytes(n), "chain state not allocated");
   const uint2 *dtasks = nullptr;
@@ -823,6 +824,7 @@ int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size
   a.L = L; a.ldl = (long)ldl; a.n = (int)n; a.dblk = dblk; a.info = ctx->d_info;
   a.tasks = dtasks; a.ntasks = ntasks; a.nchain = nchain; a.state = static_cast<unsigned *>(ctx->chain_state);
   a.trace = nullptr;
+  a.row0 = (long)row0;
   if (getenv("LGP_CHAIN_TRACE") != nullptr) {           // debugging aid: the last launch's task times, written out by lgp_ctx_destroy
     if (ctx->chain_trace != nullptr && ctx->chain_trace_tasks < (size_t)ntasks) {
       LGP_HIP(hipFree(ctx->chain_trace));

@@ -912,6 +912,38 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
   return LGP_OK;
 }
 
+// ---- pieces of a panel for the sharded factorisation (dist.hip), the same kernels as the drivers above -----------------------
+// rows below a panel's (factored) diagonal square, solved against it: left-looking over the square's 128-column blocks, as the
+// far rows of potrf_split.  Pfar: the rows (column 0 of the panel), Psq: the square, Yk: its diagonal-block workspaces.
+template <typename T>
+int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *Pfar, size_t ldl, const T *Psq, const T *Yk) {
+  if (rows == 0) return LGP_OK;
+  for (size_t j0 = 0; j0 < kb; j0 += LGP_DB) {
+    const size_t jb = (kb - j0) < (size_t)LGP_DB ? (kb - j0) : (size_t)LGP_DB;
+    if (j0 > 0) LGP_CHECK(lgp_gemm_launch<T>(ctx, st, false, true, rows, jb, j0, T(-1), Pfar, ldl, Psq + j0 * ldl, ldl, T(1), Pfar + j0, ldl, false, 2));
+    hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((rows + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, st,
+                       Yk + (j0 / LGP_DB) * (size_t)LGP_DBLK, (int)jb, Pfar + j0, (long)ldl, (long)rows);
+    LGP_LAUNCH_CHECK();
+  }
+  return LGP_OK;
+}
+template int lgp_far_rows_impl<double>(lgp_ctx *, hipStream_t, size_t, size_t, double *, size_t, const double *, const double *);
+
+// a panel's diagonal square alone (kb x kb, kb <= LGP_NB): the chain kernel's resident workers when it covers the size (8 blocks
+// in ~0.55 ms instead of 8 x (potf2 + substitution + update) launches), the launch-per-operation routine otherwise; the
+// packed images of the diagonal blocks that the solves read are extracted at the end
+int lgp_square_factor_f64(lgp_ctx *ctx, hipStream_t st, size_t kb, double *P, size_t ldl, double *Yk, size_t row0) {
+  if (kb >= 256 && lgp_chain_usable(ctx, kb, ldl)) {
+    unsigned *state = nullptr;
+    LGP_CHECK(lgp_chain_state(ctx, kb, &state));
+    LGP_HIP(hipMemsetAsync(state, 0, lgp_chain_state_bytes(kb), st));
+    LGP_CHECK(lgp_chain_launch(ctx, st, kb, P, ldl, Yk, row0));
+  } else {
+    LGP_CHECK(lgp_panel_factor_impl<double>(ctx, st, kb, kb, P, ldl, Yk, row0));
+  }
+  return lgp_extract_dblk<double>(ctx, st, P, ldl, kb, Yk);
+}
+
 template <typename T>
 int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx) {
   LGP_REQUIRE(ldl >= n, "ldl < n");

@@ -43,6 +43,32 @@ def test_distributed_chol_single_rank(lgp, n, nb, noise, rng):
     util.assert_allclose(d.logdet(), np.sum(np.log(np.diag(o._L))), rtol=1e-10 if noise else 1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize('n,nb,slab,q', [(1500, 256, 512, 0), (3300, 1024, 1024, 5), (2000, 128, 384, 3), (2048, 256, 256, 0)])
+def test_distributed_chol_single_rank_in_slabs(lgp, n, nb, slab, q, rng, monkeypatch):
+    """ one rank, but with the panels cut into row slabs as for several ranks (LGP_DIST_SLAB): pieces of a panel solved, packed,
+    "broadcast" and consumed one after the other, the bulk updates as row-offset staircase launches; with carried rows """
+    from lsqfitgp_amd._dist import DistributedChol
+    monkeypatch.setenv('LGP_DIST_SLAB', str(slab))
+    x = rng.uniform(0, n / 16, n)
+    xs = rng.uniform(0, n / 16, q) if q else None
+    y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
+    d = DistributedChol(lgp.ExpQuad(), x, noise=0.01, nb=nb, carry=(xs, y) if q else None)
+    assert d.slab == -(-slab // nb) * nb
+    K = oracle.ExpQuad()(x[:, None], x[None, :]) + 0.01 * np.eye(n)
+    o = oracle.Chol(K)
+    util.assert_allclose(d.eps, o.eps, rtol=1e-13)
+    full = np.zeros((n, n))
+    for b, blk in d.local_factor().items():
+        c0 = d.layout.col0(b)
+        full[c0:, c0:c0 + blk.shape[1]] = blk
+    util.assert_close_matrices(full, o._L, rtol=1e-11)
+    if q:
+        mean, cov, mlnd = d.posterior(lgp.ExpQuad(), x, xs, y)
+        mo = o.pinv_bilinear(oracle.ExpQuad()(x[:, None], xs[None, :]), y)
+        assert np.linalg.norm(mean - mo) <= 1e-8 * np.linalg.norm(mo)
+        util.assert_allclose(mlnd, o.minus_log_normal_density(y, value=True)[0], rtol=1e-10)
+
+
 @pytest.mark.parametrize('n,nb', [(1500, 256), (2500, 1024), (1100, 128)])
 def test_distributed_carried_posterior_single_rank(lgp, n, nb, rng):
     """ DistributedChol(carry=(xs, y)): posterior from the carried rows equals the fan-in solve and the oracle """
@@ -119,8 +145,9 @@ def test_distributed_posterior_single_rank(lgp, rng):
     assert abs(-mlnd - lo) <= 1e-8 * abs(lo) + 1e-6
 
 
-@pytest.mark.parametrize('n,nb,world,carry,amp', [(1500, 256, 2, 0, 1), (2600, 1024, 2, 1, 1), (2900, 256, 3, 1, 1), (1700, 256, 2, 1, 37)])
-def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry, amp):
+@pytest.mark.parametrize('n,nb,world,carry,amp,slab', [(1500, 256, 2, 0, 1, 512), (2600, 1024, 2, 1, 1, None), (2900, 256, 3, 1, 1, 768), (1700, 256, 2, 1, 37, 256),
+                                                        (4100, 128, 4, 1, 1, 1024)])
+def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry, amp, slab):
     """ world size 2 and 3 on the device: real kernels, real stream/event choreography of the panel look-ahead, panels
     exchanged through the host-callback transport; factor, posterior and likelihood against the oracle """
     import os
@@ -134,6 +161,8 @@ def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry, amp):
     # separate interpreters (not torch.multiprocessing: torch must not be loaded into this process next to the library)
     script = os.path.join(os.path.dirname(__file__), 'two_rank_worker.py')
     env = dict(os.environ, LGP_TEST_CARRY=str(carry), LGP_TEST_AMP=str(amp))        # carry = 1: [Kxxs | y] rides through the factorisation
+    if slab is not None:
+        env['LGP_DIST_SLAB'] = str(slab)                                            # (default for several ranks: 8 nb)
     procs = [subprocess.Popen([sys.executable, script, str(rank), str(world), str(port), str(n), str(nb), str(m), str(tmp_path)],
                               cwd=os.path.dirname(os.path.dirname(__file__)), env=env) for rank in range(world)]
     for p in procs:
@@ -167,22 +196,24 @@ def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry, amp):
     util.assert_close_matrices(full, o._L, rtol=1e-11)
 
 
-def test_sharded_path_two_ranks_large(lgp, tmp_path):
-    """ the sharded factorisation of configuration C4's workload at N = 16384 (16 block columns of 1024, 2 ranks sharing the
-    GPU, panels through the host-staged transport, [Kxxs | y] carried through the factorisation) against the single-GPU
-    driver on the same inputs: eps, the action of the factor on random vectors (L Z, L^T Z), its diagonal, posterior mean /
-    covariance and the log-density """
+def _sharded_against_single_gpu(lgp, tmp_path, n, world, slab=None):
+    """ the sharded factorisation of configuration C4's workload (block columns of 1024, `world` ranks sharing the GPU, panel
+    pieces through the host-staged transport, [Kxxs | y] carried through the factorisation) against the single-GPU driver on the
+    same inputs: eps, the action of the factor on random vectors (L Z, L^T Z), its diagonal, posterior mean / covariance and the
+    log-density """
     import os
     import socket
     import subprocess
     import sys
     from lsqfitgp_amd import _lib
-    n, nb, world, m = 16384, 1024, 2, 37
+    nb, m = 1024, 37
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     script = os.path.join(os.path.dirname(__file__), 'two_rank_worker.py')
     env = dict(os.environ, LGP_TEST_CARRY='1', LGP_TEST_BIG='1')
+    if slab is not None:
+        env['LGP_DIST_SLAB'] = str(slab)
     procs = [subprocess.Popen([sys.executable, script, str(rank), str(world), str(port), str(n), str(nb), str(m), str(tmp_path)],
                               cwd=os.path.dirname(os.path.dirname(__file__)), env=env) for rank in range(world)]
     # single-GPU reference while the ranks run (the same inputs as tests/two_rank_worker.py)
@@ -196,6 +227,7 @@ def test_sharded_path_two_ranks_large(lgp, tmp_path):
     assert _lib.load().lgp_add_diag_f64(ctx.handle, n, K.ptr, K.ld, None, ctypes.c_double(0.01)) == 0
     Kxs = kern.gram(x, xs).to_host()
     one = lgp.Chol(K, rhs=np.concatenate([Kxs, y[:, None]], axis=1))
+    del K
     S = one.solved()
     mean1 = S[:, :m].T @ S[:, m]
     Kss = np.exp(-0.5 * (xs[:, None] - xs[None, :]) ** 2)
@@ -206,11 +238,12 @@ def test_sharded_path_two_ranks_large(lgp, tmp_path):
     LtZ1 = one.back_correlate(Z)
     diag1 = np.concatenate([np.diag(one.factor().block(r0, r0 + 4096, r0, r0 + 4096).to_host()) for r0 in range(0, n, 4096)])
     for p in procs:
-        assert p.wait(timeout=900) == 0
+        assert p.wait(timeout=1000) == 0
     LZ = np.zeros((n, 2))
     seen = set()
     for rank in range(world):
         r = np.load(tmp_path / f'rank{rank}.npz')
+        assert int(r['slab']) == (8 * nb if slab is None else slab)
         util.assert_allclose(r['eps'], one.eps, rtol=1e-13)
         assert np.linalg.norm(r['mean'] - mean1) <= 1e-10 * np.linalg.norm(mean1)
         assert np.linalg.norm(r['cov'] - cov1, 2) <= 1e-10 * np.linalg.norm(Kss, 2)
@@ -224,6 +257,24 @@ def test_sharded_path_two_ranks_large(lgp, tmp_path):
             util.assert_allclose(r[f'dg{b}'], diag1[b * nb:(b + 1) * nb], rtol=1e-11)
     assert len(seen) == n // nb
     util.assert_close_matrices(LZ, LZ1, rtol=1e-12)
+
+
+def test_sharded_path_two_ranks_large(lgp, tmp_path):
+    """ N = 16384: 16 block columns, 2 ranks, slabs of 4096 rows """
+    _sharded_against_single_gpu(lgp, tmp_path, 16384, 2, slab=4096)
+
+
+def test_sharded_c4_two_ranks_full_size(lgp, tmp_path):
+    """ BASELINE configuration C4 at its own size through the sharded path: N = 65536, 64 block columns of 1024, 2 ranks (2 x 17.2 GB
+    of block columns + 6 panel slots each on the one 288 GB GPU), the default slabs of 8192 rows: 64 panels in 8 + 7 + ... pieces,
+    every panel slot reused ten times, the staircase update at full width with row offsets, the carried rows.  (RCCL itself
+    needs one GPU per rank: what travels here goes through the host-staged transport.) """
+    _sharded_against_single_gpu(lgp, tmp_path, 65536, 2)
+
+
+def test_sharded_three_ranks(lgp, tmp_path):
+    """ three ranks (block columns dealt out 0, 1, 2, 0, ...; the look-ahead column's owner changes every panel), N = 12288 """
+    _sharded_against_single_gpu(lgp, tmp_path, 12288, 3, slab=2048)
 
 
 @pytest.mark.parametrize('nb', [256, 1024])

@@ -158,3 +158,37 @@ def test_update_nt_cyclic(lgp, rng, n, nb, G, rank, q0, k):
         w = widths[q]
         np.testing.assert_array_equal(got[:c0, col:col + w], Cloc[:c0, col:col + w])
         col += w
+
+
+@pytest.mark.parametrize('n,nb,G,rank,q0,k,slab', [(3000, 128, 2, 1, 0, 128, 512), (5200, 256, 3, 0, 1, 256, 1024), (6000, 1024, 2, 0, 0, 1024, 2048),
+                                                   (3000, 128, 4, 3, 2, 130, 384), (5000, 256, 1, 0, 3, 256, 768)])
+def test_update_nt_slab(lgp, rng, n, nb, G, rank, q0, k, slab):
+    """ lgp_update_nt_slab_f64: the staircase update of `test_update_nt_cyclic` produced slab by slab (rows [roff, roff + rows)
+    below the first block column's diagonal per launch, the lower mask shifted by the row offset) -- how the sharded
+    factorisation consumes the pieces of a panel as they arrive (csrc/dist.hip).  The slabs together must give exactly the
+    one-launch result, and each launch must leave every other row untouched. """
+    from lsqfitgp_amd import _lib
+    lib = _lib.load(); ctx = lgp.Context.default()
+    nblocks = -(-n // nb)
+    owned = [b for b in range(nblocks) if b % G == rank]
+    widths = [min(nb, n - b * nb) for b in owned]
+    if q0 >= len(owned):
+        pytest.skip('no block to update')
+    g0 = owned[q0] * nb
+    rows = n - g0
+    ncols = sum(widths[q0:])
+    P = rng.standard_normal((rows, k))
+    Cloc = rng.standard_normal((rows, ncols))
+    Pd, Cd, Cs = lgp.DeviceArray.from_host(P), lgp.DeviceArray.from_host(Cloc), lgp.DeviceArray.from_host(Cloc)
+    _lib.check(lib.lgp_update_nt_cyclic_f64(ctx.handle, rows, ncols, k, Pd.ptr, Pd.ld, Cd.ptr, Cd.ld, nb, G))
+    one = Cd.to_host()
+    prev = Cloc
+    for r0 in range(0, rows, slab):
+        r1 = min(r0 + slab, rows)
+        _lib.check(lib.lgp_update_nt_slab_f64(ctx.handle, r1 - r0, ncols, k, Pd.ptr + r0 * Pd.ld * 8, Pd.ld, Pd.ptr, Pd.ld,
+                                              Cs.ptr + r0 * Cs.ld * 8, Cs.ld, nb, G, r0))
+        now = Cs.to_host()
+        np.testing.assert_array_equal(now[:r0], prev[:r0])
+        np.testing.assert_array_equal(now[r1:], prev[r1:])
+        prev = now
+    np.testing.assert_array_equal(prev, one)
