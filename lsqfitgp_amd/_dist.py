@@ -115,8 +115,10 @@ def factor_tasks(layout, plan=None, nx=0):
     with the same event waits: a list of `Task`.  Streams: ``'s1'`` (squares), ``'s3'`` (rows below them), ``'sx'``
     (broadcasts), ``'sc'`` (bulk updates).  Kinds, for a piece ``(b, i, r0, r1)``:
 
-        'U'      owner(b): rows of the piece of block column b -= P(b-1)[rows] P(b-1)[rows of block b]'  (lower part for i = 0)
-        'SQ'     owner(b), i = 0: the diagonal square factored
+        'U'      owner(b): rows of the piece of block column b -= P(b-1)[rows] P(b-1)[rows of block b]'  (i = 0: the square, on
+                 's1'; i > 0: on 'sc', enqueued with the piece of panel b-1 that holds those rows, in front of its bulk update)
+        'SQ'     owner(b), i = 0: the diagonal square factored (the library records one event per 128-column block of it and
+                 lets the rows below follow block by block; here the square is one operation)
         'SOLVE'  owner(b), i > 0: the rows solved against the square
         'PACK'   owner(b), i > 0: the rows copied into panel slot b % nslots
         'BCAST'  every rank, i > 0: the piece broadcast from owner(b) (a collective: same order on every rank)
@@ -150,32 +152,40 @@ def factor_tasks(layout, plan=None, nx=0):
         if b < nslots:
             return []
         s = b % nslots
-        return [('free_sc', s), ('free_l1', s), ('free_l3', s)]
+        return [('free_sc', s), ('free_l1', s)]
 
     mine = L.owned()
     for p in pieces:
         b, i, r0, r1 = p
         last = i == by_panel[b][-1][1]
         if L.owner(b) == me:
-            st = 's1' if i == 0 else 's3'
-            if b >= 1:
-                w = [('recv', b - 1, cover(b - 1, r0)), ('recv', b - 1, cover(b - 1, b * L.nb))]
-                if b >= 2:
-                    w.append(('bulk', b - 2, cover(b - 2, r0)))
-                t = push(st, 'U', p, w)
             if i == 0:
-                t = push(st, 'SQ', p, [])
+                if b >= 1:          # U1 on the stream of the squares
+                    w = [('recv', b - 1, cover(b - 1, b * L.nb))]
+                    if b >= 2:
+                        w.append(('bulk', b - 2, cover(b - 2, b * L.nb)))
+                    push('s1', 'U', p, w)
+                t = push('s1', 'SQ', p, [])
                 rec['sq', b] = t
                 if b >= 1:
                     rec['free_l1', (b - 1) % nslots] = t
-            else:
-                t = push(st, 'SOLVE', p, [('sq', b)])
-                if b >= 1 and last:
-                    rec['free_l3', (b - 1) % nslots] = t
-                rec['ready', b, i] = push(st, 'PACK', p, slot_events(b))
+            else:                   # (U2 of these rows: on the compute stream, with the piece of panel b - 1 that holds them, below)
+                push('s3', 'SOLVE', p, [('sq', b)] + ([('u2', b - 1, cover(b - 1, r0))] if b >= 1 else []))
+                rec['ready', b, i] = push('s3', 'PACK', p, slot_events(b))
         if i == 0:
             continue
         rec['recv', b, i] = push('sx', 'BCAST', p, [('ready', b, i)] if L.owner(b) == me else slot_events(b))
+        if b + 1 < L.nblocks and L.owner(b + 1) == me:
+            # U2: the rows of this piece below the square of the look-ahead column b + 1 = one piece of panel b + 1
+            r2 = max(r0, min((b + 2) * L.nb, L.n))
+            t = None
+            if r2 < r1:
+                q = next(q for q in by_panel[b + 1] if q[2] == r2)
+                assert q[3] == r1 and q[1] >= 1
+                t = push('sc', 'U', q, [('recv', b, i), ('recv', b, cover(b, (b + 1) * L.nb))])
+            else:
+                t = push('sc', 'NOP', p, [('recv', b, i)])
+            rec['u2', b, i] = t
         cols = [c for c in mine if c >= b + 2 and c * L.nb < r1]
         w = [('recv', b, i)]
         if cols:

@@ -21,13 +21,12 @@
 //     owner(b), piece 0     [s1]  U:  square(b) -= P(b-1)[rows of b] P(b-1)[rows of b]'   needs recv(b-1, 1), bulk(b-2, .)
 //                                 factor the square (chain kernel: resident workers, potf2m.hip); it is NOT sent: the updates
 //                                 of the other block columns only read rows below a panel's diagonal block
-//     owner(b), piece i>0   [s3]  U:  rows of the piece of block column b -= P(b-1)[rows] P(b-1)[rows of b]'
-//                                     needs recv(b-1, piece with those rows), bulk(b-2, .)
-//                                 substitution against square b (left-looking over its 128-column blocks), pack, ready(b, i)
+//     owner(b), piece i>0   [s3]  (behind U2 of those rows, below) substitution against square b (left-looking over its 128-column blocks, each behind the
+//                                 event of that block of the square), pack, ready(b, i)
 //     every rank            [comm] broadcast piece (b, i) from owner(b) into panel slot b % nslots; recv(b, i)
+//     owner(b+1)            [sc]  U2: the look-ahead column b + 1 below its square, rows of the piece -- in FRONT of:
 //     every rank            [sc]  its block columns c >= b + 2, rows of the piece: one staircase MFMA launch (row offset =
 //                                 the piece's first row below the diagonal of the first of them); bulk(b, i)
-// (block column b + 1 is the look-ahead column: its owner updates it on s1 / s3 as the first step of ITS pieces).
 // The panel slots hold (rows x ldp) with a PADDED leading dimension (ldp = nb + 16: with ld = nb = 1024 every operand row of
 // the update starts on one HBM channel, 62 instead of 68.7 TFLOP/s); a slot is reused for panel b + nslots once this rank's
 // updates with panel b are through (free events of sc and of the look-ahead streams).
@@ -35,8 +34,10 @@
 #include <algorithm>
 
 template <typename T>
-int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *Pfar, size_t ldl, const T *Psq, const T *Yk);   // potrf.hip
-int lgp_square_factor_f64(lgp_ctx *ctx, hipStream_t st, size_t kb, double *P, size_t ldl, double *Yk, size_t row0);                // potrf.hip
+int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *Pfar, size_t ldl, const T *Psq, const T *Yk,
+                      const hipEvent_t *blk_events);                                                                               // potrf.hip
+int lgp_square_factor_f64(lgp_ctx *ctx, hipStream_t st, size_t kb, double *P, size_t ldl, double *Yk, size_t row0, bool use_chain,
+                          const hipEvent_t *blk_events);                                                                           // potrf.hip
 
 namespace {
 
@@ -170,21 +171,27 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
     return v.size() - 1;
   };
   EventPool pool;
-  std::vector<std::vector<hipEvent_t>> ev_recv(nblocks), ev_ready(nblocks), ev_bulk(nblocks);
-  std::vector<hipEvent_t> ev_sq(nblocks, nullptr), ev_free_sc(nslots, nullptr), ev_free_l1(nslots, nullptr), ev_free_l3(nslots, nullptr);
+  std::vector<std::vector<hipEvent_t>> ev_recv(nblocks), ev_ready(nblocks), ev_bulk(nblocks), ev_u2(nblocks);
+  std::vector<hipEvent_t> ev_free_sc(nslots, nullptr), ev_free_l1(nslots, nullptr);
+  std::vector<std::vector<hipEvent_t>> ev_blk(nblocks);       // per 128-column block of an owned square: factored, the square's rows solved
   bool ok = true;
   auto make = [&](hipEvent_t &e) { e = pool.get(); ok = ok && e != nullptr; };
   for (size_t b = 0; b < nblocks; ++b) {
     const size_t np = pieces[b].size();
     ev_recv[b].resize(np); ev_bulk[b].resize(np);
     for (size_t i = 0; i < np; ++i) { make(ev_recv[b][i]); make(ev_bulk[b][i]); }
+    if (b + 1 < nblocks && owner(b + 1) == me) {
+      ev_u2[b].resize(np);
+      for (size_t i = 0; i < np; ++i) make(ev_u2[b][i]);
+    }
     if (owner(b) == me) {
       ev_ready[b].resize(np);
       for (size_t i = 0; i < np; ++i) make(ev_ready[b][i]);
-      make(ev_sq[b]);
+      ev_blk[b].resize((width(b) + LGP_DB - 1) / LGP_DB);
+      for (auto &e : ev_blk[b]) make(e);
     }
   }
-  for (size_t s = 0; s < nslots; ++s) { make(ev_free_sc[s]); make(ev_free_l1[s]); make(ev_free_l3[s]); }
+  for (size_t s = 0; s < nslots; ++s) { make(ev_free_sc[s]); make(ev_free_l1[s]); }
   hipEvent_t ev_start = nullptr, ev_end1 = nullptr, ev_end3 = nullptr, ev_endx = nullptr;
   make(ev_start); make(ev_end1); make(ev_end3); make(ev_endx);
   if (!ok) {
@@ -204,7 +211,6 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
     const size_t s = b % nslots;
     LGP_HIP(hipStreamWaitEvent(st, ev_free_sc[s], 0));
     LGP_HIP(hipStreamWaitEvent(st, ev_free_l1[s], 0));
-    LGP_HIP(hipStreamWaitEvent(st, ev_free_l3[s], 0));
     return LGP_OK;
   };
 
@@ -213,25 +219,27 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
     const size_t b = p.b, kb = width(b);
     hipStream_t st = p.i == 0 ? s1 : s3;
     double *C = block(b) + (p.r0 - b * nb) * ldl;
-    if (b >= 1) {
-      LGP_HIP(hipStreamWaitEvent(st, ev_recv[b - 1][cover(b - 1, p.r0)], 0));
-      LGP_HIP(hipStreamWaitEvent(st, ev_recv[b - 1][cover(b - 1, b * nb)], 0));           // the rows of block b: the B operand
-      if (b >= 2) LGP_HIP(hipStreamWaitEvent(st, ev_bulk[b - 2][cover(b - 2, p.r0)], 0));   // column b has every earlier update there
-      const double *A = panel_rows(b - 1, p.r0), *B = panel_rows(b - 1, b * nb);
-      const size_t K = width(b - 1);
-      if (p.i == 0) LGP_CHECK(lgp_gemm_launch<double>(ctx, st, false, true, kb, kb, K, -1.0, A, ldp, B, ldp, 1.0, C, ldl, true));
-      else LGP_CHECK(lgp_gemm_launch<double>(ctx, st, false, true, p.r1 - p.r0, kb, K, -1.0, A, ldp, B, ldp, 1.0, C, ldl, false, 2));
+    if (b >= 1 && p.i == 0) {
+      // U1: the square of block column b gets panel b - 1 here, on the stream that factors it (nothing else stands between the
+      // arrival of those rows and the next square)
+      LGP_HIP(hipStreamWaitEvent(st, ev_recv[b - 1][cover(b - 1, b * nb)], 0));
+      if (b >= 2) LGP_HIP(hipStreamWaitEvent(st, ev_bulk[b - 2][cover(b - 2, b * nb)], 0));   // ... and has every earlier update
+      const double *A = panel_rows(b - 1, b * nb);
+      LGP_CHECK(lgp_gemm_launch<double>(ctx, st, false, true, kb, kb, width(b - 1), -1.0, A, ldp, A, ldp, 1.0, C, ldl, true));
     }
+    // (U2, the rows below the square, was applied on the compute stream in front of the bulk update with the same piece of panel
+    // b - 1, see `bulk`: the two do not share the CUs, as in the single-GPU driver)
+    if (b >= 1 && p.i >= 1) LGP_HIP(hipStreamWaitEvent(st, ev_u2[b - 1][cover(b - 1, p.r0)], 0));
     if (p.i == 0) {
-      LGP_CHECK(lgp_square_factor_f64(ctx, st, kb, block(b), ldl, dblk(b), b * nb));
-      LGP_HIP(hipEventRecord(ev_sq[b], st));
+      // the resident workers of the chain kernel take CUs from the trailing update: worth it once this rank's share of what is
+      // left of the matrix is small enough for the squares to bound the factorisation (the single-GPU rule: N <= 16384)
+      const bool use_chain = (n - b * nb) / G <= ctx->chain_max_n;
+      LGP_CHECK(lgp_square_factor_f64(ctx, st, kb, block(b), ldl, dblk(b), b * nb, use_chain, ev_blk[b].data()));
     } else {
-      LGP_HIP(hipStreamWaitEvent(st, ev_sq[b], 0));
-      LGP_CHECK(lgp_far_rows_impl<double>(ctx, st, p.r1 - p.r0, kb, C, ldl, block(b), dblk(b)));
+      LGP_CHECK(lgp_far_rows_impl<double>(ctx, st, p.r1 - p.r0, kb, C, ldl, block(b), dblk(b), ev_blk[b].data()));
     }
-    // the look-ahead streams are through with panel b - 1 once the square (s1) and the last piece below it (s3) have used it
+    // the look-ahead stream of the squares is through with panel b - 1
     if (b >= 1 && p.i == 0) LGP_HIP(hipEventRecord(ev_free_l1[(b - 1) % nslots], st));
-    if (b >= 1 && p.i >= 1 && p.i + 1 == pieces[b].size()) LGP_HIP(hipEventRecord(ev_free_l3[(b - 1) % nslots], st));
     // the square itself stays at home: the trailing updates only read rows BELOW a panel's diagonal block
     if (p.i == 0) return LGP_OK;
     LGP_CHECK(wait_slot_free(b, st));
@@ -255,6 +263,16 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   auto bulk = [&](const Piece &p) -> int {
     const size_t b = p.b;
     LGP_HIP(hipStreamWaitEvent(sc, ev_recv[b][p.i], 0));
+    if (b + 1 < nblocks && owner(b + 1) == me) {
+      // U2: the look-ahead column b + 1 below its square, rows of this piece, FIRST: its owner solves those rows next (s3)
+      const size_t r2 = std::max(p.r0, std::min((b + 2) * nb, n));
+      if (r2 < p.r1) {
+        LGP_HIP(hipStreamWaitEvent(sc, ev_recv[b][cover(b, (b + 1) * nb)], 0));
+        LGP_CHECK(lgp_gemm_launch<double>(ctx, sc, false, true, p.r1 - r2, width(b + 1), width(b), -1.0, panel_rows(b, r2), ldp, panel_rows(b, (b + 1) * nb), ldp,
+                                          1.0, block(b + 1) + (r2 - (b + 1) * nb) * ldl, ldl, false, 2));
+      }
+      LGP_HIP(hipEventRecord(ev_u2[b][p.i], sc));
+    }
     size_t c0 = b + 2;
     while (c0 < nblocks && owner(c0) != me) ++c0;
     if (c0 < nblocks) {
@@ -265,10 +283,16 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
         for (size_t c = c0; c < nblocks; c += G) ncols += width(c);
         const double *A = panel_rows(b, rs), *B = panel_rows(b, c0 * nb);
         double *C = block(c0) + (rs - c0 * nb) * ldl;
+        // (late panels: the updates leave room on every CU for the latency-bound kernels of the look-ahead streams, as in potrf_split)
+        const size_t left = n - std::min(n, (b + 1) * nb);
+        ctx->gemm_thin_lds = left <= 6144 ? (size_t)70 * 1024 : (left <= 12288 ? (size_t)20 * 1024 : 0);
         if (nb % 128 == 0) {
-          LGP_CHECK(lgp_gemm_launch<double>(ctx, sc, false, true, p.r1 - rs, ncols, width(b), -1.0, A, ldp, B, ldp, 1.0, C, ldl, true, 3, (int)nb,
-                                            (int)(G - 1), (int)(rs - c0 * nb)));
+          const int st = lgp_gemm_launch<double>(ctx, sc, false, true, p.r1 - rs, ncols, width(b), -1.0, A, ldp, B, ldp, 1.0, C, ldl, true, 3, (int)nb,
+                                                 (int)(G - 1), (int)(rs - c0 * nb));
+          ctx->gemm_thin_lds = 0;
+          LGP_CHECK(st);
         } else {
+          ctx->gemm_thin_lds = 0;
           // block widths that are not whole tiles: one launch per block column
           for (size_t c = c0; c < nblocks; c += G) {
             const size_t rc = std::max(p.r0, c * nb);
@@ -306,13 +330,10 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
       failed = LGP_EHIP;
     }
   }
-  if (failed == LGP_OK && dsrow != nullptr && nlocal > 0) {
-    // L = L~ * s[:, None] (_decomp.py:392) on the matrix rows of every owned block column, then the packed diagonal blocks
-    // again from the scaled factor
-    failed = lgp_scale_rows_cols_f64(ctx, n, nlocal * nb, dLloc, ldl, dsrow, nullptr, 0);
-    for (size_t b = me; b < nblocks && failed == LGP_OK; b += G)
-      failed = lgp_extract_dblk_public(ctx, sc, block(b), ldl, width(b), dblk(b));
-  }
+  // L = L~ * s[:, None] (_decomp.py:392) on the matrix rows of every owned block column; then the packed images of the diagonal
+  // blocks that the solves read (D, D', 1 / diag), from the finished factor
+  if (failed == LGP_OK && dsrow != nullptr && nlocal > 0) failed = lgp_scale_rows_cols_f64(ctx, n, nlocal * nb, dLloc, ldl, dsrow, nullptr, 0);
+  for (size_t b = me; b < nblocks && failed == LGP_OK; b += G) failed = lgp_extract_dblk_public(ctx, sc, block(b), ldl, width(b), dblk(b));
   int info = 0;
   if (failed == LGP_OK && hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, sc) != hipSuccess) failed = LGP_EHIP;
   // drain everything before the events go away, on every path

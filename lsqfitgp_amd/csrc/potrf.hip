@@ -913,35 +913,64 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
 }
 
 // ---- pieces of a panel for the sharded factorisation (dist.hip), the same kernels as the drivers above -----------------------
-// rows below a panel's (factored) diagonal square, solved against it: left-looking over the square's 128-column blocks, as the
-// far rows of potrf_split.  Pfar: the rows (column 0 of the panel), Psq: the square, Yk: its diagonal-block workspaces.
+// rows below a panel's diagonal square, solved against it: left-looking over the square's 128-column blocks, as the far rows
+// of potrf_split.  Pfar: the rows (column 0 of the panel), Psq: the square, Yk: its diagonal-block workspaces.  blk_events
+// (optional): event j = "block j of the square factored and the square's rows below it solved"; block j of these rows then
+// starts behind event j - 1 (update) and event j (substitution), i.e. the rows follow the square one block behind instead of
+// waiting for all of it.
 template <typename T>
-int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *Pfar, size_t ldl, const T *Psq, const T *Yk) {
+int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *Pfar, size_t ldl, const T *Psq, const T *Yk,
+                      const hipEvent_t *blk_events) {
   if (rows == 0) return LGP_OK;
-  for (size_t j0 = 0; j0 < kb; j0 += LGP_DB) {
+  size_t j = 0;
+  for (size_t j0 = 0; j0 < kb; j0 += LGP_DB, ++j) {
     const size_t jb = (kb - j0) < (size_t)LGP_DB ? (kb - j0) : (size_t)LGP_DB;
-    if (j0 > 0) LGP_CHECK(lgp_gemm_launch<T>(ctx, st, false, true, rows, jb, j0, T(-1), Pfar, ldl, Psq + j0 * ldl, ldl, T(1), Pfar + j0, ldl, false, 2));
+    if (j0 > 0) {
+      if (blk_events) LGP_HIP(hipStreamWaitEvent(st, blk_events[j - 1], 0));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, st, false, true, rows, jb, j0, T(-1), Pfar, ldl, Psq + j0 * ldl, ldl, T(1), Pfar + j0, ldl, false, 2));
+    }
+    if (blk_events) LGP_HIP(hipStreamWaitEvent(st, blk_events[j], 0));
     hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((rows + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, st,
                        Yk + (j0 / LGP_DB) * (size_t)LGP_DBLK, (int)jb, Pfar + j0, (long)ldl, (long)rows);
     LGP_LAUNCH_CHECK();
   }
   return LGP_OK;
 }
-template int lgp_far_rows_impl<double>(lgp_ctx *, hipStream_t, size_t, size_t, double *, size_t, const double *, const double *);
+template int lgp_far_rows_impl<double>(lgp_ctx *, hipStream_t, size_t, size_t, double *, size_t, const double *, const double *, const hipEvent_t *);
 
-// a panel's diagonal square alone (kb x kb, kb <= LGP_NB): the chain kernel's resident workers when it covers the size (8 blocks
-// in ~0.55 ms instead of 8 x (potf2 + substitution + update) launches), the launch-per-operation routine otherwise; the
-// packed images of the diagonal blocks that the solves read are extracted at the end
-int lgp_square_factor_f64(lgp_ctx *ctx, hipStream_t st, size_t kb, double *P, size_t ldl, double *Yk, size_t row0) {
-  if (kb >= 256 && lgp_chain_usable(ctx, kb, ldl)) {
+// a panel's diagonal square alone (kb x kb, kb <= LGP_NB).  use_chain: the chain kernel's resident workers (8 blocks in ~0.55 ms
+// instead of 8 x (potf2 + substitution + update) launches that share the CUs with the trailing update) when it covers the
+// size; otherwise launch per operation, recording blk_events[j] (if given) behind block j's substitution so that the rows below
+// the square can follow block by block.  With the chain kernel the events are all recorded behind the kernel.
+int lgp_square_factor_f64(lgp_ctx *ctx, hipStream_t st, size_t kb, double *P, size_t ldl, double *Yk, size_t row0, bool use_chain,
+                          const hipEvent_t *blk_events) {
+  typedef double T;
+  const size_t nq = (kb + LGP_DB - 1) / LGP_DB;
+  if (use_chain && kb >= 256 && lgp_chain_usable(ctx, kb, ldl)) {
     unsigned *state = nullptr;
     LGP_CHECK(lgp_chain_state(ctx, kb, &state));
     LGP_HIP(hipMemsetAsync(state, 0, lgp_chain_state_bytes(kb), st));
     LGP_CHECK(lgp_chain_launch(ctx, st, kb, P, ldl, Yk, row0));
-  } else {
-    LGP_CHECK(lgp_panel_factor_impl<double>(ctx, st, kb, kb, P, ldl, Yk, row0));
+    if (blk_events)
+      for (size_t j = 0; j < nq; ++j) LGP_HIP(hipEventRecord(blk_events[j], st));
+    return LGP_OK;
   }
-  return lgp_extract_dblk<double>(ctx, st, P, ldl, kb, Yk);
+  size_t j = 0;
+  for (size_t j0 = 0; j0 < kb; j0 += LGP_DB, ++j) {
+    const size_t jb = (kb - j0) < (size_t)LGP_DB ? (kb - j0) : (size_t)LGP_DB;
+    T *w = Yk + j * (size_t)LGP_DBLK;
+    LGP_CHECK(lgp_potf2_launch<T>(ctx, st, P + j0 * ldl + j0, ldl, (int)jb, w, row0 + j0));
+    const size_t below = kb - (j0 + jb);
+    T *X = P + (j0 + jb) * ldl + j0;
+    if (below > 0) {
+      hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((below + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, st, w, (int)jb, X,
+                         (long)ldl, (long)below);
+      LGP_LAUNCH_CHECK();
+    }
+    if (blk_events) LGP_HIP(hipEventRecord(blk_events[j], st));
+    if (below > 0) LGP_CHECK(lgp_gemm_launch<T>(ctx, st, false, true, below, below, jb, T(-1), X, ldl, X, ldl, T(1), P + (j0 + jb) * ldl + (j0 + jb), ldl, true));
+  }
+  return LGP_OK;
 }
 
 template <typename T>

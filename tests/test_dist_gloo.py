@@ -64,6 +64,9 @@ class NumpyOps:
         self.blocks[b][r0 - c0:r1 - c0] -= A @ B.T
         self.log.append(('u', b, i))
 
+    def nop(self, p, slot):
+        pass
+
     def sq(self, p, slot):
         b = p[0]
         w = self.L.width(b)
