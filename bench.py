@@ -173,9 +173,34 @@ def _cpu_model():
     return 'unknown'
 
 
+def _cpu_share():
+    """ CPUs this process may really use: the affinity mask, cut by the cgroup CPU quota when there is one (a 1-GPU box is a
+    16-CPU share of a 256-CPU host: 64 BLAS threads on it ran LAPACK potrf at 30 GFLOP/s in round 2) """
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith('cpu.max'):
+                if parts[0] != 'max':
+                    cpus = min(cpus, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as g:
+                        cpus = min(cpus, max(1, int(q / int(g.read().split()[0]))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, cpus)
+
+
 def _oracle_fit_predict(cfg, n):
-    """ one fit+predict pass of the CPU oracle on the first n points of the workload, factoring ONCE (as the GPU step does):
-    Gram build, Chol of Kxx + noise, posterior mean / covariance and log marginal likelihood from the same factor.
+    """ one fit+predict pass of the numpy / scipy oracle on the first n points of the workload, factoring ONCE (as the GPU step
+    does): Gram build, Chol of Kxx + noise, posterior mean / covariance and log marginal likelihood from the same factor.
     Returns (seconds by phase, total seconds). """
     import oracle
     m = cfg['m']
@@ -205,37 +230,96 @@ def _oracle_fit_predict(cfg, n):
     return dict(gram=t1 - t0, decomposition=t2 - t1, solves=t3 - t2), t3 - t0
 
 
+def _backend_fit_predict(be, cfg, n):
+    """ the same pass through the C++ / OpenMP CPU backend (oracle/cpu_backend.cpp, the C-ABI of the HIP library on host
+    arrays): Gram blocks, Chol.__init__ with [Kxxs | y] solved afterwards, posterior, log marginal likelihood """
+    m = cfg['m']
+    x, xs, y = synth(cfg, n)
+    kind, p = (be.EXPQUAD, 0) if cfg['kernel'] == 'expquad' else (be.MATERNP, 2)
+    t0 = time.perf_counter()
+    Kxx = be.gram(kind, p, x, x)
+    Kxx[np.diag_indices(n)] += 0.01
+    W = np.empty((n, m + 1))
+    W[:, :m] = be.gram(kind, p, x, xs)
+    W[:, m] = y
+    Kss = be.gram(kind, p, xs, xs)
+    t1 = time.perf_counter()
+    L, eps = be.chol(Kxx)
+    t2 = time.perf_counter()
+    mean, cov, mlnd = be.posterior(L, W, Kss)
+    t3 = time.perf_counter()
+    assert np.isfinite(mlnd) and mean.shape == (m,) and cov.shape == (m, m)
+    return dict(gram=t1 - t0, decomposition=t2 - t1, solves=t3 - t2), t3 - t0, -mlnd
+
+
 def cpu_baseline(main_cfg):
-    """ the oracle (numpy/scipy restatement of the reference's path, LAPACK potrf/trsm like JAX-CPU) on bounded samples of
-    the C2 and C3 workloads, on this box's host cores: one warm-up + best of 3, with all BLAS threads and with one
-    (BASELINE.md section 3).  ~30-60 s in all. """
+    """ CPU baseline on this box's host cores: the C++ / OpenMP backend behind the
+    library's C-ABI (`kind` "port": a restatement of the reference's path, not the reference), one warm-up + best of N, with
+    all the CPUs this process may use and with one; beside it the numpy / scipy oracle (LAPACK potrf / trsm, what JAX-CPU lowers
+    to) with its BLAS threads capped to the same CPUs.  C2 at N = 8192, C3 at N = 8192 and ONCE at its full N = 32768, C5's
+    Gram rows with the numpy oracle.  About a minute in all. """
     from threadpoolctl import threadpool_limits, threadpool_info
+    from oracle import cpu as cpu_backend
     info = threadpool_info()
-    all_threads = max([p.get('num_threads', 1) for p in info] or [1])
-    try:                      # the cores this process may actually run on (a 1-GPU share of the host), not the BLAS default
-        all_threads = max(1, min(all_threads, len(os.sched_getaffinity(0))))
-    except AttributeError:
-        pass
+    cpus = _cpu_share()
     out = {}
 
-    def best(cfg, n, threads, reps=3):
+    def stats(cfg, n, t, ph, threads, reps):
+        return dict(N=n, M=cfg['m'], seconds=t, phases_s=ph, tflops=flops_fit_predict(n, cfg['m']) / t / 1e12,
+                    cholesky_gflops=n ** 3 / 3 / ph['decomposition'] / 1e9, threads=threads, best_of=reps)
+
+    def best_backend(cfg, n, threads, reps):
+        be = cpu_backend.CpuBackend(threads)
+        _backend_fit_predict(be, cfg, min(n, 1024))                          # warm-up (thread pool, page faults of the library)
+        runs = [_backend_fit_predict(be, cfg, n) for _ in range(reps)]
+        ph, t, mll = min(runs, key=lambda r: r[1])
+        d = stats(cfg, n, t, ph, threads, reps)
+        d['log_marginal_likelihood'] = mll
+        return d
+
+    def best_oracle(cfg, n, threads, reps):
         with threadpool_limits(limits=threads):
-            _oracle_fit_predict(cfg, min(n, 2048))                           # warm-up (imports, thread pools)
+            _oracle_fit_predict(cfg, min(n, 1024))
             runs = [_oracle_fit_predict(cfg, n) for _ in range(reps)]
         ph, t = min(runs, key=lambda r: r[1])
-        return dict(N=n, M=cfg['m'], seconds=t, phases_s=ph, tflops=flops_fit_predict(n, cfg['m']) / t / 1e12,
-                    cholesky_gflops=n ** 3 / 3 / ph['decomposition'] / 1e9, threads=threads)
+        return stats(cfg, n, t, ph, threads, reps)
 
     for name in ('c2', 'c3'):
         cfg = CONFIGS[name]
-        out[name] = {'all_cores': best(cfg, 8192, all_threads), 'one_core': best(cfg, 4096, 1)}
+        out[name] = {'all_cores': best_backend(cfg, 8192, cpus, 5), 'one_core': best_backend(cfg, 4096, 1, 3),
+                     'numpy_scipy_oracle_all_cores': best_oracle(cfg, 8192, cpus, 2)}
+    try:
+        out['c3']['full_size_all_cores'] = best_backend(CONFIGS['c3'], CONFIGS['c3']['n'], cpus, 1)
+    except MemoryError as exc:
+        out['c3']['full_size_all_cores'] = {'error': repr(exc)}
+    try:        # C5: rows of the BART Gram matrix of the real workload by the numpy oracle + the f64 factorisation by the backend
+        import oracle
+        from workloads import load_abalone, c5_prepare
+        X, y = load_abalone()
+        prep = c5_prepare(oracle, X, y, 4096)
+        rows = 256
+        t0 = time.perf_counter()
+        with threadpool_limits(limits=cpus):
+            blk = prep['kern'](prep['pts'][:rows, None], prep['pts'][None, :4096])
+        tg = time.perf_counter() - t0
+        be = cpu_backend.CpuBackend(cpus)
+        K = np.eye(4096) * 5 + 0.5
+        t0 = time.perf_counter(); be.chol(K); tc = time.perf_counter() - t0
+        out['c5'] = {'bart_gram_pairs_per_s': rows * 4096 / tg, 'bart_gram_rows_timed': rows, 'bart_gram_full_matrix_s_extrapolated': tg * 4096 / rows,
+                     'cholesky_4096_s': tc, 'threads': cpus, 'note': 'numpy oracle Gram rows (vectorised over pairs) + C++ backend Cholesky'}
+        assert blk.shape == (rows, 4096)
+    except Exception as exc:
+        out['c5'] = {'error': repr(exc)}
     key = 'c2' if main_cfg['kernel'] == 'expquad' else 'c3'
-    top = out[key]['all_cores']
-    return dict(value=top['tflops'], unit='TFLOP/s', cores=int(all_threads), kind='port',
-                sample=(f"{main_cfg['kernel']} d={main_cfg['d']} N={top['N']} M={top['M']} fit+predict with the numpy/scipy oracle (LAPACK potrf/trsm), "
-                        f"factored once, best of 3 after a warm-up, {top['seconds']:.2f} s"),
-                seconds=top['seconds'], host_cpus=os.cpu_count(), cpu_model=_cpu_model(), blas=[p.get('internal_api') for p in info],
-                one_core={'value': out[key]['one_core']['tflops'], 'N': out[key]['one_core']['N'], 'seconds': out[key]['one_core']['seconds']},
+    top = out[key].get('full_size_all_cores') if main_cfg['n'] == CONFIGS[key]['n'] and 'error' not in out[key].get('full_size_all_cores', {'error': 1}) \
+        else out[key]['all_cores']
+    return dict(value=top['tflops'], unit='TFLOP/s', cores=int(top['threads']), kind='port',
+                sample=(f"{main_cfg['kernel']} d={main_cfg['d']} N={top['N']} M={top['M']} fit+predict with the C++/OpenMP CPU backend behind the library's C-ABI "
+                        f"(oracle/cpu_backend.cpp), factored once, best of {top['best_of']} after a warm-up, {top['seconds']:.2f} s"),
+                seconds=top['seconds'], cholesky_gflops=top['cholesky_gflops'], host_cpus=os.cpu_count(), cpus_usable=cpus, cpu_model=_cpu_model(),
+                blas=[p.get('internal_api') for p in info],
+                one_core={'value': out[key]['one_core']['tflops'], 'N': out[key]['one_core']['N'], 'seconds': out[key]['one_core']['seconds'],
+                          'cholesky_gflops': out[key]['one_core']['cholesky_gflops']},
                 by_config=out)
 
 
