@@ -434,8 +434,32 @@ def c5_step(ctx, steps=3, warmup=1):
     return {'workload': f'C5 BART kernel p=10 fp32 on bart-data.txt, N={n} train / {nt} held out, via GP/BART/Chol host classes',
             'N': n, 'M': nt, 'ms_per_step': dt * 1e3, 'value': flops_fit_predict(n, nt) / dt / 1e12,
             'log_marginal_likelihood': float(res[2]),
-            'bart_gram': {'ms': best, 'gpairs_per_s': n * n / (best * 1e-3) / 1e9, 'bound': 'hbm', 'achieved': 4. * n * n / (best * 1e-3) / 1e9,
-                          'peak': 8000., 'unit': 'GB/s', 'note': 'bin indices uploaded once (kernel.prepare), output preallocated; includes the per-call upload of the per-axis constants'}}
+            'bart_gram': bart_roofline(n, best)}
+
+
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4          # wave64 vector instructions per ns: one per 4 cycles per SIMD, 4 SIMDs x 256 CUs x 2.4 GHz
+
+
+def bart_roofline(n, ms):
+    """ the BART Gram kernel is bound by vector-ALU ISSUE, not by HBM (4 bytes written per pair = 0.17 TB/s): its roofline is
+    the wave64 VALU instruction rate.  Instructions per pair from the committed counter pass (profiles/r03_c5_bart_valu.json:
+    SQ_INSTS_VALU of one launch / pairs, p = 10 axes x 5 iterations of the depth-2 closed form, fp32 without contraction);
+    achieved = that count x pairs of this launch / its duration measured live """
+    per_pair = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r03_c5_bart_valu.json')) as f:
+            d = json.load(f)
+        per_pair = d['SQ_INSTS_VALU'] / d['pairs']           # wave instructions per pair (each covers 64 pairs' worth of lanes)
+    except Exception:
+        pass
+    out = {'kernel': 'gram_bart_kernel<float> (N x N)', 'ms': ms, 'gpairs_per_s': n * n / (ms * 1e-3) / 1e9,
+           'hbm_written_GB_per_s': 4. * n * n / (ms * 1e-3) / 1e9,
+           'note': 'bin indices uploaded once (kernel.prepare), output preallocated; includes the per-call upload of the per-axis constants'}
+    if per_pair is not None:
+        ach = per_pair * n * n / (ms * 1e-3) / 1e9
+        out.update({'bound': 'valu', 'achieved': ach, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instructions/s', 'frac': ach / VALU_PEAK_GINSTR,
+                    'valu_lane_instructions_per_pair': per_pair * 64})
+    return out
 
 
 def c5_fit(ctx):
@@ -474,8 +498,9 @@ def main_c5(args, ctx):
         'dtype': 'f32 Gram, f64 assembly and solve (as the reference: zero cross blocks are float64)', 'data': 'reference data file (examples/bart-data.txt)',
         'config': {'workload': r['workload'], 'N': r['N'], 'M': r['M'], 'p': 10, 'parallelism': 'single GPU'},
         'log_marginal_likelihood': r['log_marginal_likelihood'],
-        'roofline': {'kernel': 'gram_bart_kernel<float> (N x N)', 'bound': 'hbm', 'achieved': g['achieved'], 'peak': 8000., 'unit': 'GB/s',
-                     'frac': g['achieved'] / 8000., 'traffic': None, 'avg_launch_ms': g['ms'], 'gpairs_per_s': g['gpairs_per_s']},
+        'roofline': {'kernel': g['kernel'], 'bound': g.get('bound'), 'achieved': g.get('achieved'), 'peak': g.get('peak'), 'unit': g.get('unit'),
+                     'frac': g.get('frac'), 'traffic': None, 'avg_launch_ms': g['ms'], 'gpairs_per_s': g['gpairs_per_s'],
+                     'hbm_written_GB_per_s': g['hbm_written_GB_per_s'], 'valu_lane_instructions_per_pair': g.get('valu_lane_instructions_per_pair')},
         'full_fit': fit,
         'cpu_baseline': None}), flush=True)
 

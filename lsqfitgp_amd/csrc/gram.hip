@@ -92,6 +92,34 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
   }
 }
 
+// Compile-time selection of the core for the kernels that evaluate n x m pairs: CORE_GENERIC keeps the run-time branches of
+// iso_core; the others fix the kernel (and the Matern order, so that the Horner loop unrolls and its coefficients become
+// immediates) -- the inner loop of the C3 Gram build lost its branch on g.kernel and its loop on g.p per element.
+constexpr int CORE_GENERIC = 0, CORE_EXPQUAD = 1, CORE_MATERN1 = 2, CORE_MATERN2 = 3, CORE_MATERN3 = 4;
+
+template <typename T, int CORE>
+__device__ __forceinline__ T iso_core_t(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
+  if constexpr (CORE == CORE_EXPQUAD) {
+    return exp(T(-0.5) * r2);
+  } else if constexpr (CORE == CORE_MATERN1 || CORE == CORE_MATERN2 || CORE == CORE_MATERN3) {
+    constexpr int P = CORE == CORE_MATERN1 ? 1 : (CORE == CORE_MATERN2 ? 2 : 3);
+    const T r2s = T(2 * P + 1) * r2;
+    const T x = sqrt(r2s + T(1e-30));
+    T poly = T(1);
+#pragma unroll
+    for (int k = 0; k < P; ++k) poly = T(1) + poly * g.coef[k] * T(2) * x;      // (the same operations in the same order as iso_core)
+    return exp(-x) * poly;
+  } else {
+    return iso_core<T>(g, r2, d0);
+  }
+}
+
+__host__ inline int core_of(int kernel, int p) {
+  if (kernel == LGP_KERNEL_EXPQUAD) return CORE_EXPQUAD;
+  if (kernel == LGP_KERNEL_MATERNP && p >= 1 && p <= 3) return CORE_MATERN1 + (p - 1);
+  return CORE_GENERIC;
+}
+
 // core value and its derivative with respect to `scale` (the inputs are divided by scale before differencing, so
 // r2 = R2 / scale^2 and d r2 / d scale = -2 r2 / scale): analytic forms of the cores above.  With scale=None the
 // derivative is taken at scale = 1.
@@ -129,7 +157,7 @@ __device__ __forceinline__ T iso_core_dscale(const IsoArgs<T> &g, T r2, T &dk) {
 }
 
 // D > 0: compile-time field count (coordinates of the lane's columns live in registers); D == 0: runtime d
-template <typename T, int D, bool GRAD = false>
+template <typename T, int D, bool GRAD = false, int CORE = CORE_GENERIC>
 __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g) {
   constexpr int W = VecOf<T>::W;
   constexpr int GT_COLS = GT_THREADS * W;
@@ -203,7 +231,7 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
         res[e] = g.ops.apply(iso_core_dscale<T>(g, r2, dk));
         dres[e] = slope * dk;
       } else {
-        res[e] = g.ops.apply(iso_core<T>(g, r2, d0));
+        res[e] = g.ops.apply(iso_core_t<T, CORE>(g, r2, d0));
       }
     }
     T *po = g.out + (long)(row0 + r) * g.ldo + col0 + c0;
@@ -322,12 +350,23 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
       default: hipLaunchKernelGGL((gram_iso_kernel<T, 0, true>), gd, bd, shmem, ctx->stream, g); break;
     }
   } else {
-    switch (d) {
-      case 1: hipLaunchKernelGGL((gram_iso_kernel<T, 1>), gd, bd, shmem, ctx->stream, g); break;
-      case 2: hipLaunchKernelGGL((gram_iso_kernel<T, 2>), gd, bd, shmem, ctx->stream, g); break;
-      case 3: hipLaunchKernelGGL((gram_iso_kernel<T, 3>), gd, bd, shmem, ctx->stream, g); break;
-      default: hipLaunchKernelGGL((gram_iso_kernel<T, 0>), gd, bd, shmem, ctx->stream, g); break;
+#define LGP_ISO_LAUNCH(DD, CC) hipLaunchKernelGGL((gram_iso_kernel<T, DD, false, CC>), gd, bd, shmem, ctx->stream, g)
+#define LGP_ISO_BY_CORE(DD)                                   \
+    switch (core_of(kernel, p)) {                             \
+      case CORE_EXPQUAD: LGP_ISO_LAUNCH(DD, CORE_EXPQUAD); break;   \
+      case CORE_MATERN1: LGP_ISO_LAUNCH(DD, CORE_MATERN1); break;   \
+      case CORE_MATERN2: LGP_ISO_LAUNCH(DD, CORE_MATERN2); break;   \
+      case CORE_MATERN3: LGP_ISO_LAUNCH(DD, CORE_MATERN3); break;   \
+      default: LGP_ISO_LAUNCH(DD, CORE_GENERIC); break;             \
     }
+    switch (d) {
+      case 1: LGP_ISO_BY_CORE(1); break;
+      case 2: LGP_ISO_BY_CORE(2); break;
+      case 3: LGP_ISO_BY_CORE(3); break;
+      default: LGP_ISO_BY_CORE(0); break;
+    }
+#undef LGP_ISO_BY_CORE
+#undef LGP_ISO_LAUNCH
   }
   LGP_LAUNCH_CHECK();
   return LGP_OK;
@@ -349,9 +388,15 @@ __device__ __forceinline__ T pow2_scale(T d) {      // _decomp.py:356-361
   return d != T(0) ? exp2(rint(T(0.5) * log2(d))) : T(1);
 }
 
-template <typename T, int D>
+// Tiles entirely above the diagonal are not evaluated (round 3: they were, for the sums only -- 1.3 of the 3.3 ms at C3): their
+// part of column j's sum, sum_{i in the tile's rows} |K~_ij| = sum |K~_ji|, is the sum ALONG ROW j of the mirrored entries, and
+// the mirror of an entry of such a tile always lies in a tile entirely BELOW the diagonal (the column blocks of 256 W entries are
+// whole multiples of the 128-row blocks).  So: tiles above: nothing; tiles below: column sums as before plus the sums along
+// their rows (per wave by lane shuffles, the four waves' partials added in fixed order) -> rpart[tile column][row]; tiles that
+// straddle the diagonal: evaluated in full as before, column sums only.  Gershgorin_j = sum_tr part[tr][j] + sum_tc rpart[tc][j].
+template <typename T, int D, int CORE>
 __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g, T noise, const T *__restrict__ noisev, T *__restrict__ svec,
-                                                              T *__restrict__ part) {
+                                                              T *__restrict__ part, T *__restrict__ rpart) {
   constexpr int W = VecOf<T>::W;
   constexpr int GT_COLS = GT_THREADS * W;
   typedef typename VecOf<T>::type vec_t;
@@ -361,12 +406,43 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
   T *sv = su + d * GR_ROWS;                            // [d][GT_COLS]
   T *sinv = sv + d * GT_COLS;                          // [GR_ROWS] 1 / s_i of the rows;  then [GR_ROWS] their noise
   T *snz = sinv + GR_ROWS;
+  T *srow = snz + GR_ROWS;                             // [4][GR_ROWS] per-wave sums along the rows (tiles below the diagonal)
   const int n = g.n;
   const int ntc = (n + GT_COLS - 1) / GT_COLS;
   const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
   const int row0 = tr * GR_ROWS, col0 = tc * GT_COLS;
   const int tid = threadIdx.x;
-  const T k0 = g.ops.apply(iso_core<T>(g, T(0)));     // the kernel on its diagonal: r2 = 0 exactly, as for the pairs (i, i)
+  const T k0 = g.ops.apply(iso_core_t<T, CORE>(g, T(0)));     // the kernel on its diagonal: r2 = 0 exactly, as for the pairs (i, i)
+  const bool above = col0 > row0 + GR_ROWS - 1;         // every column right of every row: not evaluated
+  const bool below = col0 + GT_COLS - 1 < row0;         // every entry strictly below the diagonal: sums along the rows as well
+  if (above) {
+    // (the scales of the columns are still this workgroup's to publish when it sits in the first tile row)
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+      const int j = col0 + tid * W + e;
+      if (j < n) {
+        part[(long)tr * n + j] = T(0);
+        if (tr == 0) svec[j] = pow2_scale<T>(k0 + (noisev ? noisev[j] : noise));
+      }
+    }
+    // the entries above the diagonal of the factor's storage are zero
+    const int rmax0 = (n - row0) < GR_ROWS ? (n - row0) : GR_ROWS;
+    const bool full0 = (col0 + tid * W + W <= n) && ((g.ldo % W) == 0) && ((reinterpret_cast<uintptr_t>(g.out) % 16) == 0);
+    for (int r = 0; r < rmax0; ++r) {
+      T *po = g.out + (long)(row0 + r) * g.ldo + col0 + tid * W;
+      if (full0) {
+        vec_t z;
+#pragma unroll
+        for (int e = 0; e < W; ++e) z[e] = T(0);
+        *reinterpret_cast<vec_t *>(po) = z;
+      } else {
+#pragma unroll
+        for (int e = 0; e < W; ++e)
+          if (col0 + tid * W + e < n) po[e] = T(0);
+      }
+    }
+    return;
+  }
   for (int idx = tid; idx < d * GR_ROWS; idx += GT_THREADS) {
     const int f = idx / GR_ROWS, r = idx % GR_ROWS;
     T v = T(0);
@@ -433,11 +509,20 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
           r2 = (f == 0) ? sq : r2 + sq;
         }
       }
-      T v = g.ops.apply(iso_core<T>(g, r2));
+      T v = g.ops.apply(iso_core_t<T, CORE>(g, r2));
       if (i == j) v = v + cnz[e];                       // Kxx + ycov (_compute.py:85), noise on the diagonal
       v = v * cinv[e] * rinv;                           // K / s / s[:, None] (:385): exact, s is a power of two
       if (j < n) acc[e] += fabs(v);
       res[e] = (j <= i) ? v : T(0);
+    }
+    if (below) {
+      // sum along the row over this tile's columns: lanes, then the four waves in fixed order
+      T rs = T(0);
+#pragma unroll
+      for (int e = 0; e < W; ++e) rs += (col0 + c0 + e < n) ? fabs(res[e]) : T(0);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) rs += __shfl_xor(rs, off, 64);
+      if ((tid & 63) == 0) srow[(tid >> 6) * GR_ROWS + r] = rs;
     }
     T *po = g.out + (long)i * g.ldo + col0 + c0;
     if (colfull) {
@@ -454,13 +539,18 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
 #pragma unroll
   for (int e = 0; e < W; ++e)
     if (col0 + c0 + e < n) part[(long)tr * n + col0 + c0 + e] = acc[e];
+  if (below) {
+    __syncthreads();
+    for (int r = tid; r < rmax; r += GT_THREADS)
+      rpart[(long)tc * n + row0 + r] = ((srow[r] + srow[GR_ROWS + r]) + srow[2 * GR_ROWS + r]) + srow[3 * GR_ROWS + r];
+  }
 }
 
 template <typename T>
 int gram_reg_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, int d, const T *dx, size_t ldx, size_t n, int has_loc, T loc,
                     int has_scale, T scale, int nops, const int *hops_code, const T *hops_val, T noise, const T *dnoise, T *dL, size_t ldl, T *dsvec,
-                    T *dpart, size_t *ntr_out) {
-  LGP_REQUIRE(ctx != nullptr && dx != nullptr && dL != nullptr && dsvec != nullptr && dpart != nullptr, "null pointer");
+                    T *dpart, T *drpart, size_t *ntr_out) {
+  LGP_REQUIRE(ctx != nullptr && dx != nullptr && dL != nullptr && dsvec != nullptr && dpart != nullptr && drpart != nullptr, "null pointer");
   LGP_REQUIRE(kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_MATERNP || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY,
               "unknown isotropic kernel");
   LGP_REQUIRE(d >= 1 && d <= 64 && p >= 0 && p <= MAX_P && nops >= 0 && nops <= MAX_OPS, "bad kernel parameters");
@@ -500,14 +590,25 @@ int gram_reg_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   constexpr int GT_COLS = GT_THREADS * W;
   const size_t ntr = (n + GR_ROWS - 1) / GR_ROWS, ntc = (n + GT_COLS - 1) / GT_COLS;
   LGP_REQUIRE(ntr * ntc < (1ull << 31), "gram grid too large");
-  const size_t shmem = ((size_t)d * (GR_ROWS + GT_COLS) + 2 * GR_ROWS) * sizeof(T);
+  const size_t shmem = ((size_t)d * (GR_ROWS + GT_COLS) + 6 * GR_ROWS) * sizeof(T);
   dim3 gd((unsigned)(ntr * ntc)), bd(GT_THREADS);
-  switch (d) {
-    case 1: hipLaunchKernelGGL((gram_reg_kernel<T, 1>), gd, bd, shmem, ctx->stream, g, noise, dnoise, dsvec, dpart); break;
-    case 2: hipLaunchKernelGGL((gram_reg_kernel<T, 2>), gd, bd, shmem, ctx->stream, g, noise, dnoise, dsvec, dpart); break;
-    case 3: hipLaunchKernelGGL((gram_reg_kernel<T, 3>), gd, bd, shmem, ctx->stream, g, noise, dnoise, dsvec, dpart); break;
-    default: hipLaunchKernelGGL((gram_reg_kernel<T, 0>), gd, bd, shmem, ctx->stream, g, noise, dnoise, dsvec, dpart); break;
+  // the sums along the rows: one slot per tile column, zero where no tile below the diagonal contributes
+  LGP_HIP(hipMemsetAsync(drpart, 0, ntc * n * sizeof(T), ctx->stream));
+#define LGP_REG_LAUNCH(DD, CC) hipLaunchKernelGGL((gram_reg_kernel<T, DD, CC>), gd, bd, shmem, ctx->stream, g, noise, dnoise, dsvec, dpart, drpart)
+#define LGP_REG_BY_CORE(DD)                                   \
+  switch (core_of(kernel, p)) {                               \
+    case CORE_EXPQUAD: LGP_REG_LAUNCH(DD, CORE_EXPQUAD); break;   \
+    case CORE_MATERN2: LGP_REG_LAUNCH(DD, CORE_MATERN2); break;   \
+    default: LGP_REG_LAUNCH(DD, CORE_GENERIC); break;             \
   }
+  switch (d) {
+    case 1: LGP_REG_BY_CORE(1); break;
+    case 2: LGP_REG_BY_CORE(2); break;
+    case 3: LGP_REG_BY_CORE(3); break;
+    default: LGP_REG_BY_CORE(0); break;
+  }
+#undef LGP_REG_BY_CORE
+#undef LGP_REG_LAUNCH
   LGP_LAUNCH_CHECK();
   *ntr_out = ntr;
   return LGP_OK;
@@ -938,14 +1039,16 @@ static int gram_chol_impl(lgp_ctx *ctx, int kernel, int p, int npar, const T *hp
   LGP_REQUIRE(n >= 1 && n < (1u << 30), "matrix size out of range");
   DeviceGuard dg(ctx->device);
   const size_t ntr = (n + GR_ROWS - 1) / GR_ROWS;
-  // workspace: s (n), Gershgorin sums (n), stats (16), partial column sums (ntr x n)
+  const size_t ntc_r = (n + GT_THREADS * VecOf<T>::W - 1) / (GT_THREADS * VecOf<T>::W);
+  // workspace: s (n), Gershgorin sums (n), stats (16), partial column sums (ntr x n) followed by the sums along the rows
+  // (ntc x n): the reduction adds all (ntr + ntc) x n partials in fixed order
   T *ws = nullptr;
-  LGP_CHECK(lgp_ws_alloc(ctx, ctx->stream, (2 * n + 16 + ntr * n) * sizeof(T), reinterpret_cast<void **>(&ws)));
+  LGP_CHECK(lgp_ws_alloc(ctx, ctx->stream, (2 * n + 16 + (ntr + ntc_r) * n) * sizeof(T), reinterpret_cast<void **>(&ws)));
   WsGuard ws_guard(ctx, ctx->stream, ws);      // (the calls below end with a stream synchronisation: nothing is using it by then)
   size_t got = 0;
   int st = gram_reg_launch<T>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, noise, dnoise, dL,
-                              ldl, ws, ws + 2 * n + 16, &got);
-  if (st == LGP_OK) st = lgp_chol_from_prepared<T>(ctx, n, dL, ldl, ddblk, nrhs, ws, ntr, epsrel, epsabs, flags, heps_out);
+                              ldl, ws, ws + 2 * n + 16, ws + 2 * n + 16 + ntr * n, &got);
+  if (st == LGP_OK) st = lgp_chol_from_prepared<T>(ctx, n, dL, ldl, ddblk, nrhs, ws, ntr + ntc_r, epsrel, epsabs, flags, heps_out);
   return st;
 }
 
