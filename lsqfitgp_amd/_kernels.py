@@ -375,10 +375,12 @@ class BART(Kernel):
     """
     BART kernel (``_kernels/_bart.py:32-202``): prior correlation of the
     infinite-trees limit of BART, depth-truncated, with the `reset` slicing.
-    The device path covers every slice of at most 3 probabilities (depth <= 2
-    per slice), i.e. ``maxd <= 2`` or ``maxd`` with ``reset`` depths at most 2
-    apart -- which includes the configurations the reference recommends
-    (``maxd=4, reset=2`` and ``maxd=10, reset=[2,4,6,8]``, ``_bart.py:47-49``).
+    Slices of at most 3 probabilities (depth <= 2 per slice: ``maxd <= 2`` or
+    ``reset`` depths at most 2 apart -- the configurations the reference
+    recommends, ``maxd=4, reset=2`` and ``maxd=10, reset=[2,4,6,8]``,
+    ``_bart.py:47-49``) are closed forms; deeper slices (up to depth 10, at most
+    16 covariates) recurse over the splits on the device too, much more slowly
+    (``_bart.py:759-806``).
     """
 
     def __init__(self, *, alpha=0.95, beta=2, maxd=2, gamma=1, splits=None, pnt=None,
@@ -445,11 +447,14 @@ class BART(Kernel):
         self._gamma0 = self._flt.type(gamma)
         self._weights = weights.astype(self._flt)
         self._brackets = _bart_brackets(len(pnt), reset)
+        # slices of at most three probabilities are closed forms (_bart.py:685-757); deeper ones recurse over the splits
+        # (:759-806) on the device as well, one thread per pair with an explicit stack: the slow path, as in the reference
+        self._deep = any(rep == 1 and b_ - t_ + 1 > 3 for t_, b_, rep in self._brackets)
         for t_, b_, rep in self._brackets:
-            if (b_ - t_ + 1) > 3 and rep == 1 or (rep > 1 and (b_ - t_) // rep + 1 > 3):
-                raise NotImplementedError(
-                    f'recursion slice of depth {b_ - t_} > 2: only the closed-form slices '
-                    '(_bart.py:685-757) run on the device; use `reset` depths at most 2 apart')
+            if rep == 1 and b_ - t_ + 1 > 11:
+                raise NotImplementedError(f'recursion slice of depth {b_ - t_} > 10: use `reset`')
+        if self._deep and p > 16:
+            raise NotImplementedError('recursion slices deeper than two levels take at most 16 covariates on the device: use `reset`')
 
     # ---- classmethods kept from the reference API ------------------------------
 
@@ -670,6 +675,8 @@ class BART(Kernel):
         dpnt = [numpy.asarray(t, self._flt) for t in dpnt]
         if not 1 <= len(dpnt) <= 2 or any(t.shape != self._pnt.shape for t in dpnt):
             raise ValueError(f'one or two tangent arrays of shape {self._pnt.shape} expected')
+        if self._deep:
+            raise NotImplementedError('tangents of recursion slices deeper than two levels are not available: use `reset`')
         ix = self._to_indices(xs)
         iy = ix if ys is xs else self._to_indices(ys)
         n, m, p = ix.shape[0], iy.shape[0], ix.shape[1]

@@ -846,6 +846,100 @@ __global__ void __launch_bounds__(256) bart_pairs_kernel(const BartArgs<T> g, co
   g.out[i] = g.ops.apply(bart_iterate<T, 0>(g, q, gam0, nodual));
 }
 
+// Recursion slices deeper than two levels (_bart.py:759-806): the correlation at a level is 1 - P (1 - sum_i w_i / n_i sum_k C_k / Wn)
+// with C_k the correlation one level down when the cell is cut at split k of axis i (k runs over the splits that do not
+// separate the two points: the first nminus_i cut on the left and leave k splits there, the others cut on the right).  E
+// explicit levels by depth-first search with an explicit stack (no recursion on the device), the last three probabilities by
+// the closed form above.  One thread per pair, the split counts of the pair in private arrays: the slow path -- (p n)^E closed
+// forms per pair, as in the reference, whose documentation recommends `reset` instead.
+constexpr int BART_DEEP_MAX_E = 8, BART_DEEP_MAX_P = 16;
+template <typename T>
+struct BartDeep {
+  int E;
+  T top[BART_DEEP_MAX_E];      // splitting probabilities of the explicit levels (the closed form's three are BartArgs::probs)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(128) bart_deep_kernel(const BartArgs<T> g, const BartDeep<T> dp, const int32_t *npair, int pairs) {
+  const long idx = (long)blockIdx.x * 128 + threadIdx.x;
+  const long total = pairs ? (long)g.n : (long)g.n * g.m;
+  if (idx >= total) return;
+  const long i = pairs ? idx : idx / g.m, j = pairs ? idx : idx % g.m;
+  const int p = g.p;
+  const int32_t *x = g.ix + i * p, *y = g.iy + j * p, *nn = npair ? npair + idx * p : nullptr;
+  const long oidx = pairs ? idx : i * g.ldo + j;
+  const T gam0 = g.gamma_mat ? g.gamma_mat[oidx] : g.gamma;
+  const T one = T(1);
+  int nminus[BART_DEEP_MAX_P], n0[BART_DEEP_MAX_P], nplus[BART_DEEP_MAX_P];
+  bool anyn0 = false;
+  for (int a = 0; a < p; ++a) {
+    const bool on = g.w[a] != T(0);                      // zero-weight axes are ignored (:670-672)
+    const int xa = on ? x[a] : 0, ya = on ? y[a] : 0, na = on ? (nn ? nn[a] : g.nsplits[a]) : 0;
+    const int mn = xa < ya ? xa : ya, mx = xa < ya ? ya : xa;
+    nminus[a] = mn; n0[a] = mx - mn; nplus[a] = na - mx;
+    anyn0 |= xa != ya;
+  }
+  T result = one;
+  if (anyn0 && p > 0) {
+    struct Frame { int i, k, kend, smin, splus; T sumn, sump, Wn; };
+    Frame st[BART_DEEP_MAX_E];
+    int lvl = 0;
+    T ret = T(0);
+    bool entering = true;
+    for (;;) {
+      if (entering) {
+        if (lvl == dp.E) {
+          // the closed form on the current cell: ix = nminus, iy = nminus + n0, n = nminus + n0 + nplus
+          T nodual[1];
+          const BartGeom<T> q = bart_geometry<T, false>(
+              g, [&](int a) { return nminus[a]; }, [&](int a) { return nminus[a] + n0[a]; }, [&](int a) { return nminus[a] + n0[a] + nplus[a]; });
+          ret = bart_iterate<T, 0>(g, q, gam0, nodual);
+          --lvl;
+          entering = false;
+          continue;
+        }
+        Frame &f = st[lvl];
+        T Wn = T(0);
+        for (int a = 0; a < p; ++a)
+          if (nminus[a] + n0[a] + nplus[a]) Wn += g.w[a];
+        f.Wn = Wn; f.sump = T(0); f.i = -1; f.k = 0; f.kend = 0; f.sumn = T(0);
+      } else {
+        Frame &f = st[lvl];
+        f.sumn += ret;
+        nminus[f.i] = f.smin; nplus[f.i] = f.splus;
+        ++f.k;
+      }
+      Frame &f = st[lvl];
+      // the next cut of this level, if any
+      bool descend = false;
+      for (;;) {
+        if (f.i >= 0 && f.k < f.kend) { descend = true; break; }
+        if (f.i >= 0) {
+          const int ni = f.smin + n0[f.i] + f.splus;
+          if (ni) f.sump += g.w[f.i] * f.sumn / T(ni);
+        }
+        ++f.i;
+        if (f.i >= p) break;
+        f.smin = nminus[f.i]; f.splus = nplus[f.i];
+        const int ni = f.smin + n0[f.i] + f.splus;
+        f.k = 0; f.kend = ni ? f.smin + f.splus : 0; f.sumn = T(0);
+      }
+      if (descend) {
+        if (f.k < f.smin) nminus[f.i] = f.k;
+        else nplus[f.i] = f.k - f.smin;
+        ++lvl;
+        entering = true;
+        continue;
+      }
+      ret = one - dp.top[lvl] * (one - f.sump / f.Wn);     // :806 (anyn0 holds on every level: n0 never changes)
+      if (lvl == 0) { result = ret; break; }
+      --lvl;
+      entering = false;
+    }
+  }
+  g.out[oidx] = g.ops.apply(result);
+}
+
 template <typename T>
 int gram_bart_launch(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const int32_t *diy, size_t m, const int32_t *hnsplits,
                      const T *hweights, int size, int repeat, const T *hprobs, T gamma, const T *dgamma_mat, const T *dpsi,
@@ -856,7 +950,9 @@ int gram_bart_launch(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const in
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(p >= 0 && p <= BART_MAX_P, "number of covariates must be in [0,64]");
-  LGP_REQUIRE(size >= 1 && size <= 3, "bracket size must be 1, 2 or 3 (depth <= 2 per recursion slice)");
+  const bool deep = size > 3;
+  LGP_REQUIRE(size >= 1 && size <= 3 + BART_DEEP_MAX_E, "recursion slice of at most 11 probabilities");
+  LGP_REQUIRE(!deep || (repeat == 1 && ntan == 0 && p <= BART_DEEP_MAX_P), "slices deeper than two levels: no repetition, no tangents, at most 16 covariates");
   LGP_REQUIRE(repeat >= 1 && size * repeat <= BART_MAX_ROWS, "too many probabilities");
   LGP_REQUIRE(dout != nullptr && (p == 0 || (dix != nullptr && diy != nullptr)), "null pointer");
   LGP_REQUIRE(nops >= 0 && nops <= MAX_OPS, "at most 8 output operations");
@@ -867,7 +963,15 @@ int gram_bart_launch(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const in
   BartArgs<T> g;
   memset(&g, 0, sizeof(g));
   g.ix = dix; g.iy = diy; g.out = dout; g.gamma_mat = dgamma_mat; g.psi = dpsi;
-  g.ldo = (long)ldo; g.n = (int)n; g.m = (int)m; g.p = p; g.size = size; g.repeat = repeat; g.gamma = gamma;
+  g.ldo = (long)ldo; g.n = (int)n; g.m = (int)m; g.p = p; g.size = deep ? 3 : size; g.repeat = repeat; g.gamma = gamma;
+  BartDeep<T> dp;
+  memset(&dp, 0, sizeof(dp));
+  if (deep) {
+    dp.E = size - 3;
+    for (int l = 0; l < dp.E; ++l) dp.top[l] = hprobs[l];
+    hprobs += dp.E;               // the closed form at the bottom takes the last three
+    size = 3;
+  }
   int maxn = 0;
   for (int a = 0; a < p; ++a) {
     LGP_REQUIRE(hweights[a] >= T(0), "weights must be nonnegative");
@@ -894,6 +998,13 @@ int gram_bart_launch(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const in
     LGP_REQUIRE(hops_code[i] == LGP_OP_MUL || hops_code[i] == LGP_OP_ADD, "unknown output operation");
     g.ops.code[i] = hops_code[i];
     g.ops.val[i] = hops_val[i];
+  }
+  if (deep) {
+    const size_t total = pairs ? n : n * m;
+    LGP_REQUIRE((total + 127) / 128 < (1ull << 31), "too many pairs");
+    hipLaunchKernelGGL((bart_deep_kernel<T>), dim3((unsigned)((total + 127) / 128)), dim3(128), 0, ctx->stream, g, dp, dnpair, pairs ? 1 : 0);
+    LGP_LAUNCH_CHECK();
+    return LGP_OK;
   }
   if (pairs) {
     hipLaunchKernelGGL((bart_pairs_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, g, dnpair);

@@ -266,8 +266,10 @@ def test_bart_correlation_classmethod(lgp, rng):
     assert lgp.BART.correlation(empty, empty, empty) == 1
     with pytest.raises(KeyError):
         lgp.BART.correlation([0], [0], [0], gamma='ciao')
+    # a depth-4 slice: the explicit recursion (slow path) on the device
+    util.assert_allclose(lgp.BART.correlation(*sss, maxd=4), oracle.BART.correlation(*sss, maxd=4), rtol=1e-14)
     with pytest.raises(NotImplementedError):
-        lgp.BART.correlation(*sss, maxd=4)              # a depth-4 slice is outside the device path
+        lgp.BART.correlation(*sss, maxd=12)             # a slice deeper than 10 levels: use `reset`
 
 
 def test_bart_corr_one_cases(lgp, rng):
@@ -364,3 +366,36 @@ def test_bart_gram_jvp_vs_finite_differences_of_the_oracle(lgp, kw, flt, rng):
     assert np.max(np.abs(dKa.to_host() - fa)) <= tol * max(1.0, np.max(np.abs(fa)))
     assert np.max(np.abs(dKb.to_host() - fb)) <= tol * max(1.0, np.max(np.abs(fb)))
     assert np.all(np.diag(dKa.to_host()) == 0) and np.all(np.diag(dKb.to_host()) == 0)      # k(x, x) = const
+
+
+@pytest.mark.parametrize('maxd,reset', [(3, None), (4, None), (5, None), (5, [1]), (6, [3]), (4, [1])])
+@pytest.mark.parametrize('flt', [np.float64, np.float32])
+def test_bart_deep_recursion(lgp, maxd, reset, flt, rng):
+    """ recursion slices deeper than two levels (reference _kernels/_bart.py:759-806: explicit recursion over the splits that do not
+    separate the two points) on the device -- depth-first search with an explicit stack, the closed form of the last three
+    levels at the bottom -- against the oracle's restatement of the same lines, at the reference's own tolerance for shortcuts
+    against the full recursion (tests/kernels/test_bart.py:226-235: 32 ulp); Gram form and vectorised `correlation` """
+    p = 3
+    sb, sbw, sa = rng.integers(0, 3, (3, 12, p))
+    w = np.array([1., 2., 0.5])
+    kw = dict(alpha=flt(0.9), beta=flt(1.3), gamma=flt(0.7), maxd=maxd, reset=reset, weights=w.astype(flt))
+    c1 = lgp.BART.correlation(sb, sbw, sa, **kw)
+    c2 = oracle.BART.correlation(sb, sbw, sa, **kw)
+    assert c1.dtype == flt and c1.shape == (12,)
+    assert util.ulp_distance(c1, c2) <= 32, (c1, c2)
+    if maxd <= 4 and reset is None:       # ... and the recursion all the way down (debug=True of the reference), float64 oracle
+        c3 = oracle.BART.correlation(sb, sbw, sa, debug=True, **{**kw, 'alpha': 0.9, 'beta': 1.3, 'gamma': 0.7, 'weights': w})
+        util.assert_allclose(c1, c3, rtol=2e-5 if flt == np.float32 else 1e-13)
+    # Gram form from coordinates: a kernel object with deep slices
+    X = rng.integers(0, 4, (14, p)).astype(float)
+    splits = lgp.BART.splits_from_coord(X)
+    kd = lgp.BART(splits=splits, **kw)
+    ko = oracle.BART(splits=splits, **kw)
+    G = kd.gram(_struct(X[:6]), _struct(X[6:])).to_host()
+    R = ko(_struct(X[:6])[:, None], _struct(X[6:])[None, :])
+    assert G.dtype == flt and util.ulp_distance(G, R) <= 32
+    S = kd.gram(_struct(X), _struct(X)).to_host()
+    np.testing.assert_array_equal(np.diag(S), 1)
+    assert util.ulp_distance(S, S.T) <= 64
+    with pytest.raises(NotImplementedError):
+        kd.gram_jvp(_struct(X), _struct(X))
