@@ -92,9 +92,18 @@ int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *to
 #define LGP_KERNEL_MATERNP 1   /* _kernels/_matern.py:29-49 + _special/_bessel.py:101-110 (p)  */
 #define LGP_KERNEL_GAMMAEXP 2  /* _kernels/_basic.py:94-115   exp(-r2^(gamma/2)); hpar = {gamma, gamma/2}                              */
 #define LGP_KERNEL_CAUCHY 3    /* _kernels/_basic.py:315-344  (1 + r2^(alpha/2)/beta)^(-beta/alpha); hpar = {alpha, beta, -beta/alpha}  */
-#define LGP_KERNEL_EXPQUAD_DIFF 4 /* _Kernel/_ops.py:115-211 (`diff`) on ExpQuad, one-dimensional points (d = 1): p = a + b <= 4 the total
-                                   * order of d^a/dx^a d^b/dy^b; the core is He_p(u) exp(-u^2/2), u = (x - y)/scale; the factor
-                                   * (-1)^a / scale^p of the chain rule is an output operation of the caller                      */
+#define LGP_KERNEL_EXPQUAD_DIFF 4 /* _Kernel/_ops.py:115-211 (`diff`) on ExpQuad: along field f, a_f derivatives in x and b_f in y; hpar[f]
+                                   * = a_f + b_f <= 4 for each of the d <= 8 fields (npar = 0, d = 1: p is the order); the core is
+                                   * prod_f He_{hpar[f]}(u_f) exp(-|u|^2/2), u = (x - y)/scale; the factor prod_f (-1)^{a_f} / scale^order
+                                   * of the chain rule is an output operation of the caller                                       */
+#define LGP_KERNEL_MATERNP_DIFF 5 /* the same on Maternp (_kernels/_matern.py:29-49, derivable p times), one-dimensional points: the
+                                   * derivative of total order q of exp(-t) P_p(t), t = sqrt(2p+1) |u|, is (c sign u)^q exp(-t) Q_q(t);
+                                   * hpar = {q mod 2, the p + 1 coefficients of Q_q in ascending powers}; c^q and the chain-rule
+                                   * factors are an output operation of the caller                                                */
+#define LGP_KERNEL_WENDLAND 6     /* _kernels/_wendland.py:32-84 (1 - r)_+^(nu+k) poly(r), input='posabs'; p = k in [0, 3],
+                                   * hpar = {nu + k, the k + 1 coefficients of poly, highest power first}                         */
+#define LGP_KERNEL_CAUSALEXPQUAD 7 /* _kernels/_basic.py:346-360 erfc(alpha/4 r) exp(-r^2/2), input='posabs'; hpar = {alpha / 4}  */
+#define LGP_KERNEL_LOG 8          /* _kernels/_basic.py:381-392 log1p(r) / r, input='posabs'                                     */
 #define LGP_OP_MUL 0           /* kernel * c  (_Kernel/_alg.py:58-82)  */
 #define LGP_OP_ADD 1           /* kernel + c  (_Kernel/_alg.py:32-56)  */
 

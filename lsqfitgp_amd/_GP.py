@@ -227,17 +227,47 @@ class GP:
         if key in self._elements:
             raise KeyError(f'key {key!r} already in GP')
 
+    @staticmethod
+    def _field_orders(spec):
+        """ a derivative specification as the reference's ``Deriv`` reads it (``_Deriv.py:24-97``) -> 0, a positive integer (the
+        implicit variable) or a dictionary field name -> order: an integer; a field name; a sequence of names, an integer in
+        front of a name multiplying it (``['a', 2, 'b']``: once along a, twice along b) """
+        if spec is None:
+            return 0
+        if isinstance(spec, bool):
+            raise TypeError('argument must be None, int, str, or iterable')
+        if isinstance(spec, (int, numpy.integer)):
+            if spec < 0:
+                raise ValueError(f'degree {spec} is negative')
+            return int(spec)
+        if isinstance(spec, str):
+            return {spec: 1}
+        if not numpy.iterable(spec):
+            raise TypeError('argument must be None, int, str, or iterable')
+        out, times = {}, None
+        for obj in spec:
+            if isinstance(obj, str):
+                n = 1 if times is None else times
+                if n:
+                    out[obj] = out.get(obj, 0) + n
+                times = None
+            elif isinstance(obj, (int, numpy.integer)) and not isinstance(obj, bool):
+                if times is not None:
+                    raise ValueError('consecutive integers in iterable')
+                if obj < 0:
+                    raise ValueError(f'degree {obj} is negative')
+                times = int(obj)
+            else:
+                raise TypeError('objects in iterable must be int or str')
+        if times is not None:
+            raise ValueError('dangling derivative order')
+        return out or 0
+
     def addx(self, x, key=None, *, deriv=0, proc=DefaultProcess):
-        """ Add points where the Gaussian process is evaluated (``_elements.py:158-242``) """
-        # derivative of the process along the (single, implicit) variable: Deriv(int) of the reference (_Deriv.py:24-60); named
-        # variables of structured points are not available on the device path
-        if deriv is None or deriv == ():
-            deriv = 0
-        if isinstance(deriv, bool) or not isinstance(deriv, (int, numpy.integer)):
-            raise NotImplementedError('derivatives along named fields are out of scope of the device path: use an integer order')
-        if deriv < 0:
-            raise ValueError(f'negative derivative order {deriv}')
-        deriv = int(deriv)
+        """ Add points where the Gaussian process is evaluated (``_elements.py:158-242``).  ``deriv``: derivative of the process
+        taken at the points, an integer order along the variable of one-dimensional points or, for structured points, along
+        named fields (``'f0'``, ``(2, 'f0')``, ``('f0', 'f1')``: what ``Deriv`` of the reference accepts) """
+        deriv = self._field_orders(deriv)
         if proc != self.DefaultProcess:
             raise KeyError(f'process named {proc!r} not found')
         points, isdict = self._keyed(x, key, 'x')
@@ -256,9 +286,21 @@ class GP:
                     new._dtype = numpy.result_type(new._dtype, arr.dtype)
                 except TypeError:
                     raise TypeError('x[{!r}].dtype = {!r} not compatible with {!r}'.format(k, arr.dtype, new._dtype))
-            if deriv and arr.dtype.names is not None:
-                raise NotImplementedError('derivatives of structured points are out of scope of the device path')
-            new._elements[k] = _Points(arr, deriv)
+            orders = deriv
+            if isinstance(deriv, dict):
+                # orders along the leaf fields, in the order in which the kernels read them (`_kernels._leaf_columns`)
+                names = arr.dtype.names
+                if names is None:
+                    raise ValueError(f'derivative along named fields {sorted(deriv)} of points without fields')      # _ops.py:141-148
+                missing = [nm for nm in deriv if nm not in names]
+                if missing:
+                    raise ValueError(f'derivative along missing field {missing[0]!r}')
+                if any(arr.dtype[nm].shape or arr.dtype[nm].names for nm in names):
+                    raise NotImplementedError('derivatives along fields of points with array-valued or nested fields')
+                orders = tuple(deriv.get(nm, 0) for nm in names)
+            elif deriv and arr.dtype.names is not None:
+                raise ValueError('an integer derivative order needs points without fields: name the field')        # _ops.py:141-148
+            new._elements[k] = _Points(arr, orders)
         return new
 
     def addtransf(self, tensors, key, *, axes=1):
@@ -293,6 +335,61 @@ class GP:
             raise ValueError(f'can not broadcast tensors with shapes [{left}] contracted with arrays with shapes [{right}]')
         new = self._clone()
         new._elements[key] = _LinTransf(coeffs, list(coeffs), tuple(shape), axes)
+        return new
+
+    def addlintransf(self, transf, keys, key, *, checklin=None):
+        """
+        Define a finite linear transformation of the evaluated process by a function (``_elements.py:348-406``):
+        ``transf(array1, array2, ...) -> array`` takes one array per key of ``keys`` (with the shapes of those elements) and
+        must be linear in them.  The reference traces the function with jax and applies it to the covariance blocks; here it
+        is an ordinary function of numpy arrays, evaluated ONCE per basis vector on the host to obtain its coefficient tensors
+        (``_LinTransf.matrices``, ``:129-147``), which then act on the device blocks as those of `addtransf` do.
+        ``checklin`` (default: the GP's setting): verify on random inputs that the function is linear and not affine
+        (``RuntimeError`` otherwise, as the reference).
+        """
+        if key is None:
+            raise ValueError('key can not be None')
+        self._require_new(key)
+        keys = list(keys)
+        for k in keys:
+            if k not in self._elements:
+                raise KeyError(k)
+        if not keys:
+            raise ValueError('empty keys, undetermined output shape')
+        shapes = [self._elements[k].shape for k in keys]
+        zeros = [numpy.zeros(sh) for sh in shapes]
+        out0 = numpy.asarray(transf(*zeros), float)
+        shape = out0.shape
+        if checklin is None:
+            checklin = self._checklin
+        if checklin:
+            rng = numpy.random.default_rng(202310)
+            a = [rng.standard_normal(sh) for sh in shapes]
+            b = [rng.standard_normal(sh) for sh in shapes]
+            fa, fb = numpy.asarray(transf(*a), float), numpy.asarray(transf(*b), float)
+            fab = numpy.asarray(transf(*[2. * u - 3. * v for u, v in zip(a, b)]), float)
+            scale = max(float(numpy.max(numpy.abs(fa), initial=0.)), float(numpy.max(numpy.abs(fb), initial=0.)), 1.)
+            if numpy.any(out0 != 0) or not numpy.allclose(fab, 2. * fa - 3. * fb, rtol=1e-9, atol=1e-9 * scale):
+                raise RuntimeError('the transformation is not linear')                 # _elements.py:386-388
+        tensors, axes = {}, {}
+        for pos, (k, sh) in enumerate(zip(keys, shapes)):
+            size = math.prod(sh)
+            cols = numpy.empty((math.prod(shape), size))
+            args = [z.copy() for z in zeros]
+            flat = args[pos].reshape(-1)
+            for e in range(size):
+                flat[e] = 1.
+                cols[:, e] = numpy.asarray(transf(*args), float).reshape(-1)
+                flat[e] = 0.
+            if self._checkfinite and not numpy.all(numpy.isfinite(cols)):
+                raise ValueError(f'the transformation of {k!r} contains infs/nans')
+            if k in tensors:                     # the same element passed twice: its coefficients add up
+                tensors[k] = tensors[k] + cols.reshape(shape + sh)
+            else:
+                tensors[k] = cols.reshape(shape + sh)
+            axes[k] = len(sh)
+        new = self._clone()
+        new._elements[key] = _LinTransf(tensors, list(tensors), tuple(shape), axes)
         return new
 
     def addcov(self, covblocks, key=None, *, decomps=None):
@@ -388,7 +485,11 @@ class GP:
         if kernel is None:
             raise ValueError('no covariance function: GP(covfun) is required to add points')
         xf = x.x.reshape(-1)
-        kw = {'deriv': (x.deriv, y.deriv)} if (x.deriv or y.deriv) else {}       # kernel.linop('diff', x.deriv, y.deriv), :565
+        def orders(e, other):          # per-field orders on both sides when either names its fields
+            if isinstance(e.deriv, tuple) or not isinstance(other.deriv, tuple):
+                return e.deriv
+            return (0,) * len(other.deriv)
+        kw = {'deriv': (orders(x, y), orders(y, x))} if (x.deriv or y.deriv) else {}       # kernel.linop('diff', x.deriv, y.deriv), :565
         if x is y and not self._checksym and self._halfmatrix:
             # the reference evaluates the upper triangle as a flat vector and gathers (:567-573);
             # the device Gram kernels are exactly symmetric, so the full tile evaluation gives the same matrix
@@ -411,7 +512,7 @@ class GP:
                 cov, out = _astype_dev(cov, dt), _astype_dev(out, dt)
             if t.shape:
                 # tensordot(t, cov.reshape(elem.shape + (ysize,)), axes): (out.., contracted..) x (contracted.., rest.., ysize)
-                axes = x.axes
+                axes = x.axes[k] if isinstance(x.axes, dict) else x.axes
                 csize = math.prod(elem.shape[:axes])
                 rest = math.prod(elem.shape[axes:])
                 osize = math.prod(t.shape[:t.ndim - axes])

@@ -207,48 +207,91 @@ class _Isotropic(Kernel):
         yd = xd if same else DeviceArray.from_host(numpy.stack([numpy.asarray(c, dtype) for c in yc]), ctx=ctx)
         return xd, yd, dtype, ctx, len(xc)
 
+    @staticmethod
+    def _orders(spec, d):
+        """ a derivative specification of one side -> orders along the d leaf fields: an integer (the implicit variable of
+        one-dimensional points) or a sequence of d integers """
+        if isinstance(spec, (int, numpy.integer)):
+            if spec and d != 1:
+                raise NotImplementedError('an integer derivative order refers to the one variable of one-dimensional points; name the fields')
+            orders = (int(spec),) + (0,) * (d - 1)
+        else:
+            orders = tuple(int(v) for v in spec)
+            if len(orders) != d:
+                raise ValueError(f'{len(orders)} derivative orders for {d} fields')
+        if any(o < 0 for o in orders):
+            raise ValueError(f'negative derivative order {spec!r}')
+        return orders
+
     def _diff_call(self, deriv, d):
-        """ (kernel id, order, output operations) of the derived kernel ``kernel.linop('diff', a, b)`` (``_Kernel/_ops.py:115-211``,
-        implicit variable: the points are plain one-dimensional arrays), available in closed form for `ExpQuad`:
-        d^a/dx^a d^b/dy^b exp(-u²/2), u = (x - y)/scale, is (-1)^a / scale^(a+b) He_{a+b}(u) exp(-u²/2).  Scalar factors of
-        the kernel multiply the derivative, added constants drop out of it. """
-        a, b = (int(v) for v in deriv)
-        if a < 0 or b < 0:
-            raise ValueError(f'negative derivative order {deriv!r}')
-        if a == 0 and b == 0:
-            return self._kind, int(self._p), self._outops
-        if self._kind != _lib.LGP_KERNEL_EXPQUAD:
-            raise NotImplementedError('derivatives of the kernel are available in closed form for ExpQuad only')
-        if d != 1:
-            raise NotImplementedError('derivatives are taken along the one variable of one-dimensional points')
-        if a + b > 4:
-            raise NotImplementedError('total derivative order above 4')
-        factor = (-1.) ** a / float(self._scale if self._scale is not None else 1.) ** (a + b)
+        """
+        ``(kernel id, p, real parameters, output operations)`` of the derived kernel ``kernel.linop('diff', dx, dy)``
+        (``_Kernel/_ops.py:115-211``): the process derived ``dx`` times at the first argument and ``dy`` times at the second,
+        each an order per leaf field (an integer: the implicit variable of one-dimensional points).  In closed form for
+
+        * `ExpQuad`, any fields: with u = (x - y)/scale field by field, along field f
+          d^a/dx^a d^b/dy^b exp(-|u|²/2) = (-1)^a / scale^(a+b) He_{a+b}(u_f) exp(-|u|²/2)  (total order at most 4 per field);
+        * `Maternp` (p times derivable on each side, ``_kernels/_matern.py:26-49``), one-dimensional points: K(u) = exp(-t) P(t),
+          t = c |u|, c = sqrt(2p+1), has K^(q)(u) = (c sign u)^q exp(-t) Q_q(t) with Q_0 = P, Q_{q+1} = Q_q' - Q_q, so
+          d^a/dx^a d^b/dy^b k = (-1)^b (c / scale)^(a+b) sign(u)^(a+b) exp(-t) Q_{a+b}(t).
+
+        Scalar factors of the kernel multiply the derivative, added constants drop out of it.
+        """
+        da, db = self._orders(deriv[0], d), self._orders(deriv[1], d)
+        if not any(da) and not any(db):
+            return self._kind, int(self._p), self._par, self._outops
+        scale = float(self._scale if self._scale is not None else 1.)
+        factor = 1.
         for op, c in self._outops:
             if op == 'mul':
                 factor = factor * c
-        return _lib.LGP_KERNEL_EXPQUAD_DIFF, a + b, (('mul', factor),)
+        if self._kind == _lib.LGP_KERNEL_EXPQUAD:
+            if d > 8:
+                raise NotImplementedError('derivatives of points with more than 8 fields')
+            total = [a + b for a, b in zip(da, db)]
+            if max(total) > 4:
+                raise NotImplementedError('total derivative order above 4 along one field')
+            factor = factor * (-1.) ** sum(da) / scale ** sum(total)
+            return _lib.LGP_KERNEL_EXPQUAD_DIFF, sum(total), tuple(float(t) for t in total), (('mul', factor),)
+        if self._kind == _lib.LGP_KERNEL_MATERNP:
+            p = int(self._p)
+            a, b = da[0], db[0]
+            if d != 1:
+                raise NotImplementedError('derivatives of Maternp are taken along the one variable of one-dimensional points')
+            if a > p or b > p:
+                raise ValueError(f'Maternp(p={p}) is derivable {p} times on each side, asked for {(a, b)}')      # _Kernel/_ops.py:156-165
+            if p >= 16:
+                raise NotImplementedError('Maternp derivatives for p < 16')
+            P = numpy.polynomial.Polynomial([1.])
+            t = numpy.polynomial.Polynomial([0., 1.])
+            for k in reversed(range(p)):                           # the Horner recurrence of _special/_bessel.py:106-109 as a polynomial
+                P = 1 + P * ((p - k) / ((2 * p - k) * (k + 1)) * 2) * t
+            Q = P
+            for _ in range(a + b):
+                Q = Q.deriv() - Q
+            coef = numpy.zeros(p + 1)
+            coef[:len(Q.coef)] = Q.coef
+            c = numpy.sqrt(2 * p + 1)
+            factor = factor * (-1.) ** b * (c / scale) ** (a + b)
+            return _lib.LGP_KERNEL_MATERNP_DIFF, p, (float((a + b) % 2),) + tuple(float(v) for v in coef), (('mul', factor),)
+        raise NotImplementedError('derivatives of the kernel are available in closed form for ExpQuad and Maternp only')
 
     def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
-        """ device Gram matrix of two flat point sets; ``deriv=(a, b)``: of the kernel derived a times in x, b times in y """
+        """ device Gram matrix of two flat point sets; ``deriv=(dx, dy)``: of the kernel derived in x and in y (`_diff_call`) """
         xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
         n, m = xd.shape[1], yd.shape[1]
         if out is None:
             out = DeviceArray.empty((n, m), dtype, ctx)
         assert out.shape == (n, m) and out.dtype == dtype
-        kind, order, outops = self._diff_call(deriv, d)
+        kind, order, par, outops = self._diff_call(deriv, d)
         if n == 0 or m == 0:
             return out
         f, F = _lib.fn('lgp_gram_isotropic', dtype)
         nops, codes, vals = _ops_arrays(outops, F)
-        if kind != self._kind:
-            _lib.check(f(ctx.handle, kind, order, 0, None, d, xd.ptr, xd.ld, n, yd.ptr, yd.ld, m,
-                         int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
-                         nops, codes, vals, 0, out.ptr, out.ld), 'lgp_gram_isotropic')
-            return out
-        _lib.check(f(ctx.handle, self._kind, int(self._p), *self._par_args(F), d, xd.ptr, xd.ld, n, yd.ptr, yd.ld, m,
+        npar, hpar = (len(par), (F * len(par))(*par)) if par else (0, None)
+        _lib.check(f(ctx.handle, kind, order, npar, hpar, d, xd.ptr, xd.ld, n, yd.ptr, yd.ld, m,
                      int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
-                     nops, codes, vals, int(xd is yd), out.ptr, out.ld), 'lgp_gram_isotropic')
+                     nops, codes, vals, int(xd is yd and kind == self._kind), out.ptr, out.ld), 'lgp_gram_isotropic')
         return out
 
     def gram_dscale(self, xs, ys, *, ctx=None):
@@ -329,6 +372,47 @@ class Cauchy(_Isotropic):
         super().__init__(scale=scale, loc=loc)
         self._alpha, self._beta = alpha, beta
         self._par = (float(alpha), float(beta), float(-beta / alpha))
+
+
+class Wendland(_Isotropic):
+    """ Wendland kernel, (1 - r)_+^(nu + k) poly_k(r) with nu = k + alpha: compact support r < 1, k in {0, 1, 2, 3} sets the
+    differentiability, usable up to floor(2 alpha - 1) dimensions (``_kernels/_wendland.py:26-84``); input='posabs' """
+    _kind = _lib.LGP_KERNEL_WENDLAND
+    _POLY = {0: [[1]], 1: [[1, 1], [1]], 2: [[1 / 3, 4 / 3, 1], [1, 2], [1]], 3: [[1 / 15, 3 / 5, 23 / 15, 1], [2 / 5, 12 / 5, 3], [1, 3], [1]]}
+
+    def __init__(self, *, k=0, alpha=1, scale=None, loc=None):
+        if k not in self._POLY:
+            raise NotImplementedError(k)                              # _wendland.py:77-78
+        self._maxdim = int(numpy.floor(2 * alpha - 1))               # :29-31
+        assert self._maxdim >= 1, self._maxdim
+        super().__init__(scale=scale, loc=loc)
+        nu = k + alpha
+        self._p = int(k)
+        self._par = (float(nu + k),) + tuple(float(numpy.polyval(pj, nu)) for pj in self._POLY[k])
+
+    def _prepare(self, xs, ys, ctx):
+        out = super()._prepare(xs, ys, ctx)
+        if out[4] > self._maxdim:
+            raise ValueError(f'kernel called on type with dimensionality {out[4]} > maxdim={self._maxdim}')   # _crosskernel.py maxdim check
+        return out
+
+
+class CausalExpQuad(_Isotropic):
+    """ Causal exponential quadratic kernel, k(r) = erfc(alpha r / 4) exp(-r²/2), alpha >= 0 (``_kernels/_basic.py:346-360``) """
+    _kind = _lib.LGP_KERNEL_CAUSALEXPQUAD
+
+    def __init__(self, *, alpha=1, scale=None, loc=None):
+        assert alpha >= 0, alpha
+        super().__init__(scale=scale, loc=loc)
+        self._par = (float(alpha / 4),)
+
+
+class Log(_Isotropic):
+    """ Log kernel, k(r) = log(1 + r) / r (``_kernels/_basic.py:381-392``) """
+    _kind = _lib.LGP_KERNEL_LOG
+
+    def __init__(self, *, scale=None, loc=None):
+        super().__init__(scale=scale, loc=loc)
 
 
 # ------------------------------------------------------------------------------

@@ -28,6 +28,10 @@ LGP_KERNEL_MATERNP = 1
 LGP_KERNEL_GAMMAEXP = 2
 LGP_KERNEL_CAUCHY = 3
 LGP_KERNEL_EXPQUAD_DIFF = 4
+LGP_KERNEL_MATERNP_DIFF = 5
+LGP_KERNEL_WENDLAND = 6
+LGP_KERNEL_CAUSALEXPQUAD = 7
+LGP_KERNEL_LOG = 8
 LGP_OP_MUL = 0
 LGP_OP_ADD = 1
 LGP_EPS_AUTO_REL = 1

@@ -54,7 +54,10 @@ struct IsoArgs {
   T coef[MAX_P];   // Horner coefficients c_{k+1}/c_k, k = p-1..0 in evaluation order
   T twop1;         // 2p+1
   T par[3];        // GammaExp: gamma, gamma/2;  Cauchy: alpha/2, beta, -beta/alpha  (host-evaluated like the reference's Python floats)
-  int flag;        // GammaExp: gamma == 2;  Cauchy: alpha == 2  (the branches that act on r2 itself)
+                   // Wendland: nu + k;  CausalExpQuad: alpha / 4
+  int flag;        // GammaExp: gamma == 2;  Cauchy: alpha == 2  (the branches that act on r2 itself);  MaternpDiff: odd total order
+  int posabs;      // input='posabs' of the reference (_Kernel/_isotropic.py:67-78): per field (|x - y| + eps)^2, the core takes the root
+  int dord[8];     // ExpQuadDiff: total derivative order (x side + y side) along each of the first 8 fields
   OutOps<T> ops;
 };
 
@@ -68,16 +71,31 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
   if (g.kernel == LGP_KERNEL_EXPQUAD) {
     return exp(T(-0.5) * r2);
   } else if (g.kernel == LGP_KERNEL_EXPQUAD_DIFF) {
-    // mixed derivative of order p = a + b of exp(-u^2 / 2) in one dimension, u = d0: d^a/dx^a d^b/dy^b = (-1)^a He_p(u) exp(-u^2/2)
-    // (probabilists' Hermite polynomial; the sign and the 1 / scale^p of the chain rule are an output operation of the caller).
+    // mixed derivative of exp(-|u|^2 / 2), u = x - y field by field: along field f, a_f times in x and b_f times in y, it is
+    // prod_f (-1)^{a_f} He_{a_f + b_f}(u_f) exp(-|u|^2 / 2) (probabilists' Hermite polynomials; the signs and the 1 / scale^order
+    // of the chain rule are an output operation of the caller).  d0 arrives as the product of the Hermite factors (iso_aux).
     // What jax's elementwise_grad of the core gives for _Kernel/_ops.py:115-211 (`diff`) on ExpQuad, _kernels/_basic.py:75.
-    const T u = d0, u2 = u * u;
-    T he = T(1);
-    if (g.p == 1) he = u;
-    else if (g.p == 2) he = u2 - T(1);
-    else if (g.p == 3) he = u * (u2 - T(3));
-    else if (g.p == 4) he = u2 * (u2 - T(6)) + T(3);
-    return he * exp(T(-0.5) * r2);
+    return d0 * exp(T(-0.5) * r2);
+  } else if (g.kernel == LGP_KERNEL_MATERNP_DIFF) {
+    // derivative of total order q of K(u) = exp(-t) P_p(t), t = sqrt((2p+1) u^2 + 1e-30), in one dimension (d0 = u):
+    // K^(q)(u) = (c sign u)^q exp(-t) Q_q(t), Q_0 = P_p, Q_{q+1} = Q_q' - Q_q; the coefficients of Q_q (degree g.p, ascending)
+    // come from the host, c^q and the chain-rule factors are an output operation of the caller; flag: q odd
+    const T t = sqrt(g.twop1 * r2 + T(1e-30));
+    T poly = g.coef[g.p];
+    for (int k = g.p - 1; k >= 0; --k) poly = poly * t + g.coef[k];
+    const T v = exp(-t) * poly;
+    return g.flag ? (d0 > T(0) ? v : (d0 < T(0) ? -v : T(0))) : v;
+  } else if (g.kernel == LGP_KERNEL_WENDLAND) {          // _kernels/_wendland.py:32-84: (1 - r)_+^(nu + k) poly(r), r < 1
+    const T r = sqrt(r2);
+    T poly = g.coef[0];
+    for (int k = 1; k <= g.p; ++k) poly = poly * r + g.coef[k];     // polyval: highest power first
+    return r < T(1) ? pow(T(1) - r, g.par[0]) * poly : T(0);
+  } else if (g.kernel == LGP_KERNEL_CAUSALEXPQUAD) {     // _kernels/_basic.py:346-360: erfc(alpha / 4 r) exp(-1/2 r^2)
+    const T r = sqrt(r2);
+    return erfc(g.par[0] * r) * exp(T(-0.5) * (r * r));
+  } else if (g.kernel == LGP_KERNEL_LOG) {               // _kernels/_basic.py:381-392: log1p(r) / r
+    const T r = sqrt(r2);
+    return log1p(r) / r;
   } else if (g.kernel == LGP_KERNEL_GAMMAEXP) {          // _kernels/_basic.py:111-113
     return g.flag ? exp(-r2) : exp(-pow(r2, g.par[1]));
   } else if (g.kernel == LGP_KERNEL_CAUCHY) {            // _kernels/_basic.py:340-344
@@ -90,6 +108,32 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
     for (int k = 0; k < g.p; ++k) poly = T(1) + poly * g.coef[k] * T(2) * x;
     return exp(-x) * poly;
   }
+}
+
+// what the derivative cores need beside r2: ExpQuadDiff the product over the fields of the Hermite factors He_{order_f}(u_f),
+// MaternpDiff (one field) the signed difference itself
+template <typename T>
+__device__ __forceinline__ T iso_aux(const IsoArgs<T> &g, int f, T df, T aux) {
+  if (g.kernel == LGP_KERNEL_EXPQUAD_DIFF) {
+    const int o = f < 8 ? g.dord[f] : 0;
+    const T u2 = df * df;
+    T he = T(1);
+    if (o == 1) he = df;
+    else if (o == 2) he = u2 - T(1);
+    else if (o == 3) he = df * (u2 - T(3));
+    else if (o == 4) he = u2 * (u2 - T(6)) + T(3);
+    return (f == 0 ? T(1) : aux) * he;
+  }
+  return f == 0 ? df : aux;
+}
+// the per-field term of r2: the squared difference, or (|difference| + eps)^2 for input='posabs'
+template <typename T>
+__device__ __forceinline__ T iso_sq(const IsoArgs<T> &g, T df) {
+  if (g.posabs) {
+    const T a = fabs(df) + (sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-07f));
+    return a * a;
+  }
+  return df * df;
 }
 
 // Compile-time selection of the core for the kernels that evaluate n x m pairs: CORE_GENERIC keeps the run-time branches of
@@ -214,16 +258,16 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
 #pragma unroll
         for (int f = 0; f < D; ++f) {
           const T df = su[f * GT_ROWS + r] - vreg[f][e];
-          const T sq = df * df;
+          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df) : df * df;
           r2 = (f == 0) ? sq : r2 + sq;
-          if (f == 0) d0 = df;
+          if (CORE == CORE_GENERIC) d0 = iso_aux<T>(g, f, df, d0);
         }
       } else {
         for (int f = 0; f < d; ++f) {
           const T df = su[f * GT_ROWS + r] - sv[f * GT_COLS + c0 + e];
-          const T sq = df * df;
+          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df) : df * df;
           r2 = (f == 0) ? sq : r2 + sq;
-          if (f == 0) d0 = df;
+          if (CORE == CORE_GENERIC) d0 = iso_aux<T>(g, f, df, d0);
         }
       }
       if (GRAD) {
@@ -269,9 +313,9 @@ __global__ void __launch_bounds__(256) gram_iso_pairs_kernel(const IsoArgs<T> g)
     if (g.has_loc) { u = u - g.loc; v = v - g.loc; }
     if (g.has_scale) { u = u / g.scale; v = v / g.scale; }
     const T df = u - v;
-    const T sq = df * df;
+    const T sq = iso_sq<T>(g, df);
     r2 = (f == 0) ? sq : r2 + sq;
-    if (f == 0) d0 = df;
+    d0 = iso_aux<T>(g, f, df, d0);
   }
   g.out[i] = g.ops.apply(iso_core<T>(g, r2, d0));
 }
@@ -284,13 +328,16 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_MATERNP || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY ||
-                  kernel == LGP_KERNEL_EXPQUAD_DIFF,
-              "unknown isotropic kernel");
+  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_LOG, "unknown isotropic kernel");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
   LGP_REQUIRE(p >= 0 && p <= MAX_P, "Maternp order must be in [0,16]");
-  LGP_REQUIRE(kernel != LGP_KERNEL_EXPQUAD_DIFF || (d == 1 && p <= 4 && ddsc == nullptr),
-              "the derivative kernel is for one-dimensional points, total order at most 4, without the scale tangent");
+  const bool derived = kernel == LGP_KERNEL_EXPQUAD_DIFF || kernel == LGP_KERNEL_MATERNP_DIFF;
+  const bool posabs = kernel == LGP_KERNEL_WENDLAND || kernel == LGP_KERNEL_CAUSALEXPQUAD || kernel == LGP_KERNEL_LOG;
+  LGP_REQUIRE(!(derived || posabs) || ddsc == nullptr, "no scale tangent for this kernel");
+  LGP_REQUIRE(kernel != LGP_KERNEL_EXPQUAD_DIFF || (d <= 8 && ((npar == 0 && d == 1 && p <= 4) || (npar == d && hpar != nullptr))),
+              "ExpQuadDiff: at most 8 fields, hpar = the total derivative order along each field (at most 4 each)");
+  LGP_REQUIRE(kernel != LGP_KERNEL_MATERNP_DIFF || (d == 1 && p >= 1 && p < MAX_P && npar == p + 2 && hpar != nullptr),
+              "MaternpDiff: one-dimensional points, hpar = {parity of the order, the p + 1 coefficients of Q}");
   LGP_REQUIRE(nops >= 0 && nops <= MAX_OPS, "at most 8 output operations");
   LGP_REQUIRE(n < (1u << 30) && m < (1u << 30), "too many points");
   LGP_REQUIRE(ldx >= n && ldy >= m && ldo >= m, "leading dimension too small");
@@ -311,7 +358,27 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.twop1 = (T)(2 * p + 1);
   g.par[0] = g.par[1] = g.par[2] = T(0);
   g.flag = 0;
-  if (kernel == LGP_KERNEL_GAMMAEXP) {            // hpar = {gamma, gamma / 2}
+  g.posabs = posabs ? 1 : 0;
+  for (int f = 0; f < 8; ++f) g.dord[f] = 0;
+  if (kernel == LGP_KERNEL_EXPQUAD_DIFF) {
+    if (npar == 0) g.dord[0] = p;
+    for (int f = 0; f < npar; ++f) {
+      LGP_REQUIRE(hpar[f] >= T(0) && hpar[f] <= T(4) && hpar[f] == T((int)hpar[f]), "derivative orders must be integers in [0, 4]");
+      g.dord[f] = (int)hpar[f];
+    }
+  } else if (kernel == LGP_KERNEL_MATERNP_DIFF) {
+    g.flag = hpar[0] != T(0);
+    for (int k = 0; k <= p; ++k) g.coef[k] = hpar[1 + k];
+  } else if (kernel == LGP_KERNEL_WENDLAND) {     // hpar = {nu + k, the k + 1 coefficients of the polynomial in r, highest power first}
+    LGP_REQUIRE(p <= 3 && npar == p + 2 && hpar != nullptr && hpar[0] >= T(1), "Wendland takes k in [0, 3], {nu + k, k + 1 coefficients}");
+    g.par[0] = hpar[0];
+    for (int k = 0; k <= p; ++k) g.coef[k] = hpar[1 + k];
+  } else if (kernel == LGP_KERNEL_CAUSALEXPQUAD) {   // hpar = {alpha / 4}
+    LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0), "CausalExpQuad takes {alpha / 4}, alpha >= 0");
+    g.par[0] = hpar[0];
+  } else if (kernel == LGP_KERNEL_LOG) {
+    LGP_REQUIRE(npar == 0, "this kernel takes no real parameters");
+  } else if (kernel == LGP_KERNEL_GAMMAEXP) {            // hpar = {gamma, gamma / 2}
     LGP_REQUIRE(npar == 2 && hpar != nullptr, "GammaExp takes {gamma, gamma/2}");
     LGP_REQUIRE(hpar[0] > T(0) && hpar[0] <= T(2), "gamma must be in (0, 2]");                 // _basic.py:109-110
     g.par[0] = hpar[0]; g.par[1] = hpar[1];
@@ -499,13 +566,13 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
 #pragma unroll
         for (int f = 0; f < D; ++f) {
           const T df = su[f * GR_ROWS + r] - vreg[f][e];
-          const T sq = df * df;
+          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df) : df * df;
           r2 = (f == 0) ? sq : r2 + sq;
         }
       } else {
         for (int f = 0; f < d; ++f) {
           const T df = su[f * GR_ROWS + r] - sv[f * GT_COLS + c0 + e];
-          const T sq = df * df;
+          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df) : df * df;
           r2 = (f == 0) ? sq : r2 + sq;
         }
       }
@@ -568,6 +635,8 @@ int gram_reg_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   int pos = 0;
   for (int k = p - 1; k >= 0; --k) g.coef[pos++] = (T)((double)(p - k) / ((double)(2 * p - k) * (double)(k + 1)));
   g.twop1 = (T)(2 * p + 1);
+  g.posabs = 0;
+  for (int f = 0; f < 8; ++f) g.dord[f] = 0;
   g.par[0] = g.par[1] = g.par[2] = T(0);
   g.flag = 0;
   if (kernel == LGP_KERNEL_GAMMAEXP) {

@@ -81,9 +81,36 @@ class GP:
 
     # ---- elements ------------------------------------------------------
 
+    @staticmethod
+    def _deriv(spec):
+        """ ``_Deriv.py:60-97``: None | int | str | iterable of str with int multipliers -> 0, int or {field: order} """
+        import collections
+        c = collections.Counter()
+        if spec is None:
+            return 0
+        if isinstance(spec, (int, numpy.integer)):
+            assert spec >= 0
+            return int(spec)
+        if isinstance(spec, str):
+            return {spec: 1}
+        integer = None
+        for obj in spec:
+            if isinstance(obj, str):
+                if integer is not None:
+                    if integer:
+                        c.update({obj: integer})
+                    integer = None
+                else:
+                    c.update([obj])
+            else:
+                assert integer is None and obj >= 0
+                integer = int(obj)
+        assert integer is None
+        return dict(c) or 0
+
     def addx(self, x, key=None, *, deriv=0):
-        """ ``_elements.py:158-242`` (default process only; `deriv`: integer order along the implicit variable) """
-        deriv = 0 if deriv is None else int(deriv)
+        """ ``_elements.py:158-242`` (default process only; `deriv` as ``Deriv`` reads it, ``_Deriv.py``) """
+        deriv = self._deriv(deriv)
         self = self._clone()
         if hasattr(x, 'keys'):
             if key is not None:
@@ -127,6 +154,33 @@ class GP:
         ]
         shape = numpy.broadcast_shapes(*shapes)
         self._elements[key] = _LinTransf(tens, list(tens.keys()), shape, axes)
+        return self
+
+    def addlintransf(self, transf, keys, key, *, checklin=None):
+        """ ``_elements.py:348-406``; the coefficient matrices as ``_LinTransf.matrices`` (``:129-147``): the function applied to
+        the basis vectors of one input with the others at zero """
+        self = self._clone()
+        if key is None:
+            raise ValueError('key can not be None')
+        if key in self._elements:
+            raise KeyError(f'key {key!r} already in GP')
+        for k in keys:
+            if k not in self._elements:
+                raise KeyError(k)
+        elems = [self._elements[k] for k in keys]
+        shape = numpy.asarray(transf(*[numpy.zeros(e.shape) for e in elems])).shape
+        tens, axes = {}, {}
+        for i, (k, elem) in enumerate(zip(keys, elems)):
+            rows = []
+            for e in range(elem.size):
+                inputs = [numpy.zeros(ej.shape) for ej in elems]
+                inputs[i].reshape(-1)[e] = 1
+                rows.append(numpy.asarray(transf(*inputs), float).reshape(-1))
+            M = numpy.array(rows).reshape(elem.size, -1).T if rows else numpy.zeros((int(numpy.prod(shape, dtype=int)), 0))
+            t = M.reshape(tuple(shape) + elem.shape)
+            tens[k] = tens[k] + t if k in tens else t
+            axes[k] = len(elem.shape)
+        self._elements[key] = _LinTransf(tens, list(tens.keys()), tuple(shape), axes)
         return self
 
     def addcov(self, covblocks, key=None):
@@ -232,7 +286,7 @@ class GP:
             cov = cov.reshape(elem.shape + (y.size,))
             t = x.tensors[k]
             if t.shape:
-                b = numpy.tensordot(t, cov, x.axes)
+                b = numpy.tensordot(t, cov, x.axes[k] if isinstance(x.axes, dict) else x.axes)
             else:
                 b = t * cov
             out = b if out is None else out + b

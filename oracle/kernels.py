@@ -99,31 +99,78 @@ class Kernel:
         return result
 
     def diff(self, xderiv, yderiv):
-        """ ``_Kernel/_ops.py:115-211`` (`diff`, implicit variable: plain one-dimensional points).  The reference
-        differentiates the transformed core with jax (``elementwise_grad``); here the derivative is written out, for the one
-        core that has a closed form at every order, ExpQuad (``_kernels/_basic.py:75``):
-        d^a/dx^a d^b/dy^b exp(-u²/2), u = (x - y)/scale, is (-1)^a / scale^(a+b) He_{a+b}(u) exp(-u²/2) with the
-        probabilists' Hermite polynomials; scalar factors of the kernel multiply it, added constants drop out. """
-        a, b = int(xderiv), int(yderiv)
-        assert a >= 0 and b >= 0
-        if a == 0 and b == 0:
+        """ ``_Kernel/_ops.py:115-211`` (`diff`): the kernel derived ``xderiv`` times in its first argument and ``yderiv`` times in
+        its second; each an integer (the implicit variable of plain one-dimensional points) or a dictionary field -> order.  The
+        reference differentiates the transformed core with jax (``elementwise_grad``); here the derivatives are written out for
+        the two cores that have them in closed form:
+
+        * ExpQuad (``_kernels/_basic.py:75``), any fields: along field f, d^a/dx^a d^b/dy^b exp(-|u|²/2), u = (x - y)/scale, is
+          (-1)^a / scale^(a+b) He_{a+b}(u_f) exp(-|u|²/2) (probabilists' Hermite polynomials), the fields multiply;
+        * Maternp (``_kernels/_matern.py:46-49``, derivable p times per side ``:26-27``), implicit variable: with t = c |u|,
+          c = sqrt(2p+1), K(u) = g(t), g = exp(-t) P_p: d^a/dx^a d^b/dy^b k = (-1)^b (c sign(u) / scale)^(a+b) g^(a+b)(t), and by
+          Leibniz g^(q) = exp(-t) sum_j C(q, j) (-1)^(q-j) P^(j).
+
+        Scalar factors of the kernel multiply the derivative, added constants drop out. """
+        def norm(dv):
+            if isinstance(dv, dict):
+                return {k: int(v) for k, v in dv.items() if v}
+            return {None: int(dv)} if int(dv) else {}
+        da, db = norm(xderiv), norm(yderiv)
+        assert all(v >= 0 for v in list(da.values()) + list(db.values()))
+        if not da and not db:
             return self
-        if getattr(self._core, 'hermite', None) is None:
-            raise NotImplementedError('derivatives in closed form for ExpQuad only')
+        kind = getattr(self._core, 'closed_form', None)
+        if kind is None:
+            raise NotImplementedError('derivatives in closed form for ExpQuad and Maternp only')
         scale = 1. if self._scale is None else self._scale
-        factor = (-1.) ** a / scale ** (a + b)
+        factor = 1.
         for op, c in self._outops:
             if op == 'mul':
                 factor = factor * c
-        order = a + b
+        fields = sorted(set(da) | set(db), key=lambda k: (k is not None, k))
+        order = sum(da.values()) + sum(db.values())
+        if kind == 'expquad':
+            factor = factor * (-1.) ** sum(da.values()) / scale ** order
+
+            def core(x, y):
+                x = numpy.asarray(x); y = numpy.asarray(y)
+                if fields == [None]:
+                    assert x.dtype.names is None and y.dtype.names is None, 'derivative along the implicit variable of plain arrays'
+                    u = {None: numpy.asarray(x, float) - numpy.asarray(y, float)}
+                    r2 = numpy.square(u[None])
+                else:
+                    assert x.dtype.names is not None and all(f in x.dtype.names for f in fields), 'derivative along missing field'
+                    u = {f: x[f] - y[f] for f in fields}
+                    r2 = sum_recurse_dtype(lambda a, b: numpy.square(a - b), x, y)
+                he = 1.
+                for f in fields:
+                    q = da.get(f, 0) + db.get(f, 0)
+                    he = he * numpy.polynomial.hermite_e.hermeval(u[f], [0] * q + [1])
+                return he * numpy.exp(-1/2 * r2)
+            return Kernel(core, scale=self._scale, loc=self._loc, outops=(('mul', factor),))
+        # Maternp
+        p = self._core.p
+        assert fields == [None], 'Maternp derivatives along the implicit variable of plain arrays'
+        a, b = da.get(None, 0), db.get(None, 0)
+        if a > p or b > p:
+            raise ValueError(f'Maternp(p={p}) is derivable {p} times on each side')
+        q = a + b
+        cc = numpy.sqrt(2 * p + 1)
+        factor = factor * (-1.) ** b * (cc / scale) ** q
+        # coefficients of P_p, highest power first (numpy.polyder's convention), from the Horner recurrence of _bessel.py:106-109
+        P = numpy.array([1.])
+        for k in reversed(range(p)):
+            ck = (p - k) / ((2 * p - k) * (k + 1)) * 2
+            P = numpy.polyadd(numpy.polymul(P, [ck, 0.]), [1.])
+        terms = [special.comb(q, j) * (-1.) ** (q - j) * (numpy.polyder(P, j) if j else P) for j in range(q + 1)]
 
         def core(x, y):
-            x = numpy.asarray(x, float)
-            y = numpy.asarray(y, float)
-            assert x.dtype.names is None and y.dtype.names is None, 'derivative along the implicit variable of plain arrays'
+            x = numpy.asarray(x, float); y = numpy.asarray(y, float)
+            assert x.dtype.names is None and y.dtype.names is None
             u = x - y
-            he = numpy.polynomial.hermite_e.hermeval(u, [0] * order + [1])
-            return he * numpy.exp(-1/2 * numpy.square(u))
+            t = numpy.sqrt((2 * p + 1) * numpy.square(u) + 1e-30)
+            g = sum(numpy.polyval(term, t) for term in terms) * numpy.exp(-t)
+            return numpy.sign(u) ** q * g if q % 2 else g
         return Kernel(core, scale=self._scale, loc=self._loc, outops=(('mul', factor),))
 
     def _with(self, op, c):
@@ -190,7 +237,7 @@ def cauchy_core(r2, alpha=2, beta=2):
 
 def ExpQuad(*, scale=None, loc=None):
     core = _isotropic(expquad_core)
-    core.hermite = True          # Kernel.diff has its derivatives in closed form
+    core.closed_form = 'expquad'          # Kernel.diff has its derivatives in closed form
     return Kernel(core, scale=scale, loc=loc)
 
 
@@ -204,7 +251,48 @@ def Cauchy(*, alpha=2, beta=2, scale=None, loc=None):
 
 def Maternp(*, p=None, scale=None, loc=None):
     p = int(p)
-    return Kernel(_isotropic(lambda r2: maternp_core(r2, p)), scale=scale, loc=loc)
+    core = _isotropic(lambda r2: maternp_core(r2, p))
+    core.closed_form = 'maternp'
+    core.p = p
+    return Kernel(core, scale=scale, loc=loc)
+
+
+def _isotropic_posabs(core):
+    """ ``_isotropic.py:61-81`` with input='posabs': per field (|x - y| + eps)^2 (``_stationary.py:84-85`` _softabs), summed, the
+    core takes the square root """
+    def newcore(x, y):
+        def dist(a, b):
+            d = numpy.abs(a - b)
+            return numpy.square(d + numpy.finfo(d.dtype if numpy.issubdtype(d.dtype, numpy.floating) else float).eps)
+        return core(numpy.sqrt(sum_recurse_dtype(dist, x, y)))
+    return newcore
+
+
+_WENDLAND_POLY = {0: [[1]], 1: [[1, 1], [1]], 2: [[1/3, 4/3, 1], [1, 2], [1]], 3: [[1/15, 3/5, 23/15, 1], [2/5, 12/5, 3], [1, 3], [1]]}
+
+
+def Wendland(*, k=0, alpha=1, scale=None, loc=None):
+    """ ``_kernels/_wendland.py:32-84`` """
+    assert int(numpy.floor(2 * alpha - 1)) >= 1
+    nu = k + alpha
+    coeffs = numpy.array([numpy.polyval(numpy.array(pj), nu) for pj in _WENDLAND_POLY[k]])
+
+    def core(r):
+        poly = numpy.polyval(coeffs, r)
+        with numpy.errstate(invalid='ignore'):
+            return numpy.where(r < 1, (1 - r) ** (nu + k) * poly, 0)
+    return Kernel(_isotropic_posabs(core), scale=scale, loc=loc)
+
+
+def CausalExpQuad(*, alpha=1, scale=None, loc=None):
+    """ ``_kernels/_basic.py:346-360`` """
+    assert alpha >= 0
+    return Kernel(_isotropic_posabs(lambda r: special.erfc(alpha / 4 * r) * numpy.exp(-1/2 * numpy.square(r))), scale=scale, loc=loc)
+
+
+def Log(*, scale=None, loc=None):
+    """ ``_kernels/_basic.py:381-392`` """
+    return Kernel(_isotropic_posabs(lambda r: numpy.log1p(r) / r), scale=scale, loc=loc)
 
 
 # --------------------------------------------------------------------------

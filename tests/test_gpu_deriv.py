@@ -75,11 +75,113 @@ def test_posterior_with_derivative_data_vs_oracle(lgp):
 def test_what_is_not_available_says_so(lgp):
     x = np.linspace(0, 1, 5)
     with pytest.raises(NotImplementedError):
-        lgp.GP(lgp.Maternp(p=2)).addx(x, 'a', deriv=1).prior('a', raw=True)
-    with pytest.raises(NotImplementedError):
-        lgp.GP(lgp.ExpQuad()).addx(x, 'a', deriv='f0')
+        lgp.GP(lgp.GammaExp(gamma=1.2)).addx(x, 'a', deriv=1).prior('a', raw=True)
+    with pytest.raises(ValueError):
+        lgp.GP(lgp.Maternp(p=1)).addx(x, 'a', deriv=2).prior('a', raw=True)     # derivable p times on each side
+    with pytest.raises(ValueError):
+        lgp.GP(lgp.ExpQuad()).addx(x, 'a', deriv='f0')                           # a named field of points without fields
     xs = np.zeros(5, [('f0', float), ('f1', float)])
-    with pytest.raises(NotImplementedError):
-        lgp.GP(lgp.ExpQuad()).addx(xs, 'a', deriv=1)
+    with pytest.raises(ValueError):
+        lgp.GP(lgp.ExpQuad()).addx(xs, 'a', deriv=1)                             # an implicit variable of points with fields
+    with pytest.raises(ValueError):
+        lgp.GP(lgp.ExpQuad()).addx(xs, 'a', deriv='nope')
     with pytest.raises(ValueError):
         lgp.GP(lgp.ExpQuad()).addx(x, 'a', deriv=-1)
+    with pytest.raises(ValueError):
+        lgp.GP(lgp.ExpQuad()).addx(xs, 'a', deriv=[2])                           # dangling order (_Deriv.py:88-89)
+
+
+@pytest.mark.parametrize('p,a,b', [(1, 1, 0), (1, 1, 1), (2, 1, 0), (2, 0, 2), (2, 2, 1), (2, 2, 2), (3, 3, 3), (5, 2, 4)])
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_derived_maternp_gram_vs_oracle(lgp, p, a, b, dtype):
+    """ Maternp is derivable p times on each side (_kernels/_matern.py:26-49): the device functor LGP_KERNEL_MATERNP_DIFF against the
+    oracle's closed form (itself checked against central differences on the CPU) """
+    rng = np.random.default_rng(1000 * p + 10 * a + b)
+    x = rng.uniform(-3, 3, 200).astype(dtype)
+    y = rng.uniform(-3, 3, 333).astype(dtype)
+    y[:50] = x[:50]                                            # coincident points: the odd derivatives vanish there
+    kd = 1.3 * lgp.Maternp(p=p, scale=0.8, loc=0.1) + 0.5
+    ko = 1.3 * oracle.Maternp(p=p, scale=0.8, loc=0.1) + 0.5
+    got = kd.gram(x, y, deriv=(a, b)).to_host()
+    want = ko.diff(a, b)(x.astype(float)[:, None], y.astype(float)[None, :])
+    assert got.dtype == dtype
+    tol = 1e-13 if dtype == np.float64 else 5e-5
+    np.testing.assert_allclose(got, want, rtol=0, atol=tol * np.abs(want).max())
+
+
+@pytest.mark.parametrize('dx,dy', [('a', None), ((2, 'b'), 'a'), (('a', 'b'), 'b'), (None, (2, 'c')), ((2, 'a', 'c'), (2, 'a'))])
+def test_derivatives_along_named_fields_vs_oracle(lgp, dx, dy):
+    """ GP.addx(..., deriv=<fields>) on structured points (what Deriv of the reference accepts, _Deriv.py:24-97): prior blocks of
+    the derived ExpQuad process against the oracle """
+    rng = np.random.default_rng(11)
+    dt = [('a', float), ('b', float), ('c', float)]
+    x = np.empty(40, dt); y = np.empty(31, dt)
+    for f in 'abc':
+        x[f] = rng.uniform(-1.5, 1.5, 40); y[f] = rng.uniform(-1.5, 1.5, 31)
+
+    def run(mod):
+        gp = mod.GP(0.9 * mod.ExpQuad(scale=1.2), checkpos=False, checksym=False).addx(x, 'u', deriv=dx).addx(y, 'v', deriv=dy).addx(x, 'w')
+        return gp.prior(['u', 'v', 'w'], raw=True)
+    pd, po = run(lgp), run(oracle)
+    for key in po:
+        np.testing.assert_allclose(np.asarray(pd[key]), po[key], rtol=0, atol=2e-14 * max(1., np.abs(po[key]).max()))
+
+
+def test_posterior_with_gradient_observations_2d(lgp):
+    """ a function of two variables observed through both partial derivatives (named fields), predicted itself: device vs oracle """
+    rng = np.random.default_rng(2)
+    dt = [('s', float), ('t', float)]
+    x = np.empty(60, dt); xs = np.empty(20, dt)
+    x['s'], x['t'] = rng.uniform(0, 3, 60), rng.uniform(0, 3, 60)
+    xs['s'], xs['t'] = rng.uniform(0, 3, 20), rng.uniform(0, 3, 20)
+    f0 = np.sin(x['s']) * np.cos(x['t'])
+    fs, ft = np.cos(x['s']) * np.cos(x['t']), -np.sin(x['s']) * np.sin(x['t'])
+    noise = 1e-4 * np.eye(60)
+    z = np.zeros((60, 60))
+    keys = ['f', 'ds', 'dt']
+    gc = {(a, b): (noise if a == b else z) for a in keys for b in keys}
+
+    def run(mod):
+        gp = (mod.GP(mod.ExpQuad(scale=1.5), checkpos=False).addx(x, 'f').addx(x, 'ds', deriv='s').addx(x, 'dt', deriv='t').addx(xs, 'out'))
+        m, c = gp.predfromdata({'f': f0, 'ds': fs, 'dt': ft}, 'out', gc, raw=True)
+        return m, c
+    md, cd = run(lgp)
+    mo, co = run(oracle)
+    util.assert_close_matrices(md, mo, rtol=1e-7)
+    util.assert_close_matrices(cd, co, rtol=0, atol=1e-8)
+    assert np.max(np.abs(md - np.sin(xs['s']) * np.cos(xs['t']))) < 5e-3
+
+
+def test_addlintransf_on_the_device(lgp):
+    """ GP.addlintransf (_elements.py:348-406): a linear map given as a function -- here a finite-difference second derivative and
+    a weighted sum of two processes -- evaluated once on the host and applied to the device blocks; against the oracle, against
+    the same map through addtransf, and the linearity check """
+    rng = np.random.default_rng(4)
+    x = np.linspace(0, 3, 50)
+    A = rng.standard_normal((6, 50)); B = rng.standard_normal((6, 20))
+
+    def second_difference(u):
+        return u[2:] - 2 * u[1:-1] + u[:-2]
+
+    def run(mod):
+        gp = mod.GP(mod.ExpQuad(scale=0.7), checkpos=False).addx(x, 'a').addx(x[:20] + 0.01, 'b')
+        gp = gp.addlintransf(second_difference, ['a'], 'd2').addlintransf(lambda u, v: A @ u + B @ v, ['a', 'b'], 'mix')
+        gp = gp.addlintransf(lambda u: np.sum(u), ['a'], 'total')
+        return gp, gp.prior(['d2', 'mix', 'total', 'a'], raw=True)
+    gd, pd = run(lgp)
+    go, po = run(oracle)
+    for key in po:
+        np.testing.assert_allclose(np.asarray(pd[key]), po[key], rtol=0, atol=1e-12 * max(1., np.abs(po[key]).max()))
+    ref = lgp.GP(lgp.ExpQuad(scale=0.7), checkpos=False).addx(x, 'a').addx(x[:20] + 0.01, 'b').addtransf({'a': A, 'b': B}, 'mix')
+    np.testing.assert_allclose(np.asarray(pd['mix', 'mix']), np.asarray(ref.prior('mix', raw=True)), rtol=0, atol=1e-12)
+    y = rng.standard_normal(48)
+    md, cd = gd.predfromdata({'d2': y}, 'total', {('d2', 'd2'): 0.1 * np.eye(48)}, raw=True)
+    mo, co = go.predfromdata({'d2': y}, 'total', {('d2', 'd2'): 0.1 * np.eye(48)}, raw=True)
+    assert abs(md - mo) <= 1e-8 * abs(mo) + 1e-10 and abs(cd - co) <= 1e-8 * abs(co)
+    with pytest.raises(RuntimeError):
+        gd.addlintransf(lambda u: u + 1, ['a'], 'affine')
+    with pytest.raises(RuntimeError):
+        gd.addlintransf(lambda u: u ** 2, ['a'], 'square')
+    gd.addlintransf(lambda u: u + 1, ['a'], 'affine', checklin=False)
+    with pytest.raises(KeyError):
+        gd.addlintransf(lambda u: u, ['zzz'], 'q')

@@ -399,3 +399,38 @@ def test_bart_deep_recursion(lgp, maxd, reset, flt, rng):
     assert util.ulp_distance(S, S.T) <= 64
     with pytest.raises(NotImplementedError):
         kd.gram_jvp(_struct(X), _struct(X))
+
+
+@pytest.mark.parametrize('make,d', [
+    (lambda m: m.Wendland(k=0, alpha=1, scale=2.), 1), (lambda m: m.Wendland(k=1, alpha=2, scale=3.), 2), (lambda m: m.Wendland(k=2, alpha=2.5, scale=4.), 3),
+    (lambda m: m.Wendland(k=3, alpha=2, scale=2.5, loc=0.3), 2), (lambda m: m.CausalExpQuad(alpha=1, scale=1.5), 1),
+    (lambda m: m.CausalExpQuad(alpha=0, scale=1.1), 3), (lambda m: m.CausalExpQuad(alpha=3.7), 2), (lambda m: m.Log(scale=0.7), 1), (lambda m: 2.5 * m.Log() + 1, 3),
+], ids=['wendland0', 'wendland1', 'wendland2', 'wendland3', 'causal1', 'causal0', 'causal3.7', 'log', 'log3d'])
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_posabs_kernels_vs_oracle(lgp, make, d, dtype, rng):
+    """ the isotropic kernels with input='posabs' (per field (|x - y| + eps)^2, _Kernel/_isotropic.py:67-78): Wendland
+    (_kernels/_wendland.py:32-84, compact support), CausalExpQuad (_kernels/_basic.py:346-360), Log (:381-392) """
+    n, m = 150, 270
+    dt = [(f'f{i}', dtype) for i in range(d)]
+    x = np.empty(n, dt); y = np.empty(m, dt)
+    for f in x.dtype.names:
+        x[f] = rng.uniform(-2, 2, n).astype(dtype); y[f] = rng.uniform(-2, 2, m).astype(dtype)
+    y[:20] = x[:20]
+    if d == 1:
+        x, y = x['f0'], y['f0']
+    G = make(lgp).gram(x, y).to_host()
+    R = make(oracle)(x[:, None], y[None, :])
+    assert G.dtype == dtype
+    tol = 2e-14 if dtype == np.float64 else 2e-5        # (erfc / log1p / pow of the device library vs libm)
+    np.testing.assert_allclose(G, R, rtol=0, atol=tol * np.abs(R).max())
+    # the elementwise form and symmetry / unit diagonal of the correlation kernels
+    P = make(lgp)(x[:m if m < n else n], y[:n if n < m else m])
+    np.testing.assert_allclose(P, np.diagonal(R)[:len(P)], rtol=0, atol=tol * np.abs(R).max())
+
+
+def test_wendland_dimension_limit(lgp):
+    x = np.zeros(4, [('a', float), ('b', float)])
+    with pytest.raises(ValueError):
+        lgp.Wendland(k=0, alpha=1).gram(x, x)             # maxdim = floor(2 alpha - 1) = 1
+    with pytest.raises(NotImplementedError):
+        lgp.Wendland(k=4)
