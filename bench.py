@@ -387,7 +387,8 @@ def default_path(ctx, cfg_name='c2', reps=3):
             mll = step()
         ctx.sync()
         out[label + '_ms'] = (time.perf_counter() - t0) / reps * 1e3
-    out['workload'] = cfg['name'] + ' via GP.predfromdata + GP.marginal_likelihood (two factorisations: the reference call sequence)'
+    out['workload'] = (cfg['name'] + ' via GP.predfromdata + GP.marginal_likelihood with the same givencov object: the reference call sequence; '
+                       'the decomposition of the first call serves the second (GP(reuse_givencov=True), one factorisation where the reference does two)')
     out['log_marginal_likelihood'] = float(mll)
     return out
 
@@ -720,6 +721,10 @@ def main():
             'avg_launch_ms': tot_ms.value / max(launches.value, 1),
             'avg_launch_gflop': tot_fl.value / max(launches.value, 1) / 1e9,
             'largest_launch_tflops': (max_fl.value / (max_ms.value * 1e-3) / 1e12) if max_ms.value > 0 else None,
+            'coverage': ('the timed launches are the trailing updates that keep 128 x 128 tiles (the smaller ones go to the 64-tile instantiation, '
+                         'which the other kernels of the factorisation share): %d per step, %.0f %% of the N^3/3 flops of the factorisation'
+                         % (launches.value // max(args.steps, 1), 100. * tot_fl.value / max(args.steps, 1) / (n ** 3 / 3))),
+            'whole_cholesky_frac_of_peak': (n ** 3 / 3) / (phases[1] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
         },
     }
     # the N x N Gram kernel alone against the HBM roofline (inside the step it is fused with the regularisation passes)

@@ -161,17 +161,25 @@ class GP:
     the factorisation (`Chol` ``rhs=``) instead of being solved afterwards by a latency-bound chain of small kernels.
     Cached decompositions (no ``givencov``, or one that is exactly zero) always use the separate solve, so that a cache hit
     reproduces the first call bit for bit.
+    ``reuse_givencov`` (not in the reference; default True): the reference factors ``Kxx + ycov`` anew in every call that is
+    given a ``givencov`` (``_compute.py:55-58``), so ``predfromdata(given, key, givencov)`` followed by
+    ``marginal_likelihood(given, givencov)`` -- the usual pair -- factors the same matrix twice.  Here the decomposition of the
+    last such call is kept and serves the next call on the same object when the SAME ``givencov`` object is passed again with
+    the same keys and decomposition arguments (identity of the dictionary and of its blocks, their shapes, and a strided sample
+    of their values to notice in-place edits).  The numbers are those of the factorisation that was kept.
     """
 
     DefaultProcess = 'default'
 
     def __init__(self, covfun=None, *, solver='chol', checkpos=True, checksym=True,
-        checkfinite=True, checklin=True, posepsfac=1, halfmatrix=False, ctx=None, fuse_solve=True, **kw):
+        checkfinite=True, checklin=True, posepsfac=1, halfmatrix=False, ctx=None, fuse_solve=True, reuse_givencov=True, **kw):
         if covfun is not None and not isinstance(covfun, _kernels.Kernel):
             raise TypeError('covariance function must be a lsqfitgp_amd kernel object')
         self._covfun = covfun
         self._ctx = ctx
         self._fuse_solve = bool(fuse_solve)
+        self._reuse_givencov = bool(reuse_givencov)
+        self._givencov_cache = None    # (keys, fingerprint of givencov, decomposition kwargs, decomposition) of the last call
         self._elements = {}        # key -> _Element
         self._covblocks = {}       # (key, key) -> DeviceArray (2d flattened)
         self._decompcache = {}     # tuple of keys -> Decomposition
@@ -718,6 +726,23 @@ class GP:
         """ ``_compute.py:424-428`` """
         return {'chol': Chol}[solver]
 
+    @staticmethod
+    def _fingerprint(givencov):
+        """ identity of a ``givencov`` dictionary: the object, its blocks, their shapes and a strided sample of their values """
+        if givencov is None or not hasattr(givencov, 'items'):
+            return None
+        parts = [id(givencov)]
+        for pair, block in givencov.items():
+            values = block.values if isinstance(block, Diagonal) else block
+            if isinstance(values, DeviceArray):
+                parts.append((pair, id(block), values.shape, values.ptr))
+                continue
+            arr = numpy.asarray(values)
+            flat = arr.reshape(-1)
+            step = max(1, flat.size // 257)
+            parts.append((pair, id(block), arr.shape, str(arr.dtype), flat[::step][:257].tobytes()))
+        return tuple(parts)
+
     def _solver(self, keys, ycov=None, rhs_builder=None, **kw):
         """ Decomposition of the covariance of ``keys`` plus ``ycov``
         (``_compute.py:45-94``): HOT LOOP 2.  ``rhs_builder(dtype)`` (optional) supplies right-hand sides to carry
@@ -840,7 +865,8 @@ class GP:
         self._check_ymean(ymean)
 
         Kxsxs = self._assemblecovblocks(outkeys)                          # :252
-        ycov_dev = None if ycov is None else self._upload_block(ycov)
+        kept = self._cached_given(inkeys, givencov, ycov, {}) if fromdata else None
+        ycov_dev = None if (ycov is None or kept is not None) else self._upload_block(ycov)
         n, m = Kxxs.shape
         built = {}
 
@@ -857,7 +883,11 @@ class GP:
         # (tests/GP/test_GP.py:587-596,652-660): a zero ycov has become None above, and cached decompositions never carry.
         carry = build_rhs if (self._fuse_solve and issubclass(self._decomptype, Chol) and fromdata and ycov_dev is not None) else None
         if fromdata:
-            solver = self._solver(inkeys, ycov_dev, rhs_builder=carry)   # :255
+            solver = kept
+            if solver is None:
+                solver = self._solver(inkeys, ycov_dev, rhs_builder=carry)   # :255
+                if ycov_dev is not None:
+                    self._keep_given(inkeys, givencov, {}, solver)
         else:
             solver = self._solver(inkeys)
 
@@ -916,9 +946,34 @@ class GP:
         self._check_ymean(ymean)
         ycov = self._join_ycov(ycovblocks)
         self._check_ycov(ycov)
+        if ycov is not None:
+            decomp = self._cached_given(inkeys, givencov, True, kw)
+            if decomp is not None:
+                return decomp, ymean
         ycov_dev = None if ycov is None else self._upload_block(ycov)
         decomp = self._solver(inkeys, ycov_dev, **kw)
+        if ycov is not None:
+            self._keep_given(inkeys, givencov, kw, decomp)
         return decomp, ymean
+
+    def _cached_given(self, keys, givencov, ycov, kw):
+        """ the decomposition kept by the last call with a ``givencov``, if this call is about the same matrix (see the class
+        docstring, ``reuse_givencov``) """
+        c = self._givencov_cache
+        if not self._reuse_givencov or c is None or ycov is None:
+            return None
+        if c[0] == tuple(keys) and c[2] == tuple(sorted(kw.items(), key=lambda kv: kv[0])) and c[1] == self._fingerprint(givencov):
+            return c[3]
+        return None
+
+    def _keep_given(self, keys, givencov, kw, decomp):
+        if self._reuse_givencov:
+            try:
+                kwkey = tuple(sorted(kw.items(), key=lambda kv: kv[0]))
+                hash(kwkey)
+            except TypeError:
+                return
+            self._givencov_cache = (tuple(keys), self._fingerprint(givencov), kwkey, decomp)
 
     def marginal_likelihood(self, given, givencov=None, **kw):
         """ Logarithm of the probability of the data (``_compute.py:383-422``) """

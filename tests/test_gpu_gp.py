@@ -338,3 +338,44 @@ def test_diagonal_blocks(lgp, rng):
     for z in (np.zeros((50, 50)), lgp.diag(np.zeros(50))):
         r1 = g0.predfromdata({'f': y[:50]}, 't', {('f', 'f'): z}, raw=True)
         np.testing.assert_array_equal(r0[0], r1[0]); np.testing.assert_array_equal(r0[1], r1[1])
+
+
+def test_decomposition_kept_for_the_same_givencov(lgp, rng):
+    """ predfromdata(given, key, givencov) followed by marginal_likelihood(given, givencov) with the SAME givencov object factors
+    once (not in the reference, which factors Kxx + ycov in every call, _compute.py:55-58); a different object, an edited
+    block, other decomposition arguments or reuse_givencov=False factor again; the numbers agree with the oracle either way """
+    n, m = 700, 30
+    x = rng.uniform(0, 40, n); xs = rng.uniform(0, 40, m)
+    y = np.sin(x) + 0.1 * rng.standard_normal(n)
+    gc = {('d', 'd'): 0.01 * np.eye(n)}
+    calls = []
+    orig = lgp.Chol.__init__
+
+    def counting(self, *a, **k):
+        calls.append(1)
+        return orig(self, *a, **k)
+    lgp.Chol.__init__ = counting
+    try:
+        gp = lgp.GP(lgp.ExpQuad(), checkpos=False, checksym=False).addx(x, 'd').addx(xs, 't')
+        mean, cov = gp.predfromdata({'d': y}, 't', gc, raw=True)
+        ml = gp.marginal_likelihood({'d': y}, gc)
+        assert len(calls) == 1
+        gp.marginal_likelihood({'d': y}, gc, epsrel=0)                  # other decomposition arguments
+        assert len(calls) == 2
+        gp.marginal_likelihood({'d': y}, {('d', 'd'): gc['d', 'd']})     # another dictionary
+        assert len(calls) == 3
+        gc['d', 'd'][0, 0] = 0.02                                        # the block edited in place
+        ml2 = gp.marginal_likelihood({'d': y}, gc)
+        assert len(calls) == 4 and ml2 != ml
+        gc['d', 'd'][0, 0] = 0.01
+        g2 = lgp.GP(lgp.ExpQuad(), checkpos=False, checksym=False, reuse_givencov=False).addx(x, 'd').addx(xs, 't')
+        g2.predfromdata({'d': y}, 't', gc, raw=True)
+        ml3 = g2.marginal_likelihood({'d': y}, gc)
+        assert len(calls) == 6
+    finally:
+        lgp.Chol.__init__ = orig
+    go = oracle.GP(oracle.ExpQuad(), checkpos=False, checksym=False).addx(x, 'd').addx(xs, 't')
+    mo, co = go.predfromdata({'d': y}, 't', gc, raw=True)
+    lo = go.marginal_likelihood({'d': y}, gc)
+    assert np.linalg.norm(mean - mo) <= 1e-8 * np.linalg.norm(mo)
+    assert abs(ml - lo) <= 1e-8 * abs(lo) + 1e-6 and abs(ml3 - lo) <= 1e-8 * abs(lo) + 1e-6
