@@ -710,6 +710,7 @@ struct BartArgs {
   // pair-independent per-axis constants of the depth-2 closed form, evaluated once on the host in T arithmetic with the
   // operations and the order of the per-pair code (so the Gram entries do not change): valid when `pre` (global split totals)
   int pre;
+  int sym;               // Gram form on one point set (ix == iy): evaluate one triangle, write both
   T wn[BART_MAX_P];      // [n != 0] w / n
   T invWm[BART_MAX_P];   // 1 / (Wn - [n != 0] w)
   T wiW[BART_MAX_P];     // w * (1 / Wn)
@@ -862,9 +863,30 @@ __global__ void __launch_bounds__(BT_COLS) gram_bart_kernel(const BartArgs<T> g)
   int32_t *sy = sx + BT_ROWS * g.p;                          // [p][BT_COLS]  (transposed: conflict-free)
   const int p = g.p;
   const int ntc = (g.m + BT_COLS - 1) / BT_COLS;
-  const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
+  int tr, tc;
+  if (g.sym) {
+    // One triangle when both point sets are the same (what `halfmatrix` of the reference does, _elements.py:567-573): the
+    // kernel is bound by vector-ALU issue (715 instructions per pair at C5), so half the pairs is about half the time.  Only
+    // the tiles that reach the diagonal or lie below it exist in the grid: tile row tr has tr / R + 1 of them (R = BT_COLS /
+    // BT_ROWS), numbered consecutively so that the XCDs, which take workgroups round-robin, get equal shares (skipping tiles of
+    // a rectangular grid left the XCDs of the high tile columns almost idle: 330 instead of 354 us for 53 % of the tiles).
+    constexpr int R = BT_COLS / BT_ROWS;
+    const int idx = (int)blockIdx.x;
+    int grp = (int)((sqrtf(1.0f + 0.5f * (float)idx) - 1.0f) * 0.5f);          // largest grp with (R / 2) grp (grp + 1) <= idx ...
+    while ((R / 2) * (grp + 1) * (grp + 2) <= idx) ++grp;                         // ... made exact
+    while ((R / 2) * grp * (grp + 1) > idx) --grp;
+    const int rem = idx - (R / 2) * grp * (grp + 1);
+    tr = R * grp + rem / (grp + 1);
+    tc = rem % (grp + 1);
+  } else {
+    tr = blockIdx.x / ntc;
+    tc = blockIdx.x % ntc;
+  }
   const int row0 = tr * BT_ROWS, col0 = tc * BT_COLS;
   const int tid = threadIdx.x;
+  // a tile entirely below the diagonal also writes its transpose, which lies in tiles entirely above (the 256-column blocks
+  // are whole multiples of the 16-row blocks); tiles that straddle the diagonal are evaluated in full
+  const bool mirror = g.sym && (col0 + BT_COLS - 1 < row0);
   // zero-weight axes are ignored: n, ix, iy -> 0 (_bart.py:670-672)
   for (int idx = tid; idx < BT_ROWS * p; idx += BT_COLS) {
     const int r = idx / p, a = idx % p;
@@ -893,9 +915,15 @@ __global__ void __launch_bounds__(BT_COLS) gram_bart_kernel(const BartArgs<T> g)
         g, [&](int a) { return sx[r * p + a]; }, [&](int a) { return sy[a * BT_COLS + tid]; },
         [&](int a) { return (g.w[a] != T(0)) ? g.nsplits[a] : 0; });
     const T gam = bart_iterate<T, NT>(g, q, gam0, dgam);
-    g.out[o] = g.ops.apply(gam);
+    const T val = g.ops.apply(gam);
+    g.out[o] = val;
+    const long om = (long)col * g.ldo + row0 + r;       // the mirrored entry
+    if (mirror) g.out[om] = val;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) g.tan[t][o] = slope * dgam[t];
+    for (int t = 0; t < NT; ++t) {
+      g.tan[t][o] = slope * dgam[t];
+      if (mirror) g.tan[t][om] = slope * dgam[t];
+    }
   }
 }
 
@@ -1099,10 +1127,24 @@ int gram_bart_launch(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const in
     }
     g.pre = 1;
   }
+  {
+    // the same points on both sides, and a per-pair gamma / tangent input (a deeper slice chained in place) that is this
+    // launch's own output or absent: then out(i, j) and out(j, i) are the same number up to the order of two operands
+    static const bool nosym = getenv("LGP_BART_FULL") != nullptr;
+    bool sym = !nosym && dix == diy && n == m && (dgamma_mat == nullptr || dgamma_mat == dout);
+    for (int t = 0; t < ntan; ++t) sym = sym && (g.gtan[t] == nullptr || g.gtan[t] == g.tan[t]);
+    g.sym = sym ? 1 : 0;
+  }
   const size_t ntr = (n + BT_ROWS - 1) / BT_ROWS, ntc = (m + BT_COLS - 1) / BT_COLS;
   LGP_REQUIRE(ntr * ntc < (1ull << 31), "gram grid too large");
   const size_t shmem = (size_t)(p > 0 ? p : 1) * (BT_ROWS + BT_COLS) * sizeof(int32_t);
-  const dim3 gd((unsigned)(ntr * ntc)), bd(BT_COLS);
+  size_t ntiles = ntr * ntc;
+  if (g.sym) {      // the tiles that reach the diagonal or lie below it: tile row tr has tr / R + 1
+    constexpr size_t R = BT_COLS / BT_ROWS;
+    ntiles = 0;
+    for (size_t r0 = 0; r0 < ntr; r0 += R) ntiles += (std::min(ntr, r0 + R) - r0) * (r0 / R + 1);
+  }
+  const dim3 gd((unsigned)ntiles), bd(BT_COLS);
   if (ntan == 0) hipLaunchKernelGGL((gram_bart_kernel<T, 0>), gd, bd, shmem, ctx->stream, g);
   else if (ntan == 1) hipLaunchKernelGGL((gram_bart_kernel<T, 1>), gd, bd, shmem, ctx->stream, g);
   else hipLaunchKernelGGL((gram_bart_kernel<T, 2>), gd, bd, shmem, ctx->stream, g);
