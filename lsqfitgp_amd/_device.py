@@ -40,6 +40,7 @@ class Context:
         # lgp_free synchronises the device (hipFree does); the buffers that the host classes drop all the time are
         # therefore collected here and freed in batches, large ones at once
         self._graveyard = _Graveyard(lib, handle)
+        _lib._on_enomem.append(self._graveyard.flush)
         self._finalizer = weakref.finalize(self, _destroy_context, lib, handle, self._graveyard)
 
     @property
@@ -179,6 +180,10 @@ class _Graveyard:
 
 
 def _destroy_context(lib, handle, graveyard):
+    try:
+        _lib._on_enomem.remove(graveyard.flush)
+    except ValueError:
+        pass
     graveyard.flush()
     lib.lgp_ctx_destroy(handle)
 

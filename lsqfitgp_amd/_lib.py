@@ -171,10 +171,23 @@ def last_error():
     return msg.decode('utf8', 'replace') if msg else ''
 
 
+_on_enomem = []         # callables that give cached device memory back (the contexts' block caches register here)
+
+
 def check(status, what=''):
-    """ negative status -> LibraryError; returns nonnegative status (info) """
+    """ negative status -> LibraryError; returns nonnegative status (info).  When the library itself ran out of device memory
+    (a workspace of its own: LGP_ENOMEM), the blocks that the host classes keep for reuse are given back first, so that the
+    caller's next attempt finds them free """
     if status < 0:
-        raise LibraryError(f'{what or "HIP call"} failed (status {status}): {last_error()}')
+        msg = last_error()
+        if status == LGP_ENOMEM:
+            for release in list(_on_enomem):
+                try:
+                    release()
+                except Exception:
+                    pass
+            msg += ' (the cached device blocks of the host classes have been released: retry)'
+        raise LibraryError(f'{what or "HIP call"} failed (status {status}): {msg}')
     return status
 
 

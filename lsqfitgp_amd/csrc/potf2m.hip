@@ -437,6 +437,7 @@ struct ChainArgs {
   unsigned long long *trace;   // optional (LGP_CHAIN_TRACE): per task  worker, taken, inputs ready, done  (wall_clock64)
   unsigned long long timeout;  // wall_clock64 ticks a worker waits for one input before it abandons the launch
   long row0;                   // global index of the matrix's first row (pivot indices of the info word)
+  int samexcd;                 // chain workers all on XCD 0 (experiment, env LGP_CHAIN_SAMEXCD)
 };
 
 __device__ __forceinline__ unsigned ch_peek(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -543,7 +544,9 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
   __builtin_amdgcn_s_setprio(LGP_CHAIN_PRIO);
   unsigned *const st = p.state;
   const int npanels = (p.n + LGP_NB - 1) / LGP_NB;
-  bool on_chain = (int)blockIdx.x < p.chainw;          // (thread 0's copy is the one that counts)
+  // the workers of the dependent chain: the first `chainw` workgroups, or (samexcd) the first chainw of those that the hardware
+  // places on XCD 0 (workgroup i runs on XCD i mod 8), so that what one of them writes the next finds in the same L2
+  bool on_chain = p.samexcd ? ((blockIdx.x & 7u) == 0u && (int)(blockIdx.x >> 3) < p.chainw) : (int)blockIdx.x < p.chainw;          // (thread 0's copy is the one that counts)
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -841,7 +844,9 @@ int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size
   const int want = ctx->chain_workers < 2 ? 2 : ctx->chain_workers;
   const int workers = ntasks < want ? (ntasks < 2 ? 2 : ntasks) : want;
   a.timeout = ctx->chain_timeout;
-  a.chainw = workers >= 4 ? 3 : 1;      // the chain offers three tasks at a time at most: S(2j+2), S(2j+3) / the three tiles of the next block
+  a.chainw = workers >= 4 ? 3 : 1;
+  static const bool samexcd = getenv("LGP_CHAIN_SAMEXCD") != nullptr;
+  a.samexcd = (samexcd && workers >= 17 && a.chainw == 3) ? 1 : 0;      // the chain offers three tasks at a time at most: S(2j+2), S(2j+3) / the three tiles of the next block
   // dynamic LDS that is never touched: with it no trailing-update workgroup (64 KB of LDS) fits on a worker's CU
   const size_t hog = n <= ctx->chain_hog_max_n ? (size_t)ctx->chain_lds_kb * 1024 : 0;
   if (!ctx->chain_attr_set) {      // per context (= per device; a context is used by one host thread at a time)
