@@ -593,7 +593,9 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   const size_t t64big = (tag & 2) ? lgp_gemm_t64_trailing_max() : 64;
   // ... and for outputs of at most four 128-tiles whatever K (X^T X of the posterior: 101 x 101 over N rows): with split-K below
   // they become ~100 short workgroups instead of 8 long ones (N = 4096: 90 -> 15 us per product)
-  if (!aliased && ((t128 <= t64big && k <= 2048) || (t128 <= 512 && k <= 256) || t128 <= 4))
+  // tag & 4 (the left-looking block-column updates of the chain driver, K up to N): 64 x 64 tiles while 128-tiles would not fill the GPU
+  static const size_t deep64 = getenv("LGP_GEMM_DEEP64") ? (size_t)atol(getenv("LGP_GEMM_DEEP64")) : 512;
+  if (!aliased && ((t128 <= t64big && k <= 2048) || (t128 <= 512 && k <= 256) || t128 <= 4 || ((tag & 4) && t128 <= deep64)))
     return gemm_launch_ts<T, 64, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, 0, cyc_nb, cyc_g1, roff);
   // (a 512-thread variant, 4 x 2 waves of 32 x 64 at 4 waves per SIMD, was measured equal: 61.3 vs 61.7 TFLOP/s)
   return gemm_launch_ts<T, 128, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, tag & 1, cyc_nb, cyc_g1, roff);

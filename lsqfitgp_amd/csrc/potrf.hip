@@ -741,8 +741,10 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
     // (the last panels are bound by the chain: their updates leave room on every CU, see potrf_chain)
     static const long thin_env = getenv("LGP_THIN_LDS_KB") ? atol(getenv("LGP_THIN_LDS_KB")) : -1;
     ctx->gemm_thin_lds = thin_env >= 0 ? (size_t)thin_env * 1024 : (rows_t <= 6144 ? (size_t)70 * 1024 : (rows_t <= 12288 ? (size_t)20 * 1024 : 0));
+    static const size_t u2_t128_min = getenv("LGP_U2_T128_MIN_ROWS") ? (size_t)atol(getenv("LGP_U2_T128_MIN_ROWS")) : (size_t)1 << 40;
     if (rows_r + nx > 0)
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false, 2));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false,
+                                   rows_r >= u2_t128_min ? 0 : 2));
     LGP_HIP(hipEventRecord(E(EV_U2), sg));
     LGP_HIP(hipStreamWaitEvent(s3, E(EV_U2), 0));
     // ---- sg: U3, everything right of the next panel: the N^3/3 flops, one launch
@@ -886,11 +888,27 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     // 6.92 -> 6.55 ms; thinning the large updates of N = 16384 as well: 30.4 -> 31.4 ms, so they are left alone).
     static const long thin_env = getenv("LGP_THIN_LDS_KB") ? atol(getenv("LGP_THIN_LDS_KB")) : -1;
     ctx->gemm_thin_lds = thin_env >= 0 ? (size_t)thin_env * 1024 : (rows_t <= 6144 ? (size_t)70 * 1024 : (rows_t <= 12288 ? (size_t)20 * 1024 : 0));
+    // (U2 in blocks of 128 columns with a count in u2[k] behind each, so that step j of the rows below the next square waits for
+    // block j only: measured worse, N = 8192 6.35 -> 7.2 ms -- eight 128-column products take 440 us where the one launch takes 290)
+    // small matrices: U2 behind U1 (side by side U1 takes 130 us instead of 45 and the next square waits for it; N = 4096 2.44 ->
+    // 2.37 ms.  From N = 8192 on it is the rows below the next square, which wait for U2, that must not start later: 6.33 -> 6.47 ms)
+    static const size_t u2_after_u1_max_n = getenv("LGP_CHAIN_U2_AFTER_U1_MAX_N") ? (size_t)atol(getenv("LGP_CHAIN_U2_AFTER_U1_MAX_N")) : 4096;
+    if (n <= u2_after_u1_max_n && !(ctx->chain_test_stall && k == 0)) LGP_HIP(wait_ge(s0, word(k + 1, LGP_CH_U1), 1));
     if (rows_r + nx > 0)
       LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false, 2));
     LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U2), 1, 0));
-    // ---- s0: U3, everything right of the next panel: the N^3/3 flops, one launch
-    if (rows_r > 0) {
+    // ---- s0: the bulk of the flops.  Up to N = 8192 LEFT-looking with a look-ahead of one block column: block column k+2 (its
+    // square and everything below) receives the update of ALL panels 0 .. k in one product, K = 1024 (k + 1), while the chain
+    // kernel factors the square of panel k+1 (whose block column got the same treatment one panel earlier, and panel k's share
+    // from U1 / U2).  Right-looking (everything right of block column k+1 updated with panel k alone) front-loads the work: at
+    // N = 8192 the updates with panels 0 / 1 / 2 are 51 / 37 / 26 GFLOP, more than fits beside a square's 0.55 ms, and the
+    // square of panel k+2 waits for all of update k (hand-overs of 630 / 530 / 330 us in the task trace) while the last panels
+    // leave the GPU idle; left-looking the work beside each square is 33-39 GFLOP for panels 0-3: N = 8192 6.45-6.55 -> 6.30 ms
+    // (N = 4096 equal; N = 12288 14.9 -> 16.0, N = 16384 29.8 -> 34.6 ms: there the updates bound the factorisation, and a block
+    // column of 1024 is too few tiles per launch -- right-looking stays).  LGP_CHAIN_LEFT_MAX_N.
+    static const size_t left_max_n = getenv("LGP_CHAIN_LEFT_MAX_N") ? (size_t)atol(getenv("LGP_CHAIN_LEFT_MAX_N")) : 8192;
+    const bool right_looking = n > left_max_n;
+    if (rows_r > 0 && right_looking) {
       const T *Pa = Pt + nb1 * ldl;                     // (rows_r + nx) x kb
       T *Cc = L + (t0 + nb1) * ldl + (t0 + nb1);
       const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0) + (double)nx * (double)rows_r;
@@ -899,6 +917,10 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
       if (timed) LGP_CHECK(lgp_prof_start(ctx, s0, 2.0 * (double)kb * entries));
       LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 3));
       if (timed) LGP_CHECK(lgp_prof_stop(ctx, s0));
+    } else if (rows_r > 0) {
+      const size_t t2 = t0 + nb1, nb2 = rows_r < NB ? rows_r : NB;
+      const T *Pa = L + t2 * ldl;                       // (rows_r + nx) x t0: every panel so far, the rows from square k+2 down
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, nb2, t0, T(-1), Pa, ldl, Pa, ldl, T(1), L + t2 * ldl + t2, ldl, true, 6));
     }
     ctx->gemm_thin_lds = 0;
     LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U3), 1, 0));
