@@ -148,6 +148,42 @@ def _astype_dev(A, dtype):
     return out
 
 
+class _Zero:
+    """ A covariance block that is zero by construction: two elements without a common ancestor (``_elements.py:616``,
+    ``jnp.zeros`` there, float64).  It is never written to HBM unless somebody needs the matrix itself: linear transformations
+    skip it (it still takes part in the result's dtype, as the reference's dense zeros do) and the assembly clears its region. """
+
+    __slots__ = ('shape', 'ctx')
+    dtype = numpy.dtype(numpy.float64)
+
+    def __init__(self, shape, ctx):
+        self.shape = tuple(int(v) for v in shape)
+        self.ctx = ctx
+
+    @property
+    def size(self):
+        return self.shape[0] * self.shape[1]
+
+    def transpose(self):
+        return _Zero(self.shape[::-1], self.ctx)
+
+    def dense(self):
+        return DeviceArray.zeros(self.shape, self.dtype, self.ctx)
+
+    def to_host(self):
+        return numpy.zeros(self.shape, self.dtype)
+
+
+def _transposed(block):
+    """ the transposed block: nothing to do for zeros and for blocks known to be exactly symmetric (the Gram matrix of a point set
+    with itself, an uploaded diagonal, and whatever is merely another name for one of them) """
+    if isinstance(block, _Zero):
+        return block.transpose()
+    if getattr(block, '_symm', False) and block.shape[0] == block.shape[1]:
+        return block
+    return block.transpose()
+
+
 class GP:
     """
     Object that represents a Gaussian process (device-resident subset).
@@ -480,6 +516,8 @@ class GP:
                 vec = DeviceArray.from_host(block.values, dtype=dtype, ctx=self.ctx)
                 f, F = _lib.fn('lgp_add_diag', dtype)
                 _lib.check(f(self.ctx.handle, block.shape[0], out.ptr, out.ld, vec.ptr, F(1)), 'lgp_add_diag')
+                out._diagvec = vec          # (a sum that this block joins adds the vector to its diagonal instead of reading the matrix)
+            out._symm = True
             return out
         block = numpy.asarray(block)
         dtype = numpy.float32 if block.dtype == numpy.float32 else numpy.float64
@@ -501,23 +539,39 @@ class GP:
         if x is y and not self._checksym and self._halfmatrix:
             # the reference evaluates the upper triangle as a flat vector and gathers (:567-573);
             # the device Gram kernels are exactly symmetric, so the full tile evaluation gives the same matrix
-            return kernel.gram(xf, xf, ctx=self.ctx, **kw)
-        yf = xf if y is x else y.x.reshape(-1)
-        return kernel.gram(xf, yf, ctx=self.ctx, **kw)
+            out = kernel.gram(xf, xf, ctx=self.ctx, **kw)
+        else:
+            yf = xf if y is x else y.x.reshape(-1)
+            out = kernel.gram(xf, yf, ctx=self.ctx, **kw)
+        if x is y and not kw:
+            out._symm = True              # k(x_i, x_j) and k(x_j, x_i) are the same arithmetic: its transpose is itself
+        return out
 
     def _makecovblock_lintransf_any(self, xkey, ykey):
         """ ``_elements.py:581-601`` for the tensordot transformation of `addtransf` (``:332-344``) """
         x = self._elements[xkey]
         y = self._elements[ykey]
-        out = None
+        # the terms first: blocks that are zero by construction are skipped (not read, not even allocated) but count for the
+        # dtype, as the reference's dense float64 zeros do
+        terms, dtypes = [], []
         for k in x.keys:
-            elem = self._elements[k]
             cov = self._covblock(k, ykey)
-            assert cov.shape == (elem.size, y.size)
+            assert cov.shape == (self._elements[k].size, y.size)
+            dtypes.append(cov.dtype)
+            if not isinstance(cov, _Zero):
+                terms.append((k, cov))
+        if not terms:
+            return _Zero((x.size, y.size), self.ctx)
+        dt = numpy.result_type(*dtypes)
+        if len(terms) == 1:
+            k, cov = terms[0]
             t = x.tensors[k]
-            if out is not None and cov.dtype != out.dtype:
-                dt = numpy.result_type(cov.dtype, out.dtype)
-                cov, out = _astype_dev(cov, dt), _astype_dev(out, dt)
+            if not t.shape and self._elements[k].size == x.size and float(t) == 1. and cov.dtype == dt:
+                return cov                                # the block under another name: nothing to compute
+        out = None
+        for k, cov in terms:
+            elem = self._elements[k]
+            t = x.tensors[k]
             if t.shape:
                 # tensordot(t, cov.reshape(elem.shape + (ysize,)), axes): (out.., contracted..) x (contracted.., rest.., ysize)
                 axes = x.axes[k] if isinstance(x.axes, dict) else x.axes
@@ -526,7 +580,8 @@ class GP:
                 osize = math.prod(t.shape[:t.ndim - axes])
                 if (osize * rest) != x.size:
                     raise NotImplementedError('broadcasting between transformed elements of different shapes')
-                td = DeviceArray.from_host(t.reshape(osize, csize), dtype=cov.dtype, ctx=self.ctx)
+                cov = _astype_dev(cov, dt)
+                td = DeviceArray.from_host(t.reshape(osize, csize), dtype=dt, ctx=self.ctx)
                 covr = cov if cov.contiguous else cov.copy()
                 covr = covr.reshape_contiguous((csize, rest * y.size))
                 if out is None:
@@ -534,14 +589,23 @@ class GP:
                 else:
                     _gemm(False, False, td, covr, 1., 1., out.reshape_contiguous((osize, rest * y.size)))
             elif elem.size == x.size:
+                vec = getattr(cov, '_diagvec', None)
                 if out is None:
-                    out = _axpby(float(t), cov, 0., None)
+                    conv = _astype_dev(cov, dt)
+                    if conv is not cov:                   # converted: a matrix of our own already
+                        out = conv if float(t) == 1. else _axpby(float(t), conv, 0., None, conv)
+                    else:
+                        out = _axpby(float(t), cov, 0., None)
+                elif vec is not None and out.shape[0] == out.shape[1]:
+                    f, F = _lib.fn('lgp_add_diag', dt)        # a diagonal block joins the sum through its diagonal alone
+                    _lib.check(f(self.ctx.handle, out.shape[0], out.ptr, out.ld, _astype_dev(vec, dt).ptr, F(float(t))), 'lgp_add_diag')
                 else:
-                    _axpby(float(t), cov, 1., out, out)
+                    _axpby(float(t), _astype_dev(cov, dt), 1., out, out)
             elif elem.size == 1:
                 # a scalar element broadcast over the output (e.g. the marginalised mean of
                 # bayestree/_bart.py:203): out += t * ones (x.size, 1) @ cov (1, ysize)
-                ones = DeviceArray.from_host(numpy.ones((x.size, 1)), dtype=cov.dtype, ctx=self.ctx)
+                ones = DeviceArray.from_host(numpy.ones((x.size, 1)), dtype=dt, ctx=self.ctx)
+                cov = _astype_dev(cov, dt)
                 if out is None:
                     out = _gemm(False, False, ones, cov, float(t), 0.)
                 else:
@@ -559,12 +623,12 @@ class GP:
         elif isinstance(x, _LinTransf):
             cov = self._makecovblock_lintransf_any(xkey, ykey)
         elif isinstance(y, _LinTransf):
-            cov = self._makecovblock_lintransf_any(ykey, xkey).transpose()
+            cov = _transposed(self._makecovblock_lintransf_any(ykey, xkey))
         elif isinstance(x, _Cov) and isinstance(y, _Cov) and x.blocks is y.blocks and (xkey, ykey) in x.blocks:
             cov = self._upload_block(x.blocks[xkey, ykey])
         else:
-            cov = DeviceArray.zeros((x.size, y.size), numpy.float64, self.ctx)
-        if (self._checkfinite or (self._checksym and xkey == ykey)) and cov.size:
+            cov = _Zero((x.size, y.size), self.ctx)
+        if (self._checkfinite or (self._checksym and xkey == ykey)) and cov.size and not isinstance(cov, _Zero):
             self._enqueue_check(cov, (xkey, ykey))
         return cov
 
@@ -579,12 +643,16 @@ class GP:
             self._checkkeys = []
         if len(self._checkkeys) == self._CHECK_SLOTS:
             self._resolve_checks()
+        sym = bool(self._checksym and key[0] == key[1])
+        need = (1 if self._checkfinite else 0) | (2 if sym else 0)
+        if getattr(cov, '_checks_passed', 0) & need == need:
+            return                                        # the same matrix under another key
+        cov._checks_passed = getattr(cov, '_checks_passed', 0) | need      # (or about to be judged: a failure clears it, below)
         slot = len(self._checkkeys)
         f, F = _lib.fn('lgp_check_matrix_dev', cov.dtype)
-        sym = bool(self._checksym and key[0] == key[1])
         _lib.check(f(cov.ctx.handle, cov.shape[0], cov.shape[1], cov.ptr, cov.ld, int(sym), F(1e-5), F(1e-8), self._checkflags.ptr + 8 * slot),
                    'lgp_check_matrix_dev')
-        self._checkkeys.append((key, sym))
+        self._checkkeys.append((key, sym, cov))
 
     def _resolve_checks(self):
         keys = getattr(self, '_checkkeys', None)
@@ -594,12 +662,13 @@ class GP:
         self._checkkeys = []
         if flags.any():
             self._checkflags.fill_zero()
-            bad = [(key, sym, slot) for slot, (key, sym) in enumerate(keys)
+            bad = [(key, sym, slot, cov) for slot, (key, sym, cov) in enumerate(keys)
                    if (self._checkfinite and flags[2 * slot]) or (sym and flags[2 * slot + 1])]
-            for key, _, _ in bad:                       # a block that failed is not kept (the reference raises before it caches)
-                self._covblocks.pop(key, None)
-                self._covblocks.pop(key[::-1], None)
-            for key, sym, slot in bad:
+            for key, _, _, cov in bad:                  # a block that failed is not kept (the reference raises before it caches),
+                cov._checks_passed = 0                  # under any of its names
+                for k in [k for k, v in self._covblocks.items() if v is cov or k == key or k == key[::-1]]:
+                    self._covblocks.pop(k, None)
+            for key, sym, slot, _ in bad:
                 if self._checkfinite and flags[2 * slot]:
                     raise RuntimeError(f'covariance block {key!r} is not finite')
                 raise RuntimeError(f'covariance block {key!r} is not symmetric')
@@ -612,12 +681,14 @@ class GP:
                 blockT = None
                 if self._checksym:
                     blockT = self._makecovblock(col, row)
-                    bt = block.transpose()
-                    if bt.dtype != blockT.dtype or not _allclose_dev(bt, blockT):
+                    bt = _transposed(block)
+                    if isinstance(bt, _Zero) != isinstance(blockT, _Zero):
+                        bt, blockT = (b.dense() if isinstance(b, _Zero) else b for b in (bt, blockT))
+                    if not isinstance(bt, _Zero) and (bt.dtype != blockT.dtype or not _allclose_dev(bt, blockT)):
                         if bt.dtype == blockT.dtype:
                             raise RuntimeError('covariance block {!r} is not symmetric'.format((row, col)))
                     blockT = bt
-                self._covblocks[col, row] = blockT if blockT is not None else block.transpose()
+                self._covblocks[col, row] = blockT if blockT is not None else _transposed(block)
             self._covblocks[row, col] = block
         return self._covblocks[row, col]
 
@@ -628,16 +699,19 @@ class GP:
         blocks = [[self._covblock(row, col) for col in colkeys] for row in rowkeys]
         self._resolve_checks()
         if len(blocks) == 1 and len(blocks[0]) == 1:
-            return blocks[0][0]
+            b = blocks[0][0]
+            return b.dense() if isinstance(b, _Zero) else b
         dtype = numpy.result_type(*[b.dtype for r in blocks for b in r])
         nr = sum(r[0].shape[0] for r in blocks)
         nc = sum(b.shape[1] for b in blocks[0])
-        out = DeviceArray.empty((nr, nc), dtype, self.ctx)
+        anyzero = any(isinstance(b, _Zero) and b.size for r in blocks for b in r)
+        out = (DeviceArray.zeros if anyzero else DeviceArray.empty)((nr, nc), dtype, self.ctx)      # (one clear for all the zero blocks)
         r0 = 0
         for r in blocks:
             c0 = 0
             for b in r:
-                out.block(r0, r0 + b.shape[0], c0, c0 + b.shape[1]).assign(_astype_dev(b, dtype))
+                if b.size and not isinstance(b, _Zero):
+                    out.block(r0, r0 + b.shape[0], c0, c0 + b.shape[1]).assign(_astype_dev(b, dtype))
                 c0 += b.shape[1]
             r0 += r[0].shape[0]
         return out
@@ -903,9 +977,14 @@ class GP:
                          Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld, None), 'lgp_posterior_solved')
         else:
             W = build_rhs(dtype)
-            f, _ = _lib.fn('lgp_posterior', dtype)
+            f, F = _lib.fn('lgp_posterior', dtype)
+            # (column m of W becomes L^-1 y: the density of y under this decomposition comes out of the same solve, and a
+            # `marginal_likelihood` of the same data that finds the decomposition in the cache need not solve again)
+            dens = F() if fromdata else None
             _lib.check(f(self.ctx.handle, n, m, solver._L.ptr, solver._L.ld, solver._dblk.ptr, W.ptr, W.ld,
-                         Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld, None), 'lgp_posterior')
+                         Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld, None if dens is None else ctypes.byref(dens)), 'lgp_posterior')
+            if dens is not None:
+                solver._density_memo = (numpy.array(ymean, copy=True), solver._dtype.type(dens.value))
         if not fromdata and ycov_dev is not None:
             # cov += A' ycov A, A = K^-1 Kxxs = L^-T (L^-1 Kxxs)             (:262-269)
             A = solver._solved.block(0, m, 0, n).transpose() if carried else W.block(0, n, 0, m).copy()

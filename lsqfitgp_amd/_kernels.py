@@ -115,6 +115,8 @@ class Kernel:
     def _copy(self, **kw):
         new = self.__class__.__new__(self.__class__)
         new.__dict__.update(self.__dict__)
+        for memo in ('_index_memo', '_psi_memo'):                 # device-side memos of the original (BART) are its own
+            new.__dict__.pop(memo, None)
         new.__dict__.update(kw)
         return new
 
@@ -687,9 +689,36 @@ class BART(Kernel):
         return ix
 
     def _psi_table(self, maxn, ctx):
-        k = numpy.arange(maxn + 2, dtype=float)
-        k[0] = 1
-        return DeviceArray.from_host(_special.digamma(k).astype(self._flt), ctx=ctx)
+        memo = self.__dict__.setdefault('_psi_memo', {})
+        key = (maxn, id(ctx))
+        if key not in memo:
+            k = numpy.arange(maxn + 2, dtype=float)
+            k[0] = 1
+            memo[key] = DeviceArray.from_host(_special.digamma(k).astype(self._flt), ctx=ctx)
+        return memo[key]
+
+    def _device_indices(self, xs, ctx):
+        """ bin indices of a host point set on the device.  The last few point sets are remembered (by buffer address, layout and a
+        strided sample of the bytes, so that an array modified in place is noticed): a model that rebuilds its GP at every
+        hyperparameter step on the same points -- `bayestree.bart`, the C5 loop -- neither searches the splitting grid nor uploads
+        the indices again """
+        if isinstance(xs, DevicePoints):
+            return xs.array
+        a = numpy.asarray(xs)
+        raw = a.view(numpy.uint8).reshape(-1) if a.flags.c_contiguous and a.size else None
+        key = None
+        if raw is not None:
+            step = max(1, raw.size // 4096)
+            key = (a.__array_interface__['data'][0], a.shape, str(a.dtype), id(ctx), raw[::step][:4096].tobytes())
+            memo = self.__dict__.setdefault('_index_memo', [])
+            for k, d in memo:
+                if k == key:
+                    return d
+        d = DeviceArray.from_host(self._to_indices(xs), ctx=ctx)
+        if key is not None:
+            memo.append((key, d))
+            del memo[:-4]
+        return d
 
     def _run(self, name, ctx, p, ixd, iyd, n, m, nsplits, npair, out, ld):
         f, F = _lib.fn(name, self._flt)
@@ -729,8 +758,8 @@ class BART(Kernel):
     def gram(self, xs, ys, *, ctx=None, out=None):
         ctx = ctx or Context.default()
         same = ys is xs
-        ixd = xs.array if isinstance(xs, DevicePoints) else DeviceArray.from_host(self._to_indices(xs), ctx=ctx)
-        iyd = ixd if same else (ys.array if isinstance(ys, DevicePoints) else DeviceArray.from_host(self._to_indices(ys), ctx=ctx))
+        ixd = self._device_indices(xs, ctx)
+        iyd = ixd if same else self._device_indices(ys, ctx)
         if not (ixd.contiguous and iyd.contiguous):
             raise ValueError('index arrays must be contiguous row blocks')
         n, m, p = ixd.shape[0], iyd.shape[0], ixd.shape[1]

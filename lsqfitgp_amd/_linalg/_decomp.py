@@ -435,6 +435,11 @@ class Chol(Decomposition):
         if fisher and fis is None:
             fis = 0
         if value and val is None:
+            memo = getattr(self, '_density_memo', None)
+            if memo is not None and isinstance(r, numpy.ndarray) and r.dtype == memo[0].dtype and r.shape == memo[0].shape and numpy.array_equal(r, memo[0]):
+                # the posterior of the same data solved L^-1 r on the way (`GP.pred` -> `lgp_posterior`), and kept the density
+                val = memo[1]
+        if value and val is None:
             rd, _ = self._rhs(r, copy=True)
             if rd.shape[1] != 1:
                 raise ValueError('r must be a vector')
