@@ -22,6 +22,7 @@ from . import _lib
 from ._device import Context, DeviceArray
 from ._linalg import Decomposition, Chol
 from . import _kernels
+from . import _dual
 
 
 class _Element:
@@ -44,18 +45,20 @@ class _Points(_Element):
 class _LinTransf(_Element):
     """ Linear transformation of other elements with fixed coefficient tensors
     (``_elements.py:119-147`` restricted to what `addtransf` builds, ``:332-344``) """
-    def __init__(self, tensors, keys, shape, axes):
+    def __init__(self, tensors, keys, shape, axes, dtensors=None):
         self.tensors = tensors
         self.keys = keys
         self.shape = shape
         self.axes = axes
+        self.dtensors = dtensors or {}          # element key -> {tangent key: array like the tensor}  (`_dual`)
 
 
 class _Cov(_Element):
     """ User-provided covariance matrix block(s) (``_elements.py:149-156``) """
-    def __init__(self, blocks, shape):
+    def __init__(self, blocks, shape, tangents=None):
         self.blocks = blocks
         self.shape = shape
+        self.tangents = tangents if tangents is not None else {}      # (row, col) -> {tangent key: matrix like the block}  (`_dual`)
 
 
 class Diagonal:
@@ -66,6 +69,7 @@ class Diagonal:
     """
 
     def __init__(self, values):
+        values, self.dvalues = _dual.split(values)          # (tangents of the diagonal, when it was computed from hyperparameters)
         self.values = numpy.asarray(values)
         if self.values.ndim != 1:
             raise ValueError('the diagonal must be a vector')
@@ -218,6 +222,7 @@ class GP:
         self._givencov_cache = None    # (keys, fingerprint of givencov, decomposition kwargs, decomposition) of the last call
         self._elements = {}        # key -> _Element
         self._covblocks = {}       # (key, key) -> DeviceArray (2d flattened)
+        self._tanblocks = {}       # (key, key) -> {tangent key: DeviceArray}: derivatives of the blocks (`_dual`)
         self._decompcache = {}     # tuple of keys -> Decomposition
         self._checkpositive = bool(checkpos)
         self._posepsfac = float(posepsfac)
@@ -247,6 +252,7 @@ class GP:
         new._checkkeys = []
         new._elements = self._elements.copy()
         new._covblocks = self._covblocks.copy()
+        new._tanblocks = self._tanblocks.copy()
         new._decompcache = self._decompcache.copy()
         new._checkpos_cache = list(self._checkpos_cache)
         return new
@@ -358,9 +364,12 @@ class GP:
             raise KeyError(missing[0])
         if len(tensors) == 0:
             raise ValueError('empty tensors, undetermined output shape')
-        coeffs, outshapes = {}, []
+        coeffs, dcoeffs, outshapes = {}, {}, []
         for k, t in tensors.items():
+            t, dt = _dual.split(t)
             t = numpy.asarray(t)
+            if dt:
+                dcoeffs[k] = {key: numpy.broadcast_to(numpy.asarray(v, float), t.shape) for key, v in dt.items()}
             if self._checkfinite and not numpy.all(numpy.isfinite(t)):
                 raise ValueError(f'tensors[{k!r}] contains infs/nans')
             eshape = self._elements[k].shape
@@ -378,7 +387,7 @@ class GP:
             right = ', '.join(repr(self._elements[k].shape) for k in coeffs)
             raise ValueError(f'can not broadcast tensors with shapes [{left}] contracted with arrays with shapes [{right}]')
         new = self._clone()
-        new._elements[key] = _LinTransf(coeffs, list(coeffs), tuple(shape), axes)
+        new._elements[key] = _LinTransf(coeffs, list(coeffs), tuple(shape), axes, dcoeffs)
         return new
 
     def addlintransf(self, transf, keys, key, *, checklin=None):
@@ -448,12 +457,17 @@ class GP:
             decomps = {} if decomps is None else {key: decomps}
 
         # pass 1: the diagonal blocks fix the shape of every new element
-        shapes, raw = {}, {}
+        shapes, raw, rawtan = {}, {}, {}
         for pair, block in given.items():
             for k in pair:
                 self._require_new(k)
             if block is None:
                 raise TypeError(f'block {pair!r} is None')
+            block, dblock = _dual.split(block)
+            if isinstance(block, Diagonal) and block.dvalues:
+                dblock = {key: Diagonal(numpy.broadcast_to(numpy.asarray(v, float), block.values.shape)) for key, v in block.dvalues.items()}
+            if dblock:
+                rawtan[pair] = dblock
             if not isinstance(block, Diagonal):
                 block = numpy.asarray(block)
             row, col = pair
@@ -499,9 +513,17 @@ class GP:
                 if row != col and not numpy.allclose(mat.T, flat[col, row]):
                     raise ValueError(f'block {(row, col)!r} is not the transpose of block {(col, row)!r}')
 
+        # tangents of the blocks (`_dual`), flattened like the blocks
+        flattan = {}
+        for (row, col), d in rawtan.items():
+            rs, cs = math.prod(shapes[row]), math.prod(shapes[col])
+            flattan[row, col] = {key: (v if isinstance(v, Diagonal) else numpy.broadcast_to(numpy.asarray(v, float), raw[row, col].shape).reshape(rs, cs))
+                                 for key, v in d.items()}
+            if row != col and (col, row) not in rawtan:
+                flattan[col, row] = {key: v.T for key, v in flattan[row, col].items()}
         new = self._clone()
         for k, shape in shapes.items():
-            new._elements[k] = _Cov(flat, shape)
+            new._elements[k] = _Cov(flat, shape, flattan)
             if decomps.get(k) is not None:
                 new._decompcache[k,] = decomps[k]
         return new
@@ -699,6 +721,165 @@ class GP:
                 self._covblocks[col, row] = blockT if blockT is not None else _transposed(block)
             self._covblocks[row, col] = block
         return self._covblocks[row, col]
+
+    # ---- first-order tangents of the blocks with respect to hyperparameters (`_dual`): what jax.jacfwd of the reference's
+    # gpfactory yields for the prior covariance (``_fit.py:598-616``), block by block through the same structure as the values
+
+    def _apply_tensor(self, x, k, t, cov, out):
+        """ out (+)= t applied to cov(k, .) as element k's coefficient in the transformation x (the operations of
+        `_makecovblock_lintransf_any`, one term) """
+        elem = self._elements[k]
+        t = numpy.asarray(t)
+        ysize = cov.shape[1]
+        dt = cov.dtype if out is None else numpy.result_type(cov.dtype, out.dtype)
+        cov = _astype_dev(cov, dt)
+        if out is not None and out.dtype != dt:
+            out = _astype_dev(out, dt)
+        if t.shape:
+            axes = x.axes[k] if isinstance(x.axes, dict) else x.axes
+            csize = math.prod(elem.shape[:axes])
+            rest = math.prod(elem.shape[axes:])
+            osize = math.prod(t.shape[:t.ndim - axes])
+            if (osize * rest) != x.size:
+                raise NotImplementedError('broadcasting between transformed elements of different shapes')
+            td = DeviceArray.from_host(t.reshape(osize, csize), dtype=dt, ctx=self.ctx)
+            covr = (cov if cov.contiguous else cov.copy()).reshape_contiguous((csize, rest * ysize))
+            if out is None:
+                return _gemm(False, False, td, covr).reshape_contiguous((x.size, ysize))
+            _gemm(False, False, td, covr, 1., 1., out.reshape_contiguous((osize, rest * ysize)))
+            return out
+        if elem.size == x.size:
+            return _axpby(float(t), cov, 0., None) if out is None else _axpby(float(t), cov, 1., out, out)
+        if elem.size == 1:
+            ones = DeviceArray.from_host(numpy.ones((x.size, 1)), dtype=dt, ctx=self.ctx)
+            return _gemm(False, False, ones, cov, float(t), 0.) if out is None else _gemm(False, False, ones, cov, float(t), 1., out)
+        raise NotImplementedError('broadcasting between transformed elements of different shapes')
+
+    def _tangents_lintransf(self, xkey, ykey):
+        x = self._elements[xkey]
+        out = {}
+        for k in x.keys:
+            t = x.tensors[k]
+            for key, dcov in self._tangents_of(k, ykey).items():              # t d(cov)
+                out[key] = self._apply_tensor(x, k, t, dcov, out.get(key))
+            dts = x.dtensors.get(k)
+            if dts:                                                           # d(t) cov
+                cov = self._covblock(k, ykey)
+                if not isinstance(cov, _Zero):
+                    for key, dt in dts.items():
+                        out[key] = self._apply_tensor(x, k, dt, cov, out.get(key))
+        return out
+
+    def _maketangents(self, xkey, ykey):
+        x, y = self._elements[xkey], self._elements[ykey]
+        if isinstance(x, _Points) and isinstance(y, _Points):
+            kernel = self._covfun
+            if kernel is None or not kernel.tangent_keys():
+                return {}
+            xf = x.x.reshape(-1)
+            yf = xf if y is x else y.x.reshape(-1)
+            if x.deriv or y.deriv:
+                raise NotImplementedError('tangents of the hyperparameters of derivative observations')
+            _, tans = kernel.gram_tangents(xf, yf, ctx=self.ctx)
+            return tans
+        if isinstance(x, _LinTransf):
+            return self._tangents_lintransf(xkey, ykey)
+        if isinstance(y, _LinTransf):
+            return {key: T.transpose() for key, T in self._tangents_lintransf(ykey, xkey).items()}
+        if isinstance(x, _Cov) and isinstance(y, _Cov) and x.blocks is y.blocks and (xkey, ykey) in x.tangents:
+            return {key: self._upload_block(v) for key, v in x.tangents[xkey, ykey].items()}
+        return {}
+
+    def _tangents_of(self, row, col):
+        """ ``{tangent key: d cov(row, col)}`` as device matrices; keys the block does not depend on are absent """
+        if (row, col) not in self._tanblocks:
+            tans = self._maketangents(row, col)
+            self._tanblocks[row, col] = tans
+            if row != col:
+                self._tanblocks[col, row] = {key: T.transpose() for key, T in tans.items()}
+        return self._tanblocks[row, col]
+
+    def _assembletangents(self, keys, tkeys, dtype):
+        """ d(_assemblecovblocks(keys)) / d(tangent key), one matrix per entry of ``tkeys`` """
+        sizes = [self._elements[k].size for k in keys]
+        n = sum(sizes)
+        mats = []
+        for tk in tkeys:
+            M = None
+            r0 = 0
+            for row, rs in zip(keys, sizes):
+                c0 = 0
+                for col, cs in zip(keys, sizes):
+                    T = self._tangents_of(row, col).get(tk)
+                    if T is not None and T.size:
+                        if len(keys) == 1:
+                            M = _astype_dev(T, dtype)
+                        else:
+                            if M is None:
+                                M = DeviceArray.zeros((n, n), dtype, self.ctx)
+                            M.block(r0, r0 + rs, c0, c0 + cs).assign(_astype_dev(T, dtype))
+                    c0 += cs
+                r0 += rs
+            mats.append(M)
+        return mats
+
+    def _prior_decomp_tangents(self, given, givencov=None, tkeys=(), **kw):
+        """
+        `_prior_decomp` plus the first-order tangents of what the likelihood is made of: returns
+        ``(decomp, r, dK, dr)`` with ``dK`` a list of device matrices (one per tangent key in ``tkeys``, the derivative of the
+        decomposed matrix) and ``dr`` an (n, len(tkeys)) host matrix (the derivative of the residuals) or None -- the inputs of
+        `Chol.normal_density_derivs`.  Hyperparameters enter through the kernel (`Kernel.gram_tangents`), through `addcov` blocks
+        and `addtransf` coefficients computed from `_dual.Dual` values, through ``givencov`` blocks and through ``given``.
+        """
+        tkeys = list(tkeys)
+        plain, dgiven = {}, {}
+        for k, v in given.items():
+            plain[k], dgiven[k] = _dual.split(v)
+        gc_plain, dgc = givencov, {}
+        if givencov is not None and hasattr(givencov, 'keys'):
+            gc_plain = {}
+            for pair, block in givencov.items():
+                b, db = _dual.split(block)
+                if isinstance(b, Diagonal) and b.dvalues:
+                    db = {key: Diagonal(numpy.broadcast_to(numpy.asarray(v, float), b.values.shape)) for key, v in b.dvalues.items()}
+                gc_plain[pair] = b
+                if db:
+                    dgc[pair] = db
+        decomp, ymean = self._prior_decomp(plain, gc_plain, **kw)
+        inkeys = list(plain)
+        dtype = decomp._dtype
+        mats = self._assembletangents(inkeys, tkeys, dtype)
+        sizes = [self._elements[k].size for k in inkeys]
+        n = sum(sizes)
+        offs = dict(zip(inkeys, numpy.pad(numpy.cumsum(sizes), (1, 0))[:-1]))
+        owned = set()
+        for (row, col), db in dgc.items():
+            for key, v in db.items():
+                if key not in tkeys:
+                    continue
+                i = tkeys.index(key)
+                if mats[i] is None:
+                    mats[i] = DeviceArray.zeros((n, n), dtype, self.ctx)
+                    owned.add(i)
+                elif i not in owned:                    # (possibly a cached tangent block itself: never written to)
+                    mats[i] = mats[i].copy()
+                    owned.add(i)
+                rs, cs = self._elements[row].size, self._elements[col].size
+                blk = _astype_dev(self._upload_block(v if isinstance(v, Diagonal) else numpy.broadcast_to(numpy.asarray(v, float), numpy.shape(gc_plain[row, col])).reshape(rs, cs)), dtype)
+                dst = mats[i].block(int(offs[row]), int(offs[row]) + rs, int(offs[col]), int(offs[col]) + cs)
+                _axpby(1., blk, 1., dst, dst)
+        for i, M in enumerate(mats):
+            if M is None:
+                mats[i] = DeviceArray.zeros((n, n), dtype, self.ctx)
+        dr = None
+        if any(dgiven.values()):
+            dr = numpy.zeros((n, len(tkeys)))
+            for k in inkeys:
+                for key, v in dgiven[k].items():
+                    if key in tkeys:
+                        shape = numpy.shape(plain[k])
+                        dr[int(offs[k]):int(offs[k]) + self._elements[k].size, tkeys.index(key)] = numpy.broadcast_to(numpy.asarray(v, float), shape).reshape(-1)
+        return decomp, ymean, mats, dr
 
     def _assemblecovblocks(self, rowkeys, colkeys=None):
         """ ``_elements.py:642-649`` (jnp.block): strided device copies into one matrix """

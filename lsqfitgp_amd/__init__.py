@@ -15,6 +15,7 @@ from ._GP import GP, Diagonal, diag
 from ._fit import empbayes_fit
 from ._fastraniter import raniter, sample
 from ._uncertain import UVal
+from ._dual import Dual
 from . import _linalg
 from . import copula
 from . import bayestree

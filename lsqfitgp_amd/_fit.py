@@ -15,14 +15,15 @@ Differences from the reference, all forced by the absence of jax / gvar here:
   (or `UVal`) for Normal variables, `copula` distribution objects for the others.
   gvar's key convention is kept: a key ``'log(x)'`` makes both ``hp['log(x)']``
   and ``hp['x']`` available to ``gpfactory`` (also ``sqrt``, ``erfinv``);
-* there is no automatic differentiation of ``gpfactory``.  The gradient comes from
-  ``gradfactory(hp, **gpfactorykw) -> (decomp, r, dK, dr, names)``, which returns
-  the decomposition, the residuals and their analytic derivatives with respect to
-  the hyperparameters ``names`` as device matrices (kernel tangents from
-  ``kernel.gram_dscale`` / ``BART.gram_jvp``), contracted on the device by
-  ``Chol.normal_density_derivs`` (``_linalg/_decomp.py:461-561`` of the reference);
-  without it, by central differences of the objective (2 x #hyperparameters device
-  evaluations per gradient);
+* ``gpfactory`` is not traced.  Its derivatives come, in this order, from (a) ``gradfactory(hp, **gpfactorykw) -> (decomp,
+  r, dK, dr, names)``, hand-written analytic derivatives as device matrices; (b) the factory's own arithmetic: the
+  hyperparameters are handed over as `Dual` values that carry first-order tangents, and the kernel (``scale``, ``loc``,
+  ``kernel * c``, ``kernel + c``; BART's ``alpha`` / ``beta``), `GP.addcov` / ``givencov`` blocks, `GP.addtransf` coefficients
+  and the data computed from them yield the derivative of the decomposed matrix and of the residuals next to their values
+  (`GP._prior_decomp_tangents`; the first gradient is checked once against central differences, because a factory can drop
+  a tangent silently, e.g. ``float(hp['x'])``); (c) central differences of the objective (2 x #hyperparameters device
+  evaluations per gradient) for whatever (b) does not cover.  In (a) and (b) the contraction with K^-1 runs on the device
+  (`Chol.normal_density_derivs`, ``_linalg/_decomp.py:461-561`` of the reference), Fisher matrix included;
 * results are plain dictionaries of floats (``pmean``), of `UVal` (``p``) and of
   covariance blocks (``pcov``) instead of gvars.
 """
@@ -35,6 +36,7 @@ import numpy
 from scipy import optimize, special
 
 from . import copula as _copula
+from . import _dual
 from ._uncertain import UVal
 
 # gvar.BufferDict's built-in key functions: 'f(x)' in the prior -> x = invf(value) for the model
@@ -178,6 +180,13 @@ class empbayes_fit:
     gradfactory : callable, optional
         ``gradfactory(hp, **gpfactorykw) -> (decomp, r, dK, dr, names)``: analytic derivatives (see the module
         docstring).  ``dK`` is a list of device matrices (or None), ``dr`` an (n, len(names)) array (or None).
+    autodiff : bool, default True
+        Without a ``gradfactory``: hand the hyperparameters to ``gpfactory`` (and to ``data``, if callable) as values that
+        carry first-order tangents (`lsqfitgp_amd.Dual`) and let the kernel, the covariance blocks and the transformation
+        coefficients built from them return the derivative of the prior covariance next to the matrix -- the counterpart of
+        the reference's ``jax.jacfwd`` of the factory (``_fit.py:598-616``).  Covers kernel ``scale`` / ``loc``, ``kernel * c``,
+        ``kernel + c``, `addcov` and ``givencov`` blocks, `addtransf` coefficients and the data; the first operation that is not
+        covered (a shape parameter of a kernel, say) switches the fit to central differences for good.
     jit, forward : ignored (there is no tracing compiler here; derivatives are forward-mode).
 
     Attributes
@@ -188,7 +197,7 @@ class empbayes_fit:
 
     def __init__(self, hyperprior, gpfactory, data, *, raises=True, minkw={}, gpfactorykw={}, jit=True,
                  method='gradient', initial='priormean', verbosity=0, covariance='auto', fix=None, mlkw={},
-                 forward=False, additional_loss=None, gradfactory=None, fdstep=1e-5, rng=None):
+                 forward=False, additional_loss=None, gradfactory=None, autodiff=True, fdstep=1e-5, rng=None):
         assert callable(gpfactory)
         self._verbosity = int(verbosity)
         self._log('**** call lsqfitgp_amd.empbayes_fit ****', 1)
@@ -208,7 +217,9 @@ class empbayes_fit:
             raise KeyError(covariance)
         if method not in ('nograd', 'gradient', 'fisher'):
             raise KeyError(method)
-        if (method == 'fisher' or covariance == 'fisher') and gradfactory is None:
+        self._autodiff = bool(autodiff) and gradfactory is None
+        self._autodiff_checked = False
+        if (method == 'fisher' or covariance == 'fisher') and gradfactory is None and not self._autodiff:
             raise NotImplementedError('the Fisher matrix needs analytic derivatives: pass gradfactory')
         if (method == 'fisher' or covariance == 'fisher') and additional_loss is not None:
             raise NotImplementedError('Fisher matrix not implemented with additional_loss')     # _fit.py:737-741
@@ -341,17 +352,74 @@ class empbayes_fit:
                 T[k, slopes[nm][0]] = slopes[nm][1]
         return float(value), T.T @ numpy.asarray(grad, float), (None if fish is None else T.T @ numpy.asarray(fish, float) @ T)
 
+    def _auto_derivs(self, z, fisher):
+        """ value, gradient and Fisher matrix in z by forward-mode differentiation of the factory's own arithmetic: the
+        hyperparameters go to ``gpfactory`` (and ``data``) as `_dual.Dual` values whose tangents are their slopes in z, and the
+        GP assembles the derivative of its prior covariance next to the matrix (`GP._prior_decomp_tangents`).  The counterpart
+        of ``jax.jacfwd`` in ``_fit.py:598-616``. """
+        values = self._space.unflat(z)
+        slopes = self._space.slopes(z)
+        hp = {nm: (_dual.Dual(float(v), {slopes[nm][0]: float(slopes[nm][1])}) if nm in slopes else v) for nm, v in values.items()}
+        gp = self.gpfactory(hp, **self.gpfactorykw)
+        if not hasattr(gp, '_prior_decomp_tangents'):
+            raise NotImplementedError(f'{type(gp).__module__}.{type(gp).__name__} does not assemble tangents')
+        decomp, r, dK, dr = gp._prior_decomp_tangents(*self._args(hp), tkeys=range(len(z)), **self._mlkw)
+        value, grad, fish = decomp.normal_density_derivs(numpy.asarray(r, float), dK, dr, fisher=fisher)
+        return float(value), numpy.asarray(grad, float), (None if fish is None else numpy.asarray(fish, float))
+
+    def _analytic(self, z, fisher):
+        """ ``(value, gradient, fisher)`` from `gradfactory` if given, else from the tangents the factory's arithmetic carries;
+        None when neither is available (then: central differences) """
+        if self.gradfactory is not None:
+            return self._derivs(z, fisher)
+        if self._autodiff:
+            try:
+                res = self._auto_derivs(z, fisher)
+            except (NotImplementedError, TypeError) as exc:
+                self._autodiff = False
+                self._log(f'no analytic derivatives for this factory ({exc}): central differences', 1)
+                return None
+            if not self._autodiff_checked:
+                # once per fit: a factory can lose a tangent without an error (numpy.full(n, hp[...]), math.exp(hp[...]) turn
+                # the hyperparameter into a plain number), so the first gradient is held against central differences
+                self._autodiff_checked = True
+                g = self._fd_gradient(z)
+                scale = max(float(numpy.max(numpy.abs(g), initial=0.)), 1e-8)
+                if not numpy.all(numpy.isfinite(res[1])) or numpy.max(numpy.abs(res[1] - g), initial=0.) > 1e-3 * scale + 1e-6:
+                    self._autodiff = False
+                    self._log(f'the tangents of the factory do not reproduce its finite differences ({res[1]} vs {g}): central differences', 1)
+                    return None
+            return res
+        return None
+
+    def _fd_gradient(self, z):
+        """ central differences of the likelihood term alone (what `_analytic` returns the gradient of) """
+        g = numpy.empty(len(z))
+        h = self._fdstep
+        for i in range(len(z)):
+            e = numpy.zeros(len(z)); e[i] = h
+            vals = []
+            for zz in (z + e, z - e):
+                hp = self._space.unflat(zz)
+                gp = self.gpfactory(hp, **self.gpfactorykw)
+                decomp, r = gp._prior_decomp(*self._args(hp), **self._mlkw)
+                vals.append(float(decomp.minus_log_normal_density(numpy.asarray(r, float), value=True)[0]))
+            g[i] = (vals[0] - vals[1]) / (2 * h)
+        return g
+
     def _fun_and_jac(self, z):
         """ the objective and its gradient (``_fit.py:716-725``) """
         z = numpy.asarray(z, float)
         self._calls['grad'] += 1
-        if self.gradfactory is not None:
+        if self.gradfactory is not None or self._autodiff:
             try:
-                value, g, _ = self._derivs(z, False)
+                res = self._analytic(z, False)
             except numpy.linalg.LinAlgError:
                 return numpy.nan, numpy.full(len(z), numpy.nan)
-            loss = 0. if self._additional_loss is None else float(self._additional_loss(self._space.unflat(z)))
-            return value + self._prior_value(z) + loss, g + z + self._loss_grad(z)
+            if res is not None:
+                value, g, _ = res
+                loss = 0. if self._additional_loss is None else float(self._additional_loss(self._space.unflat(z)))
+                return value + self._prior_value(z) + loss, g + z + self._loss_grad(z)
         f0 = self._fun(z)
         g = numpy.empty(len(z))
         h = self._fdstep
@@ -363,8 +431,10 @@ class empbayes_fit:
     def _fisher(self, z):
         """ Fisher information plus the prior precision (``_fit.py:733-745``) """
         self._calls['fisher'] += 1
-        _, _, F = self._derivs(numpy.asarray(z, float), True)
-        return F + numpy.eye(len(z))
+        res = self._analytic(numpy.asarray(z, float), True)
+        if res is None:
+            raise NotImplementedError('the Fisher matrix needs analytic derivatives: this factory has none, pass gradfactory')
+        return res[2] + numpy.eye(len(z))
 
     def _posterior_covariance(self, method, covariance, result):
         """ ``_fit.py:819-862`` """
@@ -374,7 +444,7 @@ class empbayes_fit:
         if covariance == 'fisher':
             prec = result.hess if method == 'fisher' and hasattr(result, 'hess') else self._fisher(result.x)
             return numpy.linalg.inv(numpy.asarray(prec, float))
-        if covariance == 'minhess' and self.gradfactory is None and method != 'nograd' and n:
+        if covariance == 'minhess' and self.gradfactory is None and not self._autodiff and method != 'nograd' and n:
             # finite-difference gradients leave the quasi-Newton estimate of the inverse Hessian rough (the line search
             # stops on rounding noise after a few updates); with so few parameters the Hessian of the objective at the mode
             # is cheap to difference directly: n^2 + n + 1 more evaluations

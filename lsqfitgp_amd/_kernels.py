@@ -21,6 +21,7 @@ from numpy.lib import recfunctions
 from scipy import special as _special   # digamma table for BART (scipy is a dependency of the reference too)
 
 from . import _lib
+from . import _dual
 from ._device import Context, DeviceArray
 
 
@@ -102,6 +103,10 @@ class Kernel:
     """ base class: input transformation, output algops, call contract """
 
     def __init__(self, *, scale=None, loc=None, outops=()):
+        # hyperparameters may carry first-order tangents (`_dual.Dual`, what `empbayes_fit` hands a gpfactory): the kernel keeps
+        # the plain values for everything it already does and the tangents for `gram_tangents`
+        scale, self._dscale = _dual.split(scale)
+        loc, self._dloc = _dual.split(loc)
         if scale is not None:
             if not (0 < scale < numpy.inf):                       # _ops.py:324-325
                 raise AssertionError(scale)
@@ -111,6 +116,7 @@ class Kernel:
         self._scale = scale
         self._loc = loc
         self._outops = tuple(outops)
+        self._doutops = tuple({} for _ in self._outops)          # tangents of the constants of `_outops`, entry by entry
 
     def _copy(self, **kw):
         new = self.__class__.__new__(self.__class__)
@@ -124,11 +130,12 @@ class Kernel:
     def _algop(self, op, c):
         if isinstance(c, Kernel):
             raise NotImplementedError('kernel-kernel algebra is out of scope of the device path; only scalars')
+        c, dc = _dual.split(c)
         if not (isinstance(c, numbers.Number) or (isinstance(c, numpy.ndarray) and c.ndim == 0) or isinstance(c, numpy.generic)):
             return NotImplemented
         if len(self._outops) >= 8:
             raise NotImplementedError('at most 8 chained scalar operations')
-        return self._copy(_outops=self._outops + ((op, c),))
+        return self._copy(_outops=self._outops + ((op, c),), _doutops=getattr(self, '_doutops', ()) + (dict(dc),))
 
     def __mul__(self, c):
         return self._algop('mul', c)
@@ -164,6 +171,22 @@ class Kernel:
 
     def pairs(self, xs, ys, *, ctx=None):  # pragma: no cover
         raise NotImplementedError
+
+    # -- first-order tangents of the hyperparameters (`_dual`)
+    def tangent_keys(self):
+        """ the keys the kernel's hyperparameters carry tangents for """
+        keys = []
+        for d in (getattr(self, '_dscale', {}), getattr(self, '_dloc', {})) + tuple(getattr(self, '_doutops', ())):
+            for k in d:
+                if k not in keys:
+                    keys.append(k)
+        return keys
+
+    def gram_tangents(self, xs, ys, *, ctx=None, **kw):
+        """ ``(K, {key: dK/dkey})`` as device matrices """
+        if self.tangent_keys():
+            raise NotImplementedError(f'tangents of the hyperparameters of {type(self).__name__}')
+        return self.gram(xs, ys, ctx=ctx, **kw), {}
 
 
 class _Isotropic(Kernel):
@@ -300,6 +323,8 @@ class _Isotropic(Kernel):
         """ ``(K, dK/dscale)`` as two device matrices from one pass over the pairs (``lgp_gram_isotropic_dscale``): the
         tangent that ``jax.jacfwd`` of a reference gpfactory produces for a ``scale`` hyperparameter
         (``_Kernel/_ops.py:310-326`` through the core); with ``scale=None`` the derivative at scale = 1 """
+        if self._kind not in (_lib.LGP_KERNEL_EXPQUAD, _lib.LGP_KERNEL_MATERNP, _lib.LGP_KERNEL_GAMMAEXP, _lib.LGP_KERNEL_CAUCHY):
+            raise NotImplementedError(f'derivative of {type(self).__name__} with respect to scale')
         xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
         n, m = xd.shape[1], yd.shape[1]
         out = DeviceArray.empty((n, m), dtype, ctx)
@@ -312,6 +337,48 @@ class _Isotropic(Kernel):
                      int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
                      nops, codes, vals, out.ptr, dout.ptr, out.ld), 'lgp_gram_isotropic_dscale')
         return out, dout
+
+    def gram_tangents(self, xs, ys, *, ctx=None, deriv=(0, 0)):
+        """
+        The Gram matrix and its tangents with respect to the keys of the hyperparameters that came as `_dual.Dual`:
+        ``scale`` (through ``lgp_gram_isotropic_dscale``: the core's derivative in one pass with the values), the constants
+        of ``kernel * c`` and ``kernel + c`` (the output operations are an affine map  a C + b  of the core's matrix C, so
+        dK = a dC/dscale dscale + da C + db), ``loc`` (nothing: the kernels are stationary).  What ``jax.jacfwd`` of a
+        reference gpfactory produces for these hyperparameters (``_Kernel/_ops.py:310-326``, ``_alg.py:32-82``).
+        """
+        keys = self.tangent_keys()
+        K = self.gram(xs, ys, ctx=ctx, deriv=deriv)
+        live = [k for k in keys if k in self._dscale or any(k in d for d in self._doutops)]
+        if not live:
+            return K, {}
+        if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
+            raise NotImplementedError('tangents of the hyperparameters of a derived kernel')
+        core = self._copy(_outops=(), _doutops=(), _dscale={})
+        if self._dscale:
+            C, dC = core.gram_dscale(xs, ys, ctx=ctx)
+        else:
+            C, dC = core.gram(xs, ys, ctx=ctx), None
+        a, b = _dual.Dual(1.), _dual.Dual(0.)
+        for (op, c), dc in zip(self._outops, self._doutops):
+            cd = _dual.Dual(float(c), dc)
+            if op == 'mul':
+                a, b = a * cd, b * cd
+            else:
+                b = b + cd
+        fa, F = _lib.fn('lgp_axpby', C.dtype)
+        fs, _ = _lib.fn('lgp_add_scalar', C.dtype)
+        tangents = {}
+        for k in live:
+            ds, da, db = float(self._dscale.get(k, 0.)), float(a.tangents.get(k, 0.)), float(b.tangents.get(k, 0.))
+            T = DeviceArray.empty(C.shape, C.dtype, C.ctx)
+            if C.size:
+                # T = (a ds) dC + da C   (+ db)
+                _lib.check(fa(C.ctx.handle, C.shape[0], C.shape[1], F(a.value * ds), None if dC is None else dC.ptr, 0 if dC is None else dC.ld,
+                              F(da), C.ptr, C.ld, T.ptr, T.ld), 'lgp_axpby')
+                if db != 0.:
+                    _lib.check(fs(C.ctx.handle, C.shape[0], C.shape[1], T.ptr, T.ld, F(db)), 'lgp_add_scalar')
+            tangents[k] = T
+        return K, tangents
 
     def pairs(self, xs, ys, *, ctx=None):
         xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
@@ -475,6 +542,8 @@ class BART(Kernel):
         if scale is not None or loc is not None:
             if indices:
                 raise ValueError('scale/loc make no sense with indices=True')
+        alpha, self._dalpha = _dual.split(alpha)                     # (tangents of the hyperparameters: `gram_tangents`)
+        beta, self._dbeta = _dual.split(beta)
         self._splits = self._check_splits(splits, indices)
         self._indices = bool(indices)
         self._dpnt_ab = None
@@ -824,6 +893,31 @@ class BART(Kernel):
                          ntan, dpr, tptr, None if first else tptr), 'lgp_gram_bart_jvp')
             first = False
         return out, tans
+
+    def tangent_keys(self):
+        keys = super().tangent_keys()
+        for d in (self._dalpha, self._dbeta):
+            for k in d:
+                if k not in keys:
+                    keys.append(k)
+        return keys
+
+    def gram_tangents(self, xs, ys, *, ctx=None):
+        """ the Gram matrix and its tangents for ``alpha`` / ``beta`` given as `_dual.Dual` (through `gram_jvp`) """
+        if self._dscale or self._dloc or any(self._doutops):
+            raise NotImplementedError('tangents of BART with respect to scale, loc or multiplied / added constants')
+        if not (self._dalpha or self._dbeta):
+            return self.gram(xs, ys, ctx=ctx), {}
+        K, (dKa, dKb) = self.gram_jvp(xs, ys, ctx=ctx)
+        f, F = _lib.fn('lgp_axpby', K.dtype)
+        tangents = {}
+        for key in self.tangent_keys():
+            T = DeviceArray.empty(K.shape, K.dtype, K.ctx)
+            if K.size:
+                _lib.check(f(K.ctx.handle, K.shape[0], K.shape[1], F(float(self._dalpha.get(key, 0.))), dKa.ptr, dKa.ld,
+                             F(float(self._dbeta.get(key, 0.))), dKb.ptr, dKb.ld, T.ptr, T.ld), 'lgp_axpby')
+            tangents[key] = T
+        return K, tangents
 
     def _pairs_indices(self, ix, iy, npair=None, ctx=None):
         ctx = ctx or Context.default()

@@ -1,0 +1,84 @@
+"""
+`lsqfitgp_amd.Dual`: the first-order tangents that `empbayes_fit` threads through a gpfactory's host arithmetic (the stand-in for
+``jax.jacfwd`` of the factory, reference ``_fit.py:598-616``), against central differences.  CPU only.
+"""
+
+import numpy as np
+import pytest
+
+from lsqfitgp_amd._dual import Dual, split
+
+
+def fd(f, x, h=1e-6):
+    return (f(x + h) - f(x - h)) / (2 * h)
+
+
+SCALAR_FUNCS = [
+    lambda s: s * s + 3 * s - 1 / s,
+    lambda s: np.exp(s) * 2 - np.log(s),
+    lambda s: np.sqrt(s) ** 3 + s ** 2.5 + 2. ** s,
+    lambda s: (1 + s) / (2 - s) - (-s),
+    lambda s: np.square(s) + np.tanh(s) + np.log1p(s) + np.expm1(s),
+    lambda s: np.sin(s) * np.cos(s) + np.arctan(s) + np.abs(s) + np.reciprocal(s),
+    lambda s: 3. - s + (s - 3.) + 2. / s,
+]
+
+
+@pytest.mark.parametrize('k', range(len(SCALAR_FUNCS)))
+def test_scalar_arithmetic(k):
+    f = SCALAR_FUNCS[k]
+    x = 0.7
+    out = f(Dual(x, {'a': 1.}))
+    assert float(out) == pytest.approx(f(x), rel=1e-15)
+    assert out.tangents['a'] == pytest.approx(fd(f, x), rel=1e-8)
+
+
+def test_two_keys_and_chain_rule():
+    a, b = Dual(1.3, {0: 2.}), Dual(0.4, {1: -1.})
+    out = a * b + a / b + a ** b
+    f = lambda u, v: u * v + u / v + u ** v
+    assert float(out) == pytest.approx(f(1.3, 0.4))
+    assert out.tangents[0] == pytest.approx(2. * fd(lambda u: f(u, 0.4), 1.3), rel=1e-8)
+    assert out.tangents[1] == pytest.approx(-1. * fd(lambda v: f(1.3, v), 0.4), rel=1e-8)
+
+
+def test_arrays():
+    s = Dual(0.3, {'s': 1.})
+    eye = np.eye(3)
+    M = s * eye + np.ones((3, 3)) * s ** 2                  # Dual on either side of an array
+    assert isinstance(M, Dual) and M.shape == (3, 3)
+    np.testing.assert_allclose(np.asarray(M), 0.3 * eye + 0.09)
+    np.testing.assert_allclose(M.tangent('s'), eye + 0.6)
+    N = eye * s                                             # ndarray.__mul__ defers to the Dual
+    assert isinstance(N, Dual)
+    np.testing.assert_allclose(N.tangent('s'), eye)
+    y = np.arange(4.)
+    r = y - s * y                                           # data that depend on a hyperparameter
+    np.testing.assert_allclose(np.asarray(r), 0.7 * y)
+    np.testing.assert_allclose(r.tangent('s'), -y)
+    np.testing.assert_allclose(r.tangent('other'), 0 * y)
+    np.testing.assert_allclose(M.reshape(9).tangent('s'), (eye + 0.6).reshape(9))
+    np.testing.assert_allclose(M[1].tangent('s'), (eye + 0.6)[1])
+    np.testing.assert_allclose((M @ y[:3]).tangent('s'), (eye + 0.6) @ y[:3])
+    np.testing.assert_allclose((y[:3] @ M).tangent('s'), y[:3] @ (eye + 0.6))
+
+
+def test_comparisons_and_validation_see_the_value():
+    s = Dual(2., {'s': 1.})
+    assert 0 < s < np.inf and s > 1 and s >= 2. and s <= 2. and s == 2. and s != 3.
+    assert np.isfinite(s) and np.all(np.isfinite(s * np.ones(3)))
+    assert float(s) == 2. and np.asarray(s * np.ones(2)).tolist() == [2., 2.]
+    v, t = split(s)
+    assert v == 2. and t == {'s': 1.}
+    assert split(3.) == (3., {})
+
+
+def test_zero_tangents_are_dropped():
+    s = Dual(2., {'a': 1., 'b': 0.})
+    assert list(s.tangents) == ['a']
+    assert list((s * 0.).tangents) == []
+
+
+def test_unsupported_ufunc_is_refused():
+    with pytest.raises(NotImplementedError):
+        np.arccosh(Dual(2., {'a': 1.}))

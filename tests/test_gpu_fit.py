@@ -324,3 +324,144 @@ def test_bart_fit_at_c5_size(lgp):
     # the objective the minimiser saw at the MAP: minus log likelihood + the standard-normal prior of z
     z = b.fit.zmean
     assert f1 == pytest.approx(-lo + 0.5 * (len(z) * np.log(2 * np.pi) + z @ z), rel=1e-9)
+
+
+# ---- derivatives of the factory's own arithmetic (`lsqfitgp_amd.Dual`, the stand-in for jax.jacfwd of the factory) ------------
+
+def test_kernel_tangents_match_finite_differences(lgp, rng):
+    """ `Kernel.gram_tangents`: scale (through a chain of host arithmetic), the constants of kernel * c and kernel + c """
+    D = lgp.Dual
+    x = rng.uniform(0, 10, 300)
+    y = rng.uniform(0, 10, 200)
+
+    def build(mod, z, a, c, cls, **kw):
+        return (cls(scale=mod_exp(z), **kw) * a ** 2 + c) * 0.5
+
+    mod_exp = np.exp
+    for cls, kw in ((lgp.ExpQuad, {}), (lgp.Maternp, dict(p=2)), (lgp.GammaExp, dict(gamma=1.3)), (lgp.Cauchy, dict(alpha=1.5, beta=2.5))):
+        z0, a0, c0 = 0.3, 1.4, 0.2
+        kern = build(lgp, D(z0, {'z': 1.}), D(a0, {'a': 1.}), D(c0, {'c': 1.}), cls, **kw)
+        assert sorted(kern.tangent_keys()) == ['a', 'c', 'z']
+        K, tans = kern.gram_tangents(x, y)
+        plain = lambda z, a, c: build(lgp, z, a, c, cls, **kw).gram(x, y).to_host()
+        np.testing.assert_array_equal(K.to_host(), plain(z0, a0, c0))          # the values are those of the plain kernel
+        h = 1e-6
+        fd = {'z': (plain(z0 + h, a0, c0) - plain(z0 - h, a0, c0)) / (2 * h),
+              'a': (plain(z0, a0 + h, c0) - plain(z0, a0 - h, c0)) / (2 * h),
+              'c': (plain(z0, a0, c0 + h) - plain(z0, a0, c0 - h)) / (2 * h)}
+        for key in 'zac':
+            np.testing.assert_allclose(tans[key].to_host(), fd[key], rtol=2e-7, atol=2e-9, err_msg=f'{cls.__name__} {key}')
+    # a kernel without tangents, and one whose tangent is not available
+    K, tans = lgp.ExpQuad(scale=2.).gram_tangents(x, y)
+    assert tans == {}
+    with pytest.raises(NotImplementedError):
+        lgp.Wendland(scale=D(2., {'s': 1.})).gram_tangents(x, y)
+
+
+def test_fit_without_gradfactory_uses_the_tangents_of_the_factory(lgp):
+    """ docs/userguide/hyper.rst:124-156 again, with no gradfactory: the gradient comes from the Dual hyperparameters """
+    fit = fit_sdev_scale(lgp, covariance='fisher')
+    assert fit._autodiff and fit._autodiff_checked
+    check_sdev_scale(fit)
+    z = np.array([0.3, -0.4])
+    f0, g = fit._fun_and_jac(z)
+    assert f0 == pytest.approx(fit._fun(z), rel=1e-12)
+    for i in range(2):
+        e = np.zeros(2); e[i] = 1e-6
+        assert g[i] == pytest.approx((fit._fun(z + e) - fit._fun(z - e)) / 2e-6, rel=2e-6, abs=1e-7)
+    # the same numbers as the hand-written gradfactory, Fisher matrix included
+    ref = fit_sdev_scale(lgp, gradfactory=_grad_sdev_scale(lgp), covariance='fisher')
+    np.testing.assert_allclose(fit._fun_and_jac(z)[1], ref._fun_and_jac(z)[1], rtol=1e-9)
+    np.testing.assert_allclose(fit._fisher(z), ref._fisher(z), rtol=1e-8)
+    np.testing.assert_allclose(fit.zcov, ref.zcov, rtol=1e-4)
+    # and Newton steps on the Fisher matrix work without a gradfactory
+    newton = fit_sdev_scale(lgp, method='fisher')
+    assert abs(newton.pmean['log(scale)'] - fit.pmean['log(scale)']) <= 1e-4
+
+
+def _composite_model(lgp, rng, n=160, lose_tangent=False, kernel=None):
+    """ kernel scale and amplitude, a noise block, a transformation coefficient, a givencov block and data that all depend on
+    hyperparameters """
+    x = np.sort(rng.uniform(0, 20, n))
+    y = np.sin(x) + 0.3 * rng.standard_normal(n)
+    prior = {'log(scale)': (np.log(2.), 0.5), 'log(amp)': (0., 0.5), 'log(s2)': (np.log(0.1), 0.5), 'w': (1., 0.2), 'mu': (0.1, 0.5),
+             'log(g)': (np.log(0.05), 0.3)}
+
+    def makegp(hp):
+        k = (kernel or lgp.Maternp)(scale=hp['scale'], **({} if kernel else dict(p=2))) * hp['amp']
+        noise = np.diag(np.full(n, float(hp['s2']))) if lose_tangent else lgp.diag(hp['s2'] * np.ones(n))
+        return (lgp.GP(k, checkpos=False).addx(x, 'f').addcov(noise, 'noise').addtransf({'f': 1., 'noise': hp['w']}, 'y'))
+
+    def data(hp):
+        return {'y': y - hp['mu']}, {('y', 'y'): hp['g'] * np.eye(n)}
+
+    return prior, makegp, data
+
+
+def test_tangents_through_blocks_transformations_and_data(lgp, rng):
+    prior, makegp, data = _composite_model(lgp, rng)
+    fit = lgp.empbayes_fit(prior, makegp, data, raises=False, minkw=dict(options=dict(maxiter=3)))
+    assert fit._autodiff and fit._autodiff_checked
+    z = np.array([0.2, -0.3, 0.1, 0.4, -0.2, 0.3])
+    value, g, F = fit._auto_derivs(z, True)
+    np.testing.assert_allclose(g, fit._fd_gradient(z), rtol=2e-6, atol=1e-6)
+    assert value + fit._prior_value(z) == pytest.approx(fit._fun(z), rel=1e-12)
+    # (s2, w and g only enter through w^2 s2 + g: two flat directions; the mean shift has information of its own, uncorrelated
+    # with the covariance parameters)
+    w = np.linalg.eigvalsh(F)
+    assert np.allclose(F, F.T) and np.all(w > -1e-10 * w[-1]) and np.sum(w > 1e-8 * w[-1]) == 4
+    assert F[4, 4] > 0 and np.all(F[4, [0, 1, 2, 3, 5]] == 0)
+    assert np.all(np.linalg.eigvalsh(fit._fisher(z)) >= 1 - 1e-9)
+
+
+def test_uncovered_factory_falls_back_to_central_differences(lgp, rng):
+    prior, makegp, data = _composite_model(lgp, rng, kernel=lgp.Wendland)       # no closed-form scale tangent for this core
+    fit = lgp.empbayes_fit(prior, makegp, data, raises=False, minkw=dict(options=dict(maxiter=2)))
+    assert not fit._autodiff
+    assert np.all(np.isfinite(fit._fun_and_jac(fit.zmean)[1]))
+
+
+def test_lost_tangent_is_noticed(lgp, rng):
+    """ ``float(hp['s2'])`` turns the hyperparameter into a plain number: the first gradient is checked against central
+    differences and the fit goes on with those """
+    prior, makegp, data = _composite_model(lgp, rng, lose_tangent=True)
+    fit = lgp.empbayes_fit(prior, makegp, data, raises=False, minkw=dict(options=dict(maxiter=2)))
+    assert fit._autodiff_checked and not fit._autodiff
+    z = fit.zmean
+    np.testing.assert_allclose(fit._fun_and_jac(z)[1] - z, fit._fd_gradient(z), rtol=1e-6, atol=1e-7)
+
+
+def test_bart_hyperparameters_as_duals(lgp, rng):
+    """ BART(alpha=Dual, beta=Dual): the tangents of `gram_jvp` combined along the keys; a factory written with them gets an
+    analytic gradient from `empbayes_fit` without a gradfactory """
+    D = lgp.Dual
+    n, p = 150, 3
+    Xp = rng.uniform(0, 1, (n, p))
+    y = np.sin(3 * Xp[:, 0]) + Xp[:, 1] ** 2 + 0.1 * rng.standard_normal(n)
+    X = np.empty(n, [(f'x{i}', float) for i in range(p)])
+    for i in range(p):
+        X[f'x{i}'] = Xp[:, i]
+    splits = lgp.BART.splits_from_coord(X)
+    za, zb = 0.4, 0.7
+    f = lambda a, b: lgp.BART(splits=splits, alpha=a, beta=b, maxd=4, reset=2)
+    k = f(D(za, {0: 1., 1: 0.5}), D(zb, {1: 2.}))
+    assert sorted(k.tangent_keys()) == [0, 1]
+    K, tans = k.gram_tangents(X, X)
+    plain = lambda a, b: f(a, b).gram(X, X).to_host()
+    h = 1e-5
+    da = (plain(za + h, zb) - plain(za - h, zb)) / (2 * h)
+    db = (plain(za, zb + h) - plain(za, zb - h)) / (2 * h)
+    np.testing.assert_allclose(K.to_host(), plain(za, zb), rtol=1e-12)
+    np.testing.assert_allclose(tans[0].to_host(), da, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(tans[1].to_host(), 0.5 * da + 2. * db, rtol=1e-5, atol=1e-7)
+
+    prior = {'alpha': lgp.copula.beta(2, 1), 'beta': lgp.copula.invgamma(1, 1), 'log(s2)': (np.log(0.05), 1.)}
+
+    def makegp(hp):
+        kern = lgp.BART(splits=splits, alpha=hp['alpha'], beta=hp['beta'], maxd=4, reset=2)
+        return lgp.GP(kern, checkpos=False).addx(X, 'f').addcov(lgp.diag(hp['s2'] * np.ones(n)), 'e').addtransf({'f': 1, 'e': 1}, 'y')
+
+    fit = lgp.empbayes_fit(prior, makegp, {'y': y}, raises=False, minkw=dict(options=dict(maxiter=4)))
+    assert fit._autodiff and fit._autodiff_checked
+    z = np.array([0.2, -0.1, 0.3])
+    np.testing.assert_allclose(fit._auto_derivs(z, False)[1], fit._fd_gradient(z), rtol=1e-5, atol=1e-6)
