@@ -730,9 +730,13 @@ def main():
         scratch = lgp.DeviceArray.empty((n, n), ctx=ctx)
         e0, e1 = ctx.event(), ctx.event()
         wl._gram(wl.x, wl.x, scratch)
-        ctx.record(e0); wl._gram(wl.x, wl.x, scratch); ctx.record(e1)
-        gms = ctx.elapsed_ms(e0, e1)
-        out['gram_build'] = {'kernel': 'gram_iso_kernel (N x N, stand-alone)', 'bound': 'hbm', 'ms': gms, 'achieved': 8. * n * n / (gms * 1e-3) / 1e9, 'peak': 8000., 'unit': 'GB/s'}
+        gms = 1e9
+        for _ in range(3):
+            ctx.record(e0); wl._gram(wl.x, wl.x, scratch); ctx.record(e1)
+            gms = min(gms, ctx.elapsed_ms(e0, e1))
+        out['gram_build'] = {'kernel': 'gram_iso_kernel (N x N, stand-alone, best of 3; the same array on both sides: one triangle evaluated and mirrored '
+                                       'for the cores heavier than ExpQuad)', 'bound': 'hbm', 'ms': gms, 'achieved': 8. * n * n / (gms * 1e-3) / 1e9,
+                             'peak': 8000., 'write_peak': 6300., 'frac_of_write_peak': 8. * n * n / (gms * 1e-3) / 1e9 / 6300., 'unit': 'GB/s'}
         del scratch
     except Exception as exc:
         out['gram_build'] = {'error': repr(exc)}

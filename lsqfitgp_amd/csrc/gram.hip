@@ -201,10 +201,16 @@ __device__ __forceinline__ T iso_core_dscale(const IsoArgs<T> &g, T r2, T &dk) {
 }
 
 // D > 0: compile-time field count (coordinates of the lane's columns live in registers); D == 0: runtime d
-template <typename T, int D, bool GRAD = false, int CORE = CORE_GENERIC>
+// SYM (both point sets the same, `symmetric` of the C-ABI, _elements.py:567-573 `halfmatrix`): only the tiles that reach the
+// diagonal or lie left of it are in the grid -- numbered consecutively, so that the XCDs (workgroup i runs on XCD i mod 8) get
+// equal shares -- and a tile entirely left of its rows' GT_COLS-block also stores its transpose: thread t keeps its W columns of
+// 16 rows in registers and writes them as W runs of 16 consecutive entries of the rows col0 + c0 + e.  The entries are exactly
+// symmetric by construction ((u - v)^2 == (v - u)^2), so the matrix is the one the full grid writes, at half the evaluations.
+template <typename T, int D, bool GRAD = false, int CORE = CORE_GENERIC, bool SYM = false>
 __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g) {
   constexpr int W = VecOf<T>::W;
   constexpr int GT_COLS = GT_THREADS * W;
+  constexpr int RPB = GT_COLS / GT_ROWS;              // tile rows per GT_COLS-block of rows
   typedef typename VecOf<T>::type vec_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *su = reinterpret_cast<T *>(smem_raw);            // [d][GT_ROWS]
@@ -212,9 +218,23 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
   T *sv = su + d * GT_ROWS;                            // [d][GT_COLS]
 
   const int ntc = (g.m + GT_COLS - 1) / GT_COLS;
-  const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
+  int tr, tc;
+  if (SYM) {
+    // row group G (RPB tile rows) has G + 1 tiles per row: RPB G (G + 1) / 2 tiles before it
+    const long b = blockIdx.x;
+    long G = (long)((sqrt(1.0 + 8.0 * (double)b / RPB) - 1.0) * 0.5);
+    while (RPB * (G + 1) * (G + 2) / 2 <= b) ++G;
+    while (RPB * G * (G + 1) / 2 > b) --G;
+    const long rem = b - RPB * G * (G + 1) / 2;
+    tr = (int)(G * RPB + rem / (G + 1));
+    tc = (int)(rem % (G + 1));
+  } else {
+    tr = blockIdx.x / ntc;
+    tc = blockIdx.x % ntc;
+  }
   const int row0 = tr * GT_ROWS, col0 = tc * GT_COLS;
   const int tid = threadIdx.x;
+  const bool mirror = SYM && tc < tr / RPB;            // (workgroup-uniform) entirely left of the rows' block: nobody else writes its transpose
 
   for (int idx = tid; idx < d * GT_ROWS; idx += GT_THREADS) {
     const int f = idx / GT_ROWS, r = idx % GT_ROWS;
@@ -249,8 +269,9 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
   const bool colfull = (col0 + c0 + W <= g.m) && ((g.ldo % W) == 0) && ((reinterpret_cast<uintptr_t>(g.out) % 16) == 0);
   const int rmax = (g.n - row0) < GT_ROWS ? (g.n - row0) : GT_ROWS;
   const T slope = GRAD ? g.ops.slope() : T(0);
-  for (int r = 0; r < rmax; ++r) {
-    T res[W], dres[W];
+  constexpr int MR = 16;                              // rows per transposed run
+  auto do_row = [&](int r, T (&res)[W]) {
+    T dres[W];
 #pragma unroll
     for (int e = 0; e < W; ++e) {
       T r2 = T(0), d0 = T(0);
@@ -298,6 +319,39 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
           if (GRAD) pd[e] = dres[e];
         }
     }
+  };
+  if (!SYM || !mirror) {
+    for (int r = 0; r < rmax; ++r) {
+      T res[W];
+      do_row(r, res);
+    }
+  } else {
+    // (measured instead: the transpose staged through LDS so that neighbouring lanes write one row -- slower, 2.6 against 2.2 ms at
+    // N = 32768: what the mirrored half costs is HBM write locality, 32-entry runs 256 KB apart, not the coalescing of a store)
+    for (int rb = 0; rb < rmax; rb += MR) {
+      T keep[MR][W];
+      const int cnt = (rmax - rb) < MR ? (rmax - rb) : MR;
+#pragma unroll
+      for (int q = 0; q < MR; ++q)
+        if (q < cnt) do_row(rb + q, keep[q]);
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        T *pt = g.out + (long)(col0 + c0 + e) * g.ldo + row0 + rb;      // row col0 + c0 + e < n: the tile lies left of the diagonal block
+        if (cnt == MR && ((g.ldo % W) == 0) && ((reinterpret_cast<uintptr_t>(g.out) % 16) == 0)) {
+#pragma unroll
+          for (int q = 0; q < MR; q += W) {
+            vec_t v;
+#pragma unroll
+            for (int w2 = 0; w2 < W; ++w2) v[w2] = keep[q + w2][e];
+            *reinterpret_cast<vec_t *>(pt + q) = v;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < MR; ++q)
+            if (q < cnt) pt[q] = keep[q][e];
+        }
+      }
+    }
   }
 }
 
@@ -323,7 +377,7 @@ __global__ void __launch_bounds__(256) gram_iso_pairs_kernel(const IsoArgs<T> g)
 template <typename T>
 int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, int d, const T *dx, size_t ldx, size_t n, const T *dy, size_t ldy, size_t m,
                     int has_loc, T loc, int has_scale, T scale, int nops, const int *hops_code, const T *hops_val, T *dout,
-                    size_t ldo, bool pairs = false, T *ddsc = nullptr) {
+                    size_t ldo, bool pairs = false, T *ddsc = nullptr, bool symmetric = false) {
   LGP_REQUIRE(ctx != nullptr, "null context");
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
@@ -407,7 +461,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   constexpr int GT_COLS = GT_THREADS * W;
   const size_t ntr = (n + GT_ROWS - 1) / GT_ROWS, ntc = (m + GT_COLS - 1) / GT_COLS;
   LGP_REQUIRE(ntr * ntc < (1ull << 31), "gram grid too large");
-  const size_t shmem = (size_t)d * (GT_ROWS + GT_COLS) * sizeof(T);
+  size_t shmem = (size_t)d * (GT_ROWS + GT_COLS) * sizeof(T);
   dim3 gd((unsigned)(ntr * ntc)), bd(GT_THREADS);
   if (ddsc) {
     switch (d) {
@@ -417,7 +471,26 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
       default: hipLaunchKernelGGL((gram_iso_kernel<T, 0, true>), gd, bd, shmem, ctx->stream, g); break;
     }
   } else {
-#define LGP_ISO_LAUNCH(DD, CC) hipLaunchKernelGGL((gram_iso_kernel<T, DD, false, CC>), gd, bd, shmem, ctx->stream, g)
+    // one triangle when both point sets are the same array (and the core is one of the plain ones: the derived kernels are not
+    // symmetric entry by entry)
+    // ... and where it pays: the mirrored half is written in runs of 16 entries 8 N bytes apart, which HBM takes at ~3.9 TB/s
+    // against 5.3-5.6 TB/s for whole tile rows.  ExpQuad, write-bound on the full grid (1.5-1.6 ms at N = 32768), would lose
+    // (2.2 ms); the cores with more arithmetic per entry gain (Matern-5/2 3-D: 2.4 -> 2.2 ms); fp32 runs would be 64 bytes
+    static const bool nosym = getenv("LGP_GRAM_FULL") != nullptr, allsym = getenv("LGP_GRAM_HALF") != nullptr;
+    const bool sym = symmetric && !nosym && dx == dy && n == m && ldx == ldy && n >= (size_t)GT_COLS &&
+                     kernel != LGP_KERNEL_EXPQUAD_DIFF && kernel != LGP_KERNEL_MATERNP_DIFF &&
+                     (allsym || (sizeof(T) == 8 && core_of(kernel, p) != CORE_EXPQUAD));
+    if (sym) {
+      constexpr size_t RPB = GT_COLS / GT_ROWS;
+      size_t tiles = 0;
+      for (size_t tr = 0; tr < ntr; ++tr) tiles += tr / RPB + 1;
+      gd = dim3((unsigned)tiles);
+    }
+#define LGP_ISO_LAUNCH(DD, CC)                                                                                   \
+    do {                                                                                                         \
+      if (sym) hipLaunchKernelGGL((gram_iso_kernel<T, DD, false, CC, true>), gd, bd, shmem, ctx->stream, g);     \
+      else hipLaunchKernelGGL((gram_iso_kernel<T, DD, false, CC>), gd, bd, shmem, ctx->stream, g);               \
+    } while (0)
 #define LGP_ISO_BY_CORE(DD)                                   \
     switch (core_of(kernel, p)) {                             \
       case CORE_EXPQUAD: LGP_ISO_LAUNCH(DD, CORE_EXPQUAD); break;   \
@@ -1157,16 +1230,15 @@ int gram_bart_launch(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const in
 extern "C" int lgp_gram_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d, const double *dx, size_t ldx, size_t n, const double *dy,
                                       size_t ldy, size_t m, int has_loc, double loc, int has_scale, double scale, int nops,
                                       const int *hops_code, const double *hops_val, int symmetric, double *dout, size_t ldo) {
-  (void)symmetric;   // (u-v)^2 == (v-u)^2 bit for bit: the full evaluation is already exactly symmetric
+  // (symmetric: (u-v)^2 == (v-u)^2 bit for bit, so one triangle evaluated and mirrored is the matrix the full evaluation writes)
   return gram_iso_launch<double>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val,
-                                 dout, ldo);
+                                 dout, ldo, false, nullptr, symmetric != 0);
 }
 extern "C" int lgp_gram_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int d, const float *dx, size_t ldx, size_t n, const float *dy,
                                       size_t ldy, size_t m, int has_loc, float loc, int has_scale, float scale, int nops,
                                       const int *hops_code, const float *hops_val, int symmetric, float *dout, size_t ldo) {
-  (void)symmetric;
   return gram_iso_launch<float>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val,
-                                dout, ldo);
+                                dout, ldo, false, nullptr, symmetric != 0);
 }
 extern "C" int lgp_gram_bart_f32(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const int32_t *diy, size_t m,
                                  const int32_t *hnsplits, const float *hweights, int size, int repeat, const float *hprobs, float gamma,

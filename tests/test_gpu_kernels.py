@@ -434,3 +434,52 @@ def test_wendland_dimension_limit(lgp):
         lgp.Wendland(k=0, alpha=1).gram(x, x)             # maxdim = floor(2 alpha - 1) = 1
     with pytest.raises(NotImplementedError):
         lgp.Wendland(k=4)
+
+
+@pytest.mark.parametrize('n', [512, 513, 1000, 2048 + 37, 4096])
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_one_triangle_gram_is_the_full_gram(n, dtype):
+    """ the same array on both sides: tiles on / left of the diagonal evaluated, the rest mirrored (`symmetric` of the C-ABI,
+    reference `halfmatrix` _elements.py:567-573) -- bit for bit the matrix of the full evaluation, for every plain core """
+    import lsqfitgp_amd as lgp
+    rng = np.random.default_rng(n)
+    for d in (1, 3, 5):
+        x = np.empty(n, [(f'f{i}', dtype) for i in range(d)]) if d > 1 else rng.uniform(0, 20, n).astype(dtype)
+        if d > 1:
+            for i in range(d):
+                x[f'f{i}'] = rng.uniform(0, 5, n)
+        kernels = [lgp.ExpQuad(scale=1.3), lgp.Maternp(p=2, scale=0.7) * 1.5 + 0.1, lgp.Maternp(p=1), lgp.Maternp(p=3, scale=2.), lgp.Maternp(p=0),
+                   lgp.GammaExp(gamma=1.2), lgp.Cauchy(alpha=1.5, beta=2.5, scale=3.)]
+        if d <= 3:
+            kernels.append(lgp.Wendland(k=1, alpha=2, scale=4.))
+        for k in kernels:
+            half = k.gram(x, x).to_host()                # xs is ys: one triangle
+            full = k.gram(x, x.copy()).to_host()         # two arrays: every tile
+            np.testing.assert_array_equal(half, full)
+            np.testing.assert_array_equal(half, half.T)
+
+
+def test_one_triangle_gram_forced_for_every_core_and_dtype():
+    """ by default the one-triangle grid is used where it pays (fp64, cores heavier than ExpQuad); LGP_GRAM_HALF=1 forces it
+    everywhere (read once per process, hence the child process): still the full grid's matrix bit for bit """
+    import os, subprocess, sys
+    code = '''
+import numpy as np, lsqfitgp_amd as lgp
+rng = np.random.default_rng(5)
+for dtype in (np.float64, np.float32):
+    for n in (1024, 1500):
+        for d in (1, 3):
+            x = np.empty(n, [(f"f{i}", dtype) for i in range(d)]) if d > 1 else rng.uniform(0, 20, n).astype(dtype)
+            if d > 1:
+                for i in range(d):
+                    x[f"f{i}"] = rng.uniform(0, 5, n)
+            for k in (lgp.ExpQuad(scale=1.3), lgp.Maternp(p=2) * 2. + 1., lgp.GammaExp(gamma=1.2)):
+                half = k.gram(x, x).to_host()
+                full = k.gram(x, x.copy()).to_host()
+                assert np.array_equal(half, full) and np.array_equal(half, half.T), (dtype, n, d, type(k).__name__)
+print("ok")
+'''
+    env = dict(os.environ, LGP_GRAM_HALF='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, '-c', code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.strip().endswith('ok'), res.stdout + res.stderr
