@@ -104,6 +104,14 @@ int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *to
                                    * hpar = {nu + k, the k + 1 coefficients of poly, highest power first}                         */
 #define LGP_KERNEL_CAUSALEXPQUAD 7 /* _kernels/_basic.py:346-360 erfc(alpha/4 r) exp(-r^2/2), input='posabs'; hpar = {alpha / 4}  */
 #define LGP_KERNEL_LOG 8          /* _kernels/_basic.py:381-392 log1p(r) / r, input='posabs'                                     */
+#define LGP_KERNEL_CONSTANT 9     /* _kernels/_basic.py:34-46   1                                                                 */
+#define LGP_KERNEL_WHITE 10       /* _kernels/_basic.py:48-59   1 where every field of x equals that of y, else 0                */
+/* stationary kernels of ONE variable (maxdim = 1, d must be 1): functions of the signed difference delta = x - y */
+#define LGP_KERNEL_EXPON 11       /* _kernels/_basic.py:254-269 exp(-|delta|), input='abs'                                       */
+#define LGP_KERNEL_HOLEEFFECT 12  /* _kernels/_basic.py:299-310 (1 - |delta|) exp(-|delta|), input='abs'                          */
+#define LGP_KERNEL_PERIODIC 13    /* _kernels/_basic.py:187-208 exp(-2 (sin(delta / 2) / outerscale)^2); hpar = {outerscale}        */
+#define LGP_KERNEL_COS 14         /* _kernels/_spectral.py:25-38 cos(delta)                                                       */
+#define LGP_KERNEL_SINC 15        /* _kernels/_spectral.py:113-122 + _special/_sinc.py:25-32 sinc(|delta| + eps), input='posabs'   */
 #define LGP_OP_MUL 0           /* kernel * c  (_Kernel/_alg.py:58-82)  */
 #define LGP_OP_ADD 1           /* kernel + c  (_Kernel/_alg.py:32-56)  */
 

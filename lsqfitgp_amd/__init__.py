@@ -10,7 +10,8 @@ surface (raw outputs).  Python host code -> ctypes -> ``liblsqfitgp_hip.so``
 from ._lib import LibraryError
 from ._device import Context, DeviceArray, asdevice
 from ._linalg import Decomposition, Chol
-from ._kernels import Kernel, ExpQuad, Maternp, GammaExp, Cauchy, Wendland, CausalExpQuad, Log, BART
+from ._kernels import (Kernel, ExpQuad, Maternp, GammaExp, Cauchy, Wendland, CausalExpQuad, Log, Constant, White, Expon, HoleEffect,
+                       Periodic, Cos, Sinc, BART)
 from ._GP import GP, Diagonal, diag
 from ._fit import empbayes_fit
 from ._fastraniter import raniter, sample

@@ -484,6 +484,69 @@ class Log(_Isotropic):
         super().__init__(scale=scale, loc=loc)
 
 
+class Constant(_Isotropic):
+    """ Constant kernel, k(x, y) = 1 (``_kernels/_basic.py:34-46``) """
+    _kind = _lib.LGP_KERNEL_CONSTANT
+
+    def __init__(self, *, scale=None, loc=None):
+        super().__init__(scale=scale, loc=loc)
+
+
+class White(_Isotropic):
+    """ White noise kernel, k(x, y) = 1 if x == y (every field) else 0 (``_kernels/_basic.py:48-59``); the values come as
+    floats where the reference returns integers """
+    _kind = _lib.LGP_KERNEL_WHITE
+
+    def __init__(self, *, scale=None, loc=None):
+        super().__init__(scale=scale, loc=loc)
+
+
+class _Stationary1D(_Isotropic):
+    """ stationary kernels of one variable (``stationarykernel(maxdim=1)``, ``_Kernel/_stationary.py``): functions of the
+    difference of the (transformed) inputs, evaluated by the generic core of the isotropic Gram kernel """
+
+    def __init__(self, *, scale=None, loc=None):
+        super().__init__(scale=scale, loc=loc)
+
+    def _prepare(self, xs, ys, ctx):
+        out = super()._prepare(xs, ys, ctx)
+        if out[4] > 1:
+            raise ValueError(f'kernel called on type with dimensionality {out[4]} > maxdim=1')                 # _crosskernel.py maxdim check
+        return out
+
+
+class Expon(_Stationary1D):
+    """ Exponential kernel, k(Δ) = exp(-|Δ|) (``_kernels/_basic.py:254-269``) """
+    _kind = _lib.LGP_KERNEL_EXPON
+
+
+class HoleEffect(_Stationary1D):
+    """ Hole effect kernel, k(Δ) = (1 - |Δ|) exp(-|Δ|) (``_kernels/_basic.py:299-310``) """
+    _kind = _lib.LGP_KERNEL_HOLEEFFECT
+
+
+class Periodic(_Stationary1D):
+    """ Periodic Gaussian kernel, k(Δ) = exp(-2 (sin(Δ/2) / outerscale)²): ``scale`` sets the period (2π at scale = 1),
+    ``outerscale`` the correlation length (``_kernels/_basic.py:187-208``) """
+    _kind = _lib.LGP_KERNEL_PERIODIC
+
+    def __init__(self, *, outerscale=1, scale=None, loc=None):
+        assert 0 < outerscale < numpy.inf, outerscale
+        super().__init__(scale=scale, loc=loc)
+        self._par = (float(outerscale),)
+
+
+class Cos(_Stationary1D):
+    """ Cosine kernel, k(Δ) = cos(Δ) (``_kernels/_spectral.py:25-38``) """
+    _kind = _lib.LGP_KERNEL_COS
+
+
+class Sinc(_Stationary1D):
+    """ Sinc kernel, k(Δ) = sin(πΔ) / (πΔ) (``_kernels/_spectral.py:113-122``; six Taylor terms below |Δ| = 0.1 as
+    ``_special/_sinc.py:25-32``), input='posabs' """
+    _kind = _lib.LGP_KERNEL_SINC
+
+
 # ------------------------------------------------------------------------------
 # BART
 

@@ -32,6 +32,13 @@ LGP_KERNEL_MATERNP_DIFF = 5
 LGP_KERNEL_WENDLAND = 6
 LGP_KERNEL_CAUSALEXPQUAD = 7
 LGP_KERNEL_LOG = 8
+LGP_KERNEL_CONSTANT = 9
+LGP_KERNEL_WHITE = 10
+LGP_KERNEL_EXPON = 11
+LGP_KERNEL_HOLEEFFECT = 12
+LGP_KERNEL_PERIODIC = 13
+LGP_KERNEL_COS = 14
+LGP_KERNEL_SINC = 15
 LGP_OP_MUL = 0
 LGP_OP_ADD = 1
 LGP_EPS_AUTO_REL = 1

@@ -15,6 +15,7 @@
 // This file is compiled with -ffp-contract=off: the reference evaluates square-then-add without fused
 // multiply-add and the entries are compared to a few ulp.
 #include "common.h"
+#include <limits>
 
 namespace {
 
@@ -96,6 +97,28 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
   } else if (g.kernel == LGP_KERNEL_LOG) {               // _kernels/_basic.py:381-392: log1p(r) / r
     const T r = sqrt(r2);
     return log1p(r) / r;
+  } else if (g.kernel == LGP_KERNEL_CONSTANT) {          // _kernels/_basic.py:34-46
+    return T(1);
+  } else if (g.kernel == LGP_KERNEL_WHITE) {             // _kernels/_basic.py:48-59: d0 is the product over the fields of (x_f == y_f)
+    return d0;
+  } else if (g.kernel == LGP_KERNEL_EXPON) {             // _kernels/_basic.py:254-269: d0 is the signed difference of the one field
+    return exp(-fabs(d0));
+  } else if (g.kernel == LGP_KERNEL_HOLEEFFECT) {        // _kernels/_basic.py:299-310
+    const T a = fabs(d0);
+    return (T(1) - a) * exp(-a);
+  } else if (g.kernel == LGP_KERNEL_PERIODIC) {          // _kernels/_basic.py:187-208
+    const T q = sin(d0 / T(2)) / g.par[0];
+    return exp(T(-2) * (q * q));
+  } else if (g.kernel == LGP_KERNEL_COS) {               // _kernels/_spectral.py:25-38
+    return cos(d0);
+  } else if (g.kernel == LGP_KERNEL_SINC) {              // _kernels/_spectral.py:113-122, _special/_sinc.py:25-32
+    const T a = fabs(d0) + (sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-07f));
+    const T pa = T(3.141592653589793238462643383279502884) * a;
+    if (a < T(0.1)) {                                    // six terms of sum (-1)^m z^m / (2 m + 1)!, z = (pi a)^2
+      const T z = pa * pa;
+      return T(1) + z * (T(-1) / T(6) + z * (T(1) / T(120) + z * (T(-1) / T(5040) + z * (T(1) / T(362880) + z * (T(-1) / T(39916800))))));
+    }
+    return sin(pa) / pa;
   } else if (g.kernel == LGP_KERNEL_GAMMAEXP) {          // _kernels/_basic.py:111-113
     return g.flag ? exp(-r2) : exp(-pow(r2, g.par[1]));
   } else if (g.kernel == LGP_KERNEL_CAUCHY) {            // _kernels/_basic.py:340-344
@@ -124,6 +147,7 @@ __device__ __forceinline__ T iso_aux(const IsoArgs<T> &g, int f, T df, T aux) {
     else if (o == 4) he = u2 * (u2 - T(6)) + T(3);
     return (f == 0 ? T(1) : aux) * he;
   }
+  if (g.kernel == LGP_KERNEL_WHITE) return (f == 0 ? T(1) : aux) * (df == T(0) ? T(1) : T(0));
   return f == 0 ? df : aux;
 }
 // the per-field term of r2: the squared difference, or (|difference| + eps)^2 for input='posabs'
@@ -382,7 +406,8 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_LOG, "unknown isotropic kernel");
+  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_SINC, "unknown isotropic kernel");
+  LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || d == 1, "this kernel is a function of one variable (maxdim = 1)");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
   LGP_REQUIRE(p >= 0 && p <= MAX_P, "Maternp order must be in [0,16]");
   const bool derived = kernel == LGP_KERNEL_EXPQUAD_DIFF || kernel == LGP_KERNEL_MATERNP_DIFF;
@@ -432,6 +457,9 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
     g.par[0] = hpar[0];
   } else if (kernel == LGP_KERNEL_LOG) {
     LGP_REQUIRE(npar == 0, "this kernel takes no real parameters");
+  } else if (kernel == LGP_KERNEL_PERIODIC) {            // hpar = {outerscale}
+    LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] > T(0) && hpar[0] < std::numeric_limits<T>::infinity(), "Periodic takes {outerscale} in (0, inf)");
+    g.par[0] = hpar[0];
   } else if (kernel == LGP_KERNEL_GAMMAEXP) {            // hpar = {gamma, gamma / 2}
     LGP_REQUIRE(npar == 2 && hpar != nullptr, "GammaExp takes {gamma, gamma/2}");
     LGP_REQUIRE(hpar[0] > T(0) && hpar[0] <= T(2), "gamma must be in (0, 2]");                 // _basic.py:109-110

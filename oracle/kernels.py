@@ -295,6 +295,92 @@ def Log(*, scale=None, loc=None):
     return Kernel(_isotropic_posabs(lambda r: numpy.log1p(r) / r), scale=scale, loc=loc)
 
 
+def Constant(*, scale=None, loc=None):
+    """ ``_kernels/_basic.py:34-46`` """
+    def core(x, y):
+        return numpy.ones(numpy.broadcast_shapes(x.shape, y.shape))
+    return Kernel(core, scale=scale, loc=loc)
+
+
+def White(*, scale=None, loc=None):
+    """ ``_kernels/_basic.py:48-59``: the product over the fields of (x_f == y_f) """
+    def core(x, y):
+        if x.dtype.names is None:
+            return (x == y).astype(int)
+        acc = None
+        for name in x.dtype.names:
+            eq = (x[name] == y[name])
+            if x.dtype[name].ndim:
+                eq = numpy.prod(eq, axis=tuple(range(-x.dtype[name].ndim, 0)))
+            acc = eq if acc is None else acc * eq
+        return acc.astype(int)
+    return Kernel(core, scale=scale, loc=loc)
+
+
+def _stationary1d(core, input='signed'):
+    """ ``_Kernel/_stationary.py:52-66`` for points of one variable (maxdim = 1): the core takes x - y, |x - y| ('abs') or
+    |x - y| + eps ('posabs', ``:84-85``) """
+    def newcore(x, y):
+        if x.dtype.names is not None:
+            if len(_leaf_columns_count(x.dtype)) > 1:
+                raise ValueError('kernel called on type with dimensionality > maxdim=1')
+            name = x.dtype.names[0]
+            x, y = x[name], y[name]
+        q = x - y
+        if input == 'abs':
+            q = numpy.abs(q)
+        elif input == 'posabs':
+            q = numpy.abs(q) + numpy.finfo(q.dtype if numpy.issubdtype(q.dtype, numpy.floating) else float).eps
+        return core(q)
+    return newcore
+
+
+def _leaf_columns_count(dtype):
+    out = []
+    for name in dtype.names:
+        sub = dtype[name]
+        if sub.names is not None:
+            out += _leaf_columns_count(sub)
+        else:
+            out += [name] * max(1, int(numpy.prod(sub.shape, dtype=int)))
+    return out
+
+
+def Expon(*, scale=None, loc=None):
+    """ ``_kernels/_basic.py:254-269`` """
+    return Kernel(_stationary1d(lambda d: numpy.exp(-d), 'abs'), scale=scale, loc=loc)
+
+
+def HoleEffect(*, scale=None, loc=None):
+    """ ``_kernels/_basic.py:299-310`` """
+    return Kernel(_stationary1d(lambda d: (1 - d) * numpy.exp(-d), 'abs'), scale=scale, loc=loc)
+
+
+def Periodic(*, outerscale=1, scale=None, loc=None):
+    """ ``_kernels/_basic.py:187-208`` """
+    assert 0 < outerscale < numpy.inf
+    return Kernel(_stationary1d(lambda d: numpy.exp(-2 * (numpy.sin(d / 2) / outerscale) ** 2)), scale=scale, loc=loc)
+
+
+def Cos(*, scale=None, loc=None):
+    """ ``_kernels/_spectral.py:25-38`` """
+    return Kernel(_stationary1d(numpy.cos), scale=scale, loc=loc)
+
+
+def sinc(x):
+    """ ``_special/_sinc.py:25-32``: six Taylor terms in (pi x)^2 below |x| = 0.1, sin(pi x) / (pi x) elsewhere """
+    z = numpy.square(numpy.pi * x)
+    m = numpy.arange(6)
+    coef = (-1.) ** m / numpy.exp(special.gammaln(2 + 2 * m))
+    near = numpy.polyval(coef[::-1], z)
+    return numpy.where(numpy.abs(x) < 1e-1, near, numpy.sinc(x))
+
+
+def Sinc(*, scale=None, loc=None):
+    """ ``_kernels/_spectral.py:113-122`` """
+    return Kernel(_stationary1d(sinc, 'posabs'), scale=scale, loc=loc)
+
+
 # --------------------------------------------------------------------------
 # fasthash (``_jaxext/_fasthash.py:56-102``; original C ``tests/fast-hash/fasthash.c:30-75``)
 

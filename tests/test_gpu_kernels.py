@@ -483,3 +483,41 @@ print("ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, '-c', code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and res.stdout.strip().endswith('ok'), res.stdout + res.stderr
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('make', [
+    lambda m: m.Constant(), lambda m: 2. * m.Constant(scale=3.) + 1., lambda m: m.White(), lambda m: m.White(scale=0.3, loc=1.) * 4.,
+    lambda m: m.Expon(scale=2.), lambda m: m.HoleEffect(scale=0.5), lambda m: m.HoleEffect(loc=0.2) * 3. + 0.5,
+    lambda m: m.Periodic(outerscale=0.7, scale=1.5), lambda m: m.Periodic(), lambda m: m.Cos(scale=0.8, loc=3.), lambda m: m.Sinc(scale=0.3), lambda m: m.Sinc(),
+])
+def test_simple_stationary_kernels_vs_oracle(lgp, make, dtype, rng):
+    """ Constant, White (any fields) and the stationary kernels of one variable Expon, HoleEffect, Periodic, Cos, Sinc
+    (``_kernels/_basic.py``, ``_spectral.py``) as cores of the generic Gram kernel """
+    n, m = 170, 300
+    x = rng.uniform(-4, 4, n).astype(dtype); y = rng.uniform(-4, 4, m).astype(dtype)
+    y[:25] = x[:25]
+    y[25:40] = x[25:40] + dtype(0.01)                     # (the Taylor branch of sinc)
+    G = make(lgp).gram(x, y).to_host()
+    R = np.asarray(make(oracle)(x[:, None], y[None, :]), float)
+    assert G.dtype == dtype
+    tol = 4e-15 if dtype == np.float64 else 4e-6           # (sin / cos / exp of the device library against libm, arguments up to 27)
+    np.testing.assert_allclose(G, R, rtol=0, atol=tol * max(1., np.abs(R).max()))
+    P = make(lgp)(x[:m if m < n else n], y[:n if n < m else m])
+    np.testing.assert_allclose(P, np.diagonal(R)[:len(P)], rtol=0, atol=tol * max(1., np.abs(R).max()))
+
+
+def test_white_and_constant_on_structured_points_and_dimension_limits(lgp):
+    a = np.zeros(6, [('u', float), ('v', float)]); a['u'] = [0, 0, 1, 1, 2, 2]; a['v'] = [0, 1, 0, 1, 1e-300, 0]
+    np.testing.assert_array_equal(lgp.White().gram(a, a).to_host(), np.asarray(oracle.White()(a[:, None], a[None, :]), float))
+    np.testing.assert_array_equal(lgp.Constant().gram(a, a).to_host(), np.ones((6, 6)))
+    for cls in (lgp.Expon, lgp.HoleEffect, lgp.Periodic, lgp.Cos, lgp.Sinc):
+        with pytest.raises(ValueError):
+            cls().gram(a, a)
+    with pytest.raises(AssertionError):
+        lgp.Periodic(outerscale=0)
+    # a GP on a periodic kernel: the posterior repeats with the period
+    x = np.linspace(0, 6, 40)
+    gp = lgp.GP(lgp.Periodic(scale=1 / (2 * np.pi), outerscale=0.5), checkpos=False).addx(x, 'd').addx(x + 1., 'shifted')
+    m1, _ = gp.predfromdata({'d': np.sin(2 * np.pi * x)}, 'shifted', raw=True)
+    np.testing.assert_allclose(m1, np.sin(2 * np.pi * x), atol=1e-6)

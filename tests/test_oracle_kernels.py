@@ -216,3 +216,29 @@ def test_gammaexp_cauchy_closed_forms(rng):
     for bad in (dict(alpha=0), dict(alpha=3), dict(beta=0)):
         with pytest.raises(AssertionError):
             oracle.Cauchy(**bad)(x, y)
+
+
+def test_simple_stationary_kernels_closed_forms(rng):
+    """ Constant, White, Expon, HoleEffect, Periodic, Cos, Sinc of the oracle against the formulas of their docstrings
+    (``_kernels/_basic.py:34-59,187-208,254-269,299-310``, ``_spectral.py:25-38,113-122``), with scale and loc """
+    x = rng.uniform(-4, 4, 60); y = rng.uniform(-4, 4, 45)
+    y[:10] = x[:10]
+    d = (x[:, None] - y[None, :])
+    eps = np.finfo(float).eps
+    np.testing.assert_array_equal(oracle.Constant(scale=2.)(x[:, None], y[None, :]), np.ones((60, 45)))
+    np.testing.assert_array_equal(oracle.White()(x[:, None], y[None, :]), (d == 0).astype(int))
+    np.testing.assert_allclose(oracle.Expon(scale=2.)(x[:, None], y[None, :]), np.exp(-np.abs(d) / 2), rtol=1e-14)
+    np.testing.assert_allclose(oracle.HoleEffect(scale=0.5)(x[:, None], y[None, :]), (1 - 2 * np.abs(d)) * np.exp(-2 * np.abs(d)), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(oracle.Periodic(outerscale=0.7, scale=1.5)(x[:, None], y[None, :]), np.exp(-2 * (np.sin(d / 3) / 0.7) ** 2), rtol=1e-13)
+    np.testing.assert_allclose(oracle.Cos(scale=0.8, loc=3.)(x[:, None], y[None, :]), np.cos(d / 0.8), rtol=0, atol=1e-14)
+    u = np.abs(d) / 0.3 + eps
+    np.testing.assert_allclose(oracle.Sinc(scale=0.3)(x[:, None], y[None, :]), np.sinc(u), rtol=0, atol=3e-14)      # (x/s - y/s against (x - y)/s, arguments up to 27)
+    # the Taylor branch of sinc meets the closed form where they switch
+    from oracle.kernels import sinc
+    t = np.array([0.0999999, 0.1, 0.1000001, 1e-3, 0.])
+    np.testing.assert_allclose(sinc(t), np.sinc(t), rtol=5e-16, atol=0)
+    # structured points: White multiplies the equalities of the fields
+    a = np.zeros(4, [('u', float), ('v', float)]); a['u'] = [0, 0, 1, 1]; a['v'] = [0, 1, 0, 1]
+    np.testing.assert_array_equal(oracle.White()(a[:, None], a[None, :]), np.eye(4, dtype=int))
+    with pytest.raises(ValueError):
+        oracle.Cos()(a[:, None], a[None, :])
