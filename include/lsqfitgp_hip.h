@@ -112,6 +112,15 @@ int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *to
 #define LGP_KERNEL_PERIODIC 13    /* _kernels/_basic.py:187-208 exp(-2 (sin(delta / 2) / outerscale)^2); hpar = {outerscale}        */
 #define LGP_KERNEL_COS 14         /* _kernels/_spectral.py:25-38 cos(delta)                                                       */
 #define LGP_KERNEL_SINC 15        /* _kernels/_spectral.py:113-122 + _special/_sinc.py:25-32 sinc(|delta| + eps), input='posabs'   */
+#define LGP_KERNEL_LINEAR 16      /* _kernels/_basic.py:76-91   sum_f x_f y_f (any fields)                                        */
+/* kernels of x and y themselves, ONE variable (maxdim = 1, d must be 1) */
+#define LGP_KERNEL_WIENER 17            /* _kernels/_randomwalk.py:26-41   min(x, y)                                             */
+#define LGP_KERNEL_ORNSTEINUHLENBECK 18 /* _kernels/_randomwalk.py:112-132 exp(-|x - y|) - exp(-(x + y))                          */
+#define LGP_KERNEL_BROWNIANBRIDGE 19    /* _kernels/_randomwalk.py:134-151 min(x, y) - x y                                       */
+#define LGP_KERNEL_DECAYING 20          /* _kernels/_basic.py:362-379      1 / (x + y + 1)^alpha; hpar = {alpha}                 */
+#define LGP_KERNEL_FRACBROWNIAN 21      /* _kernels/_randomwalk.py:46-68   2^-K ((|x|^2H + |y|^2H)^K - |x - y|^2HK); hpar = {2H, K, 2^-K, 2HK} */
+#define LGP_KERNEL_WIENERINTEGRAL 22    /* _kernels/_randomwalk.py:93-110  a^2 (b - a / 3) / 2, a = min(x, y), b = max(x, y)      */
+#define LGP_KERNEL_STATIONARYFRACBROWNIAN 23 /* _kernels/_randomwalk.py:156-172 (|d + 1|^2H + |d - 1|^2H - 2 |d|^2H) / 2, d = x - y; hpar = {2H} */
 #define LGP_OP_MUL 0           /* kernel * c  (_Kernel/_alg.py:58-82)  */
 #define LGP_OP_ADD 1           /* kernel + c  (_Kernel/_alg.py:32-56)  */
 

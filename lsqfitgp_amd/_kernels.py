@@ -547,6 +547,93 @@ class Sinc(_Stationary1D):
     _kind = _lib.LGP_KERNEL_SINC
 
 
+class StationaryFracBrownian(_Stationary1D):
+    """ Stationary fractional Brownian motion kernel, k(Δ) = (|Δ + 1|^2H + |Δ - 1|^2H - 2 |Δ|^2H) / 2, H in (0, 1]
+    (``_kernels/_randomwalk.py:156-172``) """
+    _kind = _lib.LGP_KERNEL_STATIONARYFRACBROWNIAN
+
+    def __init__(self, *, H=1 / 2, scale=None, loc=None):
+        assert 0 < H <= 1, H
+        super().__init__(scale=scale, loc=loc)
+        self._par = (float(2 * H),)
+
+
+class Linear(_Isotropic):
+    """ Dot product kernel, k(x, y) = sum_i x_i y_i (``_kernels/_basic.py:76-91``) """
+    _kind = _lib.LGP_KERNEL_LINEAR
+
+    def __init__(self, *, scale=None, loc=None):
+        super().__init__(scale=scale, loc=loc)
+
+
+class _OneVariable(_Stationary1D):
+    """ kernels of x and y themselves, one variable (``kernel(maxdim=1)``): random walks and the like, most of them defined
+    for nonnegative inputs -- checked on the transformed points, as the reference's assertions do """
+    _domain = (0., numpy.inf)
+
+    def _prepare(self, xs, ys, ctx):
+        lo, hi = self._domain
+        for pts in (xs, ys):
+            if isinstance(pts, DevicePoints) or lo == -numpy.inf:
+                continue
+            cols = _leaf_columns(numpy.asarray(pts))
+            for c in cols:
+                v = numpy.asarray(c, float)
+                if self._loc is not None:
+                    v = v - self._loc
+                if self._scale is not None:
+                    v = v / self._scale
+                assert numpy.all(v >= lo) and numpy.all(v <= hi), f'{type(self).__name__}: inputs outside [{lo}, {hi}]'
+        return super()._prepare(xs, ys, ctx)
+
+
+class Wiener(_OneVariable):
+    """ Wiener kernel, k(x, y) = min(x, y), x, y >= 0 (``_kernels/_randomwalk.py:26-41``) """
+    _kind = _lib.LGP_KERNEL_WIENER
+
+
+class OrnsteinUhlenbeck(_OneVariable):
+    """ Ornstein-Uhlenbeck process started at 0, k(x, y) = exp(-|x - y|) - exp(-(x + y)), x, y >= 0
+    (``_kernels/_randomwalk.py:112-132``) """
+    _kind = _lib.LGP_KERNEL_ORNSTEINUHLENBECK
+
+
+class BrownianBridge(_OneVariable):
+    """ Brownian bridge kernel, k(x, y) = min(x, y) - x y, x, y in [0, 1] (``_kernels/_randomwalk.py:134-151``) """
+    _kind = _lib.LGP_KERNEL_BROWNIANBRIDGE
+    _domain = (0., 1.)
+
+
+class Decaying(_OneVariable):
+    """ Decaying kernel, k(x, y) = 1 / (1 + x + y)^alpha, x, y, alpha >= 0 (``_kernels/_basic.py:362-379``) """
+    _kind = _lib.LGP_KERNEL_DECAYING
+
+    def __init__(self, *, alpha=1, scale=None, loc=None):
+        assert alpha >= 0, alpha
+        super().__init__(scale=scale, loc=loc)
+        self._par = (float(alpha),)
+
+
+class FracBrownian(_OneVariable):
+    """ Bifractional Brownian motion kernel, k(x, y) = ((|x|^2H + |y|^2H)^K - |x - y|^2HK) / 2^K, H, K in (0, 1]
+    (``_kernels/_randomwalk.py:46-68``) """
+    _kind = _lib.LGP_KERNEL_FRACBROWNIAN
+    _domain = (-numpy.inf, numpy.inf)
+
+    def __init__(self, *, H=1 / 2, K=1, scale=None, loc=None):
+        assert 0 < H <= 1, H
+        assert 0 < K <= 1, K
+        super().__init__(scale=scale, loc=loc)
+        H2 = 2 * H
+        self._par = (float(H2), float(K), float(1 / 2 ** K), float(H2 * K))
+
+
+class WienerIntegral(_OneVariable):
+    """ Integral of the Wiener process, k(x, y) = a² (b - a / 3) / 2 with a = min(x, y), b = max(x, y), x, y >= 0
+    (``_kernels/_randomwalk.py:93-110``) """
+    _kind = _lib.LGP_KERNEL_WIENERINTEGRAL
+
+
 # ------------------------------------------------------------------------------
 # BART
 

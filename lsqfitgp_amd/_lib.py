@@ -39,6 +39,14 @@ LGP_KERNEL_HOLEEFFECT = 12
 LGP_KERNEL_PERIODIC = 13
 LGP_KERNEL_COS = 14
 LGP_KERNEL_SINC = 15
+LGP_KERNEL_LINEAR = 16
+LGP_KERNEL_WIENER = 17
+LGP_KERNEL_ORNSTEINUHLENBECK = 18
+LGP_KERNEL_BROWNIANBRIDGE = 19
+LGP_KERNEL_DECAYING = 20
+LGP_KERNEL_FRACBROWNIAN = 21
+LGP_KERNEL_WIENERINTEGRAL = 22
+LGP_KERNEL_STATIONARYFRACBROWNIAN = 23
 LGP_OP_MUL = 0
 LGP_OP_ADD = 1
 LGP_EPS_AUTO_REL = 1

@@ -54,9 +54,10 @@ struct IsoArgs {
   T loc, scale;
   T coef[MAX_P];   // Horner coefficients c_{k+1}/c_k, k = p-1..0 in evaluation order
   T twop1;         // 2p+1
-  T par[3];        // GammaExp: gamma, gamma/2;  Cauchy: alpha/2, beta, -beta/alpha  (host-evaluated like the reference's Python floats)
+  T par[4];        // GammaExp: gamma, gamma/2;  Cauchy: alpha/2, beta, -beta/alpha  (host-evaluated like the reference's Python floats)
                    // Wendland: nu + k;  CausalExpQuad: alpha / 4
   int flag;        // GammaExp: gamma == 2;  Cauchy: alpha == 2  (the branches that act on r2 itself);  MaternpDiff: odd total order
+  int xy;          // 0; 1: kernels of x and y themselves, one variable: the core receives y in place of r2 and x in place of d0; 2: d0 = sum_f x_f y_f
   int posabs;      // input='posabs' of the reference (_Kernel/_isotropic.py:67-78): per field (|x - y| + eps)^2, the core takes the root
   int dord[8];     // ExpQuadDiff: total derivative order (x side + y side) along each of the first 8 fields
   OutOps<T> ops;
@@ -119,6 +120,23 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
       return T(1) + z * (T(-1) / T(6) + z * (T(1) / T(120) + z * (T(-1) / T(5040) + z * (T(1) / T(362880) + z * (T(-1) / T(39916800))))));
     }
     return sin(pa) / pa;
+  } else if (g.kernel == LGP_KERNEL_LINEAR) {            // _kernels/_basic.py:76-91: d0 = sum_f x_f y_f
+    return d0;
+  } else if (g.kernel == LGP_KERNEL_WIENER) {            // _kernels/_randomwalk.py:26-41 (from here on: x = d0, y = r2, one variable)
+    return fmin(d0, r2);
+  } else if (g.kernel == LGP_KERNEL_ORNSTEINUHLENBECK) { // _kernels/_randomwalk.py:112-132
+    return exp(-fabs(d0 - r2)) - exp(-(d0 + r2));
+  } else if (g.kernel == LGP_KERNEL_BROWNIANBRIDGE) {    // _kernels/_randomwalk.py:134-151
+    return fmin(d0, r2) - d0 * r2;
+  } else if (g.kernel == LGP_KERNEL_DECAYING) {          // _kernels/_basic.py:362-379: 1 / (x + y + 1)^alpha
+    return T(1) / pow(d0 + r2 + T(1), g.par[0]);
+  } else if (g.kernel == LGP_KERNEL_FRACBROWNIAN) {      // _kernels/_randomwalk.py:46-68: par = {2 H, K, 1 / 2^K, 2 H K}
+    return g.par[2] * (pow(pow(fabs(d0), g.par[0]) + pow(fabs(r2), g.par[0]), g.par[1]) - pow(fabs(d0 - r2), g.par[3]));
+  } else if (g.kernel == LGP_KERNEL_WIENERINTEGRAL) {    // _kernels/_randomwalk.py:93-110
+    const T a = fmin(d0, r2), b = fmax(d0, r2);
+    return T(0.5) * (a * a) * (b - a / T(3));
+  } else if (g.kernel == LGP_KERNEL_STATIONARYFRACBROWNIAN) {   // _kernels/_randomwalk.py:156-172 (stationary: d0 = delta); par = {2 H}
+    return T(0.5) * (pow(fabs(d0 + T(1)), g.par[0]) + pow(fabs(d0 - T(1)), g.par[0]) - T(2) * pow(fabs(d0), g.par[0]));
   } else if (g.kernel == LGP_KERNEL_GAMMAEXP) {          // _kernels/_basic.py:111-113
     return g.flag ? exp(-r2) : exp(-pow(r2, g.par[1]));
   } else if (g.kernel == LGP_KERNEL_CAUCHY) {            // _kernels/_basic.py:340-344
@@ -136,7 +154,9 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
 // what the derivative cores need beside r2: ExpQuadDiff the product over the fields of the Hermite factors He_{order_f}(u_f),
 // MaternpDiff (one field) the signed difference itself
 template <typename T>
-__device__ __forceinline__ T iso_aux(const IsoArgs<T> &g, int f, T df, T aux) {
+__device__ __forceinline__ T iso_aux(const IsoArgs<T> &g, int f, T xv, T yv, T df, T aux) {
+  if (g.xy == 1) return xv;
+  if (g.xy == 2) return f == 0 ? xv * yv : aux + xv * yv;
   if (g.kernel == LGP_KERNEL_EXPQUAD_DIFF) {
     const int o = f < 8 ? g.dord[f] : 0;
     const T u2 = df * df;
@@ -152,7 +172,8 @@ __device__ __forceinline__ T iso_aux(const IsoArgs<T> &g, int f, T df, T aux) {
 }
 // the per-field term of r2: the squared difference, or (|difference| + eps)^2 for input='posabs'
 template <typename T>
-__device__ __forceinline__ T iso_sq(const IsoArgs<T> &g, T df) {
+__device__ __forceinline__ T iso_sq(const IsoArgs<T> &g, T df, T yv) {
+  if (g.xy == 1) return yv;
   if (g.posabs) {
     const T a = fabs(df) + (sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-07f));
     return a * a;
@@ -302,17 +323,19 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
       if (D > 0) {
 #pragma unroll
         for (int f = 0; f < D; ++f) {
-          const T df = su[f * GT_ROWS + r] - vreg[f][e];
-          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df) : df * df;
+          const T xv = su[f * GT_ROWS + r], yv = vreg[f][e];
+          const T df = xv - yv;
+          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df, yv) : df * df;
           r2 = (f == 0) ? sq : r2 + sq;
-          if (CORE == CORE_GENERIC) d0 = iso_aux<T>(g, f, df, d0);
+          if (CORE == CORE_GENERIC) d0 = iso_aux<T>(g, f, xv, yv, df, d0);
         }
       } else {
         for (int f = 0; f < d; ++f) {
-          const T df = su[f * GT_ROWS + r] - sv[f * GT_COLS + c0 + e];
-          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df) : df * df;
+          const T xv = su[f * GT_ROWS + r], yv = sv[f * GT_COLS + c0 + e];
+          const T df = xv - yv;
+          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df, yv) : df * df;
           r2 = (f == 0) ? sq : r2 + sq;
-          if (CORE == CORE_GENERIC) d0 = iso_aux<T>(g, f, df, d0);
+          if (CORE == CORE_GENERIC) d0 = iso_aux<T>(g, f, xv, yv, df, d0);
         }
       }
       if (GRAD) {
@@ -391,9 +414,9 @@ __global__ void __launch_bounds__(256) gram_iso_pairs_kernel(const IsoArgs<T> g)
     if (g.has_loc) { u = u - g.loc; v = v - g.loc; }
     if (g.has_scale) { u = u / g.scale; v = v / g.scale; }
     const T df = u - v;
-    const T sq = iso_sq<T>(g, df);
+    const T sq = iso_sq<T>(g, df, v);
     r2 = (f == 0) ? sq : r2 + sq;
-    d0 = iso_aux<T>(g, f, df, d0);
+    d0 = iso_aux<T>(g, f, u, v, df, d0);
   }
   g.out[i] = g.ops.apply(iso_core<T>(g, r2, d0));
 }
@@ -406,8 +429,8 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_SINC, "unknown isotropic kernel");
-  LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || d == 1, "this kernel is a function of one variable (maxdim = 1)");
+  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_STATIONARYFRACBROWNIAN, "unknown isotropic kernel");
+  LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || kernel == LGP_KERNEL_LINEAR || d == 1, "this kernel is a function of one variable (maxdim = 1)");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
   LGP_REQUIRE(p >= 0 && p <= MAX_P, "Maternp order must be in [0,16]");
   const bool derived = kernel == LGP_KERNEL_EXPQUAD_DIFF || kernel == LGP_KERNEL_MATERNP_DIFF;
@@ -438,6 +461,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.par[0] = g.par[1] = g.par[2] = T(0);
   g.flag = 0;
   g.posabs = posabs ? 1 : 0;
+  g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : ((kernel >= LGP_KERNEL_WIENER && kernel <= LGP_KERNEL_WIENERINTEGRAL) ? 1 : 0);
   for (int f = 0; f < 8; ++f) g.dord[f] = 0;
   if (kernel == LGP_KERNEL_EXPQUAD_DIFF) {
     if (npar == 0) g.dord[0] = p;
@@ -457,6 +481,15 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
     g.par[0] = hpar[0];
   } else if (kernel == LGP_KERNEL_LOG) {
     LGP_REQUIRE(npar == 0, "this kernel takes no real parameters");
+  } else if (kernel == LGP_KERNEL_DECAYING) {            // hpar = {alpha}
+    LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0), "Decaying takes {alpha}, alpha >= 0");
+    g.par[0] = hpar[0];
+  } else if (kernel == LGP_KERNEL_FRACBROWNIAN) {        // hpar = {2 H, K, 1 / 2^K, 2 H K}
+    LGP_REQUIRE(npar == 4 && hpar != nullptr && hpar[0] > T(0) && hpar[0] <= T(2) && hpar[1] > T(0) && hpar[1] <= T(1), "FracBrownian takes {2H, K, 2^-K, 2HK}, H and K in (0, 1]");
+    for (int k = 0; k < 4; ++k) g.par[k] = hpar[k];
+  } else if (kernel == LGP_KERNEL_STATIONARYFRACBROWNIAN) {   // hpar = {2 H}
+    LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] > T(0) && hpar[0] <= T(2), "StationaryFracBrownian takes {2H}, H in (0, 1]");
+    g.par[0] = hpar[0];
   } else if (kernel == LGP_KERNEL_PERIODIC) {            // hpar = {outerscale}
     LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] > T(0) && hpar[0] < std::numeric_limits<T>::infinity(), "Periodic takes {outerscale} in (0, inf)");
     g.par[0] = hpar[0];
@@ -667,13 +700,13 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
 #pragma unroll
         for (int f = 0; f < D; ++f) {
           const T df = su[f * GR_ROWS + r] - vreg[f][e];
-          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df) : df * df;
+          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df, vreg[f][e]) : df * df;
           r2 = (f == 0) ? sq : r2 + sq;
         }
       } else {
         for (int f = 0; f < d; ++f) {
           const T df = su[f * GR_ROWS + r] - sv[f * GT_COLS + c0 + e];
-          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df) : df * df;
+          const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df, sv[f * GT_COLS + c0 + e]) : df * df;
           r2 = (f == 0) ? sq : r2 + sq;
         }
       }
@@ -737,6 +770,7 @@ int gram_reg_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   for (int k = p - 1; k >= 0; --k) g.coef[pos++] = (T)((double)(p - k) / ((double)(2 * p - k) * (double)(k + 1)));
   g.twop1 = (T)(2 * p + 1);
   g.posabs = 0;
+  g.xy = 0;
   for (int f = 0; f < 8; ++f) g.dord[f] = 0;
   g.par[0] = g.par[1] = g.par[2] = T(0);
   g.flag = 0;

@@ -381,6 +381,68 @@ def Sinc(*, scale=None, loc=None):
     return Kernel(_stationary1d(sinc, 'posabs'), scale=scale, loc=loc)
 
 
+def StationaryFracBrownian(*, H=1/2, scale=None, loc=None):
+    """ ``_kernels/_randomwalk.py:156-172`` """
+    assert 0 < H <= 1, H
+    H2 = 2 * H
+    return Kernel(_stationary1d(lambda d: 1/2 * (numpy.abs(d + 1) ** H2 + numpy.abs(d - 1) ** H2 - 2 * numpy.abs(d) ** H2)), scale=scale, loc=loc)
+
+
+def Linear(*, scale=None, loc=None):
+    """ ``_kernels/_basic.py:76-91`` """
+    return Kernel(lambda x, y: sum_recurse_dtype(lambda a, b: a * b, x, y), scale=scale, loc=loc)
+
+
+def _onevariable(core, lo=0., hi=numpy.inf):
+    """ ``kernel(maxdim=1)`` with the domain assertions of the reference's cores """
+    def newcore(x, y):
+        if x.dtype.names is not None:
+            if len(_leaf_columns_count(x.dtype)) > 1:
+                raise ValueError('kernel called on type with dimensionality > maxdim=1')
+            name = x.dtype.names[0]
+            x, y = x[name], y[name]
+        assert numpy.all(x >= lo) and numpy.all(x <= hi) and numpy.all(y >= lo) and numpy.all(y <= hi)
+        return core(x, y)
+    return newcore
+
+
+def Wiener(*, scale=None, loc=None):
+    """ ``_kernels/_randomwalk.py:26-41`` """
+    return Kernel(_onevariable(numpy.minimum), scale=scale, loc=loc)
+
+
+def OrnsteinUhlenbeck(*, scale=None, loc=None):
+    """ ``_kernels/_randomwalk.py:112-132`` """
+    return Kernel(_onevariable(lambda x, y: numpy.exp(-numpy.abs(x - y)) - numpy.exp(-(x + y))), scale=scale, loc=loc)
+
+
+def BrownianBridge(*, scale=None, loc=None):
+    """ ``_kernels/_randomwalk.py:134-151`` """
+    return Kernel(_onevariable(lambda x, y: numpy.minimum(x, y) - x * y, 0., 1.), scale=scale, loc=loc)
+
+
+def Decaying(*, alpha=1, scale=None, loc=None):
+    """ ``_kernels/_basic.py:362-379`` """
+    assert alpha >= 0
+    return Kernel(_onevariable(lambda x, y: 1 / (x + y + 1) ** alpha), scale=scale, loc=loc)
+
+
+def FracBrownian(*, H=1/2, K=1, scale=None, loc=None):
+    """ ``_kernels/_randomwalk.py:46-68`` """
+    assert 0 < H <= 1 and 0 < K <= 1
+    H2 = 2 * H
+    core = lambda x, y: 1 / 2 ** K * ((numpy.abs(x) ** H2 + numpy.abs(y) ** H2) ** K - numpy.abs(x - y) ** (H2 * K))
+    return Kernel(_onevariable(core, -numpy.inf, numpy.inf), scale=scale, loc=loc)
+
+
+def WienerIntegral(*, scale=None, loc=None):
+    """ ``_kernels/_randomwalk.py:93-110`` """
+    def core(x, y):
+        a, b = numpy.minimum(x, y), numpy.maximum(x, y)
+        return 1/2 * a ** 2 * (b - a / 3)
+    return Kernel(_onevariable(core), scale=scale, loc=loc)
+
+
 # --------------------------------------------------------------------------
 # fasthash (``_jaxext/_fasthash.py:56-102``; original C ``tests/fast-hash/fasthash.c:30-75``)
 

@@ -521,3 +521,46 @@ def test_white_and_constant_on_structured_points_and_dimension_limits(lgp):
     gp = lgp.GP(lgp.Periodic(scale=1 / (2 * np.pi), outerscale=0.5), checkpos=False).addx(x, 'd').addx(x + 1., 'shifted')
     m1, _ = gp.predfromdata({'d': np.sin(2 * np.pi * x)}, 'shifted', raw=True)
     np.testing.assert_allclose(m1, np.sin(2 * np.pi * x), atol=1e-6)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('make', [
+    lambda m: m.Wiener(), lambda m: m.Wiener(scale=0.5) * 2. + 1., lambda m: m.OrnsteinUhlenbeck(scale=0.5), lambda m: m.BrownianBridge(scale=2.),
+    lambda m: m.Decaying(alpha=1.5), lambda m: m.Decaying(alpha=0), lambda m: m.FracBrownian(), lambda m: m.FracBrownian(H=0.8, K=0.6, loc=0.5),
+    lambda m: m.WienerIntegral(scale=0.7), lambda m: m.StationaryFracBrownian(H=0.3, scale=0.4), lambda m: m.StationaryFracBrownian(), lambda m: m.Linear(scale=2., loc=0.3),
+])
+def test_one_variable_kernels_vs_oracle(lgp, make, dtype, rng):
+    """ the kernels of x and y themselves (``_kernels/_randomwalk.py``, Decaying, Linear): the generic Gram kernel hands the
+    core the two transformed coordinates """
+    n, m = 170, 300
+    x = rng.uniform(0, 1, n).astype(dtype); y = rng.uniform(0, 1, m).astype(dtype)
+    y[:25] = x[:25]
+    G = make(lgp).gram(x, y).to_host()
+    R = np.asarray(make(oracle)(x[:, None], y[None, :]), float)
+    assert G.dtype == dtype
+    tol = 4e-15 if dtype == np.float64 else 4e-6
+    np.testing.assert_allclose(G, R, rtol=0, atol=tol * max(1., np.abs(R).max()))
+    P = make(lgp)(x[:m if m < n else n], y[:n if n < m else m])
+    np.testing.assert_allclose(P, np.diagonal(R)[:len(P)], rtol=0, atol=tol * max(1., np.abs(R).max()))
+
+
+def test_linear_over_fields_and_domains(lgp, rng):
+    for d in (2, 3, 6):
+        a = np.empty(120, [(f'f{i}', float) for i in range(d)]); b = np.empty(90, a.dtype)
+        for f in a.dtype.names:
+            a[f] = rng.standard_normal(120); b[f] = rng.standard_normal(90)
+        k = lgp.Linear(scale=1.5) * 2.
+        np.testing.assert_allclose(k.gram(a, b).to_host(), (oracle.Linear(scale=1.5) * 2.)(a[:, None], b[None, :]), rtol=0, atol=1e-14)
+    x = np.linspace(-1, 1, 8)
+    for cls in (lgp.Wiener, lgp.OrnsteinUhlenbeck, lgp.BrownianBridge, lgp.Decaying, lgp.WienerIntegral):
+        with pytest.raises(AssertionError):
+            cls().gram(x, x)
+        with pytest.raises(ValueError):
+            cls().gram(np.zeros(3, [('a', float), ('b', float)]), np.zeros(3, [('a', float), ('b', float)]))
+    with pytest.raises(AssertionError):
+        lgp.BrownianBridge().gram(np.array([0.5, 1.5]), np.array([0.5]))
+    lgp.FracBrownian(H=0.3).gram(x, x)                   # defined on the whole line
+    # a Wiener process pinned at three points: the posterior mean interpolates linearly between them
+    gp = lgp.GP(lgp.Wiener(), checkpos=False).addx(np.array([1., 2., 4.]), 'd').addx(np.array([1.5, 3.]), 'm')
+    m, _ = gp.predfromdata({'d': np.array([1., 3., -1.])}, 'm', raw=True)
+    np.testing.assert_allclose(m, [2., 1.], atol=1e-9)

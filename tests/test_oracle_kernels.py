@@ -242,3 +242,28 @@ def test_simple_stationary_kernels_closed_forms(rng):
     np.testing.assert_array_equal(oracle.White()(a[:, None], a[None, :]), np.eye(4, dtype=int))
     with pytest.raises(ValueError):
         oracle.Cos()(a[:, None], a[None, :])
+
+
+def test_random_walk_kernels_closed_forms(rng):
+    """ Linear, Wiener, OrnsteinUhlenbeck, BrownianBridge, Decaying, FracBrownian, WienerIntegral, StationaryFracBrownian of
+    the oracle against the formulas of ``_kernels/_basic.py:76-91,362-379`` and ``_randomwalk.py`` and their known limits """
+    x = rng.uniform(0, 1, 40); y = rng.uniform(0, 1, 30)
+    X, Y = x[:, None], y[None, :]
+    np.testing.assert_allclose(oracle.Linear(scale=2.)(X, Y), X * Y / 4, rtol=1e-15)
+    np.testing.assert_array_equal(oracle.Wiener()(X, Y), np.minimum(X, Y))
+    np.testing.assert_allclose(oracle.BrownianBridge()(X, Y), np.minimum(X, Y) - X * Y, rtol=1e-15)
+    np.testing.assert_allclose(oracle.OrnsteinUhlenbeck(scale=0.5)(X, Y), np.exp(-2 * np.abs(X - Y)) - np.exp(-2 * (X + Y)), rtol=1e-13)
+    np.testing.assert_allclose(oracle.Decaying(alpha=1.5)(X, Y), (1 + X + Y) ** -1.5, rtol=1e-14)
+    a, b = np.minimum(X, Y), np.maximum(X, Y)
+    np.testing.assert_allclose(oracle.WienerIntegral()(X, Y), a * a * (b - a / 3) / 2, rtol=1e-15)
+    # H = 1/2, K = 1: the Wiener kernel; the stationary version at H = 1/2 is the triangle (1 - |d|)_+
+    np.testing.assert_allclose(oracle.FracBrownian()(X, Y), np.minimum(X, Y), rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(oracle.StationaryFracBrownian()(X, Y), np.maximum(0, 1 - np.abs(X - Y)), rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(oracle.FracBrownian(H=0.8, K=0.6)(X, Y), ((X ** 1.6 + Y ** 1.6) ** 0.6 - np.abs(X - Y) ** 0.96) / 2 ** 0.6, rtol=1e-14)
+    # Linear over fields; domains
+    s = np.empty(5, [('u', float), ('v', float)]); s['u'] = np.arange(5.); s['v'] = 2.
+    np.testing.assert_array_equal(oracle.Linear()(s[:, None], s[None, :]), np.outer(np.arange(5.), np.arange(5.)) + 4)
+    with pytest.raises(AssertionError):
+        oracle.Wiener()(np.array([-1.])[:, None], y[None, :])
+    with pytest.raises(AssertionError):
+        oracle.BrownianBridge()(np.array([1.5])[:, None], y[None, :])
