@@ -121,6 +121,9 @@ int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *to
 #define LGP_KERNEL_FRACBROWNIAN 21      /* _kernels/_randomwalk.py:46-68   2^-K ((|x|^2H + |y|^2H)^K - |x - y|^2HK); hpar = {2H, K, 2^-K, 2HK} */
 #define LGP_KERNEL_WIENERINTEGRAL 22    /* _kernels/_randomwalk.py:93-110  a^2 (b - a / 3) / 2, a = min(x, y), b = max(x, y)      */
 #define LGP_KERNEL_STATIONARYFRACBROWNIAN 23 /* _kernels/_randomwalk.py:156-172 (|d + 1|^2H + |d - 1|^2H - 2 |d|^2H) / 2, d = x - y; hpar = {2H} */
+#define LGP_KERNEL_CELERITE 24    /* _kernels/_celerite.py:34-52  exp(-gamma |d|) (cos d + B sin |d|); hpar = {gamma, B}, one variable    */
+#define LGP_KERNEL_HARMONIC 25    /* _kernels/_celerite.py:54-121 damped driven oscillator; hpar = {Q, eta Q, sqrt(1 - Q^2) - 1}, p = branch */
+#define LGP_KERNEL_CIRCULAR 26    /* _kernels/_wendland.py:88-113 W_c of the geodesic distance on the unit circle; hpar = {tau, c}          */
 #define LGP_OP_MUL 0           /* kernel * c  (_Kernel/_alg.py:58-82)  */
 #define LGP_OP_ADD 1           /* kernel + c  (_Kernel/_alg.py:32-56)  */
 

@@ -558,6 +558,48 @@ class StationaryFracBrownian(_Stationary1D):
         self._par = (float(2 * H),)
 
 
+class Celerite(_Stationary1D):
+    """ Celerite kernel, k(Δ) = exp(-γ|Δ|) (cos Δ + B sin|Δ|), |B| <= γ (``_kernels/_celerite.py:34-52``) """
+    _kind = _lib.LGP_KERNEL_CELERITE
+
+    def __init__(self, *, gamma=1, B=0, scale=None, loc=None):
+        assert 0 <= gamma < numpy.inf, gamma
+        assert abs(B) <= gamma, (B, gamma)
+        super().__init__(scale=scale, loc=loc)
+        self._par = (float(gamma), float(B))
+
+
+class Harmonic(_Stationary1D):
+    """ Damped stochastically driven harmonic oscillator of quality factor Q (``_kernels/_celerite.py:54-121``): the four
+    branches of the reference (Q < 1/2 in the cancellation-free form, Q < 1, Q = 1, Q > 1), chosen on the host """
+    _kind = _lib.LGP_KERNEL_HARMONIC
+
+    def __init__(self, *, Q=1, scale=None, loc=None):
+        assert 0 < Q < numpy.inf, Q
+        super().__init__(scale=scale, loc=loc)
+        if Q < 1 / 2:
+            self._p, eta = 0, numpy.sqrt((1 - Q) * (1 + Q))
+        elif Q < 1:
+            self._p, eta = 1, numpy.sqrt(1 - numpy.square(Q))
+        elif Q == 1:
+            self._p, eta = 2, 0.
+        else:
+            self._p, eta = 3, numpy.sqrt(numpy.square(Q) - 1)
+        self._par = (float(Q), float(eta), float(numpy.expm1(1 / 2 * numpy.log1p(-numpy.square(Q)))) if Q < 1 else 0.)
+
+
+class Circular(_Stationary1D):
+    """ Circular kernel of period 1, W_c(t) = (1 + τ t/c)(1 - t/c)_+^τ of the geodesic distance t, τ >= 4, c in (0, 1/2]
+    (``_kernels/_wendland.py:88-113``) """
+    _kind = _lib.LGP_KERNEL_CIRCULAR
+
+    def __init__(self, *, tau=4, c=1 / 2, scale=None, loc=None):
+        assert tau >= 4, tau
+        assert 0 < c <= 1 / 2, c
+        super().__init__(scale=scale, loc=loc)
+        self._par = (float(tau), float(c))
+
+
 class Linear(_Isotropic):
     """ Dot product kernel, k(x, y) = sum_i x_i y_i (``_kernels/_basic.py:76-91``) """
     _kind = _lib.LGP_KERNEL_LINEAR

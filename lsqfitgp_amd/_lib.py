@@ -47,6 +47,9 @@ LGP_KERNEL_DECAYING = 20
 LGP_KERNEL_FRACBROWNIAN = 21
 LGP_KERNEL_WIENERINTEGRAL = 22
 LGP_KERNEL_STATIONARYFRACBROWNIAN = 23
+LGP_KERNEL_CELERITE = 24
+LGP_KERNEL_HARMONIC = 25
+LGP_KERNEL_CIRCULAR = 26
 LGP_OP_MUL = 0
 LGP_OP_ADD = 1
 LGP_EPS_AUTO_REL = 1

@@ -120,6 +120,28 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
       return T(1) + z * (T(-1) / T(6) + z * (T(1) / T(120) + z * (T(-1) / T(5040) + z * (T(1) / T(362880) + z * (T(-1) / T(39916800))))));
     }
     return sin(pa) / pa;
+  } else if (g.kernel == LGP_KERNEL_CELERITE) {          // _kernels/_celerite.py:34-52: par = {gamma, B}, input='abs'
+    const T a = fabs(d0);
+    return exp(-g.par[0] * a) * (cos(a) + g.par[1] * sin(a));
+  } else if (g.kernel == LGP_KERNEL_HARMONIC) {          // _kernels/_celerite.py:54-121: par = {Q, eta Q, sqrt(1 - Q^2) - 1}, p = branch
+    const T tau = fabs(d0), tauQ = tau / g.par[0];
+    if (g.p == 0) {                                      // Q < 1/2
+      const T pexp = exp(g.par[2] * tauQ), mexp = exp(-(T(1) + g.par[1]) * tauQ);
+      return (pexp + mexp + (pexp - mexp) / g.par[1]) / T(2);
+    } else if (g.p == 1) {                               // 1/2 <= Q < 1
+      const T et = g.par[1] * tauQ;
+      return exp(-tauQ) * (cosh(et) + sinh(et) / g.par[1]);
+    } else if (g.p == 2) {                               // Q = 1: (1 + tau) exp(-tau)  (the second term of _harmonic vanishes)
+      return (T(1) + tauQ) * exp(-tauQ) + exp(-tau / g.par[0]) * (T(1) - g.par[0]) * (tau * tau) * (T(1) + tau / T(3));
+    } else {                                             // Q > 1
+      const T et = g.par[1] * tauQ;
+      return exp(-tauQ) * (cos(et) + sin(et) / g.par[1]);
+    }
+  } else if (g.kernel == LGP_KERNEL_CIRCULAR) {          // _kernels/_wendland.py:88-113: par = {tau, c}, input='posabs'
+    const T a = fabs(d0) + (sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-07f));
+    const T x = a - floor(a);                            // delta % 1 for delta > 0
+    const T t = fmin(x, T(1) - x);
+    return (T(1) + g.par[0] * t / g.par[1]) * pow(fmax(T(1) - t / g.par[1], T(0)), g.par[0]);
   } else if (g.kernel == LGP_KERNEL_LINEAR) {            // _kernels/_basic.py:76-91: d0 = sum_f x_f y_f
     return d0;
   } else if (g.kernel == LGP_KERNEL_WIENER) {            // _kernels/_randomwalk.py:26-41 (from here on: x = d0, y = r2, one variable)
@@ -429,7 +451,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_STATIONARYFRACBROWNIAN, "unknown isotropic kernel");
+  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_CIRCULAR, "unknown isotropic kernel");
   LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || kernel == LGP_KERNEL_LINEAR || d == 1, "this kernel is a function of one variable (maxdim = 1)");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
   LGP_REQUIRE(p >= 0 && p <= MAX_P, "Maternp order must be in [0,16]");
@@ -481,6 +503,15 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
     g.par[0] = hpar[0];
   } else if (kernel == LGP_KERNEL_LOG) {
     LGP_REQUIRE(npar == 0, "this kernel takes no real parameters");
+  } else if (kernel == LGP_KERNEL_CELERITE) {            // hpar = {gamma, B}
+    LGP_REQUIRE(npar == 2 && hpar != nullptr && hpar[0] >= T(0) && hpar[0] < std::numeric_limits<T>::infinity() && fabs(hpar[1]) <= hpar[0], "Celerite takes {gamma, B}, |B| <= gamma");
+    g.par[0] = hpar[0]; g.par[1] = hpar[1];
+  } else if (kernel == LGP_KERNEL_HARMONIC) {            // hpar = {Q, eta Q, sqrt(1 - Q^2) - 1}; p = 0: Q < 1/2, 1: Q < 1, 2: Q = 1, 3: Q > 1
+    LGP_REQUIRE(npar == 3 && hpar != nullptr && hpar[0] > T(0) && p >= 0 && p <= 3, "Harmonic takes {Q, eta Q, sqrt(1 - Q^2) - 1} and the branch");
+    for (int k = 0; k < 3; ++k) g.par[k] = hpar[k];
+  } else if (kernel == LGP_KERNEL_CIRCULAR) {            // hpar = {tau, c}
+    LGP_REQUIRE(npar == 2 && hpar != nullptr && hpar[0] >= T(4) && hpar[1] > T(0) && hpar[1] <= T(0.5), "Circular takes {tau >= 4, c in (0, 1/2]}");
+    g.par[0] = hpar[0]; g.par[1] = hpar[1];
   } else if (kernel == LGP_KERNEL_DECAYING) {            // hpar = {alpha}
     LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0), "Decaying takes {alpha}, alpha >= 0");
     g.par[0] = hpar[0];

@@ -388,6 +388,51 @@ def StationaryFracBrownian(*, H=1/2, scale=None, loc=None):
     return Kernel(_stationary1d(lambda d: 1/2 * (numpy.abs(d + 1) ** H2 + numpy.abs(d - 1) ** H2 - 2 * numpy.abs(d) ** H2)), scale=scale, loc=loc)
 
 
+def Celerite(*, gamma=1, B=0, scale=None, loc=None):
+    """ ``_kernels/_celerite.py:34-52`` """
+    assert 0 <= gamma < numpy.inf and abs(B) <= gamma
+    return Kernel(_stationary1d(lambda d: numpy.exp(-gamma * d) * (numpy.cos(d) + B * numpy.sin(d)), 'abs'), scale=scale, loc=loc)
+
+
+def Harmonic(*, Q=1, scale=None, loc=None):
+    """ ``_kernels/_celerite.py:54-121`` """
+    assert 0 < Q < numpy.inf
+
+    def core(delta):
+        tau = numpy.abs(delta)
+        if Q < 1/2:
+            etaQ = numpy.sqrt((1 - Q) * (1 + Q))
+            tauQ = tau / Q
+            pexp = numpy.exp(numpy.expm1(1/2 * numpy.log1p(-numpy.square(Q))) * tauQ)
+            mexp = numpy.exp(-(1 + etaQ) * tauQ)
+            return (pexp + mexp + (pexp - mexp) / etaQ) / 2
+        elif 1/2 <= Q < 1:
+            etaQ = numpy.sqrt(1 - numpy.square(Q))
+            tauQ = tau / Q
+            etatau = etaQ * tauQ
+            return numpy.exp(-tauQ) * (numpy.cosh(etatau) + numpy.sinh(etatau) / etaQ)
+        elif Q == 1:
+            x = tau
+            return (1 + x / Q) * numpy.exp(-x / Q) + numpy.exp(-x / Q) * (1 - Q) * numpy.square(x) * (1 + x / 3)
+        else:
+            etaQ = numpy.sqrt(numpy.square(Q) - 1)
+            tauQ = tau / Q
+            etatau = etaQ * tauQ
+            return numpy.exp(-tauQ) * (numpy.cos(etatau) + numpy.sin(etatau) / etaQ)
+    return Kernel(_stationary1d(core), scale=scale, loc=loc)
+
+
+def Circular(*, tau=4, c=1/2, scale=None, loc=None):
+    """ ``_kernels/_wendland.py:88-113`` """
+    assert tau >= 4 and 0 < c <= 1/2
+
+    def core(delta):
+        x = delta % 1
+        t = numpy.minimum(x, 1 - x)
+        return (1 + tau * t / c) * numpy.maximum(1 - t / c, 0) ** tau
+    return Kernel(_stationary1d(core, 'posabs'), scale=scale, loc=loc)
+
+
 def Linear(*, scale=None, loc=None):
     """ ``_kernels/_basic.py:76-91`` """
     return Kernel(lambda x, y: sum_recurse_dtype(lambda a, b: a * b, x, y), scale=scale, loc=loc)

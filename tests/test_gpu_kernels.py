@@ -564,3 +564,33 @@ def test_linear_over_fields_and_domains(lgp, rng):
     gp = lgp.GP(lgp.Wiener(), checkpos=False).addx(np.array([1., 2., 4.]), 'd').addx(np.array([1.5, 3.]), 'm')
     m, _ = gp.predfromdata({'d': np.array([1., 3., -1.])}, 'm', raw=True)
     np.testing.assert_allclose(m, [2., 1.], atol=1e-9)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('make', [
+    lambda m: m.Celerite(), lambda m: m.Celerite(gamma=0.7, B=0.7, scale=0.5), lambda m: m.Celerite(gamma=2., B=-1.5) * 2.,
+    lambda m: m.Harmonic(Q=0.2), lambda m: m.Harmonic(Q=0.7, scale=0.5), lambda m: m.Harmonic(), lambda m: m.Harmonic(Q=5., scale=0.3),
+    lambda m: m.Circular(), lambda m: m.Circular(tau=6, c=0.3, scale=2.), lambda m: m.Circular(scale=0.25, loc=1.) + 1.,
+])
+def test_oscillator_and_circular_kernels_vs_oracle(lgp, make, dtype, rng):
+    """ Celerite, Harmonic (four branches in Q) and Circular (``_kernels/_celerite.py``, ``_wendland.py:88-113``) """
+    n, m = 170, 300
+    x = rng.uniform(-4, 4, n).astype(dtype); y = rng.uniform(-4, 4, m).astype(dtype)
+    y[:25] = x[:25]
+    G = make(lgp).gram(x, y).to_host()
+    R = np.asarray(make(oracle)(x[:, None], y[None, :]), float)
+    tol = 1e-14 if dtype == np.float64 else 2e-5           # (Circular: a rounding of delta mod 1 times tau / c)
+    np.testing.assert_allclose(G, R, rtol=0, atol=tol * max(1., np.abs(R).max()))
+
+
+def test_harmonic_limits(lgp, rng):
+    """ Q = 1 with scale = sqrt(1/3) is Matern-3/2 in one dimension; B = gamma makes Celerite the Harmonic kernel with
+    eta Q = 1 / B (the remarks in the reference's docstrings) """
+    x = rng.uniform(0, 3, 200)
+    H = lgp.Harmonic(scale=np.sqrt(1 / 3)).gram(x, x).to_host()
+    M = lgp.Maternp(p=1).gram(x, x).to_host()
+    np.testing.assert_allclose(H, M, rtol=0, atol=1e-14)
+    Q = 3.
+    eta = np.sqrt(1 - 1 / Q ** 2)
+    B = 1 / (eta * Q)
+    np.testing.assert_allclose(lgp.Celerite(gamma=B, B=B, scale=1 / eta).gram(x, x).to_host(), lgp.Harmonic(Q=Q).gram(x, x).to_host(), rtol=0, atol=2e-14)

@@ -267,3 +267,25 @@ def test_random_walk_kernels_closed_forms(rng):
         oracle.Wiener()(np.array([-1.])[:, None], y[None, :])
     with pytest.raises(AssertionError):
         oracle.BrownianBridge()(np.array([1.5])[:, None], y[None, :])
+
+
+def test_oscillator_and_circular_closed_forms(rng):
+    """ Celerite, Harmonic, Circular of the oracle against ``_kernels/_celerite.py:34-121`` / ``_wendland.py:88-113``: the
+    formulas of the docstrings and the relations they state """
+    x = rng.uniform(-3, 3, 50)
+    d = x[:, None] - x[None, :]
+    a = np.abs(d)
+    np.testing.assert_allclose(oracle.Celerite(gamma=0.8, B=-0.3)(x[:, None], x[None, :]), np.exp(-0.8 * a) * (np.cos(d) - 0.3 * np.sin(a)), rtol=1e-13, atol=1e-15)
+    for Q in (0.2, 0.49, 0.5, 0.8):                       # both branches below 1 are exp(-tau / Q) (cosh + sinh / (eta Q))
+        eta = np.sqrt(1 / Q ** 2 - 1)
+        want = np.exp(-a / Q) * (np.cosh(eta * a) + np.sinh(eta * a) / (eta * Q))
+        np.testing.assert_allclose(oracle.Harmonic(Q=Q)(x[:, None], x[None, :]), want, rtol=1e-11)
+    np.testing.assert_allclose(oracle.Harmonic()(x[:, None], x[None, :]), (1 + a) * np.exp(-a), rtol=1e-14)
+    Q = 4.
+    eta = np.sqrt(1 - 1 / Q ** 2)
+    np.testing.assert_allclose(oracle.Harmonic(Q=Q)(x[:, None], x[None, :]), np.exp(-a / Q) * (np.cos(eta * a) + np.sin(eta * a) / (eta * Q)), rtol=1e-12, atol=1e-15)
+    # Circular: period 1, W_c of the geodesic distance
+    K = oracle.Circular(tau=5, c=0.4)(x[:, None], x[None, :])
+    np.testing.assert_allclose(K, oracle.Circular(tau=5, c=0.4)((x + 3.)[:, None], x[None, :]), rtol=0, atol=1e-12)
+    t = np.arccos(np.cos(2 * np.pi * d)) / (2 * np.pi)
+    np.testing.assert_allclose(K, (1 + 5 * t / 0.4) * np.maximum(1 - t / 0.4, 0) ** 5, rtol=0, atol=1e-12)
