@@ -241,6 +241,12 @@ int lgp_add_diag_f32(lgp_ctx *ctx, size_t n, float *dA, size_t lda, const float 
 /* A += c elementwise (`k_sigma_mu^2 * 11^T`) */
 int lgp_add_scalar_f64(lgp_ctx *ctx, size_t rows, size_t cols, double *dA, size_t lda, double c);
 int lgp_add_scalar_f32(lgp_ctx *ctx, size_t rows, size_t cols, float *dA, size_t lda, float c);
+/* C = alpha (A o B) + beta C0, entry by entry (C0 may be NULL, or C itself): the product of two kernels evaluated on the same
+ * points (`k1 * k2`, reference _Kernel/_alg.py:58-82) and, accumulated, the product rule of its hyperparameter tangents. */
+int lgp_mul_f64(lgp_ctx *ctx, size_t rows, size_t cols, double alpha, const double *dA, size_t lda, const double *dB, size_t ldb,
+                double beta, const double *dC0, size_t ldc0, double *dC, size_t ldc);
+int lgp_mul_f32(lgp_ctx *ctx, size_t rows, size_t cols, float alpha, const float *dA, size_t lda, const float *dB, size_t ldb,
+                float beta, const float *dC0, size_t ldc0, float *dC, size_t ldc);
 /* flags[0] = any non-finite entry, flags[1] = max |A - A^T| > atol + rtol*|A^T| anywhere (jnp.allclose),
  * checks of _GP/_elements.py:618-622 and _GP/_compute.py:369-381.  Synchronises. */
 int lgp_check_matrix_f64(lgp_ctx *ctx, size_t rows, size_t cols, const double *dA, size_t lda,

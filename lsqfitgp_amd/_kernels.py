@@ -129,7 +129,7 @@ class Kernel:
     # -- algops (``_Kernel/_alg.py:32-82``), scalars only
     def _algop(self, op, c):
         if isinstance(c, Kernel):
-            raise NotImplementedError('kernel-kernel algebra is out of scope of the device path; only scalars')
+            return _Composite(op, self, c)                          # k1 + k2, k1 * k2 (_Kernel/_alg.py:32-82)
         c, dc = _dual.split(c)
         if not (isinstance(c, numbers.Number) or (isinstance(c, numpy.ndarray) and c.ndim == 0) or isinstance(c, numpy.generic)):
             return NotImplemented
@@ -187,6 +187,139 @@ class Kernel:
         if self.tangent_keys():
             raise NotImplementedError(f'tangents of the hyperparameters of {type(self).__name__}')
         return self.gram(xs, ys, ctx=ctx, **kw), {}
+
+
+def _dev_axpby(alpha, A, beta, B, out=None):
+    ref = A if A is not None else B
+    if out is None:
+        out = DeviceArray.empty(ref.shape, ref.dtype, ref.ctx)
+    r2 = ref.as2d()
+    f, F = _lib.fn('lgp_axpby', ref.dtype)
+    _lib.check(f(ref.ctx.handle, r2.shape[0], r2.shape[1], F(alpha), None if A is None else A.ptr, 0 if A is None else A.as2d().ld,
+                 F(beta), None if B is None else B.ptr, 0 if B is None else B.as2d().ld, out.ptr, out.as2d().ld), 'lgp_axpby')
+    return out
+
+
+def _dev_mul(alpha, A, B, beta=0., C0=None, out=None):
+    """ out = alpha A o B + beta C0 """
+    if out is None:
+        out = DeviceArray.empty(A.shape, A.dtype, A.ctx)
+    a2 = A.as2d()
+    f, F = _lib.fn('lgp_mul', A.dtype)
+    _lib.check(f(A.ctx.handle, a2.shape[0], a2.shape[1], F(alpha), A.ptr, a2.ld, B.ptr, B.as2d().ld, F(beta),
+                 None if C0 is None else C0.ptr, 0 if C0 is None else C0.as2d().ld, out.ptr, out.as2d().ld), 'lgp_mul')
+    return out
+
+
+def _dev_astype(A, dtype):
+    dtype = numpy.dtype(dtype)
+    if A.dtype == dtype:
+        return A
+    out = DeviceArray.empty(A.shape, dtype, A.ctx)
+    if A.size:
+        a2, o2 = A.as2d(), out.as2d()
+        name = 'lgp_convert_f32_f64' if dtype == numpy.float64 else 'lgp_convert_f64_f32'
+        _lib.check(getattr(_lib.load(), name)(A.ctx.handle, a2.shape[0], a2.shape[1], o2.ptr, o2.ld, a2.ptr, a2.ld), name)
+    return out
+
+
+class _Composite(Kernel):
+    """
+    Sum or product of two kernels (``_Kernel/_alg.py:32-82``: ``k1 + k2``, ``k1 * k2``): each operand is evaluated by its own
+    Gram kernel on the same points and the matrices are combined entry by entry on the device (`lgp_axpby` / `lgp_mul`); scalar
+    operations applied to the composite afterwards follow.  The hyperparameter tangents (`_dual`) combine by linearity and
+    by the product rule.  Derivative observations: of a sum only (the terms' derivatives add).
+    """
+
+    def __init__(self, op, a, b):
+        super().__init__()
+        self._op, self._a, self._b = op, a, b
+
+    def _result_dtype(self, x, y):
+        return numpy.result_type(self._a._result_dtype(x, y), self._b._result_dtype(x, y))
+
+    def tangent_keys(self):
+        keys = super().tangent_keys()
+        for k in self._a.tangent_keys() + self._b.tangent_keys():
+            if k not in keys:
+                keys.append(k)
+        return keys
+
+    def _finish(self, M):
+        """ the scalar operations applied to the composite, in place """
+        for op, c in self._outops:
+            if op == 'mul':
+                _dev_axpby(float(c), M, 0., None, M)
+            else:
+                m2 = M.as2d()
+                f, F = _lib.fn('lgp_add_scalar', M.dtype)
+                _lib.check(f(M.ctx.handle, m2.shape[0], m2.shape[1], M.ptr, m2.ld, F(float(c))), 'lgp_add_scalar')
+        return M
+
+    def _combine(self, A, B, out=None):
+        dt = numpy.result_type(A.dtype, B.dtype)
+        A, B = _dev_astype(A, dt), _dev_astype(B, dt)
+        if out is not None and out.dtype != dt:
+            raise TypeError(f'output of dtype {out.dtype} for a kernel of dtype {dt}')
+        M = _dev_axpby(1., A, 1., B, out) if self._op == 'add' else _dev_mul(1., A, B, out=out)
+        return self._finish(M)
+
+    def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
+        kw = {}
+        if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
+            if self._op != 'add':
+                raise NotImplementedError('derivative observations of a product of kernels')
+            if any(op == 'add' for op, _ in self._outops):
+                raise NotImplementedError('derivative observations of a sum of kernels plus a constant: add the constant to a term')
+            kw = dict(deriv=deriv)
+        return self._combine(self._a.gram(xs, ys, ctx=ctx, **kw), self._b.gram(xs, ys, ctx=ctx, **kw), out)
+
+    def pairs(self, xs, ys, *, ctx=None):
+        return self._combine(self._a.pairs(xs, ys, ctx=ctx), self._b.pairs(xs, ys, ctx=ctx))
+
+    def gram_tangents(self, xs, ys, *, ctx=None, **kw):
+        if kw.get('deriv') and any(numpy.any(numpy.asarray(o) != 0) for o in kw['deriv']):
+            raise NotImplementedError('tangents of the hyperparameters of a derived kernel')
+        A, dA = self._a.gram_tangents(xs, ys, ctx=ctx)
+        B, dB = self._b.gram_tangents(xs, ys, ctx=ctx)
+        dt = numpy.result_type(A.dtype, B.dtype)
+        A, B = _dev_astype(A, dt), _dev_astype(B, dt)
+        K0 = _dev_axpby(1., A, 1., B) if self._op == 'add' else _dev_mul(1., A, B)
+        # the scalar operations after the composition: K = a K0 + b with Dual a, b
+        a, b = _dual.Dual(1.), _dual.Dual(0.)
+        for (op, c), dc in zip(self._outops, self._doutops):
+            cd = _dual.Dual(float(c), dc)
+            if op == 'mul':
+                a, b = a * cd, b * cd
+            else:
+                b = b + cd
+        tangents = {}
+        for k in self.tangent_keys():
+            ta, tb = dA.get(k), dB.get(k)
+            T = None
+            if self._op == 'add':
+                if ta is not None and tb is not None:
+                    T = _dev_axpby(1., _dev_astype(ta, dt), 1., _dev_astype(tb, dt))
+                elif ta is not None or tb is not None:
+                    T = _dev_axpby(1., _dev_astype(ta if ta is not None else tb, dt), 0., None)
+            else:                                              # d(A o B) = dA o B + A o dB
+                if ta is not None:
+                    T = _dev_mul(1., _dev_astype(ta, dt), B)
+                if tb is not None:
+                    T = _dev_mul(1., A, _dev_astype(tb, dt), 1. if T is not None else 0., T, T)
+            da, db = float(a.tangents.get(k, 0.)), float(b.tangents.get(k, 0.))
+            if T is None:
+                if da == 0. and db == 0.:
+                    continue
+                T = _dev_axpby(da, K0, 0., None)
+            else:
+                _dev_axpby(float(a.value), T, da, K0 if da != 0. else None, T)
+            if db != 0.:
+                t2 = T.as2d()
+                f, F = _lib.fn('lgp_add_scalar', T.dtype)
+                _lib.check(f(T.ctx.handle, t2.shape[0], t2.shape[1], T.ptr, t2.ld, F(db)), 'lgp_add_scalar')
+            tangents[k] = T
+        return self._finish(K0), tangents
 
 
 class _Isotropic(Kernel):

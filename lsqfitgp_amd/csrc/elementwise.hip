@@ -28,6 +28,22 @@ __global__ void __launch_bounds__(256) axpby_kernel(size_t rows, size_t cols, T 
   }
 }
 
+// C = alpha A o B + beta C0 (Hadamard product; C0 may be null or C itself): the product of two kernels (_Kernel/_alg.py:58-82),
+// and, with C0 = C, the product rule of its tangents
+template <typename T>
+__global__ void __launch_bounds__(256) mul_kernel(size_t rows, size_t cols, T alpha, const T *A, size_t lda, const T *B, size_t ldb, T beta,
+                                                  const T *C0, size_t ldc0, T *C, size_t ldc) {
+  const size_t nbx = (cols + 255) / 256;
+  for (size_t blk = blockIdx.x; blk < rows * nbx; blk += gridDim.x) {
+    const size_t i = blk / nbx, j = (blk % nbx) * 256 + threadIdx.x;
+    if (j < cols) {
+      T v = alpha * (A[i * lda + j] * B[i * ldb + j]);
+      if (C0) v += beta * C0[i * ldc0 + j];
+      C[i * ldc + j] = v;
+    }
+  }
+}
+
 template <typename T>
 __global__ void add_diag_kernel(size_t n, T *A, size_t lda, const T *vec, T alpha) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -227,6 +243,19 @@ int axpby_impl(lgp_ctx *ctx, size_t rows, size_t cols, T alpha, const T *A, size
 }
 
 template <typename T>
+int mul_impl(lgp_ctx *ctx, size_t rows, size_t cols, T alpha, const T *A, size_t lda, const T *B, size_t ldb, T beta, const T *C0, size_t ldc0,
+             T *C, size_t ldc) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  if (rows == 0 || cols == 0) return LGP_OK;
+  LGP_REQUIRE(A != nullptr && B != nullptr && C != nullptr && lda >= cols && ldb >= cols && ldc >= cols, "bad operands");
+  LGP_REQUIRE(C0 == nullptr || ldc0 >= cols, "leading dimension too small");
+  DeviceGuard dg(ctx->device);
+  hipLaunchKernelGGL((mul_kernel<T>), dim3(grid_for(rows, cols)), dim3(256), 0, ctx->stream, rows, cols, alpha, A, lda, B, ldb, beta, C0, ldc0, C, ldc);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
+template <typename T>
 int add_diag_impl(lgp_ctx *ctx, size_t n, T *A, size_t lda, const T *vec, T alpha) {
   LGP_REQUIRE(ctx != nullptr, "null context");
   if (n == 0) return LGP_OK;
@@ -416,6 +445,8 @@ extern "C" int lgp_colabssum_f64(lgp_ctx *c, size_t rows, size_t cols, const dou
 extern "C" {
 int lgp_axpby_f64(lgp_ctx *c, size_t r, size_t n, double a, const double *A, size_t lda, double b, const double *B, size_t ldb, double *C, size_t ldc) { return axpby_impl<double>(c, r, n, a, A, lda, b, B, ldb, C, ldc); }
 int lgp_axpby_f32(lgp_ctx *c, size_t r, size_t n, float a, const float *A, size_t lda, float b, const float *B, size_t ldb, float *C, size_t ldc) { return axpby_impl<float>(c, r, n, a, A, lda, b, B, ldb, C, ldc); }
+int lgp_mul_f64(lgp_ctx *c, size_t r, size_t n, double a, const double *A, size_t lda, const double *B, size_t ldb, double b, const double *C0, size_t ldc0, double *C, size_t ldc) { return mul_impl<double>(c, r, n, a, A, lda, B, ldb, b, C0, ldc0, C, ldc); }
+int lgp_mul_f32(lgp_ctx *c, size_t r, size_t n, float a, const float *A, size_t lda, const float *B, size_t ldb, float b, const float *C0, size_t ldc0, float *C, size_t ldc) { return mul_impl<float>(c, r, n, a, A, lda, B, ldb, b, C0, ldc0, C, ldc); }
 int lgp_add_diag_f64(lgp_ctx *c, size_t n, double *A, size_t lda, const double *v, double a) { return add_diag_impl<double>(c, n, A, lda, v, a); }
 int lgp_add_diag_f32(lgp_ctx *c, size_t n, float *A, size_t lda, const float *v, float a) { return add_diag_impl<float>(c, n, A, lda, v, a); }
 int lgp_add_scalar_f64(lgp_ctx *c, size_t r, size_t n, double *A, size_t lda, double v) { return add_scalar_impl<double>(c, r, n, A, lda, v); }

@@ -174,6 +174,11 @@ class Kernel:
         return Kernel(core, scale=self._scale, loc=self._loc, outops=(('mul', factor),))
 
     def _with(self, op, c):
+        if isinstance(c, Kernel):
+            # k1 + k2, k1 * k2 (``_alg.py:32-82``): each operand with its own input transformations
+            a, b = self, c
+            core = (lambda x, y: a(x, y) + b(x, y)) if op == 'add' else (lambda x, y: a(x, y) * b(x, y))
+            return Kernel(core)
         if not isinstance(c, numbers.Number) and numpy.ndim(c) != 0:
             return NotImplemented
         return Kernel(self._core, scale=self._scale, loc=self._loc, outops=self._outops + ((op, c),))

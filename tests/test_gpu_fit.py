@@ -465,3 +465,20 @@ def test_bart_hyperparameters_as_duals(lgp, rng):
     assert fit._autodiff and fit._autodiff_checked
     z = np.array([0.2, -0.1, 0.3])
     np.testing.assert_allclose(fit._auto_derivs(z, False)[1], fit._fd_gradient(z), rtol=1e-5, atol=1e-6)
+
+
+def test_fit_of_a_sum_of_kernels_differentiates_itself(lgp, rng):
+    """ a factory with a sum and a product of kernels: the gradient comes from the tangents of the composite """
+    n = 200
+    x = np.sort(rng.uniform(0, 20, n))
+    y = np.sin(x) + 0.5 * np.sin(0.2 * x) + 0.1 * rng.standard_normal(n)
+    prior = {'log(ls)': (np.log(2.), 0.5), 'log(ll)': (np.log(8.), 0.5), 'log(al)': (np.log(0.5), 0.5), 'log(s2)': (np.log(0.02), 0.5)}
+
+    def makegp(hp):
+        k = lgp.ExpQuad(scale=hp['ls']) * lgp.Periodic(scale=1.) + lgp.Maternp(p=2, scale=hp['ll']) * hp['al']
+        return lgp.GP(k, checkpos=False).addx(x, 'f').addcov(lgp.diag(hp['s2'] * np.ones(n)), 'e').addtransf({'f': 1, 'e': 1}, 'y')
+
+    fit = lgp.empbayes_fit(prior, makegp, {'y': y}, raises=False, minkw=dict(options=dict(maxiter=5)))
+    assert fit._autodiff and fit._autodiff_checked
+    z = np.array([0.1, -0.2, 0.3, 0.2])
+    np.testing.assert_allclose(fit._auto_derivs(z, False)[1], fit._fd_gradient(z), rtol=3e-6, atol=1e-6)

@@ -594,3 +594,52 @@ def test_harmonic_limits(lgp, rng):
     eta = np.sqrt(1 - 1 / Q ** 2)
     B = 1 / (eta * Q)
     np.testing.assert_allclose(lgp.Celerite(gamma=B, B=B, scale=1 / eta).gram(x, x).to_host(), lgp.Harmonic(Q=Q).gram(x, x).to_host(), rtol=0, atol=2e-14)
+
+
+def test_sums_and_products_of_kernels(lgp, rng):
+    """ k1 + k2 and k1 * k2 (``_Kernel/_alg.py:32-82``): every operand evaluated by its own Gram kernel on the same points, the
+    matrices combined on the device; scalar operations on the composite; mixed dtypes; nesting """
+    n, m = 210, 130
+    x = rng.uniform(0, 6, n); y = rng.uniform(0, 6, m)
+    make = lambda M: (M.ExpQuad(scale=2.) * M.Periodic(outerscale=0.5, scale=0.3) + M.Constant() * 0.3 + M.Maternp(p=1, scale=0.7) * M.Cos(scale=0.5)) * 2. + 0.1
+    G = make(lgp).gram(x, y).to_host()
+    R = make(oracle)(x[:, None], y[None, :])
+    np.testing.assert_allclose(G, R, rtol=0, atol=1e-14 * np.abs(R).max())
+    P = make(lgp)(x[:m], y)
+    np.testing.assert_allclose(P, np.diagonal(R), rtol=0, atol=1e-14 * np.abs(R).max())
+    # structured points, a float32 operand next to float64 ones
+    s = np.empty(n, [('a', float), ('b', float)]); t = np.empty(m, s.dtype)
+    for f in 'ab':
+        s[f] = rng.uniform(0, 3, n); t[f] = rng.uniform(0, 3, m)
+    make2 = lambda M: M.ExpQuad(scale=1.5) * M.Linear() + M.Maternp(p=2) + M.White()
+    np.testing.assert_allclose(make2(lgp).gram(s, t).to_host(), make2(oracle)(s[:, None], t[None, :]), rtol=0, atol=2e-14)
+    K = make2(lgp).gram(s, s).to_host()
+    np.testing.assert_array_equal(K, K.T)
+    # a GP on a sum of kernels: the prior covariance is the sum of the priors
+    gp = lgp.GP(lgp.ExpQuad(scale=2.) + lgp.Cos() * 0.5, checkpos=False).addx(x, 'x')
+    np.testing.assert_allclose(gp.prior('x', raw=True), (oracle.ExpQuad(scale=2.) + oracle.Cos() * 0.5)(x[:, None], x[None, :]), rtol=0, atol=1e-14)
+    # derivative observations pass through a sum, not through a product
+    d1 = (lgp.ExpQuad(scale=2.) + lgp.ExpQuad(scale=0.5) * 3.).gram(x, y, deriv=(1, 1)).to_host()
+    want = lgp.ExpQuad(scale=2.).gram(x, y, deriv=(1, 1)).to_host() + 3. * lgp.ExpQuad(scale=0.5).gram(x, y, deriv=(1, 1)).to_host()
+    np.testing.assert_allclose(d1, want, rtol=0, atol=1e-14 * np.abs(want).max())
+    with pytest.raises(NotImplementedError):
+        (lgp.ExpQuad() * lgp.Cos()).gram(x, y, deriv=(1, 0))
+
+
+def test_tangents_of_sums_and_products(lgp, rng):
+    """ the hyperparameter tangents of composite kernels: linearity and the product rule, against central differences """
+    D = lgp.Dual
+    x = rng.uniform(0, 6, 150); y = rng.uniform(0, 6, 110)
+
+    def build(s1, s2, a, c):
+        return (lgp.ExpQuad(scale=s1) * lgp.Maternp(p=1, scale=s2) * a + lgp.ExpQuad(scale=s2) + c) * a
+
+    p0 = dict(s1=1.7, s2=0.9, a=1.3, c=0.2)
+    K, tans = build(**{k: D(v, {k: 1.}) for k, v in p0.items()}).gram_tangents(x, y)
+    np.testing.assert_array_equal(K.to_host(), build(**p0).gram(x, y).to_host())
+    h = 1e-6
+    for key in p0:
+        up, dn = dict(p0), dict(p0)
+        up[key] += h; dn[key] -= h
+        fd = (build(**up).gram(x, y).to_host() - build(**dn).gram(x, y).to_host()) / (2 * h)
+        np.testing.assert_allclose(tans[key].to_host(), fd, rtol=3e-7, atol=3e-9, err_msg=key)
