@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) check_kernel(size_t rows, size_t cols, co
       if (!(fabs(v) <= (sizeof(T) == 8 ? T(1.7976931348623157e308) : T(3.4028234663852886e38)))) nonfinite = 1;
       if (check_sym && j < i) {
         const T u = A[j * lda + i];
-        if (!(fabs(v - u) <= atol + rtol * fabs(u))) asym = 1;
+        if (!(fabs(v - u) <= atol + rtol * fabs(u)) && !(v == u)) asym = 1;      // (equal infinities are close, as for numpy.allclose)
       }
     }
   }
