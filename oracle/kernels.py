@@ -286,7 +286,14 @@ def Wendland(*, k=0, alpha=1, scale=None, loc=None):
         poly = numpy.polyval(coeffs, r)
         with numpy.errstate(invalid='ignore'):
             return numpy.where(r < 1, (1 - r) ** (nu + k) * poly, 0)
-    return Kernel(_isotropic_posabs(core), scale=scale, loc=loc)
+    inner = _isotropic_posabs(core)
+    maxdim = int(numpy.floor(2 * alpha - 1))                       # ``_wendland.py:29-31``
+
+    def checked(x, y):
+        if x.dtype.names is not None and len(_leaf_columns_count(x.dtype)) > maxdim:
+            raise ValueError(f'kernel called on type with dimensionality > maxdim={maxdim}')
+        return inner(x, y)
+    return Kernel(checked, scale=scale, loc=loc)
 
 
 def CausalExpQuad(*, alpha=1, scale=None, loc=None):
