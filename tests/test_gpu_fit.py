@@ -482,3 +482,125 @@ def test_fit_of_a_sum_of_kernels_differentiates_itself(lgp, rng):
     assert fit._autodiff and fit._autodiff_checked
     z = np.array([0.1, -0.2, 0.3, 0.2])
     np.testing.assert_allclose(fit._auto_derivs(z, False)[1], fit._fd_gradient(z), rtol=3e-6, atol=1e-6)
+
+
+# ---- the reference's tests/test_fit.py on the device classes ------------------------------------------------------------------
+
+def _quad(A, v):
+    w, u = np.linalg.eigh(A)
+    utv = u.T @ v
+    eps = len(A) * 1e-12 * np.max(w)
+    return (utv.T / np.maximum(w, eps)) @ utv
+
+
+def _check_fit(lgp, rng, hyperprior, gpfactory, alpha=1e-5, **fitkw):
+    """ ref :61-76: hyperparameters drawn from the prior, data drawn from the GP they define, and the fit must be compatible
+    with them (chi-square of the pulls under the fit's own covariance) """
+    true = {k: m + s * rng.standard_normal() for k, (m, s) in hyperprior.items()}
+    hp = dict(true)
+    for k, v in true.items():
+        if k.startswith('log('):
+            hp[k[4:-1]] = np.exp(v)
+    gp = gpfactory(hp)
+    cov = gp.prior('x', raw=True)
+    n = len(cov)
+    data = np.linalg.cholesky(cov + 1e-12 * np.trace(cov) / n * np.eye(n)) @ rng.standard_normal(n)
+    fit = lgp.empbayes_fit(hyperprior, gpfactory, {'x': data}, raises=False, **fitkw)
+    names = list(hyperprior)
+    diff = np.array([fit.pmean[k] - true[k] for k in names])
+    C = np.array([[fit.pcov[a, b] for b in names] for a in names])
+    q = _quad(C, diff)
+    assert stats.chi2(len(names)).sf(q) > alpha / 2
+    assert stats.chi2(len(names)).cdf(q) > alpha / 2
+    return fit
+
+
+def test_fit_recovers_scale(lgp, rng):
+    """ ref :87-94 """
+    x = np.linspace(0, 2 * np.pi * 5, 20)
+    _check_fit(lgp, rng, {'log(scale)': (np.log(3), 0.2 / 3)}, lambda hp: lgp.GP(lgp.ExpQuad(scale=hp['scale'])).addx(x, 'x'), alpha=1e-7)
+
+
+def test_fit_recovers_sdev(lgp, rng):
+    """ ref :96-103 """
+    x = np.linspace(0, 5, 10)
+    _check_fit(lgp, rng, {'log(sdev)': (0., 1.)}, lambda hp: lgp.GP(lgp.ExpQuad() * hp['sdev'] ** 2).addx(x, 'x'), alpha=1e-8)
+
+
+def test_fit_recovers_scale_and_sdev(lgp, rng):
+    """ ref :106-115 """
+    x = np.linspace(0, 2 * np.pi * 5, 20)
+    fit = _check_fit(lgp, rng, {'log(scale)': (np.log(3), 0.2 / 3), 'log(sdev)': (0., 1.)},
+                     lambda hp: lgp.GP(hp['sdev'] ** 2 * lgp.ExpQuad(scale=hp['scale'])).addx(x, 'x'), alpha=1e-7)
+    assert fit._autodiff
+
+
+def _sdev_problem(lgp, rng):
+    x = np.linspace(0, 5, 10)
+    gpfactory = lambda hp: lgp.GP(lgp.ExpQuad() * hp['sdev'] ** 2).addx(x, 'x')
+    true = rng.standard_normal()
+    cov = gpfactory({'sdev': np.exp(true)}).prior('x', raw=True)
+    data = np.linalg.cholesky(cov + 1e-12 * np.eye(10)) @ rng.standard_normal(10)
+    return {'log(sdev)': (0., 1.)}, gpfactory, data, true
+
+
+def test_fit_methods_agree(lgp, rng):
+    """ ref :142-176: Nelder-Mead, BFGS, L-BFGS-B, the Fisher dogleg and trust-constr land on the same mode, with data that are
+    fixed and with data that depend on the hyperparameters """
+    hp, gpfactory, data_fixed, true = _sdev_problem(lgp, rng)
+    data_variable = lambda h: {'x': data_fixed + h['log(sdev)']}
+    for data in ({'x': data_fixed}, data_variable):
+        kws = [dict(method='nograd', minkw=dict(options=dict(xatol=1e-6))), dict(method='gradient'), dict(method='fisher'),
+               dict(method='fisher', minkw=dict(method='trust-constr')), dict(method='gradient', minkw=dict(method='l-bfgs-b'))]
+        fits = []
+        for kw in kws:
+            kw = dict(kw)
+            kw.setdefault('minkw', {}).update(x0=np.array([true]))
+            fits.append(lgp.empbayes_fit(hp, gpfactory, data, **kw))
+        p = fits[0].minresult.x
+        for fit in fits[1:]:
+            util.assert_allclose(fit.minresult.x, p, atol=1e-5)
+
+
+def test_fit_checks_and_int_data(lgp):
+    """ ref :178-190 """
+    with pytest.raises(KeyError):
+        lgp.empbayes_fit({'a': (0., 1.)}, lambda hp: None, {'x': 0.}, method='cippa')
+    makegp = lambda hp: lgp.GP(lgp.ExpQuad()).addx(hp['a'], 'x')
+    with pytest.raises(RuntimeError) as err:
+        lgp.empbayes_fit({'a': (0., 1.)}, makegp, {'x': 0.}, minkw=dict(options=dict(maxiter=0)))
+    assert 'minimization failed: ' in str(err.value)
+    lgp.empbayes_fit({'a': (0., 1.)}, makegp, {'x': 0})
+
+
+def test_fit_data_formats(lgp, rng):
+    """ ref :192-244 (without gvars): dictionaries, tuples with and without a covariance, callables of the hyperparameters """
+    hp, gpfactory, data, _ = _sdev_problem(lgp, rng)
+    d = {'x': data}
+    zerocov = {('x', 'x'): np.zeros((10, 10))}
+    err = 0.1
+    d_err = {'x': data + err * rng.standard_normal(10)}
+    cov = {('x', 'x'): err ** 2 * np.eye(10)}
+    for datasets in ([d, (d,), (d, zerocov), lambda _: d, lambda _: (d,), lambda _: (d, zerocov)],
+                     [(d_err, cov), lambda _: (d_err, cov)]):
+        fits = [lgp.empbayes_fit(hp, gpfactory, ds) for ds in datasets]
+        for fit in fits[1:]:
+            util.assert_allclose(fit.minresult.x, fits[0].minresult.x, atol=1e-6)
+
+
+def test_fit_additional_loss(lgp, rng):
+    """ ref :246-358: a zero loss changes nothing, a constant shifts the value only, a loss with its minimum elsewhere pulls the
+    mode there, and the Fisher matrix refuses a user loss """
+    hp, gpfactory, data, _ = _sdev_problem(lgp, rng)
+    common = dict(hyperprior=hp, gpfactory=gpfactory, data={'x': data}, minkw=dict(method='bfgs'))
+    fit0 = lgp.empbayes_fit(**common)
+    util.assert_allclose(lgp.empbayes_fit(**common, additional_loss=lambda _: 0.).minresult.fun, fit0.minresult.fun)
+    fit1 = lgp.empbayes_fit(**common, additional_loss=lambda _: 100.)
+    util.assert_allclose(fit0.minresult.fun + 100., fit1.minresult.fun, rtol=1e-13)
+    util.assert_allclose(fit0.minresult.x, fit1.minresult.x, rtol=1e-9, atol=1e-9)
+    loc = fit0.pmean['log(sdev)'] + 10
+    fit2 = lgp.empbayes_fit(**common, additional_loss=lambda h: (h['log(sdev)'] - loc) ** 2)
+    assert fit2.minresult.fun > fit0.minresult.fun
+    assert abs(fit2.pmean['log(sdev)'] - loc) < abs(fit0.pmean['log(sdev)'] - loc)
+    with pytest.raises(NotImplementedError):
+        lgp.empbayes_fit(hp, gpfactory, {'x': data}, method='fisher', additional_loss=lambda _: 0.)
