@@ -125,3 +125,32 @@ def test_splits_and_indices_host(rng):
     x = np.repeat(np.arange(10 * 2.).reshape(-1, 2), 2, axis=0).view('d,d').squeeze(axis=-1)
     length, _ = lgp.BART.splits_from_coord(x)
     assert np.all(length == 9)          # ref tests/kernels/test_bart.py:268-271
+
+
+def test_derivative_specifications():
+    """ the reference's ``tests/test_deriv.py`` on `GP._field_orders`, which reads a derivative specification as ``Deriv`` does
+    (``_Deriv.py:24-97``): integers, field names, sequences with multiplicities; the malformed ones raise the same errors """
+    from lsqfitgp_amd._GP import GP
+    f = GP._field_orders
+    assert f(None) == 0 and f(0) == 0 and f(3) == 3
+    assert f('a') == {'a': 1}
+    assert f(['a', 'b', 'a']) == {'a': 2, 'b': 1}
+    assert f([1, 'ciao', 2, 'pippo']) == {'ciao': 1, 'pippo': 2} and len(f([1, 'ciao', 2, 'pippo'])) == 2
+    assert f((2, 'f0')) == {'f0': 2}
+    assert f([0, 'a']) == 0                                  # zero times along a: no derivative
+    with pytest.raises(TypeError):
+        f((None,))
+    with pytest.raises(ValueError):
+        f((1, 2))
+    with pytest.raises(TypeError):
+        f(object)
+    with pytest.raises(ValueError):
+        f((1,))
+    with pytest.raises(ValueError):
+        f(('ciao', 1))
+    with pytest.raises(ValueError):
+        f(-1)
+    with pytest.raises(ValueError):
+        f((-1, 'a'))
+    with pytest.raises(TypeError):
+        f(True)
