@@ -809,6 +809,120 @@ class WienerIntegral(_OneVariable):
     _kind = _lib.LGP_KERNEL_WIENERINTEGRAL
 
 
+class Taylor(_OneVariable):
+    """ Exponential-like power series kernel, k(x, y) = sum_k x^k y^k / k!^2 = I0(2 sqrt(x y)) (``_kernels/_basic.py:393-408``;
+    J0 of the same argument where x y < 0) """
+    _kind = _lib.LGP_KERNEL_TAYLOR
+    _domain = (-numpy.inf, numpy.inf)
+
+
+class _HostFactors(Kernel):
+    """ kernels that are products of per-point quantities evaluated on the host (user functions, table look-ups): the Gram
+    matrix is a product of two thin device matrices """
+
+    def _transformed(self, x):
+        """ the inputs as the kernel's core sees them: (x - loc) / scale on every leaf field (``_crosskernel.py:172-185``) """
+        x = numpy.asarray(x)
+        if self._loc is None and self._scale is None:
+            return x
+        def tr(v):
+            if self._loc is not None:
+                v = v - self._loc
+            if self._scale is not None:
+                v = v / self._scale
+            return v
+        if x.dtype.names is None:
+            return tr(x)
+        out = numpy.empty(x.shape, [(nm, numpy.result_type(x.dtype[nm].base, float), x.dtype[nm].shape) for nm in x.dtype.names])
+        for nm in x.dtype.names:
+            if x.dtype[nm].names is not None:
+                raise NotImplementedError('nested fields')
+            out[nm] = tr(x[nm])
+        return out
+
+    def _factors(self, xs, ys):  # pragma: no cover
+        """ (U, V): K = U V^T, U (n, c), V (m, c) host arrays """
+        raise NotImplementedError
+
+    def _result_dtype(self, x, y):
+        return numpy.dtype(numpy.float64)
+
+    def _finish(self, M):
+        return _Composite._finish(self, M)
+
+    def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
+        if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
+            raise NotImplementedError(f'derivatives of {type(self).__name__}')
+        ctx = ctx or Context.default()
+        U, V = self._factors(numpy.asarray(xs).reshape(-1), numpy.asarray(ys).reshape(-1))
+        n, m, c = U.shape[0], V.shape[0], U.shape[1]
+        if out is None:
+            out = DeviceArray.empty((n, m), numpy.float64, ctx)
+        if n and m:
+            Ud = DeviceArray.from_host(numpy.ascontiguousarray(U, float), ctx=ctx)
+            Vd = DeviceArray.from_host(numpy.ascontiguousarray(V, float), ctx=ctx)
+            f, F = _lib.fn('lgp_gemm', numpy.float64)
+            _lib.check(f(ctx.handle, 0, 1, n, m, c, F(1.), Ud.ptr, Ud.ld, Vd.ptr, Vd.ld, F(0.), out.ptr, out.ld), 'lgp_gemm')
+            self._finish(out)
+        return out
+
+    def pairs(self, xs, ys, *, ctx=None):
+        ctx = ctx or Context.default()
+        U, V = self._factors(numpy.asarray(xs).reshape(-1), numpy.asarray(ys).reshape(-1))
+        out = DeviceArray.from_host(numpy.ascontiguousarray(numpy.sum(U * V, axis=1), float), ctx=ctx)
+        return self._finish(out) if out.size else out
+
+
+class Rescaling(_HostFactors):
+    """ Outer product kernel, k(x, y) = stdfun(x) stdfun(y) (``_kernels/_basic.py:231-252``): multiply another kernel by it to
+    modulate its variance.  ``stdfun`` takes the (transformed) points and returns one number per point; it is evaluated on
+    the host """
+
+    def __init__(self, *, stdfun=None, scale=None, loc=None):
+        super().__init__(scale=scale, loc=loc)
+        self._stdfun = stdfun
+
+    def _std(self, x):
+        x = self._transformed(x)
+        if self._stdfun is None:
+            return numpy.ones(x.shape)
+        s = numpy.asarray(self._stdfun(x), float)
+        if s.shape != x.shape:
+            raise ValueError(f'stdfun returned shape {s.shape} for points of shape {x.shape}')
+        return s
+
+    def _factors(self, xs, ys):
+        return self._std(xs)[:, None], self._std(ys)[:, None]
+
+
+class Categorical(_HostFactors):
+    """ Categorical kernel, k(x, y) = cov[x, y] over the integers 0 .. N - 1 (``_kernels/_basic.py:210-229``) """
+
+    def __init__(self, *, cov=None, scale=None, loc=None):
+        super().__init__(scale=scale, loc=loc)
+        cov = numpy.asarray(cov)
+        assert cov.ndim == 2 and cov.shape[0] == cov.shape[1], cov.shape
+        assert numpy.allclose(cov, cov.T)
+        self._cov = cov.astype(float)
+
+    def _index(self, x):
+        x = numpy.asarray(x)
+        if x.dtype.names is not None:
+            if len(x.dtype.names) > 1:
+                raise ValueError(f'kernel called on type with dimensionality {len(x.dtype.names)} > maxdim=1')
+            x = x[x.dtype.names[0]]
+        assert numpy.issubdtype(x.dtype, numpy.integer), x.dtype
+        if x.size and (x.min() < -len(self._cov) or x.max() >= len(self._cov)):
+            raise IndexError(f'category outside 0 .. {len(self._cov) - 1}')
+        return x
+
+    def _factors(self, xs, ys):
+        ix, iy = self._index(xs), self._index(ys)
+        onehot = numpy.zeros((len(iy), len(self._cov)))
+        onehot[numpy.arange(len(iy)), iy] = 1.
+        return self._cov[ix], onehot
+
+
 # ------------------------------------------------------------------------------
 # BART
 

@@ -157,6 +157,9 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
   } else if (g.kernel == LGP_KERNEL_WIENERINTEGRAL) {    // _kernels/_randomwalk.py:93-110
     const T a = fmin(d0, r2), b = fmax(d0, r2);
     return T(0.5) * (a * a) * (b - a / T(3));
+  } else if (g.kernel == LGP_KERNEL_TAYLOR) {            // _kernels/_basic.py:393-408: I0(2 sqrt(x y)), J0 where x y < 0
+    const T mul = d0 * r2, val = T(2) * sqrt(fabs(mul));
+    return mul >= T(0) ? T(cyl_bessel_i0((double)val)) : T(j0((double)val));
   } else if (g.kernel == LGP_KERNEL_STATIONARYFRACBROWNIAN) {   // _kernels/_randomwalk.py:156-172 (stationary: d0 = delta); par = {2 H}
     return T(0.5) * (pow(fabs(d0 + T(1)), g.par[0]) + pow(fabs(d0 - T(1)), g.par[0]) - T(2) * pow(fabs(d0), g.par[0]));
   } else if (g.kernel == LGP_KERNEL_GAMMAEXP) {          // _kernels/_basic.py:111-113
@@ -451,7 +454,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_CIRCULAR, "unknown isotropic kernel");
+  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_TAYLOR, "unknown isotropic kernel");
   LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || kernel == LGP_KERNEL_LINEAR || d == 1, "this kernel is a function of one variable (maxdim = 1)");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
   LGP_REQUIRE(p >= 0 && p <= MAX_P, "Maternp order must be in [0,16]");
@@ -483,7 +486,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.par[0] = g.par[1] = g.par[2] = T(0);
   g.flag = 0;
   g.posabs = posabs ? 1 : 0;
-  g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : ((kernel >= LGP_KERNEL_WIENER && kernel <= LGP_KERNEL_WIENERINTEGRAL) ? 1 : 0);
+  g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : ((kernel >= LGP_KERNEL_WIENER && kernel <= LGP_KERNEL_WIENERINTEGRAL) || kernel == LGP_KERNEL_TAYLOR ? 1 : 0);
   for (int f = 0; f < 8; ++f) g.dord[f] = 0;
   if (kernel == LGP_KERNEL_EXPQUAD_DIFF) {
     if (npar == 0) g.dord[0] = p;

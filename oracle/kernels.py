@@ -445,6 +445,33 @@ def Circular(*, tau=4, c=1/2, scale=None, loc=None):
     return Kernel(_stationary1d(core, 'posabs'), scale=scale, loc=loc)
 
 
+def Taylor(*, scale=None, loc=None):
+    """ ``_kernels/_basic.py:393-408`` """
+    def core(x, y):
+        mul = x * y
+        val = 2 * numpy.sqrt(numpy.abs(mul))
+        return numpy.where(mul >= 0, special.i0(val), special.j0(val))
+    return Kernel(_onevariable(core, -numpy.inf, numpy.inf), scale=scale, loc=loc)
+
+
+def Rescaling(*, stdfun=None, scale=None, loc=None):
+    """ ``_kernels/_basic.py:231-252`` """
+    if stdfun is None:
+        stdfun = lambda x: numpy.ones(x.shape)
+    return Kernel(lambda x, y: stdfun(x) * stdfun(y), scale=scale, loc=loc)
+
+
+def Categorical(*, cov=None, scale=None, loc=None):
+    """ ``_kernels/_basic.py:210-229`` """
+    cov = numpy.asarray(cov)
+    assert cov.ndim == 2 and cov.shape[0] == cov.shape[1] and numpy.allclose(cov, cov.T)
+
+    def core(x, y):
+        assert numpy.issubdtype(x.dtype, numpy.integer)
+        return cov[x, y]
+    return Kernel(core, scale=scale, loc=loc)
+
+
 def Linear(*, scale=None, loc=None):
     """ ``_kernels/_basic.py:76-91`` """
     return Kernel(lambda x, y: sum_recurse_dtype(lambda a, b: a * b, x, y), scale=scale, loc=loc)

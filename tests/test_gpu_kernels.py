@@ -643,3 +643,31 @@ def test_tangents_of_sums_and_products(lgp, rng):
         up[key] += h; dn[key] -= h
         fd = (build(**up).gram(x, y).to_host() - build(**dn).gram(x, y).to_host()) / (2 * h)
         np.testing.assert_allclose(tans[key].to_host(), fd, rtol=3e-7, atol=3e-9, err_msg=key)
+
+
+def test_taylor_rescaling_categorical(lgp, rng):
+    """ Taylor (I0 / J0 of 2 sqrt|xy|, ``_kernels/_basic.py:393-408``), Rescaling (a user function of the points evaluated on the
+    host, ``:231-252``) and Categorical (a covariance table, ``:210-229``) against the oracle; Rescaling as a factor of a product """
+    x = rng.uniform(-2, 2, 150); y = rng.uniform(-2, 2, 90)
+    y[:10] = x[:10]
+    for dtype, tol in ((np.float64, 1e-13), (np.float32, 1e-5)):
+        G = lgp.Taylor(scale=0.7).gram(x.astype(dtype), y.astype(dtype)).to_host()
+        R = oracle.Taylor(scale=0.7)(x.astype(dtype)[:, None], y.astype(dtype)[None, :])
+        np.testing.assert_allclose(G, R, rtol=tol, atol=tol)
+    std = lambda v: 1 + 0.5 * np.sin(v)
+    make = lambda M: M.ExpQuad(scale=1.5) * M.Rescaling(stdfun=std, loc=0.2) * 2. + M.Rescaling() * 0.1
+    np.testing.assert_allclose(make(lgp).gram(x, y).to_host(), make(oracle)(x[:, None], y[None, :]), rtol=0, atol=1e-14)
+    np.testing.assert_allclose(make(lgp)(x[:90], y), np.diagonal(make(oracle)(x[:, None], y[None, :])), rtol=0, atol=1e-14)
+    s = np.empty(40, [('a', float), ('b', float)]); s['a'] = rng.uniform(0, 1, 40); s['b'] = rng.uniform(0, 1, 40)
+    f2 = lambda p: p['a'] + 2 * p['b']
+    np.testing.assert_allclose(lgp.Rescaling(stdfun=f2, scale=2.).gram(s, s).to_host(), oracle.Rescaling(stdfun=f2, scale=2.)(s[:, None], s[None, :]), rtol=1e-14)
+    with pytest.raises(ValueError):
+        lgp.Rescaling(stdfun=lambda v: v[:3]).gram(x, y)
+    a = rng.standard_normal((5, 5)); cov = a @ a.T
+    i = rng.integers(0, 5, 200); j = rng.integers(0, 5, 120)
+    np.testing.assert_allclose(lgp.Categorical(cov=cov).gram(i, j).to_host(), cov[i[:, None], j[None, :]], rtol=1e-15)
+    np.testing.assert_allclose((lgp.Categorical(cov=cov) * 2.)(i[:120], j), 2 * cov[i[:120], j], rtol=1e-15)
+    with pytest.raises(AssertionError):
+        lgp.Categorical(cov=cov).gram(x, y)                    # not integers
+    with pytest.raises(IndexError):
+        lgp.Categorical(cov=cov).gram(np.array([7]), j)

@@ -49,6 +49,8 @@ KERNELS = {
     'BrownianBridge': ([{}], 1, False, (0, 1), 0),
     'FracBrownian': ([dict(H=0.1), dict(H=0.5), dict(H=1), dict(H=0.3, K=0.4), dict(H=1, K=0.7)], 1, False, (-5, 5), 0),
     'Decaying': ([dict(alpha=1), dict(alpha=0.3), dict(alpha=3)], 1, False, (0, 5), 0),
+    'Taylor': ([{}], 1, False, (-2, 2), 0),
+    'Rescaling': ([{}], None, False, (-5, 5), 0),
 }
 CASES = [(name, kw) for name, spec in KERNELS.items() for kw in spec[0]]
 IDS = [f'{n}-{"-".join(f"{k}{v}" for k, v in kw.items())}' for n, kw in CASES]
@@ -172,5 +174,5 @@ def test_every_kernel_is_listed(lgp):
     if not hasattr(lgp, 'Context'):
         assert all(hasattr(lgp, n) for n in KERNELS)
         return
-    exported = {n for n in dir(lgp) if isinstance(getattr(lgp, n), type) and issubclass(getattr(lgp, n), lgp.Kernel) and n not in ('Kernel', 'BART')}
+    exported = {n for n in dir(lgp) if isinstance(getattr(lgp, n), type) and issubclass(getattr(lgp, n), lgp.Kernel) and n not in ('Kernel', 'BART', 'Categorical')}
     assert exported == set(KERNELS)
