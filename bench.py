@@ -589,11 +589,39 @@ def timed(step, args, ctx, dist):
 
 
 def main_multi(args, ctx, dist, rank, world):
-    """ --gpus N > 1: BASELINE configuration C4 (or --config) as ONE problem sharded by block columns over the N GPUs; then N
-    independent C3 replicas as the extra "replicas" entry """
+    """ --gpus N > 1: N independent C3 replicas first (no data-path collective: always measurable), then BASELINE configuration C4
+    (or --config) as ONE problem sharded by block columns over the N GPUs -- the headline line when it runs.  RCCL with more than
+    one rank has never run on the builder's one-GPU boxes: the sharded attempt sits under a watchdog, so that a communicator that
+    hangs still leaves the replicas line (with the reason) instead of no line at all """
+    import threading
     import lsqfitgp_amd as lgp
     lgp.Context._default = ctx
     cfg = CONFIGS[args.config if args.config_given else 'c4']
+    # replicas: every rank runs the single-GPU C3 step on its own GPU
+    rcfg = CONFIGS['c3']
+    wl = Workload(rcfg, ctx)
+    relapsed, _ = timed(lambda: wl.step(), args, ctx, dist)
+    del wl
+    replicas = {'workload': rcfg['name'], 'scaling': 'weak', 'value': flops_fit_predict(rcfg['n'], rcfg['m']) * args.steps * world / relapsed / 1e12,
+                'unit': 'TFLOP/s', 'ms_per_step': relapsed / args.steps * 1e3, 'parallelism': f'{world} independent replicas, one per GPU (no collective)'}
+
+    def replicas_line(err):
+        return {'metric': 'GP fit+predict fp64 throughput (Gram build + Cholesky + solves; flops N^3/3 + N^2(M+1) + N M^2)',
+                'value': replicas['value'], 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': replicas['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+                'data': 'synthetic', 'config': {'workload': rcfg['name'], 'N': rcfg['n'], 'M': rcfg['m'], 'parallelism': replicas['parallelism']},
+                'roofline': None, 'cpu_baseline': None, 'sharded_path_error': err}
+
+    limit = float(os.environ.get('LGP_BENCH_SHARDED_TIMEOUT', 240 + 20 * (args.steps + args.warmup)))
+
+    def give_up():
+        if rank == 0:
+            print(json.dumps(replicas_line(f'the sharded step did not finish within {limit:.0f} s (communicator or schedule stalled)')), flush=True)
+        os._exit(0)
+
+    dog = threading.Timer(limit, give_up)
+    dog.daemon = True
+    dog.start()
     ok, err = init_transport(ctx, dist, rank, world)
     sharded = None
     if ok:
@@ -602,12 +630,7 @@ def main_multi(args, ctx, dist, rank, world):
             sharded = dict(elapsed=elapsed, mll=mll)
         except Exception as exc:             # (a rank that fails here leaves the others in a collective: reported, not hidden)
             err = repr(exc)
-    # replicas: every rank runs the single-GPU C3 step on its own GPU, no data-path collective
-    rcfg = CONFIGS['c3']
-    wl = Workload(rcfg, ctx)
-    relapsed, _ = timed(lambda: wl.step(), args, ctx, dist)
-    replicas = {'workload': rcfg['name'], 'scaling': 'weak', 'value': flops_fit_predict(rcfg['n'], rcfg['m']) * args.steps * world / relapsed / 1e12,
-                'unit': 'TFLOP/s', 'ms_per_step': relapsed / args.steps * 1e3, 'parallelism': f'{world} independent replicas, one per GPU (no collective)'}
+    dog.cancel()
     if rank == 0:
         transport = 'host-staged gloo' if os.environ.get('LGP_DIST_TRANSPORT') == 'host' else 'RCCL over xGMI'
         if sharded is not None:
@@ -620,14 +643,13 @@ def main_multi(args, ctx, dist, rank, world):
                               'parallelism': f'1-D block-column-cyclic Cholesky over {world} GPUs, nb=1024, {transport} panel broadcast with look-ahead (lgp_chol_factor_dist)'},
                    'log_marginal_likelihood': sharded['mll'], 'roofline': None, 'cpu_baseline': None, 'replicas': replicas}
         else:
-            out = {'metric': 'GP fit+predict fp64 throughput (Gram build + Cholesky + solves; flops N^3/3 + N^2(M+1) + N M^2)',
-                   'value': replicas['value'], 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                   'ms_per_step': replicas['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
-                   'data': 'synthetic', 'config': {'workload': rcfg['name'], 'N': rcfg['n'], 'M': rcfg['m'], 'parallelism': replicas['parallelism']},
-                   'roofline': None, 'cpu_baseline': None, 'sharded_path_error': err}
+            out = replicas_line(err)
         print(json.dumps(out), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        pass
 
 
 def main():
