@@ -198,9 +198,9 @@ def test_bart_gradient_matches_finite_differences(lgp, rng):
 
 
 def test_bart_scale_shift(lgp, rng):
-    """ reference tests/bayestree/test_bart.py:65-78: the regression is equivariant under affine maps of the outcome.  The
-    reference asserts rtol 1e-10 / 1e-11 on its jax build; here the two L-BFGS runs see objectives that differ by a
-    constant and gradients equal to rounding, and the tolerance is what that leaves after 100 iterations """
+    """ reference tests/bayestree/test_bart.py:65-78: the regression is equivariant under affine maps of the outcome, at the
+    reference's own tolerances (rtol 1e-10 on the mean, 1e-11 on the covariance): the two L-BFGS runs see objectives that differ
+    by a constant and gradients equal to rounding, and follow the same path (measured: 3e-11 / 8e-14, tools/bart_equivariance.py) """
     X, y = bart_problem(rng)
     kw = dict(fitkw=dict(verbosity=0))
     bart1 = lgp.bayestree.bart(X, y, **kw)
@@ -208,10 +208,10 @@ def test_bart_scale_shift(lgp, rng):
     bart2 = lgp.bayestree.bart(X, offset + y * scale, **kw)
     m1, cov1 = bart1.pred()
     m2, cov2 = bart2.pred()
-    util.assert_allclose(m2, offset + m1 * scale, rtol=1e-6)
-    util.assert_allclose(cov2, cov1 * scale ** 2, rtol=1e-6, atol=1e-12)
-    assert bart2.fit.pmean['alpha'] == pytest.approx(bart1.fit.pmean['alpha'], rel=1e-6)
-    assert bart2.sigma.mean == pytest.approx(bart1.sigma.mean * scale, rel=1e-6)
+    util.assert_allclose(m2, offset + m1 * scale, rtol=1e-10)
+    util.assert_allclose(cov2, cov1 * scale ** 2, rtol=1e-11, atol=1e-12 * np.max(np.abs(cov2)))
+    assert bart2.fit.pmean['alpha'] == pytest.approx(bart1.fit.pmean['alpha'], rel=1e-10)
+    assert bart2.sigma.mean == pytest.approx(bart1.sigma.mean * scale, rel=1e-10)
     # sanity of the regression itself: in-sample residuals are of the order of the noise
     assert np.std(m1 - y) < 0.5 * np.std(y)
     text = repr(bart1)
