@@ -99,6 +99,20 @@ class DevicePoints:
         return DevicePoints(self.kind, self.array.block(i0, i1, 0, self.array.shape[1]), self.dtype, self.ctx)
 
 
+class _PointBundle:
+    """ what `prepare` of a composite kernel returns: the prepared points of each operand (uploaded once per operand), sliced
+    together; for kernels evaluated from host quantities, the host array itself """
+
+    def __init__(self, parts, n, dtype):
+        self.parts, self._n, self.dtype = parts, n, numpy.dtype(dtype)
+
+    def __len__(self):
+        return self._n
+
+    def sub(self, i0, i1):
+        return _PointBundle([p.sub(i0, i1) if hasattr(p, 'sub') else p[i0:i1] for p in self.parts], i1 - i0, self.dtype)
+
+
 class Kernel:
     """ base class: input transformation, output algops, call contract """
 
@@ -264,7 +278,18 @@ class _Composite(Kernel):
         M = _dev_axpby(1., A, 1., B, out) if self._op == 'add' else _dev_mul(1., A, B, out=out)
         return self._finish(M)
 
+    def prepare(self, xs, *, ctx=None, dtype=None):
+        """ the operands' prepared points, side by side (`_PointBundle`) """
+        parts = [self._a.prepare(xs, ctx=ctx), self._b.prepare(xs, ctx=ctx)]
+        return _PointBundle(parts, len(parts[0]), dtype or numpy.result_type(*[p.dtype for p in parts]))
+
+    @staticmethod
+    def _part(pts, i):
+        return pts.parts[i] if isinstance(pts, _PointBundle) else pts
+
     def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
+        if isinstance(xs, _PointBundle) != isinstance(ys, _PointBundle):
+            raise TypeError('prepared and plain points mixed')
         kw = {}
         if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
             if self._op != 'add':
@@ -272,7 +297,8 @@ class _Composite(Kernel):
             if any(op == 'add' for op, _ in self._outops):
                 raise NotImplementedError('derivative observations of a sum of kernels plus a constant: add the constant to a term')
             kw = dict(deriv=deriv)
-        return self._combine(self._a.gram(xs, ys, ctx=ctx, **kw), self._b.gram(xs, ys, ctx=ctx, **kw), out)
+        return self._combine(self._a.gram(self._part(xs, 0), self._part(ys, 0), ctx=ctx, **kw),
+                             self._b.gram(self._part(xs, 1), self._part(ys, 1), ctx=ctx, **kw), out)
 
     def pairs(self, xs, ys, *, ctx=None):
         return self._combine(self._a.pairs(xs, ys, ctx=ctx), self._b.pairs(xs, ys, ctx=ctx))
@@ -850,10 +876,16 @@ class _HostFactors(Kernel):
     def _finish(self, M):
         return _Composite._finish(self, M)
 
+    def prepare(self, xs, *, ctx=None, dtype=None):
+        xs = numpy.asarray(xs).reshape(-1)
+        return _PointBundle([xs], len(xs), dtype or numpy.float64)
+
     def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
         if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
             raise NotImplementedError(f'derivatives of {type(self).__name__}')
         ctx = ctx or Context.default()
+        xs = xs.parts[0] if isinstance(xs, _PointBundle) else xs
+        ys = ys.parts[0] if isinstance(ys, _PointBundle) else ys
         U, V = self._factors(numpy.asarray(xs).reshape(-1), numpy.asarray(ys).reshape(-1))
         n, m, c = U.shape[0], V.shape[0], U.shape[1]
         if out is None:

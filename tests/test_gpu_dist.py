@@ -311,3 +311,22 @@ def test_distributed_scaled_kernel_and_bart(lgp, nb, rng):
         c0 = d.layout.col0(b)
         full[c0:, c0:c0 + blk.shape[1]] = blk
     util.assert_close_matrices(full, o._L, rtol=1e-10)
+
+
+def test_distributed_composite_kernel(lgp, rng):
+    """ sums and products of kernels (and a host-evaluated factor) through the sharded path: every operand's points are prepared
+    once, the block columns are combined on the device """
+    from lsqfitgp_amd._dist import DistributedChol
+    n = 1300
+    x = rng.uniform(0, 40, n)
+    std = lambda v: 1 + 0.3 * np.sin(v)
+    make = lambda M: (M.ExpQuad(scale=2.) * M.Periodic(scale=1.5) + M.Maternp(p=1, scale=5.) * 0.5) * M.Rescaling(stdfun=std)
+    d = DistributedChol(make(lgp), x, noise=0.05, nb=256)
+    K = make(oracle)(x[:, None], x[None, :]) + 0.05 * np.eye(n)
+    o = oracle.Chol(K)
+    util.assert_allclose(d.eps, o.eps, rtol=1e-12)
+    full = np.zeros((n, n))
+    for b, blk in d.local_factor().items():
+        c0 = d.layout.col0(b)
+        full[c0:, c0:c0 + blk.shape[1]] = blk
+    util.assert_close_matrices(full, o._L, rtol=1e-10)
