@@ -248,6 +248,11 @@ int lgp_mul_f64(lgp_ctx *ctx, size_t rows, size_t cols, double alpha, const doub
                 double beta, const double *dC0, size_t ldc0, double *dC, size_t ldc);
 int lgp_mul_f32(lgp_ctx *ctx, size_t rows, size_t cols, float alpha, const float *dA, size_t lda, const float *dB, size_t ldb,
                 float beta, const float *dC0, size_t ldc0, float *dC, size_t ldc);
+/* A <- a f(A) + b entry by entry; op 0: f = asin.  The outer function of a kernel that is a function of another kernel's value
+ * (NNKernel, reference _kernels/_basic.py:122-154). */
+#define LGP_UNARY_ASIN 0
+int lgp_unary_f64(lgp_ctx *ctx, size_t rows, size_t cols, double *dA, size_t lda, int op, double a, double b);
+int lgp_unary_f32(lgp_ctx *ctx, size_t rows, size_t cols, float *dA, size_t lda, int op, float a, float b);
 /* flags[0] = any non-finite entry, flags[1] = max |A - A^T| > atol + rtol*|A^T| anywhere (jnp.allclose),
  * checks of _GP/_elements.py:618-622 and _GP/_compute.py:369-381.  Synchronises. */
 int lgp_check_matrix_f64(lgp_ctx *ctx, size_t rows, size_t cols, const double *dA, size_t lda,

@@ -927,6 +927,45 @@ class Rescaling(_HostFactors):
         return self._std(xs)[:, None], self._std(ys)[:, None]
 
 
+class NNKernel(Kernel):
+    """ Neural network kernel, k(x, y) = 2/π asin(2 (q + x·y) / ((1 + 2 (q + x·x)) (1 + 2 (q + y·y)))), q = sigma0²
+    (``_kernels/_basic.py:122-154``): the argument is `Linear` + q times an outer product of per-point factors, a composite of
+    this package's own kernels, and the arcsine is applied to the matrix on the device """
+
+    def __init__(self, *, sigma0=1, scale=None, loc=None):
+        assert 0 < sigma0 < numpy.inf, sigma0
+        super().__init__()
+        q = float(sigma0) ** 2
+
+        def inv_norm(x):
+            if x.dtype.names is None:
+                xx = x * x
+            else:
+                xx = sum(numpy.sum(numpy.square(x[nm]), axis=tuple(range(x.ndim, x[nm].ndim))) for nm in x.dtype.names)
+            return 1 / (1 + 2 * (q + xx))
+        self._inner = (Linear(scale=scale, loc=loc) + q) * Rescaling(stdfun=inv_norm, scale=scale, loc=loc) * 2.
+
+    def _result_dtype(self, x, y):
+        return numpy.dtype(numpy.float64)
+
+    def _outer(self, M):
+        m2 = M.as2d()
+        f, F = _lib.fn('lgp_unary', M.dtype)
+        _lib.check(f(M.ctx.handle, m2.shape[0], m2.shape[1], M.ptr, m2.ld, 0, F(2 / numpy.pi), F(0.)), 'lgp_unary')
+        return _Composite._finish(self, M)
+
+    def prepare(self, xs, *, ctx=None, dtype=None):
+        return self._inner.prepare(xs, ctx=ctx, dtype=dtype)
+
+    def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
+        if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
+            raise NotImplementedError('derivatives of NNKernel')
+        return self._outer(self._inner.gram(xs, ys, ctx=ctx, out=out))
+
+    def pairs(self, xs, ys, *, ctx=None):
+        return self._outer(self._inner.pairs(xs, ys, ctx=ctx))
+
+
 class Categorical(_HostFactors):
     """ Categorical kernel, k(x, y) = cov[x, y] over the integers 0 .. N - 1 (``_kernels/_basic.py:210-229``) """
 

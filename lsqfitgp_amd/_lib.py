@@ -131,6 +131,7 @@ def _signatures():
             'lgp_add_diag_' + suf: (c_int, [c_void_p, _S, _P, _S, _P, F]),
             'lgp_add_scalar_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, F]),
             'lgp_mul_' + suf: (c_int, [c_void_p, _S, _S, F, _P, _S, _P, _S, F, _P, _S, _P, _S]),
+            'lgp_unary_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, c_int, F, F]),
             'lgp_check_matrix_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, c_int, F, F, POINTER(c_int)]),
             'lgp_check_matrix_dev_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, c_int, F, F, _P]),
             'lgp_chol_factor_' + suf: (c_int, [c_void_p, _S, _P, _S, F, F, c_int, _P, _S, _P, POINTER(F)]),

@@ -44,6 +44,21 @@ __global__ void __launch_bounds__(256) mul_kernel(size_t rows, size_t cols, T al
   }
 }
 
+// A <- a f(A) + b entry by entry, f chosen by `op` (0: asin): the outer function of kernels that are a function of another
+// kernel's value (NNKernel, _kernels/_basic.py:122-154: 2 / pi asin(...))
+template <typename T>
+__global__ void __launch_bounds__(256) unary_kernel(size_t rows, size_t cols, T *A, size_t lda, int op, T a, T b) {
+  const size_t nbx = (cols + 255) / 256;
+  for (size_t blk = blockIdx.x; blk < rows * nbx; blk += gridDim.x) {
+    const size_t i = blk / nbx, j = (blk % nbx) * 256 + threadIdx.x;
+    if (j < cols) {
+      T v = A[i * lda + j];
+      if (op == 0) v = asin(v);
+      A[i * lda + j] = a * v + b;
+    }
+  }
+}
+
 template <typename T>
 __global__ void add_diag_kernel(size_t n, T *A, size_t lda, const T *vec, T alpha) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -256,6 +271,18 @@ int mul_impl(lgp_ctx *ctx, size_t rows, size_t cols, T alpha, const T *A, size_t
 }
 
 template <typename T>
+int unary_impl(lgp_ctx *ctx, size_t rows, size_t cols, T *A, size_t lda, int op, T a, T b) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  if (rows == 0 || cols == 0) return LGP_OK;
+  LGP_REQUIRE(A != nullptr && lda >= cols, "bad matrix");
+  LGP_REQUIRE(op == 0, "unknown function");
+  DeviceGuard dg(ctx->device);
+  hipLaunchKernelGGL((unary_kernel<T>), dim3(grid_for(rows, cols)), dim3(256), 0, ctx->stream, rows, cols, A, lda, op, a, b);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
+template <typename T>
 int add_diag_impl(lgp_ctx *ctx, size_t n, T *A, size_t lda, const T *vec, T alpha) {
   LGP_REQUIRE(ctx != nullptr, "null context");
   if (n == 0) return LGP_OK;
@@ -447,6 +474,8 @@ int lgp_axpby_f64(lgp_ctx *c, size_t r, size_t n, double a, const double *A, siz
 int lgp_axpby_f32(lgp_ctx *c, size_t r, size_t n, float a, const float *A, size_t lda, float b, const float *B, size_t ldb, float *C, size_t ldc) { return axpby_impl<float>(c, r, n, a, A, lda, b, B, ldb, C, ldc); }
 int lgp_mul_f64(lgp_ctx *c, size_t r, size_t n, double a, const double *A, size_t lda, const double *B, size_t ldb, double b, const double *C0, size_t ldc0, double *C, size_t ldc) { return mul_impl<double>(c, r, n, a, A, lda, B, ldb, b, C0, ldc0, C, ldc); }
 int lgp_mul_f32(lgp_ctx *c, size_t r, size_t n, float a, const float *A, size_t lda, const float *B, size_t ldb, float b, const float *C0, size_t ldc0, float *C, size_t ldc) { return mul_impl<float>(c, r, n, a, A, lda, B, ldb, b, C0, ldc0, C, ldc); }
+int lgp_unary_f64(lgp_ctx *c, size_t r, size_t n, double *A, size_t lda, int op, double a, double b) { return unary_impl<double>(c, r, n, A, lda, op, a, b); }
+int lgp_unary_f32(lgp_ctx *c, size_t r, size_t n, float *A, size_t lda, int op, float a, float b) { return unary_impl<float>(c, r, n, A, lda, op, a, b); }
 int lgp_add_diag_f64(lgp_ctx *c, size_t n, double *A, size_t lda, const double *v, double a) { return add_diag_impl<double>(c, n, A, lda, v, a); }
 int lgp_add_diag_f32(lgp_ctx *c, size_t n, float *A, size_t lda, const float *v, float a) { return add_diag_impl<float>(c, n, A, lda, v, a); }
 int lgp_add_scalar_f64(lgp_ctx *c, size_t r, size_t n, double *A, size_t lda, double v) { return add_scalar_impl<double>(c, r, n, A, lda, v); }

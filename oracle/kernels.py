@@ -472,6 +472,18 @@ def Categorical(*, cov=None, scale=None, loc=None):
     return Kernel(core, scale=scale, loc=loc)
 
 
+def NNKernel(*, sigma0=1, scale=None, loc=None):
+    """ ``_kernels/_basic.py:122-154`` """
+    assert 0 < sigma0 < numpy.inf
+    q = sigma0 ** 2
+    dot = lambda x, y: sum_recurse_dtype(lambda a, b: a * b, x, y)
+
+    def core(x, y):
+        denom = (1 + 2 * (q + dot(x, x))) * (1 + 2 * (q + dot(y, y)))
+        return 2 / numpy.pi * numpy.arcsin(2 * (q + dot(x, y)) / denom)
+    return Kernel(core, scale=scale, loc=loc)
+
+
 def Linear(*, scale=None, loc=None):
     """ ``_kernels/_basic.py:76-91`` """
     return Kernel(lambda x, y: sum_recurse_dtype(lambda a, b: a * b, x, y), scale=scale, loc=loc)

@@ -671,3 +671,14 @@ def test_taylor_rescaling_categorical(lgp, rng):
         lgp.Categorical(cov=cov).gram(x, y)                    # not integers
     with pytest.raises(IndexError):
         lgp.Categorical(cov=cov).gram(np.array([7]), j)
+
+
+def test_nnkernel_vs_oracle(lgp, rng):
+    """ NNKernel (``_kernels/_basic.py:122-154``) as a composite of Linear, a host-evaluated outer product and the device arcsine """
+    x = rng.uniform(-3, 3, 160); y = rng.uniform(-3, 3, 110)
+    for kw in (dict(), dict(sigma0=0.4, scale=2., loc=0.5)):
+        np.testing.assert_allclose(lgp.NNKernel(**kw).gram(x, y).to_host(), oracle.NNKernel(**kw)(x[:, None], y[None, :]), rtol=0, atol=2e-15)
+        np.testing.assert_allclose((lgp.NNKernel(**kw) * 3. + 1.)(x[:110], y), 3 * np.diagonal(oracle.NNKernel(**kw)(x[:, None], y[None, :])) + 1, rtol=0, atol=1e-14)
+    s = np.empty(90, [('a', float), ('b', float, (2,))])
+    s['a'] = rng.standard_normal(90); s['b'] = rng.standard_normal((90, 2))
+    np.testing.assert_allclose(lgp.NNKernel(sigma0=2.).gram(s, s).to_host(), oracle.NNKernel(sigma0=2.)(s[:, None], s[None, :]), rtol=0, atol=2e-15)
