@@ -927,6 +927,62 @@ class Rescaling(_HostFactors):
         return self._std(xs)[:, None], self._std(ys)[:, None]
 
 
+class Gibbs(_Isotropic):
+    """ Gibbs kernel, k(x, y) = sqrt(2 s(x) s(y) / (s(x)² + s(y)²)) exp(-|x - y|² / (s(x)² + s(y)²)), s = ``scalefun``
+    (``_kernels/_basic.py:156-185``): a Gaussian kernel whose scale changes from point to point.  ``scalefun`` takes the
+    (transformed) points and returns a positive number per point; it is evaluated on the host and travels to the device as one
+    more coordinate row, so the input transformation (``loc``, ``scale``: they act BEFORE ``scalefun``, as in the reference) is
+    applied on the host too -- the same two IEEE operations """
+    _kind = _lib.LGP_KERNEL_GIBBS
+
+    def __init__(self, *, scalefun=None, scale=None, loc=None):
+        super().__init__(scale=scale, loc=loc)
+        self._hloc, self._hscale = self._loc, self._scale
+        self._loc = self._scale = None                   # (nothing left for the device to transform)
+        self._scalefun = scalefun
+
+    def _rows(self, xs, dtype=None):
+        """ the SoA rows of a point set: transformed coordinates, then scalefun of the transformed points """
+        x = numpy.asarray(xs)
+        helper = _HostFactors.__new__(_HostFactors)
+        helper._loc, helper._scale = self._hloc, self._hscale
+        xt = _HostFactors._transformed(helper, x.reshape(-1))
+        cols = _leaf_columns(xt)
+        s = numpy.ones(xt.shape) if self._scalefun is None else numpy.asarray(self._scalefun(xt), float)
+        if s.shape != xt.shape:
+            raise ValueError(f'scalefun returned shape {s.shape} for points of shape {xt.shape}')
+        assert numpy.all(s > 0), 'scalefun must be positive'
+        dtype = dtype or _float_dtype_of(cols, self._hscale, self._hloc)
+        return numpy.stack([numpy.asarray(c, dtype) for c in cols] + [numpy.asarray(s, dtype)]), numpy.dtype(dtype)
+
+    def prepare(self, xs, *, ctx=None, dtype=None):
+        ctx = ctx or Context.default()
+        rows, dtype = self._rows(xs, dtype)
+        return DevicePoints('coords', DeviceArray.from_host(rows, ctx=ctx), dtype, ctx)
+
+    def _result_dtype(self, x, y):
+        return _float_dtype_of(_leaf_columns(x.reshape(-1)[:0]) + _leaf_columns(y.reshape(-1)[:0]), self._hscale, self._hloc)
+
+    def _prepare(self, xs, ys, ctx):
+        if isinstance(xs, DevicePoints) or isinstance(ys, DevicePoints):
+            return super()._prepare(xs, ys, ctx)
+        ctx = ctx or Context.default()
+        rx, dtx = self._rows(xs)
+        same = xs is ys
+        ry, dty = (rx, dtx) if same else self._rows(ys)
+        dtype = numpy.result_type(dtx, dty)
+        if rx.shape[0] != ry.shape[0]:
+            raise ValueError(f'x has {rx.shape[0] - 1} leaf fields, y has {ry.shape[0] - 1}')
+        xd = DeviceArray.from_host(rx.astype(dtype), ctx=ctx)
+        yd = xd if same else DeviceArray.from_host(ry.astype(dtype), ctx=ctx)
+        return xd, yd, dtype, ctx, rx.shape[0]
+
+    def _diff_call(self, deriv, d):
+        if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
+            raise NotImplementedError('derivatives of Gibbs')
+        return self._kind, 0, (), self._outops
+
+
 class NNKernel(Kernel):
     """ Neural network kernel, k(x, y) = 2/π asin(2 (q + x·y) / ((1 + 2 (q + x·x)) (1 + 2 (q + y·y)))), q = sigma0²
     (``_kernels/_basic.py:122-154``): the argument is `Linear` + q times an outer product of per-point factors, a composite of

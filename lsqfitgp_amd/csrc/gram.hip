@@ -69,7 +69,7 @@ template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_t
 
 // d0: the signed difference of the (transformed) first coordinates, used by the derivative kernel only
 template <typename T>
-__device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
+__device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0), T d1 = T(0)) {
   if (g.kernel == LGP_KERNEL_EXPQUAD) {
     return exp(T(-0.5) * r2);
   } else if (g.kernel == LGP_KERNEL_EXPQUAD_DIFF) {
@@ -157,6 +157,9 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
   } else if (g.kernel == LGP_KERNEL_WIENERINTEGRAL) {    // _kernels/_randomwalk.py:93-110
     const T a = fmin(d0, r2), b = fmax(d0, r2);
     return T(0.5) * (a * a) * (b - a / T(3));
+  } else if (g.kernel == LGP_KERNEL_GIBBS) {             // _kernels/_basic.py:156-185: d0 = s(x), d1 = s(y) (the last coordinate row), r2 over the others
+    const T den = d0 * d0 + d1 * d1;
+    return sqrt(T(2) * d0 * d1 / den) * exp(-r2 / den);
   } else if (g.kernel == LGP_KERNEL_TAYLOR) {            // _kernels/_basic.py:393-408: I0(2 sqrt(x y)), J0 where x y < 0
     const T mul = d0 * r2, val = T(2) * sqrt(fabs(mul));
     return mul >= T(0) ? T(cyl_bessel_i0((double)val)) : T(j0((double)val));
@@ -212,7 +215,7 @@ __device__ __forceinline__ T iso_sq(const IsoArgs<T> &g, T df, T yv) {
 constexpr int CORE_GENERIC = 0, CORE_EXPQUAD = 1, CORE_MATERN1 = 2, CORE_MATERN2 = 3, CORE_MATERN3 = 4;
 
 template <typename T, int CORE>
-__device__ __forceinline__ T iso_core_t(const IsoArgs<T> &g, T r2, T d0 = T(0)) {
+__device__ __forceinline__ T iso_core_t(const IsoArgs<T> &g, T r2, T d0 = T(0), T d1 = T(0)) {
   if constexpr (CORE == CORE_EXPQUAD) {
     return exp(T(-0.5) * r2);
   } else if constexpr (CORE == CORE_MATERN1 || CORE == CORE_MATERN2 || CORE == CORE_MATERN3) {
@@ -224,7 +227,7 @@ __device__ __forceinline__ T iso_core_t(const IsoArgs<T> &g, T r2, T d0 = T(0)) 
     for (int k = 0; k < P; ++k) poly = T(1) + poly * g.coef[k] * T(2) * x;      // (the same operations in the same order as iso_core)
     return exp(-x) * poly;
   } else {
-    return iso_core<T>(g, r2, d0);
+    return iso_core<T>(g, r2, d0, d1);
   }
 }
 
@@ -344,12 +347,16 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
     T dres[W];
 #pragma unroll
     for (int e = 0; e < W; ++e) {
-      T r2 = T(0), d0 = T(0);
+      T r2 = T(0), d0 = T(0), d1 = T(0);
       if (D > 0) {
 #pragma unroll
         for (int f = 0; f < D; ++f) {
           const T xv = su[f * GT_ROWS + r], yv = vreg[f][e];
           const T df = xv - yv;
+          if (CORE == CORE_GENERIC && g.xy == 3 && f == D - 1) {       // (Gibbs: the last row holds the per-point scales)
+            d0 = xv; d1 = yv;
+            continue;
+          }
           const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df, yv) : df * df;
           r2 = (f == 0) ? sq : r2 + sq;
           if (CORE == CORE_GENERIC) d0 = iso_aux<T>(g, f, xv, yv, df, d0);
@@ -358,6 +365,10 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
         for (int f = 0; f < d; ++f) {
           const T xv = su[f * GT_ROWS + r], yv = sv[f * GT_COLS + c0 + e];
           const T df = xv - yv;
+          if (CORE == CORE_GENERIC && g.xy == 3 && f == d - 1) {
+            d0 = xv; d1 = yv;
+            continue;
+          }
           const T sq = CORE == CORE_GENERIC ? iso_sq<T>(g, df, yv) : df * df;
           r2 = (f == 0) ? sq : r2 + sq;
           if (CORE == CORE_GENERIC) d0 = iso_aux<T>(g, f, xv, yv, df, d0);
@@ -368,7 +379,7 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
         res[e] = g.ops.apply(iso_core_dscale<T>(g, r2, dk));
         dres[e] = slope * dk;
       } else {
-        res[e] = g.ops.apply(iso_core_t<T, CORE>(g, r2, d0));
+        res[e] = g.ops.apply(iso_core_t<T, CORE>(g, r2, d0, d1));
       }
     }
     T *po = g.out + (long)(row0 + r) * g.ldo + col0 + c0;
@@ -433,17 +444,21 @@ template <typename T>
 __global__ void __launch_bounds__(256) gram_iso_pairs_kernel(const IsoArgs<T> g) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= g.n) return;
-  T r2 = T(0), d0 = T(0);
+  T r2 = T(0), d0 = T(0), d1 = T(0);
   for (int f = 0; f < g.d; ++f) {
     T u = g.x[(long)f * g.ldx + i], v = g.y[(long)f * g.ldy + i];
     if (g.has_loc) { u = u - g.loc; v = v - g.loc; }
     if (g.has_scale) { u = u / g.scale; v = v / g.scale; }
+    if (g.xy == 3 && f == g.d - 1) {
+      d0 = u; d1 = v;
+      continue;
+    }
     const T df = u - v;
     const T sq = iso_sq<T>(g, df, v);
     r2 = (f == 0) ? sq : r2 + sq;
     d0 = iso_aux<T>(g, f, u, v, df, d0);
   }
-  g.out[i] = g.ops.apply(iso_core<T>(g, r2, d0));
+  g.out[i] = g.ops.apply(iso_core<T>(g, r2, d0, d1));
 }
 
 template <typename T>
@@ -454,8 +469,9 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_TAYLOR, "unknown isotropic kernel");
-  LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || kernel == LGP_KERNEL_LINEAR || d == 1, "this kernel is a function of one variable (maxdim = 1)");
+  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_GIBBS, "unknown isotropic kernel");
+  LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_GIBBS || d == 1, "this kernel is a function of one variable (maxdim = 1)");
+  LGP_REQUIRE(kernel != LGP_KERNEL_GIBBS || (d >= 2 && !has_loc && !has_scale), "Gibbs takes the per-point scales as the last coordinate row, inputs already transformed");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
   LGP_REQUIRE(p >= 0 && p <= MAX_P, "Maternp order must be in [0,16]");
   const bool derived = kernel == LGP_KERNEL_EXPQUAD_DIFF || kernel == LGP_KERNEL_MATERNP_DIFF;
@@ -486,7 +502,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.par[0] = g.par[1] = g.par[2] = T(0);
   g.flag = 0;
   g.posabs = posabs ? 1 : 0;
-  g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : ((kernel >= LGP_KERNEL_WIENER && kernel <= LGP_KERNEL_WIENERINTEGRAL) || kernel == LGP_KERNEL_TAYLOR ? 1 : 0);
+  g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : ((kernel >= LGP_KERNEL_WIENER && kernel <= LGP_KERNEL_WIENERINTEGRAL) || kernel == LGP_KERNEL_TAYLOR ? 1 : (kernel == LGP_KERNEL_GIBBS ? 3 : 0));
   for (int f = 0; f < 8; ++f) g.dord[f] = 0;
   if (kernel == LGP_KERNEL_EXPQUAD_DIFF) {
     if (npar == 0) g.dord[0] = p;

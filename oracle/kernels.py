@@ -472,6 +472,21 @@ def Categorical(*, cov=None, scale=None, loc=None):
     return Kernel(core, scale=scale, loc=loc)
 
 
+def Gibbs(*, scalefun=None, scale=None, loc=None):
+    """ ``_kernels/_basic.py:156-185`` """
+    if scalefun is None:
+        scalefun = lambda x: numpy.ones(x.shape)
+
+    def core(x, y):
+        sx, sy = scalefun(x), scalefun(y)
+        assert numpy.all(sx > 0) and numpy.all(sy > 0)
+        denom = sx ** 2 + sy ** 2
+        factor = numpy.sqrt(2 * sx * sy / denom)
+        distsq = sum_recurse_dtype(lambda a, b: (a - b) ** 2, x, y)
+        return factor * numpy.exp(-distsq / denom)
+    return Kernel(core, scale=scale, loc=loc)
+
+
 def NNKernel(*, sigma0=1, scale=None, loc=None):
     """ ``_kernels/_basic.py:122-154`` """
     assert 0 < sigma0 < numpy.inf

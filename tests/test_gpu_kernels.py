@@ -682,3 +682,27 @@ def test_nnkernel_vs_oracle(lgp, rng):
     s = np.empty(90, [('a', float), ('b', float, (2,))])
     s['a'] = rng.standard_normal(90); s['b'] = rng.standard_normal((90, 2))
     np.testing.assert_allclose(lgp.NNKernel(sigma0=2.).gram(s, s).to_host(), oracle.NNKernel(sigma0=2.)(s[:, None], s[None, :]), rtol=0, atol=2e-15)
+
+
+def test_gibbs_vs_oracle(lgp, rng):
+    """ Gibbs (``_kernels/_basic.py:156-185``): the per-point scales evaluated on the host ride as one more coordinate row """
+    x = rng.uniform(-3, 3, 170); y = rng.uniform(-3, 3, 120)
+    y[:15] = x[:15]
+    sf = lambda v: 0.5 + 0.3 * np.abs(v)
+    for kw in (dict(), dict(scalefun=sf), dict(scalefun=sf, scale=2., loc=0.5)):
+        G = lgp.Gibbs(**kw).gram(x, y).to_host()
+        np.testing.assert_allclose(G, oracle.Gibbs(**kw)(x[:, None], y[None, :]), rtol=0, atol=2e-15)
+        np.testing.assert_allclose((lgp.Gibbs(**kw) * 2.)(x[:120], y), 2 * np.diagonal(oracle.Gibbs(**kw)(x[:, None], y[None, :])), rtol=0, atol=4e-15)
+    np.testing.assert_allclose(lgp.Gibbs().gram(x, y).to_host(), lgp.ExpQuad().gram(x, y).to_host(), rtol=0, atol=2e-16)       # s = 1: the Gaussian kernel
+    s = np.empty(140, [('a', float), ('b', float), ('c', float), ('d', float)])
+    for f in s.dtype.names:
+        s[f] = rng.uniform(-1, 1, 140)
+    sf4 = lambda p: 0.7 + p['a'] ** 2
+    K = lgp.Gibbs(scalefun=sf4).gram(s, s).to_host()
+    np.testing.assert_allclose(K, oracle.Gibbs(scalefun=sf4)(s[:, None], s[None, :]), rtol=0, atol=2e-15)
+    np.testing.assert_array_equal(K, K.T)
+    with pytest.raises(AssertionError):
+        lgp.Gibbs(scalefun=lambda v: v).gram(x, y)          # not positive
+    # as an operand of a product, and under a GP
+    gp = lgp.GP(lgp.Gibbs(scalefun=sf) * lgp.Constant() * 1.5, checkpos=False).addx(x, 'x')
+    np.testing.assert_allclose(gp.prior('x', raw=True), 1.5 * oracle.Gibbs(scalefun=sf)(x[:, None], x[None, :]), rtol=0, atol=4e-15)

@@ -52,6 +52,7 @@ KERNELS = {
     'Taylor': ([{}], 1, False, (-2, 2), 0),
     'Rescaling': ([{}], None, False, (-5, 5), 0),
     'NNKernel': ([dict(sigma0=1), dict(sigma0=0.3)], None, False, (-5, 5), 0),
+    'Gibbs': ([{}], None, True, (-5, 5), 0),
 }
 CASES = [(name, kw) for name, spec in KERNELS.items() for kw in spec[0]]
 IDS = [f'{n}-{"-".join(f"{k}{v}" for k, v in kw.items())}' for n, kw in CASES]
