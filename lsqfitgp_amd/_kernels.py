@@ -116,7 +116,7 @@ class _PointBundle:
 class Kernel:
     """ base class: input transformation, output algops, call contract """
 
-    def __init__(self, *, scale=None, loc=None, outops=()):
+    def __init__(self, *, scale=None, loc=None, dim=None, outops=()):
         # hyperparameters may carry first-order tangents (`_dual.Dual`, what `empbayes_fit` hands a gpfactory): the kernel keeps
         # the plain values for everything it already does and the tangents for `gram_tangents`
         scale, self._dscale = _dual.split(scale)
@@ -127,10 +127,26 @@ class Kernel:
         if loc is not None:
             if not (-numpy.inf < loc < numpy.inf):                # _ops.py:306-307
                 raise AssertionError(loc)
+        if dim is not None and not isinstance(dim, (str, list)):
+            raise TypeError(f'dim must be a (list of) string, found {dim!r}')           # _Kernel/_ops.py:250-251
         self._scale = scale
         self._loc = loc
+        self._dim = dim
         self._outops = tuple(outops)
         self._doutops = tuple({} for _ in self._outops)          # tangents of the constants of `_outops`, entry by entry
+
+    def _select(self, x):
+        """ ``dim=``: the kernel acts on one field (or a list of fields) of structured points, T(f)(x) = f(x[dim])
+        (``_Kernel/_ops.py:233-260``); applied before everything else, so ``maxdim`` counts the selected fields """
+        dim = getattr(self, '_dim', None)
+        if dim is None or isinstance(x, (DevicePoints, _PointBundle)):
+            return x
+        x = numpy.asarray(x)
+        if x.dtype.names is None:
+            raise ValueError(f'cannot get dim={dim!r} from non-structured input')
+        if isinstance(dim, str) and x.dtype[dim].shape:
+            return x[[dim]]
+        return x[dim]
 
     def _copy(self, **kw):
         new = self.__class__.__new__(self.__class__)
@@ -362,12 +378,13 @@ class _Isotropic(Kernel):
         return len(self._par), (F * len(self._par))(*self._par)
 
     def _result_dtype(self, x, y):
+        x, y = self._select(x), self._select(y)
         return _float_dtype_of(_leaf_columns(x.reshape(-1)[:0]) + _leaf_columns(y.reshape(-1)[:0]), self._scale, self._loc)
 
     def prepare(self, xs, *, ctx=None, dtype=None):
         """ upload a flat point set once: `DevicePoints` accepted by `gram` in place of the host array """
         ctx = ctx or Context.default()
-        xc = _leaf_columns(numpy.asarray(xs))
+        xc = _leaf_columns(numpy.asarray(self._select(xs)))
         dtype = dtype or _float_dtype_of(xc, self._scale, self._loc)
         return DevicePoints('coords', DeviceArray.from_host(numpy.stack([numpy.asarray(c, dtype) for c in xc]), ctx=ctx), numpy.dtype(dtype), ctx)
 
@@ -380,8 +397,8 @@ class _Isotropic(Kernel):
             if xs.dtype != ys.dtype or xs.array.shape[0] != ys.array.shape[0]:
                 raise ValueError('device point sets of different dtype or field count')
             return xs.array, ys.array, xs.dtype, xs.ctx, xs.array.shape[0]
-        xc = _leaf_columns(numpy.asarray(xs))
-        yc = _leaf_columns(numpy.asarray(ys))
+        xc = _leaf_columns(numpy.asarray(self._select(xs)))
+        yc = _leaf_columns(numpy.asarray(self._select(ys)))
         if len(xc) != len(yc):
             raise ValueError(f'x has {len(xc)} leaf fields, y has {len(yc)}')
         dtype = _float_dtype_of(xc + yc, self._scale, self._loc)
@@ -558,20 +575,20 @@ class ExpQuad(_Isotropic):
     """ Exponential quadratic kernel, k(r) = exp(-r²/2) (``_kernels/_basic.py:61-75``) """
     _kind = _lib.LGP_KERNEL_EXPQUAD
 
-    def __init__(self, *, scale=None, loc=None):
-        super().__init__(scale=scale, loc=loc)
+    def __init__(self, *, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
 
 
 class Maternp(_Isotropic):
     """ Matérn kernel of half-integer order ν = p + 1/2 (``_kernels/_matern.py:29-49``) """
     _kind = _lib.LGP_KERNEL_MATERNP
 
-    def __init__(self, *, p=None, scale=None, loc=None):
+    def __init__(self, *, p=None, scale=None, loc=None, dim=None):
         if p is None or int(p) != p or p < 0:                      # _matern.py:46-47
             raise AssertionError(p)
         if p > 16:
             raise NotImplementedError('Maternp order above 16')
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         self._p = int(p)
 
 
@@ -579,10 +596,10 @@ class GammaExp(_Isotropic):
     """ Gamma exponential kernel, k(r) = exp(-r^γ), γ ∈ (0, 2] (``_kernels/_basic.py:94-115``) """
     _kind = _lib.LGP_KERNEL_GAMMAEXP
 
-    def __init__(self, *, gamma=1, scale=None, loc=None):
+    def __init__(self, *, gamma=1, scale=None, loc=None, dim=None):
         if not 0 < gamma <= 2:                                     # _basic.py:109-110
             raise AssertionError(gamma)
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         self._gamma = gamma
         self._par = (float(gamma), float(gamma / 2))
 
@@ -592,12 +609,12 @@ class Cauchy(_Isotropic):
     α = 2 is the rational quadratic kernel """
     _kind = _lib.LGP_KERNEL_CAUCHY
 
-    def __init__(self, *, alpha=2, beta=2, scale=None, loc=None):
+    def __init__(self, *, alpha=2, beta=2, scale=None, loc=None, dim=None):
         if not 0 < alpha <= 2:                                     # _basic.py:336-338
             raise AssertionError(alpha)
         if not 0 < beta:
             raise AssertionError(beta)
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         self._alpha, self._beta = alpha, beta
         self._par = (float(alpha), float(beta), float(-beta / alpha))
 
@@ -608,12 +625,12 @@ class Wendland(_Isotropic):
     _kind = _lib.LGP_KERNEL_WENDLAND
     _POLY = {0: [[1]], 1: [[1, 1], [1]], 2: [[1 / 3, 4 / 3, 1], [1, 2], [1]], 3: [[1 / 15, 3 / 5, 23 / 15, 1], [2 / 5, 12 / 5, 3], [1, 3], [1]]}
 
-    def __init__(self, *, k=0, alpha=1, scale=None, loc=None):
+    def __init__(self, *, k=0, alpha=1, scale=None, loc=None, dim=None):
         if k not in self._POLY:
             raise NotImplementedError(k)                              # _wendland.py:77-78
         self._maxdim = int(numpy.floor(2 * alpha - 1))               # :29-31
         assert self._maxdim >= 1, self._maxdim
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         nu = k + alpha
         self._p = int(k)
         self._par = (float(nu + k),) + tuple(float(numpy.polyval(pj, nu)) for pj in self._POLY[k])
@@ -629,9 +646,9 @@ class CausalExpQuad(_Isotropic):
     """ Causal exponential quadratic kernel, k(r) = erfc(alpha r / 4) exp(-r²/2), alpha >= 0 (``_kernels/_basic.py:346-360``) """
     _kind = _lib.LGP_KERNEL_CAUSALEXPQUAD
 
-    def __init__(self, *, alpha=1, scale=None, loc=None):
+    def __init__(self, *, alpha=1, scale=None, loc=None, dim=None):
         assert alpha >= 0, alpha
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         self._par = (float(alpha / 4),)
 
 
@@ -639,16 +656,16 @@ class Log(_Isotropic):
     """ Log kernel, k(r) = log(1 + r) / r (``_kernels/_basic.py:381-392``) """
     _kind = _lib.LGP_KERNEL_LOG
 
-    def __init__(self, *, scale=None, loc=None):
-        super().__init__(scale=scale, loc=loc)
+    def __init__(self, *, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
 
 
 class Constant(_Isotropic):
     """ Constant kernel, k(x, y) = 1 (``_kernels/_basic.py:34-46``) """
     _kind = _lib.LGP_KERNEL_CONSTANT
 
-    def __init__(self, *, scale=None, loc=None):
-        super().__init__(scale=scale, loc=loc)
+    def __init__(self, *, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
 
 
 class White(_Isotropic):
@@ -656,16 +673,16 @@ class White(_Isotropic):
     floats where the reference returns integers """
     _kind = _lib.LGP_KERNEL_WHITE
 
-    def __init__(self, *, scale=None, loc=None):
-        super().__init__(scale=scale, loc=loc)
+    def __init__(self, *, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
 
 
 class _Stationary1D(_Isotropic):
     """ stationary kernels of one variable (``stationarykernel(maxdim=1)``, ``_Kernel/_stationary.py``): functions of the
     difference of the (transformed) inputs, evaluated by the generic core of the isotropic Gram kernel """
 
-    def __init__(self, *, scale=None, loc=None):
-        super().__init__(scale=scale, loc=loc)
+    def __init__(self, *, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
 
     def _prepare(self, xs, ys, ctx):
         out = super()._prepare(xs, ys, ctx)
@@ -689,9 +706,9 @@ class Periodic(_Stationary1D):
     ``outerscale`` the correlation length (``_kernels/_basic.py:187-208``) """
     _kind = _lib.LGP_KERNEL_PERIODIC
 
-    def __init__(self, *, outerscale=1, scale=None, loc=None):
+    def __init__(self, *, outerscale=1, scale=None, loc=None, dim=None):
         assert 0 < outerscale < numpy.inf, outerscale
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         self._par = (float(outerscale),)
 
 
@@ -711,9 +728,9 @@ class StationaryFracBrownian(_Stationary1D):
     (``_kernels/_randomwalk.py:156-172``) """
     _kind = _lib.LGP_KERNEL_STATIONARYFRACBROWNIAN
 
-    def __init__(self, *, H=1 / 2, scale=None, loc=None):
+    def __init__(self, *, H=1 / 2, scale=None, loc=None, dim=None):
         assert 0 < H <= 1, H
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         self._par = (float(2 * H),)
 
 
@@ -721,10 +738,10 @@ class Celerite(_Stationary1D):
     """ Celerite kernel, k(Δ) = exp(-γ|Δ|) (cos Δ + B sin|Δ|), |B| <= γ (``_kernels/_celerite.py:34-52``) """
     _kind = _lib.LGP_KERNEL_CELERITE
 
-    def __init__(self, *, gamma=1, B=0, scale=None, loc=None):
+    def __init__(self, *, gamma=1, B=0, scale=None, loc=None, dim=None):
         assert 0 <= gamma < numpy.inf, gamma
         assert abs(B) <= gamma, (B, gamma)
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         self._par = (float(gamma), float(B))
 
 
@@ -733,9 +750,9 @@ class Harmonic(_Stationary1D):
     branches of the reference (Q < 1/2 in the cancellation-free form, Q < 1, Q = 1, Q > 1), chosen on the host """
     _kind = _lib.LGP_KERNEL_HARMONIC
 
-    def __init__(self, *, Q=1, scale=None, loc=None):
+    def __init__(self, *, Q=1, scale=None, loc=None, dim=None):
         assert 0 < Q < numpy.inf, Q
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         if Q < 1 / 2:
             self._p, eta = 0, numpy.sqrt((1 - Q) * (1 + Q))
         elif Q < 1:
@@ -752,10 +769,10 @@ class Circular(_Stationary1D):
     (``_kernels/_wendland.py:88-113``) """
     _kind = _lib.LGP_KERNEL_CIRCULAR
 
-    def __init__(self, *, tau=4, c=1 / 2, scale=None, loc=None):
+    def __init__(self, *, tau=4, c=1 / 2, scale=None, loc=None, dim=None):
         assert tau >= 4, tau
         assert 0 < c <= 1 / 2, c
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         self._par = (float(tau), float(c))
 
 
@@ -763,8 +780,8 @@ class Linear(_Isotropic):
     """ Dot product kernel, k(x, y) = sum_i x_i y_i (``_kernels/_basic.py:76-91``) """
     _kind = _lib.LGP_KERNEL_LINEAR
 
-    def __init__(self, *, scale=None, loc=None):
-        super().__init__(scale=scale, loc=loc)
+    def __init__(self, *, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
 
 
 class _OneVariable(_Stationary1D):
@@ -777,7 +794,7 @@ class _OneVariable(_Stationary1D):
         for pts in (xs, ys):
             if isinstance(pts, DevicePoints) or lo == -numpy.inf:
                 continue
-            cols = _leaf_columns(numpy.asarray(pts))
+            cols = _leaf_columns(numpy.asarray(self._select(pts)))
             for c in cols:
                 v = numpy.asarray(c, float)
                 if self._loc is not None:
@@ -809,9 +826,9 @@ class Decaying(_OneVariable):
     """ Decaying kernel, k(x, y) = 1 / (1 + x + y)^alpha, x, y, alpha >= 0 (``_kernels/_basic.py:362-379``) """
     _kind = _lib.LGP_KERNEL_DECAYING
 
-    def __init__(self, *, alpha=1, scale=None, loc=None):
+    def __init__(self, *, alpha=1, scale=None, loc=None, dim=None):
         assert alpha >= 0, alpha
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         self._par = (float(alpha),)
 
 
@@ -821,10 +838,10 @@ class FracBrownian(_OneVariable):
     _kind = _lib.LGP_KERNEL_FRACBROWNIAN
     _domain = (-numpy.inf, numpy.inf)
 
-    def __init__(self, *, H=1 / 2, K=1, scale=None, loc=None):
+    def __init__(self, *, H=1 / 2, K=1, scale=None, loc=None, dim=None):
         assert 0 < H <= 1, H
         assert 0 < K <= 1, K
-        super().__init__(scale=scale, loc=loc)
+        super().__init__(scale=scale, loc=loc, dim=dim)
         H2 = 2 * H
         self._par = (float(H2), float(K), float(1 / 2 ** K), float(H2 * K))
 
@@ -848,7 +865,7 @@ class _HostFactors(Kernel):
 
     def _transformed(self, x):
         """ the inputs as the kernel's core sees them: (x - loc) / scale on every leaf field (``_crosskernel.py:172-185``) """
-        x = numpy.asarray(x)
+        x = numpy.asarray(self._select(x)) if hasattr(self, '_select') else numpy.asarray(x)
         if self._loc is None and self._scale is None:
             return x
         def tr(v):
@@ -910,8 +927,8 @@ class Rescaling(_HostFactors):
     modulate its variance.  ``stdfun`` takes the (transformed) points and returns one number per point; it is evaluated on
     the host """
 
-    def __init__(self, *, stdfun=None, scale=None, loc=None):
-        super().__init__(scale=scale, loc=loc)
+    def __init__(self, *, stdfun=None, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
         self._stdfun = stdfun
 
     def _std(self, x):
@@ -935,16 +952,17 @@ class Gibbs(_Isotropic):
     applied on the host too -- the same two IEEE operations """
     _kind = _lib.LGP_KERNEL_GIBBS
 
-    def __init__(self, *, scalefun=None, scale=None, loc=None):
-        super().__init__(scale=scale, loc=loc)
+    def __init__(self, *, scalefun=None, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
         self._hloc, self._hscale = self._loc, self._scale
         self._loc = self._scale = None                   # (nothing left for the device to transform)
         self._scalefun = scalefun
 
     def _rows(self, xs, dtype=None):
         """ the SoA rows of a point set: transformed coordinates, then scalefun of the transformed points """
-        x = numpy.asarray(xs)
+        x = numpy.asarray(self._select(xs))
         helper = _HostFactors.__new__(_HostFactors)
+        helper._dim = None
         helper._loc, helper._scale = self._hloc, self._hscale
         xt = _HostFactors._transformed(helper, x.reshape(-1))
         cols = _leaf_columns(xt)
@@ -961,6 +979,7 @@ class Gibbs(_Isotropic):
         return DevicePoints('coords', DeviceArray.from_host(rows, ctx=ctx), dtype, ctx)
 
     def _result_dtype(self, x, y):
+        x, y = self._select(x), self._select(y)
         return _float_dtype_of(_leaf_columns(x.reshape(-1)[:0]) + _leaf_columns(y.reshape(-1)[:0]), self._hscale, self._hloc)
 
     def _prepare(self, xs, ys, ctx):
@@ -988,7 +1007,7 @@ class NNKernel(Kernel):
     (``_kernels/_basic.py:122-154``): the argument is `Linear` + q times an outer product of per-point factors, a composite of
     this package's own kernels, and the arcsine is applied to the matrix on the device """
 
-    def __init__(self, *, sigma0=1, scale=None, loc=None):
+    def __init__(self, *, sigma0=1, scale=None, loc=None, dim=None):
         assert 0 < sigma0 < numpy.inf, sigma0
         super().__init__()
         q = float(sigma0) ** 2
@@ -999,7 +1018,7 @@ class NNKernel(Kernel):
             else:
                 xx = sum(numpy.sum(numpy.square(x[nm]), axis=tuple(range(x.ndim, x[nm].ndim))) for nm in x.dtype.names)
             return 1 / (1 + 2 * (q + xx))
-        self._inner = (Linear(scale=scale, loc=loc) + q) * Rescaling(stdfun=inv_norm, scale=scale, loc=loc) * 2.
+        self._inner = (Linear(scale=scale, loc=loc, dim=dim) + q) * Rescaling(stdfun=inv_norm, scale=scale, loc=loc, dim=dim) * 2.
 
     def _result_dtype(self, x, y):
         return numpy.dtype(numpy.float64)
@@ -1025,15 +1044,15 @@ class NNKernel(Kernel):
 class Categorical(_HostFactors):
     """ Categorical kernel, k(x, y) = cov[x, y] over the integers 0 .. N - 1 (``_kernels/_basic.py:210-229``) """
 
-    def __init__(self, *, cov=None, scale=None, loc=None):
-        super().__init__(scale=scale, loc=loc)
+    def __init__(self, *, cov=None, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
         cov = numpy.asarray(cov)
         assert cov.ndim == 2 and cov.shape[0] == cov.shape[1], cov.shape
         assert numpy.allclose(cov, cov.T)
         self._cov = cov.astype(float)
 
     def _index(self, x):
-        x = numpy.asarray(x)
+        x = numpy.asarray(self._select(x))
         if x.dtype.names is not None:
             if len(x.dtype.names) > 1:
                 raise ValueError(f'kernel called on type with dimensionality {len(x.dtype.names)} > maxdim=1')
@@ -1103,8 +1122,8 @@ class BART(Kernel):
     """
 
     def __init__(self, *, alpha=0.95, beta=2, maxd=2, gamma=1, splits=None, pnt=None,
-                 intercept=True, weights=None, reset=None, indices=False, scale=None, loc=None):
-        super().__init__(scale=scale, loc=loc)
+                 intercept=True, weights=None, reset=None, indices=False, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
         if scale is not None or loc is not None:
             if indices:
                 raise ValueError('scale/loc make no sense with indices=True')
@@ -1304,7 +1323,7 @@ class BART(Kernel):
         return self._flt
 
     def _to_indices(self, xs):
-        xs = numpy.asarray(xs)
+        xs = numpy.asarray(self._select(xs))
         if not xs.dtype.names:
             xs = xs[..., None]
         if self._indices:

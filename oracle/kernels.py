@@ -64,10 +64,11 @@ class Kernel:
     (``:172-185``; see ``_transf_inputs`` for the order).
     """
 
-    def __init__(self, core, *, scale=None, loc=None, outops=()):
+    def __init__(self, core, *, scale=None, loc=None, dim=None, outops=()):
         self._core = core
         self._scale = scale
         self._loc = loc
+        self._dim = dim                                   # ``_Kernel/_ops.py:233-260``: T(f)(x) = f(x[dim]), applied first
         # output algops applied in order: ('mul', c) is kernel * c
         # (``_alg.py:58-82``), ('add', c) is kernel + c (``_alg.py:32-56``)
         self._outops = tuple(outops)
@@ -77,6 +78,10 @@ class Kernel:
         # linop('loc') (dict order); each linop wraps the core as
         # core'(x) = core(T(x)): k1(x) = k0(x / scale), then
         # k2(x) = k1(x - loc) = k0((x - loc) / scale).
+        if self._dim is not None:
+            if x.dtype.names is None:
+                raise ValueError(f'cannot get dim={self._dim!r} from non-structured input')
+            x = x[[self._dim]] if (isinstance(self._dim, str) and x.dtype[self._dim].shape) else x[self._dim]
         if self._loc is not None:
             l = self._loc
             x = _leaf_apply(lambda v: v - l, x)
@@ -181,7 +186,7 @@ class Kernel:
             return Kernel(core)
         if not isinstance(c, numbers.Number) and numpy.ndim(c) != 0:
             return NotImplemented
-        return Kernel(self._core, scale=self._scale, loc=self._loc, outops=self._outops + ((op, c),))
+        return Kernel(self._core, scale=self._scale, loc=self._loc, dim=self._dim, outops=self._outops + ((op, c),))
 
     def __mul__(self, c):
         return self._with('mul', c)
@@ -240,26 +245,26 @@ def cauchy_core(r2, alpha=2, beta=2):
     return (1 + power / beta) ** (-beta / alpha)
 
 
-def ExpQuad(*, scale=None, loc=None):
+def ExpQuad(*, scale=None, loc=None, dim=None):
     core = _isotropic(expquad_core)
     core.closed_form = 'expquad'          # Kernel.diff has its derivatives in closed form
-    return Kernel(core, scale=scale, loc=loc)
+    return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
-def GammaExp(*, gamma=1, scale=None, loc=None):
-    return Kernel(_isotropic(lambda r2: gammaexp_core(r2, gamma)), scale=scale, loc=loc)
+def GammaExp(*, gamma=1, scale=None, loc=None, dim=None):
+    return Kernel(_isotropic(lambda r2: gammaexp_core(r2, gamma)), scale=scale, loc=loc, dim=dim)
 
 
-def Cauchy(*, alpha=2, beta=2, scale=None, loc=None):
-    return Kernel(_isotropic(lambda r2: cauchy_core(r2, alpha, beta)), scale=scale, loc=loc)
+def Cauchy(*, alpha=2, beta=2, scale=None, loc=None, dim=None):
+    return Kernel(_isotropic(lambda r2: cauchy_core(r2, alpha, beta)), scale=scale, loc=loc, dim=dim)
 
 
-def Maternp(*, p=None, scale=None, loc=None):
+def Maternp(*, p=None, scale=None, loc=None, dim=None):
     p = int(p)
     core = _isotropic(lambda r2: maternp_core(r2, p))
     core.closed_form = 'maternp'
     core.p = p
-    return Kernel(core, scale=scale, loc=loc)
+    return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
 def _isotropic_posabs(core):
@@ -276,7 +281,7 @@ def _isotropic_posabs(core):
 _WENDLAND_POLY = {0: [[1]], 1: [[1, 1], [1]], 2: [[1/3, 4/3, 1], [1, 2], [1]], 3: [[1/15, 3/5, 23/15, 1], [2/5, 12/5, 3], [1, 3], [1]]}
 
 
-def Wendland(*, k=0, alpha=1, scale=None, loc=None):
+def Wendland(*, k=0, alpha=1, scale=None, loc=None, dim=None):
     """ ``_kernels/_wendland.py:32-84`` """
     assert int(numpy.floor(2 * alpha - 1)) >= 1
     nu = k + alpha
@@ -293,28 +298,28 @@ def Wendland(*, k=0, alpha=1, scale=None, loc=None):
         if x.dtype.names is not None and len(_leaf_columns_count(x.dtype)) > maxdim:
             raise ValueError(f'kernel called on type with dimensionality > maxdim={maxdim}')
         return inner(x, y)
-    return Kernel(checked, scale=scale, loc=loc)
+    return Kernel(checked, scale=scale, loc=loc, dim=dim)
 
 
-def CausalExpQuad(*, alpha=1, scale=None, loc=None):
+def CausalExpQuad(*, alpha=1, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:346-360`` """
     assert alpha >= 0
-    return Kernel(_isotropic_posabs(lambda r: special.erfc(alpha / 4 * r) * numpy.exp(-1/2 * numpy.square(r))), scale=scale, loc=loc)
+    return Kernel(_isotropic_posabs(lambda r: special.erfc(alpha / 4 * r) * numpy.exp(-1/2 * numpy.square(r))), scale=scale, loc=loc, dim=dim)
 
 
-def Log(*, scale=None, loc=None):
+def Log(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:381-392`` """
-    return Kernel(_isotropic_posabs(lambda r: numpy.log1p(r) / r), scale=scale, loc=loc)
+    return Kernel(_isotropic_posabs(lambda r: numpy.log1p(r) / r), scale=scale, loc=loc, dim=dim)
 
 
-def Constant(*, scale=None, loc=None):
+def Constant(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:34-46`` """
     def core(x, y):
         return numpy.ones(numpy.broadcast_shapes(x.shape, y.shape))
-    return Kernel(core, scale=scale, loc=loc)
+    return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
-def White(*, scale=None, loc=None):
+def White(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:48-59``: the product over the fields of (x_f == y_f) """
     def core(x, y):
         if x.dtype.names is None:
@@ -326,7 +331,7 @@ def White(*, scale=None, loc=None):
                 eq = numpy.prod(eq, axis=tuple(range(-x.dtype[name].ndim, 0)))
             acc = eq if acc is None else acc * eq
         return acc.astype(int)
-    return Kernel(core, scale=scale, loc=loc)
+    return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
 def _stationary1d(core, input='signed'):
@@ -358,25 +363,25 @@ def _leaf_columns_count(dtype):
     return out
 
 
-def Expon(*, scale=None, loc=None):
+def Expon(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:254-269`` """
-    return Kernel(_stationary1d(lambda d: numpy.exp(-d), 'abs'), scale=scale, loc=loc)
+    return Kernel(_stationary1d(lambda d: numpy.exp(-d), 'abs'), scale=scale, loc=loc, dim=dim)
 
 
-def HoleEffect(*, scale=None, loc=None):
+def HoleEffect(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:299-310`` """
-    return Kernel(_stationary1d(lambda d: (1 - d) * numpy.exp(-d), 'abs'), scale=scale, loc=loc)
+    return Kernel(_stationary1d(lambda d: (1 - d) * numpy.exp(-d), 'abs'), scale=scale, loc=loc, dim=dim)
 
 
-def Periodic(*, outerscale=1, scale=None, loc=None):
+def Periodic(*, outerscale=1, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:187-208`` """
     assert 0 < outerscale < numpy.inf
-    return Kernel(_stationary1d(lambda d: numpy.exp(-2 * (numpy.sin(d / 2) / outerscale) ** 2)), scale=scale, loc=loc)
+    return Kernel(_stationary1d(lambda d: numpy.exp(-2 * (numpy.sin(d / 2) / outerscale) ** 2)), scale=scale, loc=loc, dim=dim)
 
 
-def Cos(*, scale=None, loc=None):
+def Cos(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_spectral.py:25-38`` """
-    return Kernel(_stationary1d(numpy.cos), scale=scale, loc=loc)
+    return Kernel(_stationary1d(numpy.cos), scale=scale, loc=loc, dim=dim)
 
 
 def sinc(x):
@@ -388,25 +393,25 @@ def sinc(x):
     return numpy.where(numpy.abs(x) < 1e-1, near, numpy.sinc(x))
 
 
-def Sinc(*, scale=None, loc=None):
+def Sinc(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_spectral.py:113-122`` """
-    return Kernel(_stationary1d(sinc, 'posabs'), scale=scale, loc=loc)
+    return Kernel(_stationary1d(sinc, 'posabs'), scale=scale, loc=loc, dim=dim)
 
 
-def StationaryFracBrownian(*, H=1/2, scale=None, loc=None):
+def StationaryFracBrownian(*, H=1/2, scale=None, loc=None, dim=None):
     """ ``_kernels/_randomwalk.py:156-172`` """
     assert 0 < H <= 1, H
     H2 = 2 * H
-    return Kernel(_stationary1d(lambda d: 1/2 * (numpy.abs(d + 1) ** H2 + numpy.abs(d - 1) ** H2 - 2 * numpy.abs(d) ** H2)), scale=scale, loc=loc)
+    return Kernel(_stationary1d(lambda d: 1/2 * (numpy.abs(d + 1) ** H2 + numpy.abs(d - 1) ** H2 - 2 * numpy.abs(d) ** H2)), scale=scale, loc=loc, dim=dim)
 
 
-def Celerite(*, gamma=1, B=0, scale=None, loc=None):
+def Celerite(*, gamma=1, B=0, scale=None, loc=None, dim=None):
     """ ``_kernels/_celerite.py:34-52`` """
     assert 0 <= gamma < numpy.inf and abs(B) <= gamma
-    return Kernel(_stationary1d(lambda d: numpy.exp(-gamma * d) * (numpy.cos(d) + B * numpy.sin(d)), 'abs'), scale=scale, loc=loc)
+    return Kernel(_stationary1d(lambda d: numpy.exp(-gamma * d) * (numpy.cos(d) + B * numpy.sin(d)), 'abs'), scale=scale, loc=loc, dim=dim)
 
 
-def Harmonic(*, Q=1, scale=None, loc=None):
+def Harmonic(*, Q=1, scale=None, loc=None, dim=None):
     """ ``_kernels/_celerite.py:54-121`` """
     assert 0 < Q < numpy.inf
 
@@ -431,10 +436,10 @@ def Harmonic(*, Q=1, scale=None, loc=None):
             tauQ = tau / Q
             etatau = etaQ * tauQ
             return numpy.exp(-tauQ) * (numpy.cos(etatau) + numpy.sin(etatau) / etaQ)
-    return Kernel(_stationary1d(core), scale=scale, loc=loc)
+    return Kernel(_stationary1d(core), scale=scale, loc=loc, dim=dim)
 
 
-def Circular(*, tau=4, c=1/2, scale=None, loc=None):
+def Circular(*, tau=4, c=1/2, scale=None, loc=None, dim=None):
     """ ``_kernels/_wendland.py:88-113`` """
     assert tau >= 4 and 0 < c <= 1/2
 
@@ -442,26 +447,26 @@ def Circular(*, tau=4, c=1/2, scale=None, loc=None):
         x = delta % 1
         t = numpy.minimum(x, 1 - x)
         return (1 + tau * t / c) * numpy.maximum(1 - t / c, 0) ** tau
-    return Kernel(_stationary1d(core, 'posabs'), scale=scale, loc=loc)
+    return Kernel(_stationary1d(core, 'posabs'), scale=scale, loc=loc, dim=dim)
 
 
-def Taylor(*, scale=None, loc=None):
+def Taylor(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:393-408`` """
     def core(x, y):
         mul = x * y
         val = 2 * numpy.sqrt(numpy.abs(mul))
         return numpy.where(mul >= 0, special.i0(val), special.j0(val))
-    return Kernel(_onevariable(core, -numpy.inf, numpy.inf), scale=scale, loc=loc)
+    return Kernel(_onevariable(core, -numpy.inf, numpy.inf), scale=scale, loc=loc, dim=dim)
 
 
-def Rescaling(*, stdfun=None, scale=None, loc=None):
+def Rescaling(*, stdfun=None, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:231-252`` """
     if stdfun is None:
         stdfun = lambda x: numpy.ones(x.shape)
-    return Kernel(lambda x, y: stdfun(x) * stdfun(y), scale=scale, loc=loc)
+    return Kernel(lambda x, y: stdfun(x) * stdfun(y), scale=scale, loc=loc, dim=dim)
 
 
-def Categorical(*, cov=None, scale=None, loc=None):
+def Categorical(*, cov=None, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:210-229`` """
     cov = numpy.asarray(cov)
     assert cov.ndim == 2 and cov.shape[0] == cov.shape[1] and numpy.allclose(cov, cov.T)
@@ -469,10 +474,10 @@ def Categorical(*, cov=None, scale=None, loc=None):
     def core(x, y):
         assert numpy.issubdtype(x.dtype, numpy.integer)
         return cov[x, y]
-    return Kernel(core, scale=scale, loc=loc)
+    return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
-def Gibbs(*, scalefun=None, scale=None, loc=None):
+def Gibbs(*, scalefun=None, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:156-185`` """
     if scalefun is None:
         scalefun = lambda x: numpy.ones(x.shape)
@@ -484,10 +489,10 @@ def Gibbs(*, scalefun=None, scale=None, loc=None):
         factor = numpy.sqrt(2 * sx * sy / denom)
         distsq = sum_recurse_dtype(lambda a, b: (a - b) ** 2, x, y)
         return factor * numpy.exp(-distsq / denom)
-    return Kernel(core, scale=scale, loc=loc)
+    return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
-def NNKernel(*, sigma0=1, scale=None, loc=None):
+def NNKernel(*, sigma0=1, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:122-154`` """
     assert 0 < sigma0 < numpy.inf
     q = sigma0 ** 2
@@ -496,12 +501,12 @@ def NNKernel(*, sigma0=1, scale=None, loc=None):
     def core(x, y):
         denom = (1 + 2 * (q + dot(x, x))) * (1 + 2 * (q + dot(y, y)))
         return 2 / numpy.pi * numpy.arcsin(2 * (q + dot(x, y)) / denom)
-    return Kernel(core, scale=scale, loc=loc)
+    return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
-def Linear(*, scale=None, loc=None):
+def Linear(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:76-91`` """
-    return Kernel(lambda x, y: sum_recurse_dtype(lambda a, b: a * b, x, y), scale=scale, loc=loc)
+    return Kernel(lambda x, y: sum_recurse_dtype(lambda a, b: a * b, x, y), scale=scale, loc=loc, dim=dim)
 
 
 def _onevariable(core, lo=0., hi=numpy.inf):
@@ -517,41 +522,41 @@ def _onevariable(core, lo=0., hi=numpy.inf):
     return newcore
 
 
-def Wiener(*, scale=None, loc=None):
+def Wiener(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_randomwalk.py:26-41`` """
-    return Kernel(_onevariable(numpy.minimum), scale=scale, loc=loc)
+    return Kernel(_onevariable(numpy.minimum), scale=scale, loc=loc, dim=dim)
 
 
-def OrnsteinUhlenbeck(*, scale=None, loc=None):
+def OrnsteinUhlenbeck(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_randomwalk.py:112-132`` """
-    return Kernel(_onevariable(lambda x, y: numpy.exp(-numpy.abs(x - y)) - numpy.exp(-(x + y))), scale=scale, loc=loc)
+    return Kernel(_onevariable(lambda x, y: numpy.exp(-numpy.abs(x - y)) - numpy.exp(-(x + y))), scale=scale, loc=loc, dim=dim)
 
 
-def BrownianBridge(*, scale=None, loc=None):
+def BrownianBridge(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_randomwalk.py:134-151`` """
-    return Kernel(_onevariable(lambda x, y: numpy.minimum(x, y) - x * y, 0., 1.), scale=scale, loc=loc)
+    return Kernel(_onevariable(lambda x, y: numpy.minimum(x, y) - x * y, 0., 1.), scale=scale, loc=loc, dim=dim)
 
 
-def Decaying(*, alpha=1, scale=None, loc=None):
+def Decaying(*, alpha=1, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:362-379`` """
     assert alpha >= 0
-    return Kernel(_onevariable(lambda x, y: 1 / (x + y + 1) ** alpha), scale=scale, loc=loc)
+    return Kernel(_onevariable(lambda x, y: 1 / (x + y + 1) ** alpha), scale=scale, loc=loc, dim=dim)
 
 
-def FracBrownian(*, H=1/2, K=1, scale=None, loc=None):
+def FracBrownian(*, H=1/2, K=1, scale=None, loc=None, dim=None):
     """ ``_kernels/_randomwalk.py:46-68`` """
     assert 0 < H <= 1 and 0 < K <= 1
     H2 = 2 * H
     core = lambda x, y: 1 / 2 ** K * ((numpy.abs(x) ** H2 + numpy.abs(y) ** H2) ** K - numpy.abs(x - y) ** (H2 * K))
-    return Kernel(_onevariable(core, -numpy.inf, numpy.inf), scale=scale, loc=loc)
+    return Kernel(_onevariable(core, -numpy.inf, numpy.inf), scale=scale, loc=loc, dim=dim)
 
 
-def WienerIntegral(*, scale=None, loc=None):
+def WienerIntegral(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_randomwalk.py:93-110`` """
     def core(x, y):
         a, b = numpy.minimum(x, y), numpy.maximum(x, y)
         return 1/2 * a ** 2 * (b - a / 3)
-    return Kernel(_onevariable(core), scale=scale, loc=loc)
+    return Kernel(_onevariable(core), scale=scale, loc=loc, dim=dim)
 
 
 # --------------------------------------------------------------------------
@@ -1037,7 +1042,7 @@ def _digamma_at_integers(count, flt):
 
 
 def _make_bart_kernel(*, alpha=0.95, beta=2, maxd=2, gamma=1, splits=None, pnt=None,
-    intercept=True, weights=None, reset=None, indices=False, scale=None, loc=None):
+    intercept=True, weights=None, reset=None, indices=False, scale=None, loc=None, dim=None):
     """ ``_bart.py:32-202`` wrapper: kernel(x, y) -> BART.correlation(splits[0], ix, iy, altinput=True) """
     checked = BART._check_splits(splits, indices)
 
@@ -1058,4 +1063,4 @@ def _make_bart_kernel(*, alpha=0.95, beta=2, maxd=2, gamma=1, splits=None, pnt=N
             intercept=intercept, weights=weights, reset=reset, altinput=True,
         )
 
-    return Kernel(core, scale=scale, loc=loc)
+    return Kernel(core, scale=scale, loc=loc, dim=dim)

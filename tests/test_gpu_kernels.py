@@ -706,3 +706,32 @@ def test_gibbs_vs_oracle(lgp, rng):
     # as an operand of a product, and under a GP
     gp = lgp.GP(lgp.Gibbs(scalefun=sf) * lgp.Constant() * 1.5, checkpos=False).addx(x, 'x')
     np.testing.assert_allclose(gp.prior('x', raw=True), 1.5 * oracle.Gibbs(scalefun=sf)(x[:, None], x[None, :]), rtol=0, atol=4e-15)
+
+
+def test_dim_selects_fields(lgp, rng):
+    """ ``dim=`` (``_Kernel/_ops.py:233-260``): a kernel acts on one field or a list of fields of structured points -- the way
+    separable kernels over mixed inputs are written, with products and sums on top; ``maxdim`` counts the selected fields """
+    n, m = 140, 90
+    dt = [('t', float), ('c', int), ('v', float, (2,)), ('w', float)]
+    x = np.zeros(n, dt); y = np.zeros(m, dt)
+    for a, k in ((x, n), (y, m)):
+        a['t'] = rng.uniform(0, 5, k); a['c'] = rng.integers(0, 3, k); a['v'] = rng.uniform(-1, 1, (k, 2)); a['w'] = rng.uniform(0, 1, k)
+    y[:10] = x[:10]
+    b = rng.standard_normal((3, 3)); cov = b @ b.T
+    make = lambda M: (M.ExpQuad(dim='t', scale=2.) * M.Categorical(cov=cov, dim='c') + M.Maternp(p=1, dim='v') * M.Expon(dim='w', scale=0.5)
+                      + M.GammaExp(gamma=1.3, dim=['t', 'w'], scale=1.5) * 0.3)
+    G = make(lgp).gram(x, y).to_host()
+    R = make(oracle)(x[:, None], y[None, :])
+    np.testing.assert_allclose(G, R, rtol=0, atol=1e-14 * np.abs(R).max())
+    np.testing.assert_allclose(make(lgp)(x[:m], y), np.diagonal(R), rtol=0, atol=1e-14 * np.abs(R).max())
+    # one field of many satisfies maxdim = 1; all of them do not
+    lgp.Cos(dim='w').gram(x, y)
+    with pytest.raises(ValueError):
+        lgp.Cos().gram(x, y)
+    with pytest.raises(ValueError):
+        lgp.ExpQuad(dim='t').gram(x['t'], y['t'])              # not structured
+    with pytest.raises(TypeError):
+        lgp.ExpQuad(dim=3)
+    # under a GP
+    gp = lgp.GP(lgp.ExpQuad(dim='t', scale=2.) * lgp.Categorical(cov=cov, dim='c'), checkpos=False).addx(x, 'x')
+    np.testing.assert_allclose(gp.prior('x', raw=True), (oracle.ExpQuad(dim='t', scale=2.) * oracle.Categorical(cov=cov, dim='c'))(x[:, None], x[None, :]), rtol=0, atol=1e-14)
