@@ -10,7 +10,7 @@ surface (raw outputs).  Python host code -> ctypes -> ``liblsqfitgp_hip.so``
 from ._lib import LibraryError
 from ._device import Context, DeviceArray, asdevice
 from ._linalg import Decomposition, Chol
-from ._kernels import (Kernel, ExpQuad, Maternp, GammaExp, Cauchy, Wendland, CausalExpQuad, Log, Constant, White, Expon, HoleEffect,
+from ._kernels import (Kernel, ExpQuad, Maternp, Matern, GammaExp, Cauchy, Wendland, CausalExpQuad, Log, Constant, White, Expon, HoleEffect,
                        Periodic, Cos, Sinc, StationaryFracBrownian, Linear, Wiener, OrnsteinUhlenbeck, BrownianBridge, Decaying,
                        FracBrownian, WienerIntegral, Celerite, Harmonic, Circular, Taylor, Rescaling, Categorical, NNKernel, Gibbs, BART)
 from ._GP import GP, Diagonal, diag

@@ -592,6 +592,19 @@ class Maternp(_Isotropic):
         self._p = int(p)
 
 
+class Matern(Maternp):
+    """ Matérn kernel of real order ν (``_kernels/_matern.py:54-76``), for the half-integer orders ν = p + 1/2, where
+    2^(1-ν)/Γ(ν) x^ν K_ν(x), x = sqrt(2ν) r, is the polynomial-times-exponential form that `Maternp` evaluates; other orders
+    need the modified Bessel function of real order, which has no device core """
+
+    def __init__(self, *, nu=None, scale=None, loc=None, dim=None):
+        assert nu is not None and 0 <= nu < numpy.inf, nu
+        p = float(nu) - 0.5
+        if p < 0 or p != int(p):
+            raise NotImplementedError(f'Matern(nu={nu!r}): only half-integer orders (Maternp) have a device core')
+        super().__init__(p=int(p), scale=scale, loc=loc, dim=dim)
+
+
 class GammaExp(_Isotropic):
     """ Gamma exponential kernel, k(r) = exp(-r^γ), γ ∈ (0, 2] (``_kernels/_basic.py:94-115``) """
     _kind = _lib.LGP_KERNEL_GAMMAEXP

@@ -267,6 +267,19 @@ def Maternp(*, p=None, scale=None, loc=None, dim=None):
     return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
+def Matern(*, nu=None, scale=None, loc=None, dim=None):
+    """ ``_kernels/_matern.py:54-76``: 2^(1-nu)/Gamma(nu) x^nu K_nu(x), x = sqrt(2 nu) r, with scipy's K_nu (the reference has its own
+    series, ``_special/_bessel.py``) """
+    assert 0 <= nu < numpy.inf
+
+    def core(r2):
+        x = numpy.sqrt(2 * (nu if nu else 1) * r2)
+        with numpy.errstate(invalid='ignore', divide='ignore', over='ignore'):
+            val = 2 ** (1 - nu) / special.gamma(nu) * x ** nu * special.kv(nu, x)
+        return numpy.where(x == 0, 1., val)
+    return Kernel(_isotropic(core), scale=scale, loc=loc, dim=dim)
+
+
 def _isotropic_posabs(core):
     """ ``_isotropic.py:61-81`` with input='posabs': per field (|x - y| + eps)^2 (``_stationary.py:84-85`` _softabs), summed, the
     core takes the square root """

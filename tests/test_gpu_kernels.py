@@ -735,3 +735,15 @@ def test_dim_selects_fields(lgp, rng):
     # under a GP
     gp = lgp.GP(lgp.ExpQuad(dim='t', scale=2.) * lgp.Categorical(cov=cov, dim='c'), checkpos=False).addx(x, 'x')
     np.testing.assert_allclose(gp.prior('x', raw=True), (oracle.ExpQuad(dim='t', scale=2.) * oracle.Categorical(cov=cov, dim='c'))(x[:, None], x[None, :]), rtol=0, atol=1e-14)
+
+
+def test_matern_half_integer_orders(lgp, rng):
+    """ `Matern(nu=p + 1/2)` is `Maternp(p)` (reference ``tests/kernels/test_kernels.py:501-512``) and agrees with the Bessel-function
+    form of the oracle; other orders have no device core """
+    x = rng.uniform(-3, 3, 120); y = rng.uniform(-3, 3, 80)
+    for p in range(4):
+        G = lgp.Matern(nu=p + 0.5, scale=1.3).gram(x, y).to_host()
+        np.testing.assert_array_equal(G, lgp.Maternp(p=p, scale=1.3).gram(x, y).to_host())
+        np.testing.assert_allclose(G, oracle.Matern(nu=p + 0.5, scale=1.3)(x[:, None], y[None, :]), rtol=1e-12, atol=1e-15)
+    with pytest.raises(NotImplementedError):
+        lgp.Matern(nu=1.2)

@@ -26,6 +26,7 @@ def lgp(request):
 KERNELS = {
     'ExpQuad': ([{}], None, True, (-5, 5), 2),
     'Maternp': ([dict(p=0), dict(p=1), dict(p=2), dict(p=3), dict(p=7)], None, True, (-5, 5), 'p'),
+    'Matern': ([dict(nu=0.5), dict(nu=1.5), dict(nu=2.5)], None, True, (-5, 5), 0),
     'GammaExp': ([dict(gamma=0.3), dict(gamma=1), dict(gamma=1.7), dict(gamma=2)], None, True, (-5, 5), 0),
     'Cauchy': ([dict(alpha=0.5, beta=1), dict(alpha=1, beta=2), dict(alpha=2, beta=2), dict(alpha=2, beta=0.3)], None, True, (-5, 5), 0),
     'Wendland': ([dict(k=0, alpha=1), dict(k=1, alpha=2), dict(k=2, alpha=2.5), dict(k=3, alpha=2)], 'alpha', True, (-5, 5), 0),
