@@ -126,6 +126,7 @@ int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *to
 #define LGP_KERNEL_CIRCULAR 26    /* _kernels/_wendland.py:88-113 W_c of the geodesic distance on the unit circle; hpar = {tau, c}          */
 #define LGP_KERNEL_TAYLOR 27      /* _kernels/_basic.py:393-408  I0(2 sqrt(x y)) for x y >= 0, J0(2 sqrt(-x y)) otherwise; one variable                   */
 #define LGP_KERNEL_GIBBS 28       /* _kernels/_basic.py:156-185  sqrt(2 s s' / (s^2 + s'^2)) exp(-|x - y|^2 / (s^2 + s'^2)): the LAST coordinate row holds s = scalefun(x), evaluated by the caller; no loc / scale */
+#define LGP_KERNEL_MATERN 29      /* _kernels/_matern.py:56-76  2^(1-nu)/Gamma(nu) x^nu K_nu(x), x = sqrt(2 nu) r, real nu in [0, 100]: hpar = {nu}; p ignored.  K_nu by Temme's series / Steed's continued fraction + upward recurrence; nu = 0 is 1 where r = 0.  (Half-integer nu: LGP_KERNEL_MATERNP is the closed form.)  Has a scale tangent. */
 #define LGP_OP_MUL 0           /* kernel * c  (_Kernel/_alg.py:58-82)  */
 #define LGP_OP_ADD 1           /* kernel + c  (_Kernel/_alg.py:32-56)  */
 

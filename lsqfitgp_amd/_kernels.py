@@ -499,7 +499,7 @@ class _Isotropic(Kernel):
         """ ``(K, dK/dscale)`` as two device matrices from one pass over the pairs (``lgp_gram_isotropic_dscale``): the
         tangent that ``jax.jacfwd`` of a reference gpfactory produces for a ``scale`` hyperparameter
         (``_Kernel/_ops.py:310-326`` through the core); with ``scale=None`` the derivative at scale = 1 """
-        if self._kind not in (_lib.LGP_KERNEL_EXPQUAD, _lib.LGP_KERNEL_MATERNP, _lib.LGP_KERNEL_GAMMAEXP, _lib.LGP_KERNEL_CAUCHY):
+        if self._kind not in (_lib.LGP_KERNEL_EXPQUAD, _lib.LGP_KERNEL_MATERNP, _lib.LGP_KERNEL_GAMMAEXP, _lib.LGP_KERNEL_CAUCHY, _lib.LGP_KERNEL_MATERN):
             raise NotImplementedError(f'derivative of {type(self).__name__} with respect to scale')
         xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
         n, m = xd.shape[1], yd.shape[1]
@@ -593,16 +593,23 @@ class Maternp(_Isotropic):
 
 
 class Matern(Maternp):
-    """ Matérn kernel of real order ν (``_kernels/_matern.py:54-76``), for the half-integer orders ν = p + 1/2, where
-    2^(1-ν)/Γ(ν) x^ν K_ν(x), x = sqrt(2ν) r, is the polynomial-times-exponential form that `Maternp` evaluates; other orders
-    need the modified Bessel function of real order, which has no device core """
+    """ Matérn kernel of real order ν, 2^(1-ν)/Γ(ν) x^ν K_ν(x), x = sqrt(2ν) r (``_kernels/_matern.py:54-76``).  For the half-integer
+    orders ν = p + 1/2 this is the polynomial-times-exponential form that `Maternp` evaluates, and that core is used; the other
+    orders go through ``LGP_KERNEL_MATERN``, which evaluates the modified Bessel function of real order on the device (Temme's
+    series / Steed's continued fraction and the upward recurrence); ν = 0 is 1 where r = 0 (``_matern.py:74``) """
 
     def __init__(self, *, nu=None, scale=None, loc=None, dim=None):
         assert nu is not None and 0 <= nu < numpy.inf, nu
         p = float(nu) - 0.5
-        if p < 0 or p != int(p):
-            raise NotImplementedError(f'Matern(nu={nu!r}): only half-integer orders (Maternp) have a device core')
-        super().__init__(p=int(p), scale=scale, loc=loc, dim=dim)
+        if p >= 0 and p == int(p) and p <= 16:
+            super().__init__(p=int(p), scale=scale, loc=loc, dim=dim)
+        else:
+            if nu > 100:
+                raise NotImplementedError('Matern order above 100')
+            _Isotropic.__init__(self, scale=scale, loc=loc, dim=dim)
+            self._kind = _lib.LGP_KERNEL_MATERN
+            self._par = (float(nu),)
+        self._nu = nu
 
 
 class GammaExp(_Isotropic):

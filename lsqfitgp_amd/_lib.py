@@ -52,6 +52,7 @@ LGP_KERNEL_HARMONIC = 25
 LGP_KERNEL_CIRCULAR = 26
 LGP_KERNEL_TAYLOR = 27
 LGP_KERNEL_GIBBS = 28
+LGP_KERNEL_MATERN = 29
 LGP_OP_MUL = 0
 LGP_OP_ADD = 1
 LGP_EPS_AUTO_REL = 1

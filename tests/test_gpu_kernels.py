@@ -739,11 +739,111 @@ def test_dim_selects_fields(lgp, rng):
 
 def test_matern_half_integer_orders(lgp, rng):
     """ `Matern(nu=p + 1/2)` is `Maternp(p)` (reference ``tests/kernels/test_kernels.py:501-512``) and agrees with the Bessel-function
-    form of the oracle; other orders have no device core """
+    form of the oracle """
     x = rng.uniform(-3, 3, 120); y = rng.uniform(-3, 3, 80)
     for p in range(4):
         G = lgp.Matern(nu=p + 0.5, scale=1.3).gram(x, y).to_host()
         np.testing.assert_array_equal(G, lgp.Maternp(p=p, scale=1.3).gram(x, y).to_host())
         np.testing.assert_allclose(G, oracle.Matern(nu=p + 0.5, scale=1.3)(x[:, None], y[None, :]), rtol=1e-12, atol=1e-15)
+
+
+def _fields(a):
+    """ (n, d) coordinates as a structured array with one array field """
+    s = np.empty(len(a), dtype=[('v', float, (a.shape[1],))])
+    s['v'] = a
+    return s
+
+
+def _matern_core(nu, r2):
+    """ ``_kernels/_matern.py:73-76`` with scipy's K_nu """
+    from scipy import special
+    x = np.sqrt(2 * nu * r2)
+    with np.errstate(all='ignore'):
+        v = 2 ** (1 - nu) / special.gamma(nu) * x ** nu * special.kv(nu, x)
+    return np.where(x == 0, 1., v)
+
+
+@pytest.mark.parametrize('nu', [0.05, 0.3, 0.49999, 0.50001, 0.75, 1.0, 1.2, 1.999, 2.0, 2.3, 3.7, 7.1, 10.0, 33.3, 100.0])
+def test_matern_real_order_against_scipy_bessel(lgp, rng, nu):
+    """ ``LGP_KERNEL_MATERN``: the device's K_nu (Temme series below x = 2, continued fraction above, upward recurrence) against the
+    oracle's ``scipy.special.kv`` form of ``_kernels/_matern.py:56-76``: 1e-12 relative -- distances from 1e-9 (series, one term)
+    through the switch at x = 2 to the far tail, and exact zeros """
+    x = np.concatenate([[0.], rng.uniform(-3, 3, 150), 10. ** rng.uniform(-9, 1.5, 150)])
+    y = np.concatenate([[0., 1e-300], rng.uniform(-3, 3, 100)])
+    for scale in (1., 0.37):
+        G = lgp.Matern(nu=nu, scale=scale).gram(x, y).to_host()
+        ref = oracle.Matern(nu=nu, scale=scale)(x[:, None], y[None, :])
+        # the oracle's product 2^(1-nu)/Gamma(nu) x^nu K_nu(x) overflows -- or passes through subnormal numbers and keeps a few
+        # digits -- at small x for the larger orders: there, the leading series sum_k (-x^2/4)^k / (k! (nu-1) ... (nu-k))
+        # (the x^(2 nu) series is far below the last bit)
+        lost = ~np.isfinite(ref)
+        xx = np.sqrt(2 * nu) * np.abs(x[:, None] - y[None, :]) / scale
+        if nu > 30:
+            lost |= xx < 0.3
+            q = xx ** 2 / 4
+            series = 1 - q / (nu - 1) + q ** 2 / (2 * (nu - 1) * (nu - 2)) - q ** 3 / (6 * (nu - 1) * (nu - 2) * (nu - 3))
+            assert xx[lost].max() < 0.3
+        else:
+            assert not lost.any()
+            series = ref
+        np.testing.assert_allclose(G, np.where(lost, series, ref), rtol=1e-12, atol=1e-200)
+    assert G[0, 0] == 1. and np.all(np.isfinite(G))
+    # a distance at which K_nu itself overflows: the limit (the oracle's product overflow * underflow is not a number there)
+    tiny = lgp.Matern(nu=nu).gram(np.array([0.]), np.array([1e-300, 1e-160])).to_host()
+    if nu >= 2:
+        np.testing.assert_allclose(tiny, 1., rtol=0, atol=1e-15)
+
+
+def test_matern_real_order_forms(lgp, rng):
+    """ the other entry points of the same core: several fields (compile-time and run-time field counts), the one-triangle grid
+    with its mirrored stores against the full grid, the pairs kernel (diagonal), fp32, nu = 0 (``_matern.py:74``: white in the
+    distance), output operations, and the GP on top """
+    for d in (1, 2, 3, 5):
+        x = rng.standard_normal((700, d)); y = rng.standard_normal((90, d))
+        k = lgp.Matern(nu=1.7, scale=1.9) * 2.5 + 0.25
+        r2 = ((x[:, None, :] - y[None, :, :]) ** 2).sum(-1)
+        ref = 2.5 * _matern_core(1.7, r2 / 1.9 ** 2) + 0.25
+        xs_, ys_ = _fields(x), _fields(y)
+        np.testing.assert_allclose(k.gram(xs_, ys_).to_host(), ref, rtol=1e-12)
+        S = k.gram(xs_, xs_).to_host()                              # n >= 512: lower tiles + mirrored stores
+        np.testing.assert_array_equal(S, S.T)
+        rs = ((x[:, None, :] - x[None, :, :]) ** 2).sum(-1)
+        np.testing.assert_allclose(S, 2.5 * _matern_core(1.7, rs / 1.9 ** 2) + 0.25, rtol=1e-12)
+        np.testing.assert_allclose(k.pairs(xs_[:90], ys_).to_host(), np.diag(ref[:90]), rtol=1e-12)
+    x = rng.uniform(-3, 3, 300).astype(np.float32)
+    G32 = lgp.Matern(nu=0.8).gram(x, x[:40])
+    assert G32.dtype == np.float32
+    np.testing.assert_allclose(G32.to_host(), oracle.Matern(nu=0.8)(x[:, None].astype(float), x[None, :40].astype(float)), rtol=0, atol=3e-6)
+    z = np.array([0., 1., 1., 2.5])
+    np.testing.assert_array_equal(lgp.Matern(nu=0).gram(z, z).to_host(), (z[:, None] == z[None, :]).astype(float))
     with pytest.raises(NotImplementedError):
-        lgp.Matern(nu=1.2)
+        lgp.Matern(nu=150.3)
+    with pytest.raises(AssertionError):
+        lgp.Matern(nu=-0.5)
+    xs = np.linspace(0, 4, 60); xt = np.linspace(0.1, 3.9, 7); yv = np.sin(xs)
+    post = {}
+    for mod in (lgp, oracle):
+        gp = mod.GP(mod.Matern(nu=2.2, scale=0.8), checkpos=False, checksym=False).addx(xs, 'a').addx(xt, 'b')
+        post[mod] = gp.predfromdata({'a': yv}, 'b', raw=True), gp.marginal_likelihood({'a': yv})
+    np.testing.assert_allclose(post[lgp][0][0], post[oracle][0][0], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(post[lgp][0][1], post[oracle][0][1], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(post[lgp][1], post[oracle][1], rtol=1e-9)
+
+
+@pytest.mark.parametrize('nu', [0.3, 1.0, 1.2, 2.7, 6.4])
+def test_matern_real_order_scale_tangent(lgp, rng, nu):
+    """ dK/dscale from the same pass (-c (x/2)^nu K_{nu-1}(x) dx/dscale, K_{nu-1} a by-product of the recurrence) against central
+    differences of the oracle, and through `Dual` hyperparameters """
+    x = rng.uniform(-3, 3, (130, 2)); y = rng.uniform(-3, 3, (70, 2))
+    s, h = 1.3, 1e-5
+    r2 = ((x[:, None, :] - y[None, :, :]) ** 2).sum(-1)
+    x, y = _fields(x), _fields(y)
+    K, dK = lgp.Matern(nu=nu, scale=s).gram_dscale(x, y)
+    core = lambda r2: _matern_core(nu, r2)
+    fd = (core(r2 / (s + h) ** 2) - core(r2 / (s - h) ** 2)) / (2 * h)
+    np.testing.assert_allclose(K.to_host(), core(r2 / s ** 2), rtol=1e-12)
+    np.testing.assert_allclose(dK.to_host(), fd, rtol=0, atol=2e-9)
+    k = lgp.Matern(nu=nu, scale=lgp.Dual(s, {'s': 1.})) * lgp.Dual(2., {'a': 1.})
+    G, tan = k.gram_tangents(x, y)
+    np.testing.assert_allclose(tan['s'].to_host(), 2 * fd, rtol=0, atol=4e-9)
+    np.testing.assert_allclose(tan['a'].to_host(), core(r2 / s ** 2), rtol=1e-12)

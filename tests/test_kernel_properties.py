@@ -26,7 +26,8 @@ def lgp(request):
 KERNELS = {
     'ExpQuad': ([{}], None, True, (-5, 5), 2),
     'Maternp': ([dict(p=0), dict(p=1), dict(p=2), dict(p=3), dict(p=7)], None, True, (-5, 5), 'p'),
-    'Matern': ([dict(nu=0.5), dict(nu=1.5), dict(nu=2.5)], None, True, (-5, 5), 0),
+    'Matern': ([dict(nu=v + 0.5) for v in range(5)] + [dict(nu=v + 0.49) for v in range(5)] + [dict(nu=v + 0.51) for v in range(5)]      # ref :483-490
+               + [dict(nu=v) for v in range(5)] + [dict(nu=v - 0.01) for v in range(1, 5)] + [dict(nu=v + 0.01) for v in range(5)], None, True, (-5, 5), 0),
     'GammaExp': ([dict(gamma=0.3), dict(gamma=1), dict(gamma=1.7), dict(gamma=2)], None, True, (-5, 5), 0),
     'Cauchy': ([dict(alpha=0.5, beta=1), dict(alpha=1, beta=2), dict(alpha=2, beta=2), dict(alpha=2, beta=0.3)], None, True, (-5, 5), 0),
     'Wendland': ([dict(k=0, alpha=1), dict(k=1, alpha=2), dict(k=2, alpha=2.5), dict(k=3, alpha=2)], 'alpha', True, (-5, 5), 0),
@@ -146,7 +147,7 @@ def test_stationary_normalized_continuous(lgp, rng, name, kw):
     x = scalar_x(rng, name)
     var = k(x, x)
     util.assert_allclose(var, 1, rtol=1e-14, atol=1e-15)
-    discontinuous = ((name == 'Cauchy' and kw.get('alpha', 2) < 1) or (name == 'GammaExp' and kw.get('gamma', 1) < 1) or name == 'White'
+    discontinuous = ((name == 'Cauchy' and kw.get('alpha', 2) < 1) or (name == 'GammaExp' and kw.get('gamma', 1) < 1) or name == 'White' or (name == 'Matern' and kw['nu'] < 0.5)
                      or (name == 'StationaryFracBrownian' and kw.get('H', 0.5) < 0.5))
     if not discontinuous:
         util.assert_allclose(k(np.zeros(1), np.full(1, 1e-15)), k(np.zeros(1), np.zeros(1)), rtol=1e-10)
