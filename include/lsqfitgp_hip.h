@@ -127,6 +127,7 @@ int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *to
 #define LGP_KERNEL_TAYLOR 27      /* _kernels/_basic.py:393-408  I0(2 sqrt(x y)) for x y >= 0, J0(2 sqrt(-x y)) otherwise; one variable                   */
 #define LGP_KERNEL_GIBBS 28       /* _kernels/_basic.py:156-185  sqrt(2 s s' / (s^2 + s'^2)) exp(-|x - y|^2 / (s^2 + s'^2)): the LAST coordinate row holds s = scalefun(x), evaluated by the caller; no loc / scale */
 #define LGP_KERNEL_MATERN 29      /* _kernels/_matern.py:56-76  2^(1-nu)/Gamma(nu) x^nu K_nu(x), x = sqrt(2 nu) r, real nu in [0, 100]: hpar = {nu}; p ignored.  K_nu by Temme's series / Steed's continued fraction + upward recurrence; nu = 0 is 1 where r = 0.  (Half-integer nu: LGP_KERNEL_MATERNP is the closed form.)  Has a scale tangent. */
+#define LGP_KERNEL_LAGTABLE 30    /* _kernels/_arma.py:31-63,180-189  values tabulated over the integer lag |x - y| (MA, AR): only through lgp_gram_lagtable / lgp_pairs_lagtable, which take the table */
 #define LGP_OP_MUL 0           /* kernel * c  (_Kernel/_alg.py:58-82)  */
 #define LGP_OP_ADD 1           /* kernel + c  (_Kernel/_alg.py:32-56)  */
 
@@ -152,6 +153,24 @@ int lgp_gram_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int npar, const floa
                            int has_loc, float loc, int has_scale, float scale,
                            int nops, const int *hops_code, const float *hops_val,
                            int symmetric, float *dout, size_t ldo);
+
+/* Stationary kernels of one integer variable given by a table of their values (the reference's discrete-time kernels MA and AR,
+ * _kernels/_arma.py:31-63 `cov.at[delta + len(w) - 1].get(mode='fill', fill_value=0)` and :180-189 `acf.at[delta].get(mode='fill',
+ * fill_value=nan)`): out[i][j] = dtable[|x_i - y_j|] where the lag is below ntable, `fill` elsewhere.  dtable: DEVICE array.  The
+ * lags are integers (the reference indexes with them); a fractional lag is truncated.  Points, loc / scale, output operations and
+ * `symmetric` as for lgp_gram_isotropic with d = 1. */
+int lgp_gram_lagtable_f64(lgp_ctx *ctx, const double *dtable, size_t ntable, double fill, const double *dx, size_t ldx, size_t n,
+                          const double *dy, size_t ldy, size_t m, int has_loc, double loc, int has_scale, double scale,
+                          int nops, const int *hops_code, const double *hops_val, int symmetric, double *dout, size_t ldo);
+int lgp_gram_lagtable_f32(lgp_ctx *ctx, const float *dtable, size_t ntable, float fill, const float *dx, size_t ldx, size_t n,
+                          const float *dy, size_t ldy, size_t m, int has_loc, float loc, int has_scale, float scale,
+                          int nops, const int *hops_code, const float *hops_val, int symmetric, float *dout, size_t ldo);
+int lgp_pairs_lagtable_f64(lgp_ctx *ctx, const double *dtable, size_t ntable, double fill, const double *dx, size_t ldx,
+                           const double *dy, size_t ldy, size_t npairs, int has_loc, double loc, int has_scale, double scale,
+                           int nops, const int *hops_code, const double *hops_val, double *dout);
+int lgp_pairs_lagtable_f32(lgp_ctx *ctx, const float *dtable, size_t ntable, float fill, const float *dx, size_t ldx,
+                           const float *dy, size_t ldy, size_t npairs, int has_loc, float loc, int has_scale, float scale,
+                           int nops, const int *hops_code, const float *hops_val, float *dout);
 
 /* BART correlation Gram matrix, the `altinput=True` path of _kernels/_bart.py:301-455,628-757 for one
  * recursion slice ("bracket") of `size` = 1, 2 or 3 probabilities, iterated `repeat` times (the folding of

@@ -13,8 +13,10 @@ call contract of ``lsqfitgp.CrossKernel`` (``src/lsqfitgp/_Kernel/_crosskernel.p
 All evaluation happens in ``csrc/gram.hip``.
 """
 
+import collections
 import ctypes
 import numbers
+import re
 
 import numpy
 from numpy.lib import recfunctions
@@ -754,6 +756,198 @@ class StationaryFracBrownian(_Stationary1D):
         self._par = (float(2 * H),)
 
 
+class _LagTable(Kernel):
+    """ stationary kernels of one INTEGER variable tabulated over the lag |x - y| (the reference's discrete-time kernels,
+    ``_kernels/_arma.py``): the host computes the table, the device looks it up pair by pair (``lgp_gram_lagtable``) """
+
+    _fill = 0.
+
+    def __init__(self, *, scale=None, loc=None, dim=None):
+        if scale is not None or loc is not None:
+            # (x - loc) / scale makes the lags floating point numbers, which the reference cannot index its table with either
+            raise TypeError(f'{type(self).__name__}: the inputs must be integers, scale and loc do not apply')
+        super().__init__(dim=dim)
+        self._table_memo = {}
+
+    def _copy(self, **kw):
+        new = super()._copy(**kw)
+        new._table_memo = {}
+        return new
+
+    def _table(self, maxlag):  # pragma: no cover
+        """ values at the lags 0 .. (at least) maxlag, or fewer when the kernel is defined by a fixed table """
+        raise NotImplementedError
+
+    def _result_dtype(self, x, y):
+        return numpy.dtype(numpy.float64)
+
+    def _ints(self, x):
+        x = numpy.asarray(self._select(x))
+        if x.dtype.names is not None:
+            cols = _leaf_columns(x.reshape(-1))
+            if len(cols) != 1:
+                raise ValueError(f'kernel called on type with dimensionality {len(cols)} > maxdim=1')
+            x = cols[0]
+        x = x.reshape(-1)
+        if not (numpy.issubdtype(x.dtype, numpy.integer) or numpy.issubdtype(x.dtype, numpy.bool_)):
+            raise TypeError(f'{type(self).__name__}: the inputs must be integers, got {x.dtype}')
+        return x.astype(numpy.int64)
+
+    def prepare(self, xs, *, ctx=None, dtype=None):
+        x = self._ints(xs)
+        return _PointBundle([x], len(x), numpy.float64)
+
+    def _device_args(self, xs, ys, ctx):
+        ctx = ctx or Context.default()
+        x = xs.parts[0] if isinstance(xs, _PointBundle) else self._ints(xs)
+        y = x if ys is xs else (ys.parts[0] if isinstance(ys, _PointBundle) else self._ints(ys))
+        maxlag = 0
+        if x.size and y.size:
+            maxlag = int(max(x.max() - y.min(), y.max() - x.min(), 0))
+        key = (id(ctx), maxlag)
+        tab = self._table_memo.get(key)
+        if tab is None:
+            host = numpy.ascontiguousarray(self._table(maxlag), float).reshape(-1)
+            tab = (DeviceArray.from_host(host, ctx=ctx) if host.size else None, host.size)
+            self._table_memo = {key: tab}
+        # the device works on the points as doubles: shift them so that the offsets stay exact whatever the absolute times
+        base = int(min(x.min(), y.min())) if x.size and y.size else 0
+        xd = DeviceArray.from_host((x - base).astype(float)[None, :], ctx=ctx)
+        yd = xd if y is x else DeviceArray.from_host((y - base).astype(float)[None, :], ctx=ctx)
+        return ctx, xd, yd, tab
+
+    def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
+        if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
+            raise NotImplementedError(f'derivatives of {type(self).__name__}')         # derivable=False
+        ctx, xd, yd, (tab, ntab) = self._device_args(xs, ys, ctx)
+        n, m = xd.shape[1], yd.shape[1]
+        if out is None:
+            out = DeviceArray.empty((n, m), numpy.float64, ctx)
+        if n == 0 or m == 0:
+            return out
+        f, F = _lib.fn('lgp_gram_lagtable', numpy.float64)
+        nops, codes, vals = _ops_arrays(self._outops, F)
+        _lib.check(f(ctx.handle, None if tab is None else tab.ptr, ntab, F(self._fill), xd.ptr, xd.ld, n, yd.ptr, yd.ld, m, 0, F(0), 0, F(1),
+                     nops, codes, vals, int(xd is yd), out.ptr, out.ld), 'lgp_gram_lagtable')
+        return out
+
+    def pairs(self, xs, ys, *, ctx=None):
+        ctx, xd, yd, (tab, ntab) = self._device_args(xs, ys, ctx)
+        n = xd.shape[1]
+        assert yd.shape[1] == n
+        out = DeviceArray.empty((n,), numpy.float64, ctx)
+        if n == 0:
+            return out
+        f, F = _lib.fn('lgp_pairs_lagtable', numpy.float64)
+        nops, codes, vals = _ops_arrays(self._outops, F)
+        _lib.check(f(ctx.handle, None if tab is None else tab.ptr, ntab, F(self._fill), xd.ptr, xd.ld, yd.ptr, yd.ld, n, 0, F(0), 0, F(1),
+                     nops, codes, vals, out.ptr), 'lgp_pairs_lagtable')
+        return out
+
+
+class MA(_LagTable):
+    """ Discrete moving average kernel, k(Δ) = Σ_{k ≥ |Δ|} w_k w_{k-|Δ|} on integer inputs: the autocovariance of the moving
+    average with weights w of white noise; ``norm=True`` makes the variance 1 (``_kernels/_arma.py:31-63``) """
+
+    def __init__(self, *, w=None, norm=False, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
+        w = numpy.asarray([] if w is None else w, float)
+        assert w.ndim == 1
+        acov = numpy.correlate(w, w, 'full')[len(w) - 1:] if len(w) else numpy.zeros(0)     # lags 0 .. len(w) - 1
+        if norm and len(w):
+            with numpy.errstate(invalid='ignore', divide='ignore'):      # all-zero weights: not a number, as in the reference
+                acov = acov / acov[0]
+        self._acov = acov
+
+    def _table(self, maxlag):
+        return self._acov                                              # beyond the last weight: 0 (`mode='fill', fill_value=0`)
+
+
+class AR(_LagTable):
+    """ Discrete autoregressive kernel on integer inputs: the autocovariance γ_m of  y_i = Σ_k φ_k y_{i-k} + ε_i  with unit
+    white noise ε (``_kernels/_arma.py:65-189``).  One of three parametrisations: ``phi`` (coefficients at lag 1..p) with
+    ``maxlag``; ``gamma`` (autocovariance at lag 0..p) with ``maxlag``; the roots of the characteristic polynomial
+    1 - Σ φ_k x^k as ``slnr`` (real roots: sign = sign of the root, magnitude = log |root|) and ``lnc`` (logarithms of the complex
+    roots, each standing for itself and its conjugate).  Lags above ``maxlag`` give nan; ``norm=True`` makes the variance 1.
+    The first p + 1 values come from the Yule-Walker equations; all three parametrisations then run the recursion
+    γ_m = Σ_k φ_k γ_{m-k} (the reference evaluates the roots' form through amplitudes of |m|^l x_j^-|m|, the same function) """
+
+    _fill = numpy.nan
+
+    def __init__(self, *, phi=None, gamma=None, maxlag=None, slnr=None, lnc=None, norm=False, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
+        given = (phi is not None, gamma is not None, maxlag is not None, slnr is not None, lnc is not None)
+        if given not in ((True, False, True, False, False), (False, True, True, False, False), (False, False, False, True, True)):
+            raise ValueError('invalid set of specified parameters')                                   # _arma.py:164-170
+        if slnr is not None:
+            phi = self.phi_from_roots(slnr, lnc)
+        elif phi is None:
+            phi = self.phi_from_gamma(gamma)
+        if gamma is None:
+            gamma = self.gamma_from_phi(phi)
+        gamma = numpy.asarray(gamma, float)
+        self._phi = numpy.asarray(phi, float)
+        with numpy.errstate(invalid='ignore', divide='ignore'):
+            self._gamma = gamma / gamma[0] if norm else gamma
+        self._maxlag = None if maxlag is None else int(maxlag)
+        if slnr is not None:
+            self._fill = 0.     # never used: the table covers every lag of the inputs
+
+    def _table(self, maxlag):
+        last = self._maxlag if self._maxlag is not None else maxlag
+        return self.extend_gamma(self._gamma, self._phi, max(0, last + 1 - len(self._gamma)))[:last + 1]
+
+    @staticmethod
+    def phi_from_gamma(gamma):
+        """ autoregressive coefficients at lag 1..p from the autocovariance at lag 0..p (Yule-Walker: the symmetric Toeplitz
+        system  Σ_k φ_k γ_|m-k| = γ_m, m = 1..p) """
+        gamma = numpy.asarray(gamma, float)
+        assert gamma.ndim == 1 and gamma.size >= 1
+        p = gamma.size - 1
+        if p == 0:
+            return numpy.empty(0)
+        lag = numpy.abs(numpy.arange(p)[:, None] - numpy.arange(p)[None, :])
+        return numpy.linalg.solve(gamma[lag], gamma[1:])
+
+    @staticmethod
+    def gamma_from_phi(phi):
+        """ autocovariance at lag 0..p from the coefficients, unit noise variance:  γ_m - Σ_k φ_k γ_|m-k| = δ_m0, m = 0..p """
+        phi = numpy.asarray(phi, float)
+        assert phi.ndim == 1
+        p = phi.size
+        A = numpy.eye(p + 1)
+        for m in range(p + 1):
+            for k in range(1, p + 1):
+                A[m, abs(m - k)] -= phi[k - 1]
+        rhs = numpy.zeros(p + 1)
+        rhs[0] = 1
+        return numpy.linalg.solve(A, rhs)
+
+    @staticmethod
+    def extend_gamma(gamma, phi, n):
+        """ ``n`` further lags of an autocovariance (at least p + 1 consecutive values given) by γ_m = Σ_k φ_k γ_{m-k} """
+        gamma = numpy.asarray(gamma, float)
+        phi = numpy.asarray(phi, float)
+        assert gamma.ndim == 1 and phi.ndim == 1 and gamma.size > phi.size
+        out = numpy.concatenate([gamma, numpy.zeros(max(0, int(n)))])
+        rev = phi[::-1]
+        for i in range(gamma.size, out.size):
+            out[i] = rev @ out[i - phi.size:i] if phi.size else 0.
+        return out
+
+    @staticmethod
+    def phi_from_roots(slnr, lnc):
+        """ the coefficients from the roots of 1 - Σ φ_k x^k:  Π_j (z - 1/x_j) = z^p - Σ_k φ_k z^(p-k) """
+        slnr = numpy.asarray(slnr, float)
+        lnc = numpy.asarray(lnc, complex)
+        assert slnr.ndim == lnc.ndim == 1
+        inv_real = numpy.copysign(numpy.exp(-numpy.abs(slnr)), slnr)
+        inv_cplx = numpy.exp(-lnc)
+        coef = numpy.atleast_1d(numpy.poly(numpy.sort(numpy.concatenate([inv_real, inv_cplx, inv_cplx.conj()]))))
+        assert numpy.all(numpy.abs(numpy.imag(coef)) <= 1e-4)
+        return -numpy.real(coef)[1:]
+
+
 class Celerite(_Stationary1D):
     """ Celerite kernel, k(Δ) = exp(-γ|Δ|) (cos Δ + B sin|Δ|), |B| <= γ (``_kernels/_celerite.py:34-52``) """
     _kind = _lib.LGP_KERNEL_CELERITE
@@ -1091,6 +1285,42 @@ class Categorical(_HostFactors):
 
 # ------------------------------------------------------------------------------
 # BART
+
+# What the reference's pattern  r'\s|[!«»"“”‘’/()\'?¡¿„‚<>,;.:-–—]'  (``_kernels/_basic.py:270``) matches, written out: white space, the
+# listed punctuation -- and, because ':-–' inside a character class is a RANGE, every character from ':' (U+003A) to the en
+# dash (U+2013), which contains all letters.  In effect only digits and a few symbols (# $ % & * +) make words.  Kept as it
+# is: a drop-in gives the reference's numbers.
+_BOW_DELIMITERS = re.compile('\\s|[!«»"“”‘’/()\'?¡¿„‚<>,;.—]|[\u003a-\u2013]')
+
+
+class BagOfWords(_HostFactors):
+    """ Bag of words kernel, k(x, y) = Σ_w c_w(x) c_w(y) with c_w(x) the number of times word w appears in the string x
+    (``_kernels/_basic.py:272-296``).  The counts are taken on the host; the Gram matrix is the product of the two count
+    matrices on the device.  Words are what is left between the reference's delimiters -- see `_BOW_DELIMITERS` """
+
+    def __init__(self, *, scale=None, loc=None, dim=None):
+        if scale is not None or loc is not None:
+            raise TypeError('BagOfWords: the inputs are strings, scale and loc do not apply')
+        super().__init__(dim=dim)
+
+    @staticmethod
+    def _bags(strings):
+        return [collections.Counter(w for w in _BOW_DELIMITERS.split(str(s)) if w != '') for s in strings]
+
+    def _factors(self, xs, ys):
+        xs, ys = self._transformed(xs), self._transformed(ys)
+        bx, by = self._bags(xs), self._bags(ys)
+        words = sorted(set().union(*bx) & set().union(*by)) if bx and by else []
+        col = {w: i for i, w in enumerate(words)}
+        U = numpy.zeros((len(bx), max(len(words), 1)))
+        V = numpy.zeros((len(by), max(len(words), 1)))
+        for M, bags in ((U, bx), (V, by)):
+            for i, bag in enumerate(bags):
+                for w, c in bag.items():
+                    if w in col:
+                        M[i, col[w]] = c
+        return U, V
+
 
 def _bart_brackets(npnt, reset, altinput=True, debug=False):
     """

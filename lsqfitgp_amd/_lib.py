@@ -53,6 +53,7 @@ LGP_KERNEL_CIRCULAR = 26
 LGP_KERNEL_TAYLOR = 27
 LGP_KERNEL_GIBBS = 28
 LGP_KERNEL_MATERN = 29
+LGP_KERNEL_LAGTABLE = 30
 LGP_OP_MUL = 0
 LGP_OP_ADD = 1
 LGP_EPS_AUTO_REL = 1
@@ -115,6 +116,10 @@ def _signatures():
             'lgp_transpose_' + suf: (c_int, [c_void_p, _P, _S, _P, _S, _S, _S]),
             'lgp_gram_isotropic_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, _P, _S, _S, _P, _S, _S,
                                                  c_int, F, c_int, F, c_int, POINTER(c_int), POINTER(F), c_int, _P, _S]),
+            'lgp_gram_lagtable_' + suf: (c_int, [c_void_p, _P, _S, F, _P, _S, _S, _P, _S, _S, c_int, F, c_int, F,
+                                                c_int, POINTER(c_int), POINTER(F), c_int, _P, _S]),
+            'lgp_pairs_lagtable_' + suf: (c_int, [c_void_p, _P, _S, F, _P, _S, _P, _S, _S, c_int, F, c_int, F,
+                                                 c_int, POINTER(c_int), POINTER(F), _P]),
             'lgp_gram_bart_' + suf: (c_int, [c_void_p, c_int, _P, _S, _P, _S, POINTER(c_int32), POINTER(F),
                                             c_int, c_int, POINTER(F), F, _P, _P, _S,
                                             c_int, POINTER(c_int), POINTER(F), _P, _S]),

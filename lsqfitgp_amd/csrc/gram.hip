@@ -59,6 +59,9 @@ struct IsoArgs {
   int flag;        // GammaExp: gamma == 2;  Cauchy: alpha == 2  (the branches that act on r2 itself);  MaternpDiff: odd total order
   int xy;          // 0; 1: kernels of x and y themselves, one variable: the core receives y in place of r2 and x in place of d0; 2: d0 = sum_f x_f y_f
   int posabs;      // input='posabs' of the reference (_Kernel/_isotropic.py:67-78): per field (|x - y| + eps)^2, the core takes the root
+  const T *table;  // LagTable: device array of the values at the integer lags 0 .. ntable - 1, `fill` beyond
+  int ntable;
+  T fill;
   int dord[8];     // ExpQuadDiff: total derivative order (x side + y side) along each of the first 8 fields
   OutOps<T> ops;
 };
@@ -232,6 +235,9 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0), T 
     const T x = a - floor(a);                            // delta % 1 for delta > 0
     const T t = fmin(x, T(1) - x);
     return (T(1) + g.par[0] * t / g.par[1]) * pow(fmax(T(1) - t / g.par[1], T(0)), g.par[0]);
+  } else if (g.kernel == LGP_KERNEL_LAGTABLE) {          // _kernels/_arma.py:31-63,180-189: a table over the integer lag |x - y|
+    const T a = fabs(d0);
+    return a < (T)g.ntable ? g.table[(long)a] : g.fill;  // (a NaN lag compares false: the fill value)
   } else if (g.kernel == LGP_KERNEL_LINEAR) {            // _kernels/_basic.py:76-91: d0 = sum_f x_f y_f
     return d0;
   } else if (g.kernel == LGP_KERNEL_WIENER) {            // _kernels/_randomwalk.py:26-41 (from here on: x = d0, y = r2, one variable)
@@ -568,12 +574,13 @@ __global__ void __launch_bounds__(256) gram_iso_pairs_kernel(const IsoArgs<T> g)
 template <typename T>
 int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, int d, const T *dx, size_t ldx, size_t n, const T *dy, size_t ldy, size_t m,
                     int has_loc, T loc, int has_scale, T scale, int nops, const int *hops_code, const T *hops_val, T *dout,
-                    size_t ldo, bool pairs = false, T *ddsc = nullptr, bool symmetric = false) {
+                    size_t ldo, bool pairs = false, T *ddsc = nullptr, bool symmetric = false, const T *dtable = nullptr, size_t ntable = 0, T fill = T(0)) {
   LGP_REQUIRE(ctx != nullptr, "null context");
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_MATERN, "unknown isotropic kernel");
+  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_LAGTABLE, "unknown isotropic kernel");
+  LGP_REQUIRE(kernel != LGP_KERNEL_LAGTABLE || ((dtable != nullptr || ntable == 0) && ntable < (1u << 30) && ddsc == nullptr), "LagTable takes a device table (lgp_gram_lagtable), no scale tangent");
   LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_GIBBS || kernel == LGP_KERNEL_MATERN || d == 1, "this kernel is a function of one variable (maxdim = 1)");
   LGP_REQUIRE(kernel != LGP_KERNEL_GIBBS || (d >= 2 && !has_loc && !has_scale), "Gibbs takes the per-point scales as the last coordinate row, inputs already transformed");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
@@ -604,6 +611,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   for (int k = p - 1; k >= 0; --k) g.coef[pos++] = (T)((double)(p - k) / ((double)(2 * p - k) * (double)(k + 1)));
   g.twop1 = (T)(2 * p + 1);
   g.par[0] = g.par[1] = g.par[2] = T(0);
+  g.table = dtable; g.ntable = (int)ntable; g.fill = fill;
   g.flag = 0;
   g.posabs = posabs ? 1 : 0;
   g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : ((kernel >= LGP_KERNEL_WIENER && kernel <= LGP_KERNEL_WIENERINTEGRAL) || kernel == LGP_KERNEL_TAYLOR ? 1 : (kernel == LGP_KERNEL_GIBBS ? 3 : 0));
@@ -955,6 +963,7 @@ int gram_reg_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.twop1 = (T)(2 * p + 1);
   g.posabs = 0;
   g.xy = 0;
+  g.table = nullptr; g.ntable = 0; g.fill = T(0);
   for (int f = 0; f < 8; ++f) g.dord[f] = 0;
   g.par[0] = g.par[1] = g.par[2] = T(0);
   g.flag = 0;
@@ -1499,6 +1508,31 @@ extern "C" int lgp_gram_bart_f64(lgp_ctx *ctx, int p, const int32_t *dix, size_t
                                  const int *hops_code, const double *hops_val, double *dout, size_t ldo) {
   return gram_bart_launch<double>(ctx, p, dix, n, diy, m, hnsplits, hweights, size, repeat, hprobs, gamma, dgamma_mat, dpsi, npsi, nops,
                                   hops_code, hops_val, dout, ldo);
+}
+
+extern "C" int lgp_gram_lagtable_f64(lgp_ctx *ctx, const double *dtable, size_t ntable, double fill, const double *dx, size_t ldx, size_t n, const double *dy,
+                                     size_t ldy, size_t m, int has_loc, double loc, int has_scale, double scale, int nops, const int *hops_code,
+                                     const double *hops_val, int symmetric, double *dout, size_t ldo) {
+  return gram_iso_launch<double>(ctx, LGP_KERNEL_LAGTABLE, 0, 0, nullptr, 1, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val,
+                                 dout, ldo, false, nullptr, symmetric != 0, dtable, ntable, fill);
+}
+extern "C" int lgp_gram_lagtable_f32(lgp_ctx *ctx, const float *dtable, size_t ntable, float fill, const float *dx, size_t ldx, size_t n, const float *dy,
+                                     size_t ldy, size_t m, int has_loc, float loc, int has_scale, float scale, int nops, const int *hops_code,
+                                     const float *hops_val, int symmetric, float *dout, size_t ldo) {
+  return gram_iso_launch<float>(ctx, LGP_KERNEL_LAGTABLE, 0, 0, nullptr, 1, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val,
+                                dout, ldo, false, nullptr, symmetric != 0, dtable, ntable, fill);
+}
+extern "C" int lgp_pairs_lagtable_f64(lgp_ctx *ctx, const double *dtable, size_t ntable, double fill, const double *dx, size_t ldx, const double *dy, size_t ldy,
+                                      size_t npairs, int has_loc, double loc, int has_scale, double scale, int nops, const int *hops_code,
+                                      const double *hops_val, double *dout) {
+  return gram_iso_launch<double>(ctx, LGP_KERNEL_LAGTABLE, 0, 0, nullptr, 1, dx, ldx, npairs, dy, ldy, npairs, has_loc, loc, has_scale, scale, nops, hops_code,
+                                 hops_val, dout, npairs, true, nullptr, false, dtable, ntable, fill);
+}
+extern "C" int lgp_pairs_lagtable_f32(lgp_ctx *ctx, const float *dtable, size_t ntable, float fill, const float *dx, size_t ldx, const float *dy, size_t ldy,
+                                      size_t npairs, int has_loc, float loc, int has_scale, float scale, int nops, const int *hops_code,
+                                      const float *hops_val, float *dout) {
+  return gram_iso_launch<float>(ctx, LGP_KERNEL_LAGTABLE, 0, 0, nullptr, 1, dx, ldx, npairs, dy, ldy, npairs, has_loc, loc, has_scale, scale, nops, hops_code,
+                                hops_val, dout, npairs, true, nullptr, false, dtable, ntable, fill);
 }
 
 // ---- elementwise ("pairs") forms: out[i] = k(x_i, y_i) ------------------------------------------------

@@ -12,11 +12,13 @@ Follows (reference paths):
 ``_jaxext/_fasthash.py:56-102`` (fasthash64/32).
 """
 
+import collections
 import numbers
+import re
 
 import numpy
 from numpy.lib import recfunctions
-from scipy import special
+from scipy import linalg, special
 
 
 # --------------------------------------------------------------------------
@@ -470,6 +472,145 @@ def Taylor(*, scale=None, loc=None, dim=None):
         val = 2 * numpy.sqrt(numpy.abs(mul))
         return numpy.where(mul >= 0, special.i0(val), special.j0(val))
     return Kernel(_onevariable(core, -numpy.inf, numpy.inf), scale=scale, loc=loc, dim=dim)
+
+
+def MA(*, w=None, norm=False, scale=None, loc=None, dim=None):
+    """ ``_kernels/_arma.py:31-63``: cov = convolve(w, reversed w), looked up at delta + len(w) - 1, 0 beyond """
+    w = numpy.asarray([] if w is None else w, float)
+    assert w.ndim == 1
+
+    def core(delta):
+        assert numpy.issubdtype(delta.dtype, numpy.integer), 'the inputs must be integers'
+        if not len(w):
+            return numpy.zeros(delta.shape)
+        cov = numpy.convolve(w, w[::-1])
+        if norm:
+            with numpy.errstate(invalid='ignore', divide='ignore'):
+                cov = cov / cov[len(w) - 1]
+        idx = delta + len(w) - 1
+        return numpy.where(idx < len(cov), cov[numpy.minimum(idx, len(cov) - 1)], 0.)
+    return Kernel(_stationary1d(core, 'abs'), scale=scale, loc=loc, dim=dim)
+
+
+class AR:
+    """ ``_kernels/_arma.py:65-640``: the three parametrisations; with roots, the reference's own evaluation -- amplitudes of
+    the mixed power-exponentials |m|^l x_j^-|m| fitted to the first p + 1 Yule-Walker values (``:226-232,316-383,484-507``) """
+
+    def __new__(cls, *, phi=None, gamma=None, maxlag=None, slnr=None, lnc=None, norm=False, scale=None, loc=None, dim=None):
+        given = (phi is not None, gamma is not None, maxlag is not None, slnr is not None, lnc is not None)
+        if given not in ((True, False, True, False, False), (False, True, True, False, False), (False, False, False, True, True)):
+            raise ValueError('invalid set of specified parameters')
+        if slnr is not None:
+            slnr, lnc = cls._process_roots(slnr, lnc)
+            ph = cls.phi_from_roots(slnr, lnc)
+            gam = cls.gamma_from_phi(ph)
+            if norm:
+                gam = gam / gam[0]
+            ampl = cls.ampl_from_roots(slnr, lnc, gam)
+
+            def core(delta):
+                assert numpy.issubdtype(delta.dtype, numpy.integer), 'the inputs must be integers'
+                return (cls._columns(slnr, lnc, delta.reshape(-1)) @ ampl).reshape(delta.shape)
+        else:
+            ph = cls.phi_from_gamma(gamma) if phi is None else numpy.asarray(phi, float)
+            gam = cls.gamma_from_phi(ph) if gamma is None else numpy.asarray(gamma, float)
+            if norm:
+                with numpy.errstate(invalid='ignore', divide='ignore'):
+                    gam = gam / gam[0]
+            acf = cls.extend_gamma(gam, ph, maxlag + 1 - len(gam))
+
+            def core(delta):
+                assert numpy.issubdtype(delta.dtype, numpy.integer), 'the inputs must be integers'
+                return numpy.where(delta < len(acf), acf[numpy.minimum(delta, len(acf) - 1)], numpy.nan)
+        return Kernel(_stationary1d(core, 'abs'), scale=scale, loc=loc, dim=dim)
+
+    @staticmethod
+    def _process_roots(slnr, lnc):
+        slnr = numpy.sort(numpy.asarray(slnr, float))
+        lnc = numpy.asarray(lnc, complex)
+        imag = numpy.abs(lnc.imag) % (2 * numpy.pi)
+        imag = numpy.where(imag > numpy.pi, 2 * numpy.pi - imag, imag)
+        return slnr, numpy.sort(lnc.real + 1j * imag)
+
+    @staticmethod
+    def phi_from_gamma(gamma):
+        gamma = numpy.asarray(gamma, float)
+        t, b = gamma[:-1], gamma[1:]
+        return linalg.solve_toeplitz(t, b) if t.size else numpy.empty(0)
+
+    @staticmethod
+    def gamma_from_phi(phi):
+        phi = numpy.asarray(phi, float)
+        p = len(phi)
+        m = numpy.arange(p + 1)[:, None]
+        n = m.T
+        padded = numpy.pad(phi, (1, 1))
+        a = numpy.eye(p + 1) - (padded[numpy.clip(m + n, 0, p + 1)] + padded[numpy.clip(m - n, 0, p + 1)]) / numpy.where(n, 1, 2)
+        b = numpy.zeros(p + 1)
+        b[0] = 1
+        return numpy.linalg.solve(a, b)
+
+    @staticmethod
+    def extend_gamma(gamma, phi, n):
+        vals = list(numpy.asarray(gamma, float))
+        phi = numpy.asarray(phi, float)
+        for _ in range(max(0, n)):
+            vals.append(float(sum(phi[k] * vals[-1 - k] for k in range(len(phi)))))
+        return numpy.array(vals)
+
+    @staticmethod
+    def phi_from_roots(slnr, lnc):
+        r = numpy.copysign(numpy.exp(-numpy.abs(slnr)), slnr)
+        c = numpy.exp(-lnc)
+        coef = numpy.atleast_1d(numpy.poly(numpy.sort(numpy.concatenate([r, c, c.conj()]))))
+        return -coef.real[1:]
+
+    @staticmethod
+    def _columns(slnr, lnc, lag):
+        """ the basis functions at the given lags (``_gamma_from_ampl_matmul``, without its per-column normalisation) """
+        lag = numpy.asarray(lag, float)
+        cols = [numpy.where(lag, 0., 1.)]
+        with numpy.errstate(divide='ignore'):
+            llag = numpy.log(lag)
+        prev, repeat = None, 0
+        for root in slnr:
+            repeat = repeat + 1 if root == prev else 0
+            prev = root
+            lc = -abs(root) * lag + (repeat * llag if repeat else 0.)
+            cols.append(numpy.sign(root) ** lag * numpy.exp(lc))
+        prev, repeat = None, 0
+        for root in lnc:
+            repeat = repeat + 1 if root == prev else 0
+            prev = root
+            col = numpy.exp(-root * lag + (repeat * llag if repeat else 0.))
+            cols.append(col.real)
+            cols.append(-col.imag if root.imag else col.real * lag)
+        return numpy.stack(cols, axis=-1)
+
+    @classmethod
+    def ampl_from_roots(cls, slnr, lnc, gamma):
+        mat = cls._columns(slnr, lnc, numpy.arange(len(gamma)))
+        return numpy.linalg.lstsq(mat, gamma, rcond=None)[0]
+
+
+_bow_regexp = re.compile('\\s|[!«»"“”‘’/()\'?¡¿„‚<>,;.\u003a-\u2013—]')      # ``_basic.py:270``; ':-–' there is a range (U+003A..U+2013)
+
+
+def BagOfWords(*, scale=None, loc=None, dim=None):
+    """ ``_kernels/_basic.py:272-296`` """
+    def one(x, y):
+        xbag = collections.Counter(_bow_regexp.split(str(x)))
+        ybag = collections.Counter(_bow_regexp.split(str(y)))
+        xbag[''] = 0
+        ybag[''] = 0
+        return sum(xbag[k] * ybag[k] for k in set(xbag) & set(ybag))
+
+    def core(x, y):
+        if x.dtype.names is not None:
+            name = x.dtype.names[0]
+            x, y = x[name], y[name]
+        return numpy.vectorize(one, otypes=[float])(x, y)
+    return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
 def Rescaling(*, stdfun=None, scale=None, loc=None, dim=None):

@@ -847,3 +847,55 @@ def test_matern_real_order_scale_tangent(lgp, rng, nu):
     G, tan = k.gram_tangents(x, y)
     np.testing.assert_allclose(tan['s'].to_host(), 2 * fd, rtol=0, atol=4e-9)
     np.testing.assert_allclose(tan['a'].to_host(), core(r2 / s ** 2), rtol=1e-12)
+
+
+def test_discrete_time_kernels_against_oracle(lgp, rng):
+    """ MA and AR (``lgp_gram_lagtable``: a device look-up over the integer lag): full grid, the one-triangle grid (n >= 512), the
+    pairs form, output operations, large absolute times, and a GP with them """
+    t = rng.integers(0, 400, 700)
+    s = rng.integers(-50, 500, 90)
+    cases = [(lgp.MA(w=[1, 2, 3, 4, 5]), oracle.MA(w=[1, 2, 3, 4, 5])),
+             (lgp.MA(w=rng.standard_normal(30), norm=True), None),
+             (lgp.AR(phi=[0.5, -0.3, 0.1], maxlag=600), oracle.AR(phi=[0.5, -0.3, 0.1], maxlag=600)),
+             (lgp.AR(gamma=[1, 0.5, 0.25], maxlag=300, norm=True), oracle.AR(gamma=[1, 0.5, 0.25], maxlag=300, norm=True)),
+             (lgp.AR(slnr=[1 / 10, 1 / 10, -1 / 2], lnc=[1 / 10 + 1j, 1 / 2 + 2j]), oracle.AR(slnr=[1 / 10, 1 / 10, -1 / 2], lnc=[1 / 10 + 1j, 1 / 2 + 2j]))]
+    for kd, ko in cases:
+        if ko is None:
+            continue
+        ref = ko(t[:, None], s[None, :])
+        scale = np.nanmax(np.abs(ref))
+        got = kd.gram(t, s).to_host()
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+        np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(ref), rtol=0, atol=1e-12 * scale)
+        S = kd.gram(t, t).to_host()
+        np.testing.assert_array_equal(S, S.T)
+        np.testing.assert_allclose(S, ko(t[:, None], t[None, :]), rtol=0, atol=1e-12 * scale)
+        np.testing.assert_allclose((kd * 3. + 0.5).pairs(t[:90], s).to_host(), 3. * np.diag(ref[:90]) + 0.5, rtol=0, atol=1e-12 * scale, equal_nan=True)
+        big = 2 ** 40
+        np.testing.assert_array_equal(kd.gram(t + big, s + big).to_host(), got)
+    x = np.arange(200)
+    y = np.cumsum(rng.standard_normal(200)) * 0.1
+    post = {}
+    for mod in (lgp, oracle):
+        gp = mod.GP(mod.AR(phi=[0.9], maxlag=300) * 0.1 + mod.MA(w=[1., 0.4]) * 0.01, checkpos=False, checksym=False).addx(x[:150], 'a').addx(x[150:], 'b')
+        post[mod] = gp.predfromdata({'a': y[:150]}, 'b', raw=True), gp.marginal_likelihood({'a': y[:150]})
+    np.testing.assert_allclose(post[lgp][0][0], post[oracle][0][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(post[lgp][0][1], post[oracle][0][1], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(post[lgp][1], post[oracle][1], rtol=1e-10)
+    with pytest.raises(TypeError):
+        lgp.MA(w=[1, 1], scale=2.)
+    with pytest.raises(TypeError):
+        lgp.MA(w=[1, 1]).gram(np.linspace(0, 1, 5), np.linspace(0, 1, 5))
+
+
+def test_bag_of_words_against_oracle(lgp, rng):
+    """ ``BagOfWords``: counts on the host, the product of the count matrices on the device """
+    vocab = np.array(['12', '7', '3', '100', '44', '#', '$', '+', 'lorem', 'ipsum', 'a1b2'])
+    x = np.array([' '.join(rng.choice(vocab, 12)) for _ in range(60)])
+    y = np.array([', '.join(rng.choice(vocab, 5)) for _ in range(25)])
+    k = lgp.BagOfWords() * 0.5
+    np.testing.assert_allclose(k.gram(x, y).to_host(), 0.5 * oracle.BagOfWords()(x[:, None], y[None, :]), rtol=1e-15)
+    np.testing.assert_allclose(k(x[:25], y), 0.5 * oracle.BagOfWords()(x[:25], y), rtol=1e-15)
+    gp = lgp.GP(lgp.BagOfWords() * 2., checkpos=False).addx(x, 'x').addx(y, 'y')
+    np.testing.assert_allclose(gp.prior('x', raw=True), 2 * oracle.BagOfWords()(x[:, None], x[None, :]), rtol=1e-14)
+    np.testing.assert_allclose(gp.prior(raw=True)['x', 'y'], 2 * oracle.BagOfWords()(x[:, None], y[None, :]), rtol=1e-14)

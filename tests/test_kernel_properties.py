@@ -179,4 +179,103 @@ def test_every_kernel_is_listed(lgp):
         assert all(hasattr(lgp, n) for n in KERNELS)
         return
     exported = {n for n in dir(lgp) if isinstance(getattr(lgp, n), type) and issubclass(getattr(lgp, n), lgp.Kernel) and n not in ('Kernel', 'BART', 'Categorical')}
-    assert exported == set(KERNELS)
+    assert exported == set(KERNELS) | {n for n, _ in DISCRETE}                  # (the kernels of integers and of strings: checked below)
+
+
+# ---- kernels whose inputs are not real numbers: the discrete-time MA / AR (integers) and BagOfWords (strings) -------------------
+
+_rng_ma = np.random.default_rng([2023, 8, 25, 0, 25])                         # ref tests/kernels/test_kernels.py:754
+DISCRETE = ([('MA', dict(w=w)) for w in ([], [0], [1], [1, 1], [1, -1], [2, 1], [1, 2, 3, 4, 5], _rng_ma.standard_normal(30))]      # ref :756-761
+            + [('AR', dict(phi=phi, maxlag=100)) for phi in ([], [0], [-0.5], [0.5], [0.9], [-0.9], [0.5, 0], [0, 0.5], 3 * [0] + [0.5])]   # ref :769-770
+            + [('AR', dict(gamma=g, maxlag=100)) for g in ([0], [1], [1, 0], [1, 0.5], [1, 0.5, 0.25], [1, -0.9])]                  # ref :771-772
+            + [('AR', dict(slnr=r, lnc=c)) for r, c in (([], []), ([1 / 10], []), ([1 / 2], []), ([1 / 10, 1 / 2], []), ([1 / 10, 1 / 10], []),
+                                                       ([1 / 10, 1 / 10, -1 / 2], []), ([], [1 / 10 + 1j]), ([], [1 / 2 + 1j]),
+                                                       ([], [1 / 10 + 1j, 1 / 2 + 2j]), ([], [1 / 10 + 1j, 1 / 10 + 2j]),
+                                                       ([1 / 10], [1 / 2 + 1j]), ([-1 / 10, 1 / 3], [1 / 10 + 1j, 1 / 2 + 0.5j]))]      # ref :773-790
+            + [('BagOfWords', {})])
+DISCRETE_IDS = [f'{n}-{i}' for i, (n, _) in enumerate(DISCRETE)]
+
+LIPSUM = """Duis mollis 12 est non 7 commodo luctus, nisi erat 12 porttitor ligula 3 eget lacinia 44 odio sem nec elit 7 7 Curabitur
+blandit # tempus porttitor $ Sed posuere 100 consectetur est at 3 lobortis % Cras mattis & consectetur purus + sit amet 12"""
+
+
+def discrete_x(rng, name, size=100):
+    if name == 'BagOfWords':
+        words = np.array(LIPSUM.split())
+        return np.array([' '.join(rng.choice(words, 10)) for _ in range(30)])
+    return rng.integers(0, 100, size)                                           # ref :763-765
+
+
+@pytest.mark.parametrize('name,kw', DISCRETE, ids=DISCRETE_IDS)
+def test_discrete_positive_symmetric_stationary(lgp, rng, name, kw):
+    """ ref `Base` / `Stationary` checks over the kernels of integers and strings: positive semidefinite and symmetric, the
+    off-diagonal blocks transposes of each other, shift invariance of the discrete-time kernels, normalisation """
+    k = getattr(lgp, name)(**kw)
+    x = discrete_x(rng, name)
+    cov = k(x[None, :], x[:, None])
+    assert cov.shape == (len(x), len(x)) and np.all(np.isfinite(cov))
+    scale = max(np.max(np.abs(cov)), 1e-300)
+    check_sym_and_psd(cov / scale, eps=(200 if name == 'AR' else 1) * np.finfo(float).eps)
+    check_sym_and_psd((k * 2.5 + 0.3)(x[None, :], x[:, None]) / scale, eps=(200 if name == 'AR' else 1) * np.finfo(float).eps)
+    h = len(x) // 2
+    util.assert_allclose(k(x[:h, None], x[None, h:]), k(x[None, h:], x[:h, None]), atol=1e-10 * scale)
+    if hasattr(k, 'gram'):
+        util.assert_allclose(k.gram(x, x).to_host(), cov, rtol=1e-13, atol=1e-14 * scale)
+        util.assert_allclose(k.gram(x[:h], x[h:]).to_host(), k.gram(x[h:], x[:h]).to_host().T, atol=1e-10 * scale)
+    if name != 'BagOfWords':
+        util.assert_allclose(k((x + 1000)[None, :], (x + 1000)[:, None]), cov, atol=1e-13 * scale)      # stationary (ref :296-301)
+        kn = getattr(lgp, name)(**kw, norm=True)
+        var = kn(x, x)
+        if np.all(np.isfinite(var)) and scale > 1e-300 and not (name == 'MA' and not np.any(kw['w'])) and not (name == 'AR' and 'gamma' in kw and kw['gamma'][0] == 0):
+            util.assert_allclose(var, 1, rtol=1e-13)
+        with pytest.raises((TypeError, AssertionError, IndexError)):
+            k(x.astype(float)[None, :] + 0.5, x.astype(float)[:, None])                                      # the inputs must be integers
+    # structured points with one field
+    xs = np.empty(len(x), [('t', x.dtype)])
+    xs['t'] = x
+    util.assert_allclose(k(xs[None, :], xs[:, None]), cov, atol=1e-13 * scale)
+
+
+def test_ar_parametrisations_agree(lgp, rng):
+    """ the three parametrisations of AR describe the same process (``_kernels/_arma.py:141-160``), and AR(1) / MA(1) have the
+    textbook autocovariances """
+    x = rng.integers(0, 60, 80)
+    phi = lgp.AR.phi_from_roots(np.sort(np.array([0.2, -0.4])), np.array([0.3 + 1.1j]))
+    assert phi.shape == (4,)
+    gamma = lgp.AR.gamma_from_phi(phi)
+    util.assert_allclose(lgp.AR.phi_from_gamma(gamma), phi, rtol=1e-10, atol=1e-12)
+    a = lgp.AR(slnr=[0.2, -0.4], lnc=[0.3 + 1.1j])(x[:, None], x[None, :])
+    b = lgp.AR(phi=phi, maxlag=60)(x[:, None], x[None, :])
+    c = lgp.AR(gamma=gamma, maxlag=60)(x[:, None], x[None, :])
+    util.assert_allclose(b, a, rtol=1e-10, atol=1e-12)
+    util.assert_allclose(c, a, rtol=1e-10, atol=1e-12)
+    lag = np.abs(x[:, None] - x[None, :])
+    util.assert_allclose(lgp.AR(phi=[0.7], maxlag=60)(x[:, None], x[None, :]), 0.7 ** lag / (1 - 0.49), rtol=1e-12)
+    util.assert_allclose(lgp.MA(w=[1, 0.5])(x[:, None], x[None, :]), np.where(lag == 0, 1.25, np.where(lag == 1, 0.5, 0.)), rtol=1e-15)
+    # the autocovariance against a long moving-average representation of the same process (an independent route)
+    psi = np.zeros(4000)
+    psi[0] = 1
+    for i in range(1, len(psi)):
+        psi[i] = sum(phi[k] * psi[i - 1 - k] for k in range(min(len(phi), i)))
+    brute = np.array([psi[:len(psi) - m] @ psi[m:] for m in range(61)])
+    util.assert_allclose(a, brute[lag], rtol=1e-9)
+    # lags beyond maxlag are not numbers; bad parameter sets are refused
+    far = lgp.AR(phi=[0.5], maxlag=5)(np.array([0]), np.array([9]))
+    assert np.isnan(far).all()
+    for bad in (dict(phi=[0.5]), dict(phi=[0.5], gamma=[1, 0.5], maxlag=3), dict(slnr=[0.1]), dict()):
+        with pytest.raises(ValueError):
+            lgp.AR(**bad)
+
+
+def test_bag_of_words_counts(lgp):
+    """ ``_kernels/_basic.py:272-296`` with the delimiters the reference really has: its pattern contains the range ':'..'–', so
+    letters separate words too and only digits (and # $ % & * +) make them """
+    x = np.array(['12 7 12', 'a12b7', '7;7;7 +', '', 'word words'])
+    k = lgp.BagOfWords()
+    cov = k(x[:, None], x[None, :])
+    expect = np.array([[5., 3., 3., 0., 0.],          # {12: 2, 7: 1}
+                       [3., 2., 3., 0., 0.],          # {12: 1, 7: 1}
+                       [3., 3., 10., 0., 0.],         # {7: 3, +: 1}
+                       [0., 0., 0., 0., 0.],
+                       [0., 0., 0., 0., 0.]])
+    util.assert_allclose(cov, expect)
