@@ -756,6 +756,29 @@ class StationaryFracBrownian(_Stationary1D):
         self._par = (float(2 * H),)
 
 
+class Color(_Stationary1D):
+    """ Colored noise kernel, k(Δ) = (n - 1) Re E_n(-iΔ) = (n - 1) ∫_1^∞ cos(ωΔ) / ω^n dω, integer n >= 2: a power spectrum
+    1/ω^n truncated below ω = 1 (``_kernels/_spectral.py:70-111``).  E_n on the device by its power series and its continued
+    fraction (the reference's closed form and asymptotic series meet at a knee where both have lost digits, 1e-4 at n = 20) """
+    _kind = _lib.LGP_KERNEL_COLOR
+
+    def __init__(self, *, n=2, scale=None, loc=None, dim=None):
+        assert int(n) == n and n >= 2, n                                   # _spectral.py:110
+        super().__init__(scale=scale, loc=loc, dim=dim)
+        self._p = int(n)
+
+
+class Pink(_Stationary1D):
+    """ Pink noise kernel, k(Δ) = (Ci(Δ (1 + dw)) - Ci(Δ)) / log(1 + dw): a power spectrum 1/ω between 1 and 1 + dw
+    (``_kernels/_spectral.py:41-66``); where Δ dw is below sqrt(eps), cos(Δ (1 + dw/2)) """
+    _kind = _lib.LGP_KERNEL_PINK
+
+    def __init__(self, *, dw=1, scale=None, loc=None, dim=None):
+        assert 0 <= dw < numpy.inf, dw
+        super().__init__(scale=scale, loc=loc, dim=dim)
+        self._par = (float(dw),)
+
+
 class _LagTable(Kernel):
     """ stationary kernels of one INTEGER variable tabulated over the lag |x - y| (the reference's discrete-time kernels,
     ``_kernels/_arma.py``): the host computes the table, the device looks it up pair by pair (``lgp_gram_lagtable``) """

@@ -54,6 +54,8 @@ LGP_KERNEL_TAYLOR = 27
 LGP_KERNEL_GIBBS = 28
 LGP_KERNEL_MATERN = 29
 LGP_KERNEL_LAGTABLE = 30
+LGP_KERNEL_COLOR = 31
+LGP_KERNEL_PINK = 32
 LGP_OP_MUL = 0
 LGP_OP_ADD = 1
 LGP_EPS_AUTO_REL = 1

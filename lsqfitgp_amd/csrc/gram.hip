@@ -158,6 +158,68 @@ __device__ __forceinline__ T matern_real_of(const IsoArgs<T> &g, T r2, T *xdk) {
   return T(k);
 }
 
+// Re E_n(-i x), x > 0, n >= 1: the generalised exponential integral on the imaginary axis (Color: (n - 1) Re E_n(-i x),
+// _kernels/_spectral.py:73-111; Pink through Ci(x) = -Re E_1(-i x), :41-66).  For x <= 2 the power series of E_n (DLMF 8.19.8 /
+// 6.6.6 for n = 1): sum_{m != n-1} -(i x)^m / ((m - n + 1) m!) + (i x)^(n-1) / (n-1)! (psi(n) - ln x + i pi/2), real part; above,
+// the continued fraction e^(-z) / (z + n - 1 n / (z + n + 2 - 2 (n + 1) / (z + n + 4 - ...))) at z = -i x by the modified Lentz
+// recurrence in complex arithmetic (92 steps at x = 2, 8 at x = 100).  The two agree to 4e-15 where they overlap (x in [1, 4],
+// n = 1 .. 50); psi(n) comes from the host.  (The reference switches between the closed form 8.19.7 and a 20-term asymptotic
+// series at a "knee" where both have lost digits -- 1e-4 at n = 20; the values here are good to the last few bits everywhere.)
+__device__ inline double expn_imag_re(int n, double psin, double x) {
+  const int nm1 = n - 1;
+  if (x <= 2.) {
+    const double a = psin - log(x), b = 1.5707963267948966;
+    const int r = nm1 & 3;
+    const double lead = r == 0 ? a : (r == 1 ? -b : (r == 2 ? -a : b));    // Re(i^(n-1) (a + i b))
+    double ans = nm1 == 0 ? lead : 1. / (double)nm1, fact = 1.;
+    for (int m = 1; m < 200; ++m) {
+      fact *= x / (double)m;
+      if (m == nm1) ans += lead * fact;
+      else if ((m & 1) == 0) ans -= ((m & 2) ? -fact : fact) / (double)(m - nm1);
+      if ((m & 1) == 0 && fact * (1. + fabs(lead)) < 1e-17 * fabs(ans)) break;
+    }
+    return ans;
+  }
+  // complex Lentz: b = z + n, c = 1 / tiny, d = 1 / b, h = d; a_i = -i (n - 1 + i), b += 2
+  double br = (double)n, bi = -x;
+  double den = br * br + bi * bi;
+  double dr = br / den, di = -bi / den;
+  double cr = 1e300, ci = 0.;
+  double hr = dr, hi = di;
+  for (int i = 1; i < 400; ++i) {
+    const double ai = -(double)i * (double)(nm1 + i);
+    br += 2.;
+    // d = 1 / (a d + b)
+    const double tr = ai * dr + br, ti = ai * di + bi;
+    den = tr * tr + ti * ti;
+    dr = tr / den; di = -ti / den;
+    // c = b + a / c
+    den = cr * cr + ci * ci;
+    const double qr = br + ai * cr / den, qi = bi - ai * ci / den;
+    cr = qr; ci = qi;
+    const double er = cr * dr - ci * di, ei = cr * di + ci * dr;             // del = c d
+    const double nr = hr * er - hi * ei, ni = hr * ei + hi * er;
+    hr = nr; hi = ni;
+    if (fabs(er - 1.) + fabs(ei) < 1e-16) break;
+  }
+  double sn, cs;
+  sincos(x, &sn, &cs);
+  return hr * cs - hi * sn;                                                  // Re(h e^(i x))
+}
+// the cores that need loops of their own (one compile-time core, CORE_SPECIAL, for all of them)
+template <typename T>
+__device__ __forceinline__ T special_core(const IsoArgs<T> &g, T r2) {
+  const double x = (double)sqrt(r2);                      // one variable: sqrt(d^2) = |d| exactly
+  if (g.kernel == LGP_KERNEL_COLOR) {                     // par = {psi(n)}, p = n
+    if (x == 0.) return T(1);
+    return T((double)(g.p - 1) * expn_imag_re(g.p, (double)g.par[0], x));
+  } else {                                                // Pink: par = {dw, log1p(dw), sqrt(eps)}
+    const double dw = (double)g.par[0];
+    if (x * dw < (double)g.par[2]) return T(cos(x * (1. + 0.5 * dw)));
+    return T((expn_imag_re(1, -0.5772156649015329, x) - expn_imag_re(1, -0.5772156649015329, x * (1. + dw))) / (double)g.par[1]);
+  }
+}
+
 // d0: the signed difference of the (transformed) first coordinates, used by the derivative kernel only
 // NU: with the real-order Matern branch (the pairs kernel; the Gram kernels have a compile-time core for it, CORE_MATERNNU, so that
 // its loops do not weigh on the registers of the other generic cores)
@@ -264,6 +326,8 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0), T 
   } else if (NU && g.kernel == LGP_KERNEL_MATERN) {      // _kernels/_matern.py:56-76
     T unused;
     return matern_real_of<T>(g, r2, &unused);
+  } else if (NU && (g.kernel == LGP_KERNEL_COLOR || g.kernel == LGP_KERNEL_PINK)) {
+    return special_core<T>(g, r2);
   } else if (g.kernel == LGP_KERNEL_GAMMAEXP) {          // _kernels/_basic.py:111-113
     return g.flag ? exp(-r2) : exp(-pow(r2, g.par[1]));
   } else if (g.kernel == LGP_KERNEL_CAUCHY) {            // _kernels/_basic.py:340-344
@@ -311,7 +375,7 @@ __device__ __forceinline__ T iso_sq(const IsoArgs<T> &g, T df, T yv) {
 // Compile-time selection of the core for the kernels that evaluate n x m pairs: CORE_GENERIC keeps the run-time branches of
 // iso_core; the others fix the kernel (and the Matern order, so that the Horner loop unrolls and its coefficients become
 // immediates) -- the inner loop of the C3 Gram build lost its branch on g.kernel and its loop on g.p per element.
-constexpr int CORE_GENERIC = 0, CORE_EXPQUAD = 1, CORE_MATERN1 = 2, CORE_MATERN2 = 3, CORE_MATERN3 = 4, CORE_MATERNNU = 5;
+constexpr int CORE_GENERIC = 0, CORE_EXPQUAD = 1, CORE_MATERN1 = 2, CORE_MATERN2 = 3, CORE_MATERN3 = 4, CORE_MATERNNU = 5, CORE_SPECIAL = 6;
 
 template <typename T, int CORE>
 __device__ __forceinline__ T iso_core_t(const IsoArgs<T> &g, T r2, T d0 = T(0), T d1 = T(0)) {
@@ -328,6 +392,8 @@ __device__ __forceinline__ T iso_core_t(const IsoArgs<T> &g, T r2, T d0 = T(0), 
   } else if constexpr (CORE == CORE_MATERNNU) {
     T unused;
     return matern_real_of<T>(g, r2, &unused);
+  } else if constexpr (CORE == CORE_SPECIAL) {
+    return special_core<T>(g, r2);
   } else {
     return iso_core<T>(g, r2, d0, d1);
   }
@@ -337,6 +403,7 @@ __host__ inline int core_of(int kernel, int p) {
   if (kernel == LGP_KERNEL_EXPQUAD) return CORE_EXPQUAD;
   if (kernel == LGP_KERNEL_MATERNP && p >= 1 && p <= 3) return CORE_MATERN1 + (p - 1);
   if (kernel == LGP_KERNEL_MATERN) return CORE_MATERNNU;
+  if (kernel == LGP_KERNEL_COLOR || kernel == LGP_KERNEL_PINK) return CORE_SPECIAL;
   return CORE_GENERIC;
 }
 
@@ -579,12 +646,12 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_LAGTABLE, "unknown isotropic kernel");
+  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_PINK, "unknown isotropic kernel");
   LGP_REQUIRE(kernel != LGP_KERNEL_LAGTABLE || ((dtable != nullptr || ntable == 0) && ntable < (1u << 30) && ddsc == nullptr), "LagTable takes a device table (lgp_gram_lagtable), no scale tangent");
   LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_GIBBS || kernel == LGP_KERNEL_MATERN || d == 1, "this kernel is a function of one variable (maxdim = 1)");
   LGP_REQUIRE(kernel != LGP_KERNEL_GIBBS || (d >= 2 && !has_loc && !has_scale), "Gibbs takes the per-point scales as the last coordinate row, inputs already transformed");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
-  LGP_REQUIRE(p >= 0 && p <= MAX_P, "Maternp order must be in [0,16]");
+  LGP_REQUIRE(p >= 0 && (p <= MAX_P || kernel == LGP_KERNEL_COLOR), "Maternp order must be in [0,16]");
   const bool derived = kernel == LGP_KERNEL_EXPQUAD_DIFF || kernel == LGP_KERNEL_MATERNP_DIFF;
   const bool posabs = kernel == LGP_KERNEL_WENDLAND || kernel == LGP_KERNEL_CAUSALEXPQUAD || kernel == LGP_KERNEL_LOG;
   LGP_REQUIRE(!(derived || posabs) || ddsc == nullptr, "no scale tangent for this kernel");
@@ -608,7 +675,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   // _bessel.py:106-109: for k in reversed(range(p)): c = (p - k) / ((2p - k)(k + 1)); poly = 1 + poly*c*2*x
   for (int i = 0; i < MAX_P; ++i) g.coef[i] = T(0);
   int pos = 0;
-  for (int k = p - 1; k >= 0; --k) g.coef[pos++] = (T)((double)(p - k) / ((double)(2 * p - k) * (double)(k + 1)));
+  for (int k = (p <= MAX_P ? p : 0) - 1; k >= 0; --k) g.coef[pos++] = (T)((double)(p - k) / ((double)(2 * p - k) * (double)(k + 1)));
   g.twop1 = (T)(2 * p + 1);
   g.par[0] = g.par[1] = g.par[2] = T(0);
   g.table = dtable; g.ntable = (int)ntable; g.fill = fill;
@@ -655,6 +722,14 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   } else if (kernel == LGP_KERNEL_PERIODIC) {            // hpar = {outerscale}
     LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] > T(0) && hpar[0] < std::numeric_limits<T>::infinity(), "Periodic takes {outerscale} in (0, inf)");
     g.par[0] = hpar[0];
+  } else if (kernel == LGP_KERNEL_COLOR) {               // p = n
+    LGP_REQUIRE(npar == 0 && p >= 2 && ddsc == nullptr, "Color takes the integer n >= 2 as p, no real parameters");       // _spectral.py:110
+    double psi = -0.5772156649015329;
+    for (int k = 1; k < p; ++k) psi += 1. / (double)k;
+    g.par[0] = (T)psi;
+  } else if (kernel == LGP_KERNEL_PINK) {                // hpar = {dw}
+    LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0) && hpar[0] < std::numeric_limits<T>::infinity() && ddsc == nullptr, "Pink takes {dw}, dw >= 0");
+    g.par[0] = hpar[0]; g.par[1] = (T)log1p((double)hpar[0]); g.par[2] = (T)sqrt((double)std::numeric_limits<T>::epsilon());   // _spectral.py:62-66
   } else if (kernel == LGP_KERNEL_MATERN) {              // hpar = {nu}
     LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0) && hpar[0] <= T(100), "Matern takes {nu} in [0, 100]");   // _matern.py:73
     const double nu = (double)hpar[0];
@@ -750,6 +825,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
       case CORE_MATERN2: LGP_ISO_LAUNCH(DD, CORE_MATERN2); break;   \
       case CORE_MATERN3: LGP_ISO_LAUNCH(DD, CORE_MATERN3); break;   \
       case CORE_MATERNNU: LGP_ISO_LAUNCH(DD, CORE_MATERNNU); break; \
+      case CORE_SPECIAL: LGP_ISO_LAUNCH(DD, CORE_SPECIAL); break;   \
       default: LGP_ISO_LAUNCH(DD, CORE_GENERIC); break;             \
     }
     switch (d) {

@@ -474,6 +474,50 @@ def Taylor(*, scale=None, loc=None, dim=None):
     return Kernel(_onevariable(core, -numpy.inf, numpy.inf), scale=scale, loc=loc, dim=dim)
 
 
+def exp1_imag(x):
+    """ E_1(-ix) = -Ci(x) + i (pi/2 - Si(x)) (``_special/_expint.py:238-262``; the reference evaluates Si and Ci by the rational
+    approximations of Rowe et al. 2015, scipy's sici here) """
+    si, ci = special.sici(x)
+    return -ci + 1j * (numpy.pi / 2 - si)
+
+
+def expn_imag(n, x):
+    """ E_n(-ix), integer n >= 2, x >= 0 (``_special/_expint.py:31-64``): the closed form DLMF 8.19.7 below the knee
+    (Γ(n + nt) / eps)^(1 / (n + nt - 1)), the asymptotic series 8.20.2 with nt = 20 terms above """
+    x = numpy.asarray(x, float)
+    nt = 20
+    eps = numpy.finfo(float).eps
+    knee = (special.gamma(n + nt) / eps) ** (1 / (n + nt - 1))
+    with numpy.errstate(all='ignore'):
+        # small x (``:76-90``)
+        fact = numpy.cumprod(numpy.concatenate([[1.], numpy.arange(1., n)]))       # 0!, 1!, ..., (n-1)!
+        ix = 1j * x
+        e1 = numpy.where(x, exp1_imag(numpy.where(x, x, 1.)), 0)
+        small = (ix ** (n - 1) * e1 + numpy.exp(ix) * numpy.polyval(fact[:-1], ix)) / fact[-1]
+        # large x (``:93-106``): e^-z / z sum_k (-1)^k (n)_k / z^k
+        z = -1j * x
+        k = numpy.arange(nt)
+        coef = (-1.) ** k * numpy.exp(special.gammaln(n + k) - special.gammaln(n))
+        large = numpy.exp(-z) / z * numpy.polyval(coef[::-1], 1 / z)
+    return numpy.where(x < knee, small, large)
+
+
+def Color(*, n=2, scale=None, loc=None, dim=None):
+    """ ``_kernels/_spectral.py:73-111`` """
+    assert int(n) == n and n >= 2, n
+    return Kernel(_stationary1d(lambda delta: (n - 1) * expn_imag(n, delta).real, 'abs'), scale=scale, loc=loc, dim=dim)
+
+
+def Pink(*, dw=1, scale=None, loc=None, dim=None):
+    """ ``_kernels/_spectral.py:41-66`` """
+    def core(delta):
+        with numpy.errstate(all='ignore'):
+            l = special.sici(delta)[1]
+            r = special.sici(delta * (1 + dw))[1]
+            return numpy.where(delta * dw < numpy.sqrt(numpy.finfo(float).eps), numpy.cos(delta * (1 + dw / 2)), (r - l) / numpy.log1p(dw))
+    return Kernel(_stationary1d(core, 'abs'), scale=scale, loc=loc, dim=dim)
+
+
 def MA(*, w=None, norm=False, scale=None, loc=None, dim=None):
     """ ``_kernels/_arma.py:31-63``: cov = convolve(w, reversed w), looked up at delta + len(w) - 1, 0 beyond """
     w = numpy.asarray([] if w is None else w, float)

@@ -899,3 +899,62 @@ def test_bag_of_words_against_oracle(lgp, rng):
     gp = lgp.GP(lgp.BagOfWords() * 2., checkpos=False).addx(x, 'x').addx(y, 'y')
     np.testing.assert_allclose(gp.prior('x', raw=True), 2 * oracle.BagOfWords()(x[:, None], x[None, :]), rtol=1e-14)
     np.testing.assert_allclose(gp.prior(raw=True)['x', 'y'], 2 * oracle.BagOfWords()(x[:, None], y[None, :]), rtol=1e-14)
+
+
+def _expn_imag_re_quad(n, x):
+    """ Re E_n(-ix) = int_1^inf cos(x w) / w^n dw by QUADPACK's Fourier integrator (an independent route, good to ~1e-10) """
+    from scipy import integrate
+    return integrate.quad(lambda w: w ** -float(n), 1, np.inf, weight='cos', wvar=float(x), limlst=500, limit=500)[0]
+
+
+@pytest.mark.parametrize('n', [2, 3, 4, 5, 6, 20, 51])
+def test_color_against_closed_forms_and_quadrature(lgp, rng, n):
+    """ ``Color(n)`` = (n - 1) Re E_n(-i D): against E_2, E_3 from scipy's complex E_1 by the recurrence n E_{n+1} = e^-z - z E_n
+    (1e-14), against the oracle's restatement of the reference's two-branch algorithm where that is accurate (well below its knee,
+    or far above it), and everywhere against numerical quadrature of the defining integral at 3e-10 """
+    from scipy import special
+    x0 = np.zeros(1)
+    d = np.concatenate([[0., 1e-12, 1e-6], np.linspace(0.01, 4, 60), [1.99, 2.0, 2.01], np.geomspace(4, 3000, 40)])
+    got = lgp.Color(n=n).gram(x0, d).to_host()[0]
+    assert got[0] == 1. and np.all(np.abs(got) <= 1 + 1e-14)
+    if n in (2, 3):
+        z = -1j * d[1:]
+        e = np.exp(-z) - z * special.exp1(z)
+        if n == 3:
+            e = (np.exp(-z) - z * e) / 2
+        # (the upward recurrence cancels |z| e^-z against z E_n: its own error grows like eps |z|)
+        assert np.all(np.abs(got[1:] - (n - 1) * e.real) <= 2e-14 + 3e-16 * d[1:])
+    ref = oracle.Color(n=n)(x0[:, None], d[None, :])[0]
+    knee = (special.gamma(n + 20) / np.finfo(float).eps) ** (1 / (n + 19))
+    trust = (d < min(3., knee / 4)) | (d > 4 * knee)                    # (the reference's own error estimate, _expint.py:37-51)
+    np.testing.assert_allclose(got[trust], ref[trust], rtol=0, atol=1e-11)
+    if n <= 20:
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9 if n <= 6 else 3e-2)   # (n = 20: the reference is 1.4e-2 off just below its knee; n = 51: 2e2)
+    pick = np.arange(len(d))[3::4]
+    pick = pick[d[pick] >= 0.1]                                         # (QUADPACK's Fourier integrator gives up at slow oscillations)
+    quad = np.array([(n - 1) * _expn_imag_re_quad(n, v) for v in d[pick]])
+    np.testing.assert_allclose(got[pick], quad, rtol=0, atol=3e-10 * n)
+    # a GP on top, scale and output operations
+    x = rng.uniform(-5, 5, 600)
+    G = (lgp.Color(n=n, scale=0.7) * 2.).gram(x, x).to_host()
+    np.testing.assert_array_equal(G, G.T)
+    if n <= 20:
+        np.testing.assert_allclose(G, 2 * oracle.Color(n=n, scale=0.7)(x[:, None], x[None, :]), rtol=0, atol=2e-9 if n <= 6 else 6e-2)
+
+
+@pytest.mark.parametrize('dw', [1e-9, 0.01, 1., 30., 1e4])
+def test_pink_against_scipy_sici(lgp, rng, dw):
+    """ ``Pink(dw)``: (Ci(D (1 + dw)) - Ci(D)) / log1p(dw) with scipy's Ci; the cosine branch for D dw < sqrt(eps) """
+    x0 = np.zeros(1)
+    d = np.concatenate([[0., 1e-12, 1e-7], np.linspace(0.01, 4, 60), np.geomspace(4, 3000, 40)])
+    got = lgp.Pink(dw=dw).gram(x0, d).to_host()[0]
+    ref = oracle.Pink(dw=dw)(x0[:, None], d[None, :])[0]
+    assert got[0] == 1.
+    # (Ci at large arguments: the difference of two values each good to 1e-16 absolute, divided by log1p(dw))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-14 / min(1., np.log1p(dw)) + 1e-14)
+    x = rng.uniform(-5, 5, 600)
+    G = (lgp.Pink(dw=dw, scale=1.3) * 0.5 + 1.).gram(x, x).to_host()
+    np.testing.assert_array_equal(G, G.T)
+    np.testing.assert_allclose(G, 0.5 * oracle.Pink(dw=dw, scale=1.3)(x[:, None], x[None, :]) + 1., rtol=0, atol=1e-14 / min(1., np.log1p(dw)) + 1e-14)
+    np.testing.assert_allclose((lgp.Pink(dw=dw) * 3.).pairs(x[:50], x[50:100]).to_host(), 3 * oracle.Pink(dw=dw)(x[:50], x[50:100]), rtol=0,
+                               atol=3e-14 / min(1., np.log1p(dw)) + 3e-14)
