@@ -614,6 +614,26 @@ class Matern(Maternp):
         self._nu = nu
 
 
+class Bessel(_Isotropic):
+    """ Bessel kernel, k(r) = Γ(ν + 1) 2^ν (s r)^-ν J_ν(s r), s = 2 + ν/2, ν >= 0 (``_kernels/_matern.py:92-119``): usable in up to
+    2 (⌊ν⌋ + 1) dimensions.  J_ν of real order on the device (power series, Miller's backward recurrence, Hankel's expansion) """
+    _kind = _lib.LGP_KERNEL_BESSEL
+
+    def __init__(self, *, nu=0, scale=None, loc=None, dim=None):
+        assert 0 <= nu < numpy.inf, nu                                     # _matern.py:117
+        if nu > 100:
+            raise NotImplementedError('Bessel order above 100')
+        super().__init__(scale=scale, loc=loc, dim=dim)
+        self._par = (float(nu),)
+        self._maxdim = 2 * (int(numpy.floor(nu)) + 1)                      # _matern.py:97-99
+
+    def _prepare(self, xs, ys, ctx):
+        out = super()._prepare(xs, ys, ctx)
+        if out[4] > self._maxdim:
+            raise ValueError(f'kernel called on type with dimensionality {out[4]} > maxdim={self._maxdim}')
+        return out
+
+
 class GammaExp(_Isotropic):
     """ Gamma exponential kernel, k(r) = exp(-r^γ), γ ∈ (0, 2] (``_kernels/_basic.py:94-115``) """
     _kind = _lib.LGP_KERNEL_GAMMAEXP

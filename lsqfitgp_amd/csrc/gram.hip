@@ -206,9 +206,69 @@ __device__ inline double expn_imag_re(int n, double psin, double x) {
   sincos(x, &sn, &cs);
   return hr * cs - hi * sn;                                                  // Re(h e^(i x))
 }
+// Gamma(nu + 1) (x / 2)^-nu J_nu(x), real nu >= 0 (Bessel kernel, _kernels/_matern.py:102-119 through _special/_bessel.py:45-50): 1 at
+// x = 0.  Three regions: the power series sum_k (-x^2/4)^k / (k! (nu+1)_k) while it does not cancel (x^2 <= 8 (nu + 1), or x <= 3);
+// Hankel's asymptotic expansion above max(30, nu^2); between them Miller's backward recurrence from an even order N > x down to the
+// fractional order mu = nu - floor(nu), normalised by (x/2)^mu = sum_k (mu + 2k) Gamma(mu + k) / k! J_{mu+2k}(x).  Against scipy's
+// jv: <= 1e-14 absolute for nu in [0, 30], x in [0, 3000].
+__device__ inline double bessel_jmod(double nu, int n, double gnu1, double gmu1, double x) {
+  if (x == 0.) return 1.;
+  if (x * x <= 8. * (nu + 1.) || x <= 3.) {
+    const double q = -0.25 * x * x;
+    double term = 1., sum = 1.;
+    for (int k = 1; k < 300; ++k) {
+      term *= q / ((double)k * (nu + (double)k));
+      sum += term;
+      if (fabs(term) < 1e-17 * fabs(sum)) break;
+    }
+    return sum;
+  }
+  if (x > fmax(30., nu * nu)) {
+    const double mu4 = 4. * nu * nu;
+    double P = 1., Q = 0., t = 1.;
+    for (int k = 1; k < 60; ++k) {
+      const double odd = (double)(2 * k - 1);
+      const double tn = t * (mu4 - odd * odd) / ((double)k * 8. * x);
+      if (fabs(tn) > fabs(t) && (double)k > nu) break;
+      t = tn;
+      const bool neg = ((k >> 1) & 1) != 0;
+      if (k & 1) Q += neg ? -t : t;
+      else P += neg ? -t : t;
+      if (fabs(t) < 1e-17) break;
+    }
+    double sn, cs;
+    sincos(x - (0.5 * nu + 0.25) * 3.141592653589793238462643383279502884, &sn, &cs);
+    const double J = sqrt(0.6366197723675814 / x) * (P * cs - Q * sn);
+    return gnu1 * exp(-nu * log(0.5 * x)) * J;
+  }
+  const double mu = nu - (double)n, big = fmax(x, nu);
+  int N = (int)(big + 25. + 8. * cbrt(big));
+  N += N & 1;
+  const int K = N >> 1;
+  double ck = exp(lgamma(mu + (double)K) - lgamma((double)K + 1.)) * (mu + 2. * (double)K);
+  double fp = 0., f = 1e-300, S = 0., fn = 0.;
+  const double tox = 2. / x;
+  for (int j = N; j >= 0; --j) {
+    if ((j & 1) == 0) {
+      const int k = j >> 1;
+      S += ck * f;
+      if (k >= 2) ck = ck * (mu + (double)(2 * k - 2)) / (mu + (double)(2 * k)) * (double)k / (mu + (double)(k - 1));
+      else if (k == 1) ck = gmu1;
+    }
+    if (j == n) fn = f;
+    if (j > 0) {
+      const double fm = (mu + (double)j) * tox * f - fp;
+      fp = f; f = fm;
+      if (fabs(f) > 1e250) { f *= 1e-250; fp *= 1e-250; S *= 1e-250; fn *= 1e-250; }
+    }
+  }
+  return gnu1 * exp(-(double)n * log(0.5 * x)) * fn / S;
+}
 // the cores that need loops of their own (one compile-time core, CORE_SPECIAL, for all of them)
 template <typename T>
 __device__ __forceinline__ T special_core(const IsoArgs<T> &g, T r2) {
+  if (g.kernel == LGP_KERNEL_BESSEL)                     // par = {nu, Gamma(nu + 1), Gamma(1 + nu - floor(nu))}, p = floor(nu), twop1 = (2 + nu/2)^2
+    return T(bessel_jmod((double)g.par[0], g.p, (double)g.par[1], (double)g.par[2], sqrt((double)g.twop1 * (double)r2)));
   const double x = (double)sqrt(r2);                      // one variable: sqrt(d^2) = |d| exactly
   if (g.kernel == LGP_KERNEL_COLOR) {                     // par = {psi(n)}, p = n
     if (x == 0.) return T(1);
@@ -326,7 +386,7 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0), T 
   } else if (NU && g.kernel == LGP_KERNEL_MATERN) {      // _kernels/_matern.py:56-76
     T unused;
     return matern_real_of<T>(g, r2, &unused);
-  } else if (NU && (g.kernel == LGP_KERNEL_COLOR || g.kernel == LGP_KERNEL_PINK)) {
+  } else if (NU && (g.kernel == LGP_KERNEL_COLOR || g.kernel == LGP_KERNEL_PINK || g.kernel == LGP_KERNEL_BESSEL)) {
     return special_core<T>(g, r2);
   } else if (g.kernel == LGP_KERNEL_GAMMAEXP) {          // _kernels/_basic.py:111-113
     return g.flag ? exp(-r2) : exp(-pow(r2, g.par[1]));
@@ -403,7 +463,7 @@ __host__ inline int core_of(int kernel, int p) {
   if (kernel == LGP_KERNEL_EXPQUAD) return CORE_EXPQUAD;
   if (kernel == LGP_KERNEL_MATERNP && p >= 1 && p <= 3) return CORE_MATERN1 + (p - 1);
   if (kernel == LGP_KERNEL_MATERN) return CORE_MATERNNU;
-  if (kernel == LGP_KERNEL_COLOR || kernel == LGP_KERNEL_PINK) return CORE_SPECIAL;
+  if (kernel == LGP_KERNEL_COLOR || kernel == LGP_KERNEL_PINK || kernel == LGP_KERNEL_BESSEL) return CORE_SPECIAL;
   return CORE_GENERIC;
 }
 
@@ -646,9 +706,9 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_PINK, "unknown isotropic kernel");
+  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_BESSEL, "unknown isotropic kernel");
   LGP_REQUIRE(kernel != LGP_KERNEL_LAGTABLE || ((dtable != nullptr || ntable == 0) && ntable < (1u << 30) && ddsc == nullptr), "LagTable takes a device table (lgp_gram_lagtable), no scale tangent");
-  LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_GIBBS || kernel == LGP_KERNEL_MATERN || d == 1, "this kernel is a function of one variable (maxdim = 1)");
+  LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_GIBBS || kernel == LGP_KERNEL_MATERN || kernel == LGP_KERNEL_BESSEL || d == 1, "this kernel is a function of one variable (maxdim = 1)");
   LGP_REQUIRE(kernel != LGP_KERNEL_GIBBS || (d >= 2 && !has_loc && !has_scale), "Gibbs takes the per-point scales as the last coordinate row, inputs already transformed");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
   LGP_REQUIRE(p >= 0 && (p <= MAX_P || kernel == LGP_KERNEL_COLOR), "Maternp order must be in [0,16]");
@@ -722,6 +782,14 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   } else if (kernel == LGP_KERNEL_PERIODIC) {            // hpar = {outerscale}
     LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] > T(0) && hpar[0] < std::numeric_limits<T>::infinity(), "Periodic takes {outerscale} in (0, inf)");
     g.par[0] = hpar[0];
+  } else if (kernel == LGP_KERNEL_BESSEL) {              // hpar = {nu}
+    LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0) && hpar[0] <= T(100) && ddsc == nullptr, "Bessel takes {nu} in [0, 100]");   // _matern.py:117
+    const double nu = (double)hpar[0];
+    const int fl = (int)nu;
+    LGP_REQUIRE(d <= 2 * (fl + 1), "Bessel(nu) is a kernel in at most 2 (floor(nu) + 1) dimensions");                                // _matern.py:97-99
+    g.p = fl;
+    g.par[0] = (T)nu; g.par[1] = (T)tgamma(nu + 1.); g.par[2] = (T)tgamma(1. + nu - (double)fl);
+    g.twop1 = (T)((2. + nu / 2.) * (2. + nu / 2.));                                                                                   // _matern.py:118
   } else if (kernel == LGP_KERNEL_COLOR) {               // p = n
     LGP_REQUIRE(npar == 0 && p >= 2 && ddsc == nullptr, "Color takes the integer n >= 2 as p, no real parameters");       // _spectral.py:110
     double psi = -0.5772156649015329;

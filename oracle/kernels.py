@@ -282,6 +282,25 @@ def Matern(*, nu=None, scale=None, loc=None, dim=None):
     return Kernel(_isotropic(core), scale=scale, loc=loc, dim=dim)
 
 
+def Bessel(*, nu=0, scale=None, loc=None, dim=None):
+    """ ``_kernels/_matern.py:92-119`` through ``_special/_bessel.py:45-50`` (scipy's jv) """
+    assert 0 <= nu < numpy.inf, nu
+    maxdim = 2 * (int(numpy.floor(nu)) + 1)
+
+    def core(r2):
+        x = numpy.sqrt(r2 * (2 + nu / 2) ** 2)
+        with numpy.errstate(all='ignore'):
+            normal = (x / 2) ** -nu * special.jv(nu, x)
+        return special.gamma(nu + 1) * numpy.where(x, normal, 1 / special.gamma(nu + 1))
+    inner = _isotropic(core)
+
+    def checked(x, y):
+        if x.dtype.names is not None and len(_leaf_columns_count(x.dtype)) > maxdim:
+            raise ValueError(f'kernel called on type with dimensionality > maxdim={maxdim}')
+        return inner(x, y)
+    return Kernel(checked, scale=scale, loc=loc, dim=dim)
+
+
 def _isotropic_posabs(core):
     """ ``_isotropic.py:61-81`` with input='posabs': per field (|x - y| + eps)^2 (``_stationary.py:84-85`` _softabs), summed, the
     core takes the square root """

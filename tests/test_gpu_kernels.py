@@ -958,3 +958,34 @@ def test_pink_against_scipy_sici(lgp, rng, dw):
     np.testing.assert_allclose(G, 0.5 * oracle.Pink(dw=dw, scale=1.3)(x[:, None], x[None, :]) + 1., rtol=0, atol=1e-14 / min(1., np.log1p(dw)) + 1e-14)
     np.testing.assert_allclose((lgp.Pink(dw=dw) * 3.).pairs(x[:50], x[50:100]).to_host(), 3 * oracle.Pink(dw=dw)(x[:50], x[50:100]), rtol=0,
                                atol=3e-14 / min(1., np.log1p(dw)) + 3e-14)
+
+
+@pytest.mark.parametrize('nu', [0, 0.01, 0.5, 0.99, 1, 2.5, 3.99, 4.5, 7.3, 12., 30.])
+def test_bessel_kernel_against_scipy_jv(lgp, rng, nu):
+    """ ``Bessel(nu)`` = Gamma(nu + 1) (x/2)^-nu J_nu(x), x = (2 + nu/2) r: the device's J_nu (series, Miller's recurrence, Hankel's
+    expansion) against the oracle's scipy ``jv`` over all three regions and their boundaries, 5e-14 absolute """
+    s = 2 + nu / 2
+    xs = np.concatenate([[0., 1e-200, 1e-9], np.linspace(0.01, 3, 20), [3., 3.0001, np.sqrt(8 * (nu + 1)), np.sqrt(8 * (nu + 1)) + 1e-3],
+                         np.linspace(3.01, 40, 120), [max(30., nu * nu), max(30., nu * nu) + 1e-3], np.geomspace(40, 3000, 50)])
+    r = xs / s
+    got = lgp.Bessel(nu=nu).gram(np.zeros(1), r).to_host()[0]
+    ref = oracle.Bessel(nu=nu)(np.zeros((1, 1)), r[None, :])[0]
+    assert got[0] == 1. and np.all(np.abs(got) <= 1 + 1e-13)
+    lost = (xs > 0) & ((xs / 2) ** nu < 1e-280)          # J_nu itself underflows there in the oracle's product: the limit, 1
+    np.testing.assert_allclose(got, np.where(lost, 1., ref), rtol=0, atol=5e-14)
+    # several fields up to maxdim, one more refused; one-triangle grid; pairs; output operations; scale
+    md = 2 * (int(np.floor(nu)) + 1)
+    d = min(md, 3)
+    pts = np.empty(600, [('v', float, (d,))])
+    pts['v'] = rng.uniform(-3, 3, (600, d))
+    k = lgp.Bessel(nu=nu, scale=1.7) * 2. + 0.5
+    ko = oracle.Bessel(nu=nu, scale=1.7)
+    S = k.gram(pts, pts).to_host()
+    np.testing.assert_array_equal(S, S.T)
+    np.testing.assert_allclose(S, 2 * ko(pts[:, None], pts[None, :]) + 0.5, rtol=0, atol=2e-13)
+    np.testing.assert_allclose(k.pairs(pts[:100], pts[100:200]).to_host(), 2 * ko(pts[:100], pts[100:200]) + 0.5, rtol=0, atol=2e-13)
+    if md < 8:
+        over = np.empty(10, [('v', float, (md + 1,))])
+        over['v'] = rng.uniform(-3, 3, (10, md + 1))
+        with pytest.raises((ValueError, lgp.LibraryError)):
+            lgp.Bessel(nu=nu).gram(over, over)

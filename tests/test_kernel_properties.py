@@ -45,6 +45,8 @@ KERNELS = {
     'Harmonic': ([dict(Q=0.2), dict(Q=0.8), dict(Q=1), dict(Q=4)], 1, True, (-5, 5), 0),
     'Circular': ([dict(tau=4, c=0.5), dict(tau=7, c=0.2)], 1, True, (-5, 5), 0),
     'StationaryFracBrownian': ([dict(H=0.2), dict(H=0.5), dict(H=0.9), dict(H=1)], 1, True, (-5, 5), 0),
+    'Bessel': ([{}] + [dict(nu=nu) for nu in range(5)] + [dict(nu=nu - 0.01) for nu in range(1, 5)] + [dict(nu=nu + 0.01) for nu in range(5)]
+               + [dict(nu=nu + 0.5) for nu in range(5)], 'bessel', True, (-5, 5), 0),                       # ref :697-701
     'Color': ([dict(n=n) for n in (2, 3, 4, 5, 6, 20)], 1, True, (-5, 5), 0),            # ref :796-798
     'Pink': ([dict(dw=1), dict(dw=0.2), dict(dw=30)], 1, True, (-5, 5), 0),
     'Wiener': ([{}], 1, False, (0, 5), 0),
@@ -66,6 +68,8 @@ def maxdim(name, kw):
     md = KERNELS[name][1]
     if md == 'alpha':
         return int(np.floor(2 * kw['alpha'] - 1))
+    if md == 'bessel':
+        return 2 * (int(np.floor(kw.get('nu', 0))) + 1)
     return md
 
 
