@@ -131,6 +131,7 @@ int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *to
 #define LGP_KERNEL_COLOR 31       /* _kernels/_spectral.py:73-111  (n - 1) Re E_n(-i |x - y|), integer n >= 2 passed as p: power spectrum 1/omega^n above omega = 1.  E_n by its power series (|x - y| <= 2) and its continued fraction */
 #define LGP_KERNEL_PINK 32        /* _kernels/_spectral.py:41-66   (Ci(D (1 + dw)) - Ci(D)) / log(1 + dw), D = |x - y|; cos(D (1 + dw/2)) where D dw < sqrt(eps): hpar = {dw} */
 #define LGP_KERNEL_BESSEL 33      /* _kernels/_matern.py:102-119   Gamma(nu + 1) (s r / 2)^-nu J_nu(s r), s = 2 + nu / 2, real nu in [0, 100]: hpar = {nu}; at most 2 (floor(nu) + 1) fields.  J_nu by series / Miller's recurrence / Hankel's expansion */
+#define LGP_KERNEL_PSERIES 34     /* even 1-periodic functions of |x - y| from host-computed coefficients (the Zeta kernel, _kernels/_zeta.py:37-70): only through lgp_gram_pseries / lgp_pairs_pseries */
 #define LGP_OP_MUL 0           /* kernel * c  (_Kernel/_alg.py:58-82)  */
 #define LGP_OP_ADD 1           /* kernel + c  (_Kernel/_alg.py:32-56)  */
 
@@ -174,6 +175,32 @@ int lgp_pairs_lagtable_f64(lgp_ctx *ctx, const double *dtable, size_t ntable, do
 int lgp_pairs_lagtable_f32(lgp_ctx *ctx, const float *dtable, size_t ntable, float fill, const float *dx, size_t ldx,
                            const float *dy, size_t ldy, size_t npairs, int has_loc, float loc, int has_scale, float scale,
                            int nops, const int *hops_code, const float *hops_val, float *dout);
+
+/* Even, 1-periodic stationary kernels of one variable from host-computed coefficients -- the evaluation half of the reference's Zeta
+ * kernel, k(D) = Re Li_s(e^{2 pi i D}) / zeta(s), s = 1 + 2 nu (_kernels/_zeta.py:37-70, _special/_zeta.py:76-177).  With
+ * theta = 2 pi (|x - y| mod 1, reflected into [0, 1/2]):
+ *   mode 0: sum_{j=1..ntable} dtable[j-1] cos(j theta)                  (the Fourier series itself: s >= 10, table j^-s / zeta(s))
+ *   mode 1: sum_{n<ntable} dtable[n] theta^(2n) + theta^pw (A g + D),  g = 1 (uselog 0), log theta (uselog 1, eps = 0) or
+ *           expm1(eps log theta) (uselog 1, eps != 0)                   (the polylogarithm's expansion on the unit circle,
+ *           table (-1)^n zeta(s-2n) / ((2n)! zeta(s)), A theta^(s-1) its non-analytic term, regrouped near odd s)
+ *   mode 2: 1 where theta = 0, else 0                                   (nu = 0)
+ * hpar4 = {A, pw, eps, D} (host); dtable: DEVICE array.  lsqfitgp_amd/_zeta.py computes the coefficients for Zeta(nu). */
+int lgp_gram_pseries_f64(lgp_ctx *ctx, int mode, int uselog, const double *dtable, size_t ntable, const double *hpar4,
+                         const double *dx, size_t ldx, size_t n, const double *dy, size_t ldy, size_t m,
+                         int has_loc, double loc, int has_scale, double scale,
+                         int nops, const int *hops_code, const double *hops_val, int symmetric, double *dout, size_t ldo);
+int lgp_gram_pseries_f32(lgp_ctx *ctx, int mode, int uselog, const float *dtable, size_t ntable, const float *hpar4,
+                         const float *dx, size_t ldx, size_t n, const float *dy, size_t ldy, size_t m,
+                         int has_loc, float loc, int has_scale, float scale,
+                         int nops, const int *hops_code, const float *hops_val, int symmetric, float *dout, size_t ldo);
+int lgp_pairs_pseries_f64(lgp_ctx *ctx, int mode, int uselog, const double *dtable, size_t ntable, const double *hpar4,
+                          const double *dx, size_t ldx, const double *dy, size_t ldy, size_t npairs,
+                          int has_loc, double loc, int has_scale, double scale,
+                          int nops, const int *hops_code, const double *hops_val, double *dout);
+int lgp_pairs_pseries_f32(lgp_ctx *ctx, int mode, int uselog, const float *dtable, size_t ntable, const float *hpar4,
+                          const float *dx, size_t ldx, const float *dy, size_t ldy, size_t npairs,
+                          int has_loc, float loc, int has_scale, float scale,
+                          int nops, const int *hops_code, const float *hops_val, float *dout);
 
 /* BART correlation Gram matrix, the `altinput=True` path of _kernels/_bart.py:301-455,628-757 for one
  * recursion slice ("bracket") of `size` = 1, 2 or 3 probabilities, iterated `repeat` times (the folding of

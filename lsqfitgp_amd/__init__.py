@@ -12,7 +12,7 @@ from ._device import Context, DeviceArray, asdevice
 from ._linalg import Decomposition, Chol
 from ._kernels import (Kernel, ExpQuad, Maternp, Matern, GammaExp, Cauchy, Wendland, CausalExpQuad, Log, Constant, White, Expon, HoleEffect,
                        Periodic, Cos, Sinc, StationaryFracBrownian, Linear, Wiener, OrnsteinUhlenbeck, BrownianBridge, Decaying,
-                       FracBrownian, WienerIntegral, Celerite, Harmonic, Circular, Taylor, Rescaling, Categorical, NNKernel, Gibbs, MA, AR, BagOfWords, Color, Pink, Bessel, BART)
+                       FracBrownian, WienerIntegral, Celerite, Harmonic, Circular, Taylor, Rescaling, Categorical, NNKernel, Gibbs, MA, AR, BagOfWords, Color, Pink, Bessel, Zeta, BART)
 from ._GP import GP, Diagonal, diag
 from ._fit import empbayes_fit
 from ._fastraniter import raniter, sample

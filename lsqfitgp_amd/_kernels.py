@@ -24,6 +24,7 @@ from scipy import special as _special   # digamma table for BART (scipy is a dep
 
 from . import _lib
 from . import _dual
+from . import _zeta
 from ._device import Context, DeviceArray
 
 
@@ -797,6 +798,69 @@ class Pink(_Stationary1D):
         assert 0 <= dw < numpy.inf, dw
         super().__init__(scale=scale, loc=loc, dim=dim)
         self._par = (float(dw),)
+
+
+class Zeta(_Stationary1D):
+    """ Zeta kernel, k(Δ) = Re Li_s(e^{2πiΔ}) / ζ(s) = Σ_k cos(2πkΔ) / k^s / ζ(s), s = 1 + 2ν, ν >= 0: a Fourier series of period 1
+    with independent coefficients of variance 1 / (ζ(s) k^s) (``_kernels/_zeta.py:37-70``).  The host computes the coefficients of
+    the polylogarithm's expansion on the unit circle once per kernel (`_zeta.coefficients`), the device sums it pair by pair
+    (``lgp_gram_pseries``) """
+
+    def __init__(self, *, nu=None, scale=None, loc=None, dim=None):
+        assert nu is not None and 0 <= nu < numpy.inf, nu              # _zeta.py:28-30
+        super().__init__(scale=scale, loc=loc, dim=dim)
+        self._nu = float(nu)
+        self._mode, self._uselog, self._coef, self._hpar4 = _zeta.coefficients(nu)
+        self._coef_memo = {}
+
+    def _copy(self, **kw):
+        new = super()._copy(**kw)
+        new._coef_memo = {}
+        return new
+
+    def _table(self, ctx, dtype):
+        key = (id(ctx), numpy.dtype(dtype).str)
+        tab = self._coef_memo.get(key)
+        if tab is None:
+            tab = DeviceArray.from_host(numpy.ascontiguousarray(self._coef, dtype), ctx=ctx) if self._coef.size else None
+            self._coef_memo = {key: tab}
+        return tab
+
+    def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
+        if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
+            raise NotImplementedError('derivatives of Zeta')
+        xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
+        n, m = xd.shape[1], yd.shape[1]
+        if out is None:
+            out = DeviceArray.empty((n, m), dtype, ctx)
+        assert out.shape == (n, m) and out.dtype == dtype
+        if n == 0 or m == 0:
+            return out
+        f, F = _lib.fn('lgp_gram_pseries', dtype)
+        tab = self._table(ctx, dtype)
+        nops, codes, vals = _ops_arrays(self._outops, F)
+        _lib.check(f(ctx.handle, self._mode, self._uselog, None if tab is None else tab.ptr, self._coef.size, (F * 4)(*self._hpar4),
+                     xd.ptr, xd.ld, n, yd.ptr, yd.ld, m, int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
+                     nops, codes, vals, int(xd is yd), out.ptr, out.ld), 'lgp_gram_pseries')
+        return out
+
+    def gram_dscale(self, xs, ys, *, ctx=None):
+        raise NotImplementedError('derivative of Zeta with respect to scale')
+
+    def pairs(self, xs, ys, *, ctx=None):
+        xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
+        n = xd.shape[1]
+        assert yd.shape[1] == n
+        out = DeviceArray.empty((n,), dtype, ctx)
+        if n == 0:
+            return out
+        f, F = _lib.fn('lgp_pairs_pseries', dtype)
+        tab = self._table(ctx, dtype)
+        nops, codes, vals = _ops_arrays(self._outops, F)
+        _lib.check(f(ctx.handle, self._mode, self._uselog, None if tab is None else tab.ptr, self._coef.size, (F * 4)(*self._hpar4),
+                     xd.ptr, xd.ld, yd.ptr, yd.ld, n, int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1),
+                     nops, codes, vals, out.ptr), 'lgp_pairs_pseries')
+        return out
 
 
 class _LagTable(Kernel):

@@ -57,6 +57,7 @@ LGP_KERNEL_LAGTABLE = 30
 LGP_KERNEL_COLOR = 31
 LGP_KERNEL_PINK = 32
 LGP_KERNEL_BESSEL = 33
+LGP_KERNEL_PSERIES = 34
 LGP_OP_MUL = 0
 LGP_OP_ADD = 1
 LGP_EPS_AUTO_REL = 1
@@ -119,6 +120,10 @@ def _signatures():
             'lgp_transpose_' + suf: (c_int, [c_void_p, _P, _S, _P, _S, _S, _S]),
             'lgp_gram_isotropic_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, _P, _S, _S, _P, _S, _S,
                                                  c_int, F, c_int, F, c_int, POINTER(c_int), POINTER(F), c_int, _P, _S]),
+            'lgp_gram_pseries_' + suf: (c_int, [c_void_p, c_int, c_int, _P, _S, POINTER(F), _P, _S, _S, _P, _S, _S, c_int, F, c_int, F,
+                                               c_int, POINTER(c_int), POINTER(F), c_int, _P, _S]),
+            'lgp_pairs_pseries_' + suf: (c_int, [c_void_p, c_int, c_int, _P, _S, POINTER(F), _P, _S, _P, _S, _S, c_int, F, c_int, F,
+                                                c_int, POINTER(c_int), POINTER(F), _P]),
             'lgp_gram_lagtable_' + suf: (c_int, [c_void_p, _P, _S, F, _P, _S, _S, _P, _S, _S, c_int, F, c_int, F,
                                                 c_int, POINTER(c_int), POINTER(F), c_int, _P, _S]),
             'lgp_pairs_lagtable_' + suf: (c_int, [c_void_p, _P, _S, F, _P, _S, _P, _S, _S, c_int, F, c_int, F,

@@ -270,6 +270,31 @@ __device__ __forceinline__ T special_core(const IsoArgs<T> &g, T r2) {
   if (g.kernel == LGP_KERNEL_BESSEL)                     // par = {nu, Gamma(nu + 1), Gamma(1 + nu - floor(nu))}, p = floor(nu), twop1 = (2 + nu/2)^2
     return T(bessel_jmod((double)g.par[0], g.p, (double)g.par[1], (double)g.par[2], sqrt((double)g.twop1 * (double)r2)));
   const double x = (double)sqrt(r2);                      // one variable: sqrt(d^2) = |d| exactly
+  if (g.kernel == LGP_KERNEL_PSERIES) {
+    // even 1-periodic functions of the difference given by host-computed coefficients (Zeta kernel, _kernels/_zeta.py:37-70):
+    // theta = 2 pi (|d| mod 1, reflected into [0, 1/2]); p = 0: sum_j table[j-1] cos(j theta); p = 1: sum_n table[n] theta^(2n) +
+    // theta^pw (A g + D), g = 1 | log theta | expm1(eps log theta) (flag: with the logarithm); p = 2: 1 where theta = 0.
+    // par = {A, pw, eps, D}
+    double y = x - floor(x);
+    if (y > 0.5) y = 1. - y;
+    const double th = 6.283185307179586476925286766559 * y;
+    if (g.p == 2) return y == 0. ? T(1) : T(0);
+    if (!(x < 1e300)) return T(NAN);
+    if (g.p == 0) {
+      double acc = 0.;
+      for (int j = g.ntable; j >= 1; --j) acc += (double)g.table[j - 1] * cos((double)j * th);    // smallest terms first
+      return T(acc);
+    }
+    const double t2 = th * th;
+    double acc = 0.;
+    for (int n = g.ntable - 1; n >= 0; --n) acc = acc * t2 + (double)g.table[n];
+    if (th > 0.) {
+      const double lt = log(th), A = (double)g.par[0], pw = (double)g.par[1], eps = (double)g.par[2];
+      const double gl = g.flag ? (eps == 0. ? lt : expm1(eps * lt)) : 1.;
+      acc += exp(pw * lt) * (A * gl + (double)g.par[3]);
+    }
+    return T(acc);
+  }
   if (g.kernel == LGP_KERNEL_COLOR) {                     // par = {psi(n)}, p = n
     if (x == 0.) return T(1);
     return T((double)(g.p - 1) * expn_imag_re(g.p, (double)g.par[0], x));
@@ -386,7 +411,7 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0), T 
   } else if (NU && g.kernel == LGP_KERNEL_MATERN) {      // _kernels/_matern.py:56-76
     T unused;
     return matern_real_of<T>(g, r2, &unused);
-  } else if (NU && (g.kernel == LGP_KERNEL_COLOR || g.kernel == LGP_KERNEL_PINK || g.kernel == LGP_KERNEL_BESSEL)) {
+  } else if (NU && (g.kernel == LGP_KERNEL_COLOR || g.kernel == LGP_KERNEL_PINK || g.kernel == LGP_KERNEL_BESSEL || g.kernel == LGP_KERNEL_PSERIES)) {
     return special_core<T>(g, r2);
   } else if (g.kernel == LGP_KERNEL_GAMMAEXP) {          // _kernels/_basic.py:111-113
     return g.flag ? exp(-r2) : exp(-pow(r2, g.par[1]));
@@ -463,7 +488,7 @@ __host__ inline int core_of(int kernel, int p) {
   if (kernel == LGP_KERNEL_EXPQUAD) return CORE_EXPQUAD;
   if (kernel == LGP_KERNEL_MATERNP && p >= 1 && p <= 3) return CORE_MATERN1 + (p - 1);
   if (kernel == LGP_KERNEL_MATERN) return CORE_MATERNNU;
-  if (kernel == LGP_KERNEL_COLOR || kernel == LGP_KERNEL_PINK || kernel == LGP_KERNEL_BESSEL) return CORE_SPECIAL;
+  if (kernel == LGP_KERNEL_COLOR || kernel == LGP_KERNEL_PINK || kernel == LGP_KERNEL_BESSEL || kernel == LGP_KERNEL_PSERIES) return CORE_SPECIAL;
   return CORE_GENERIC;
 }
 
@@ -706,12 +731,12 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   if (n == 0 || m == 0) return LGP_OK;
   if (pairs) { LGP_REQUIRE(n == m, "pairs mode needs as many x as y points"); ldo = m; }
   LGP_REQUIRE(dx != nullptr && dy != nullptr && dout != nullptr, "null pointer");
-  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_BESSEL, "unknown isotropic kernel");
-  LGP_REQUIRE(kernel != LGP_KERNEL_LAGTABLE || ((dtable != nullptr || ntable == 0) && ntable < (1u << 30) && ddsc == nullptr), "LagTable takes a device table (lgp_gram_lagtable), no scale tangent");
+  LGP_REQUIRE(kernel >= LGP_KERNEL_EXPQUAD && kernel <= LGP_KERNEL_PSERIES, "unknown isotropic kernel");
+  LGP_REQUIRE((kernel != LGP_KERNEL_LAGTABLE && kernel != LGP_KERNEL_PSERIES) || ((dtable != nullptr || ntable == 0) && ntable < (1u << 30) && ddsc == nullptr), "LagTable takes a device table (lgp_gram_lagtable), no scale tangent");
   LGP_REQUIRE(kernel < LGP_KERNEL_EXPON || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_GIBBS || kernel == LGP_KERNEL_MATERN || kernel == LGP_KERNEL_BESSEL || d == 1, "this kernel is a function of one variable (maxdim = 1)");
   LGP_REQUIRE(kernel != LGP_KERNEL_GIBBS || (d >= 2 && !has_loc && !has_scale), "Gibbs takes the per-point scales as the last coordinate row, inputs already transformed");
   LGP_REQUIRE(d >= 1 && d <= 64, "field count must be in [1,64]");
-  LGP_REQUIRE(p >= 0 && (p <= MAX_P || kernel == LGP_KERNEL_COLOR), "Maternp order must be in [0,16]");
+  LGP_REQUIRE(p >= 0 && (p <= MAX_P || kernel == LGP_KERNEL_COLOR || kernel == LGP_KERNEL_PSERIES), "Maternp order must be in [0,16]");
   const bool derived = kernel == LGP_KERNEL_EXPQUAD_DIFF || kernel == LGP_KERNEL_MATERNP_DIFF;
   const bool posabs = kernel == LGP_KERNEL_WENDLAND || kernel == LGP_KERNEL_CAUSALEXPQUAD || kernel == LGP_KERNEL_LOG;
   LGP_REQUIRE(!(derived || posabs) || ddsc == nullptr, "no scale tangent for this kernel");
@@ -782,6 +807,11 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   } else if (kernel == LGP_KERNEL_PERIODIC) {            // hpar = {outerscale}
     LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] > T(0) && hpar[0] < std::numeric_limits<T>::infinity(), "Periodic takes {outerscale} in (0, inf)");
     g.par[0] = hpar[0];
+  } else if (kernel == LGP_KERNEL_PSERIES) {             // p = mode | 16 uselog, hpar = {A, pw, eps, D}
+    LGP_REQUIRE(npar == 4 && hpar != nullptr && (p & 15) <= 2 && ntable <= 4096, "PSeries takes the mode in p and {A, pw, eps, D}");
+    for (int k = 0; k < 4; ++k) g.par[k] = hpar[k];
+    g.flag = (p >> 4) & 1;
+    g.p = p & 15;
   } else if (kernel == LGP_KERNEL_BESSEL) {              // hpar = {nu}
     LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0) && hpar[0] <= T(100) && ddsc == nullptr, "Bessel takes {nu} in [0, 100]");   // _matern.py:117
     const double nu = (double)hpar[0];
@@ -1665,6 +1695,30 @@ extern "C" int lgp_gram_lagtable_f32(lgp_ctx *ctx, const float *dtable, size_t n
                                      const float *hops_val, int symmetric, float *dout, size_t ldo) {
   return gram_iso_launch<float>(ctx, LGP_KERNEL_LAGTABLE, 0, 0, nullptr, 1, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val,
                                 dout, ldo, false, nullptr, symmetric != 0, dtable, ntable, fill);
+}
+extern "C" int lgp_gram_pseries_f64(lgp_ctx *ctx, int mode, int uselog, const double *dtable, size_t ntable, const double *hpar4, const double *dx, size_t ldx,
+                                    size_t n, const double *dy, size_t ldy, size_t m, int has_loc, double loc, int has_scale, double scale, int nops,
+                                    const int *hops_code, const double *hops_val, int symmetric, double *dout, size_t ldo) {
+  return gram_iso_launch<double>(ctx, LGP_KERNEL_PSERIES, (mode & 15) | (uselog ? 16 : 0), 4, hpar4, 1, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops,
+                                 hops_code, hops_val, dout, ldo, false, nullptr, symmetric != 0, dtable, ntable, 0.);
+}
+extern "C" int lgp_gram_pseries_f32(lgp_ctx *ctx, int mode, int uselog, const float *dtable, size_t ntable, const float *hpar4, const float *dx, size_t ldx,
+                                    size_t n, const float *dy, size_t ldy, size_t m, int has_loc, float loc, int has_scale, float scale, int nops,
+                                    const int *hops_code, const float *hops_val, int symmetric, float *dout, size_t ldo) {
+  return gram_iso_launch<float>(ctx, LGP_KERNEL_PSERIES, (mode & 15) | (uselog ? 16 : 0), 4, hpar4, 1, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, nops,
+                                hops_code, hops_val, dout, ldo, false, nullptr, symmetric != 0, dtable, ntable, 0.f);
+}
+extern "C" int lgp_pairs_pseries_f64(lgp_ctx *ctx, int mode, int uselog, const double *dtable, size_t ntable, const double *hpar4, const double *dx, size_t ldx,
+                                     const double *dy, size_t ldy, size_t npairs, int has_loc, double loc, int has_scale, double scale, int nops,
+                                     const int *hops_code, const double *hops_val, double *dout) {
+  return gram_iso_launch<double>(ctx, LGP_KERNEL_PSERIES, (mode & 15) | (uselog ? 16 : 0), 4, hpar4, 1, dx, ldx, npairs, dy, ldy, npairs, has_loc, loc, has_scale, scale,
+                                 nops, hops_code, hops_val, dout, npairs, true, nullptr, false, dtable, ntable, 0.);
+}
+extern "C" int lgp_pairs_pseries_f32(lgp_ctx *ctx, int mode, int uselog, const float *dtable, size_t ntable, const float *hpar4, const float *dx, size_t ldx,
+                                     const float *dy, size_t ldy, size_t npairs, int has_loc, float loc, int has_scale, float scale, int nops,
+                                     const int *hops_code, const float *hops_val, float *dout) {
+  return gram_iso_launch<float>(ctx, LGP_KERNEL_PSERIES, (mode & 15) | (uselog ? 16 : 0), 4, hpar4, 1, dx, ldx, npairs, dy, ldy, npairs, has_loc, loc, has_scale, scale,
+                                nops, hops_code, hops_val, dout, npairs, true, nullptr, false, dtable, ntable, 0.f);
 }
 extern "C" int lgp_pairs_lagtable_f64(lgp_ctx *ctx, const double *dtable, size_t ntable, double fill, const double *dx, size_t ldx, const double *dy, size_t ldy,
                                       size_t npairs, int has_loc, double loc, int has_scale, double scale, int nops, const int *hops_code,

@@ -56,5 +56,5 @@ LAPACK family here.  What *is* pinned, in ``tests/test_oracle_*.py``:
 from . import decomp, kernels, gp  # noqa: F401
 from .decomp import Decomposition, Chol  # noqa: F401
 from .kernels import (ExpQuad, Maternp, Matern, GammaExp, Cauchy, Wendland, CausalExpQuad, Log, Constant, White, Expon, HoleEffect, Periodic, Cos,  # noqa: F401
-                      Sinc, StationaryFracBrownian, Linear, Wiener, OrnsteinUhlenbeck, BrownianBridge, Decaying, FracBrownian, WienerIntegral, Celerite, Harmonic, Circular, Taylor, Rescaling, Categorical, NNKernel, Gibbs, MA, AR, BagOfWords, Color, Pink, Bessel, BART)
+                      Sinc, StationaryFracBrownian, Linear, Wiener, OrnsteinUhlenbeck, BrownianBridge, Decaying, FracBrownian, WienerIntegral, Celerite, Harmonic, Circular, Taylor, Rescaling, Categorical, NNKernel, Gibbs, MA, AR, BagOfWords, Color, Pink, Bessel, Zeta, BART)
 from .gp import GP  # noqa: F401

@@ -537,6 +537,71 @@ def Pink(*, dw=1, scale=None, loc=None, dim=None):
     return Kernel(_stationary1d(core, 'abs'), scale=scale, loc=loc, dim=dim)
 
 
+def _eta_borwein(z, n=40):
+    """ Dirichlet eta, P. Borwein's algorithm 2 (2000) """
+    k = numpy.arange(n + 1)
+    d = numpy.cumsum(n * numpy.exp(special.gammaln(n + k) - special.gammaln(n - k + 1) - special.gammaln(2 * k + 1) + k * numpy.log(4.)))
+    kk = numpy.arange(n)
+    return -numpy.sum((-1.) ** kk * (d[kk] - d[n]) / (kk + 1.) ** z) / d[n]
+
+
+def riemann_zeta(z):
+    """ ζ(z), real z != 1 (the reference has its own ``_special/_zeta.py:206-264``): scipy above 1, eta on [0, 1), reflection below """
+    if z > 1:
+        return float(special.zeta(z, 1))
+    if z >= 0:
+        return _eta_borwein(z) / (1 - 2. ** (1 - z))
+    return 2 * (2 * numpy.pi) ** (z - 1) * numpy.sin(numpy.pi * z / 2) * special.gamma(1 - z) * riemann_zeta(1 - z)
+
+
+def periodic_zeta_real(x, s, nmax=62):
+    """ Re Li_s(e^{2πix}), s > 1 (``_special/_zeta.py:76-177``).  s >= 10: the Fourier series, 50 terms (``:96-105,121-131``).  Below:
+    DLMF 25.13.2 with ζ(1-s, x) + ζ(1-s, 1-x) = x^(s-1) + 2 Σ_{n even} (1-s)_n / n! ζ(n+1-s) x^n (25.11.3, 25.11.10; ``:133-177``,
+    ``:34-74``).  At odd integer s that form is 0 times infinity (the reference moves s by one part in 2^52 and guards the
+    cancellation); there, the limit in closed form: (-1)^m θ^(2m) (H_2m - log θ) / (2m)! + Σ_{n != m} (-1)^n ζ(2m+1-2n) θ^(2n) / (2n)! """
+    x = numpy.asarray(x, float) % 1
+    x = numpy.where(x > 0.5, 1 - x, x)
+    if s >= 10:
+        n = numpy.arange(1, 51.)
+        with numpy.errstate(over='ignore'):
+            return numpy.sum(numpy.cos(2 * numpy.pi * n * x[..., None]) / n ** s, axis=-1)
+    if s == round(s) and int(round(s)) % 2 == 1:
+        m = (int(round(s)) - 1) // 2
+        th = 2 * numpy.pi * x
+        out = numpy.zeros(x.shape)
+        for n in range(nmax // 2, -1, -1):
+            out = out * th * th + (0. if n == m else (-1.) ** n * riemann_zeta(s - 2 * n) / special.gamma(2 * n + 1) if s - 2 * n > -20 else
+                                   (-1.) ** n * 2 * (2 * numpy.pi) ** (s - 2 * n - 1) * numpy.sin(numpy.pi * (s - 2 * n) / 2) *
+                                   numpy.exp(special.gammaln(1 - s + 2 * n) - special.gammaln(2 * n + 1)) * float(special.zeta(1 - s + 2 * n, 1)))
+        with numpy.errstate(all='ignore'):
+            extra = numpy.where(th > 0, (-1.) ** m * th ** (2 * m) / special.gamma(2 * m + 1) * (numpy.sum(1. / numpy.arange(1, 2 * m + 1)) - numpy.log(th)), 0.)
+        return out + extra
+    s1 = 1 - s
+    coef = numpy.pi * (2 * numpy.pi) ** (s - 1) / (2 * numpy.cos(numpy.pi * s / 2) * special.gamma(s))     # = Γ(s1) (2π)^-s1 cos(π s1 / 2)
+    series = numpy.zeros(x.shape)
+    for n in range(nmax, -1, -2):
+        if n + s1 == 1:
+            b = -1. / n                                              # the zero of the Pochhammer symbol against the pole of ζ
+        else:
+            b = numpy.prod(s1 + numpy.arange(n)) / special.gamma(n + 1) * riemann_zeta(n + s1)
+        series = series * x * x + b
+    with numpy.errstate(all='ignore'):
+        power = numpy.where(x > 0, x ** (s - 1), 0.)
+    return coef * (power + 2 * series)
+
+
+def Zeta(*, nu=None, scale=None, loc=None, dim=None):
+    """ ``_kernels/_zeta.py:37-70`` """
+    assert nu is not None and 0 <= nu < numpy.inf, nu
+    s = 1 + 2 * nu
+
+    def core(delta):
+        if s > 1:
+            return periodic_zeta_real(delta, s) / special.zeta(s, 1)
+        return numpy.where(delta % 1, 0., 1.)
+    return Kernel(_stationary1d(core), scale=scale, loc=loc, dim=dim)
+
+
 def MA(*, w=None, norm=False, scale=None, loc=None, dim=None):
     """ ``_kernels/_arma.py:31-63``: cov = convolve(w, reversed w), looked up at delta + len(w) - 1, 0 beyond """
     w = numpy.asarray([] if w is None else w, float)

@@ -989,3 +989,67 @@ def test_bessel_kernel_against_scipy_jv(lgp, rng, nu):
         over['v'] = rng.uniform(-3, 3, (10, md + 1))
         with pytest.raises((ValueError, lgp.LibraryError)):
             lgp.Bessel(nu=nu).gram(over, over)
+
+
+def _polylog_re_quad(s, theta):
+    """ Re Li_s(e^{i theta}) = 1/Gamma(s) int_0^inf t^(s-1) Re[z / (e^t - z)] dt, z = e^{i theta}: the Bose-Einstein integral by QUADPACK """
+    from scipy import integrate, special
+    c = np.cos(theta)
+    f = lambda t: t ** (s - 1) * (np.exp(t) * c - 1) / (np.exp(2 * t) - 2 * np.exp(t) * c + 1)
+    pts = sorted({min(theta, 0.999), 0.5 * min(theta, 0.999), min(2 * theta, 0.9995)})
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        v = (integrate.quad(f, 0, 1., limit=800, points=pts, epsabs=1e-14, epsrel=1e-13)[0] + integrate.quad(f, 1., 40., limit=400, epsabs=1e-14, epsrel=1e-13)[0]
+             + integrate.quad(f, 40., 300., limit=400, epsabs=1e-14, epsrel=1e-13)[0])
+    return v / special.gamma(s)
+
+
+@pytest.mark.parametrize('nu', [0, 0.1, 0.3, 0.5, 0.99, 0.9995, 1, 1.0002, 1.01, 1.5, 2, 2.5, 3.7, 4.4, 4.5, 4.9, 7, 1000])
+def test_zeta_kernel(lgp, rng, nu):
+    """ ``Zeta(nu)``: the device's sum of the host-computed expansion against (i) the oracle's restatement of the reference's Hurwitz
+    series form (and its closed-form limit at integer nu), (ii) the Bernoulli polynomials at half-integer nu, (iii) the
+    Bose-Einstein integral of the polylogarithm by quadrature, (iv) the Fourier series itself where it converges fast """
+    from scipy import special
+    s = 1 + 2 * nu
+    d = np.concatenate([[0., 1., -3., 1e-9, 1e-6], np.linspace(0.001, 0.5, 40), rng.uniform(-4, 4, 80)])
+    got = lgp.Zeta(nu=nu).gram(np.zeros(1), d).to_host()[0]
+    # (the reference reduces the SIGNED difference modulo 1, which costs a tiny negative difference its digits: the oracle gets |d|)
+    ref = oracle.Zeta(nu=nu)(np.abs(d)[None, :], np.zeros((1, 1)))[0]
+    frac = abs(s - (2 * round((s - 1) / 2) + 1))                       # distance of s from an odd integer: the oracle's form loses eps / distance there
+    tol = 2e-14 if frac == 0 or frac > 0.5 else 2e-14 + 1e-13 / frac
+    np.testing.assert_allclose(got, ref, rtol=0, atol=tol)
+    assert np.all(np.abs(got[:3] - 1.) <= 1e-14) and np.all(np.abs(got) <= 1 + 1e-14)
+    if nu == 0.5:
+        x = np.abs(d) % 1
+        np.testing.assert_allclose(got, 6 * (x * x - x + 1 / 6), rtol=0, atol=2e-14)                     # B_2
+    if nu == 1.5:
+        x = np.abs(d) % 1
+        np.testing.assert_allclose(got, -30 * (x ** 4 - 2 * x ** 3 + x * x - 1 / 30), rtol=0, atol=2e-14)   # B_4
+    if 0 < nu < 10:
+        pick = [5, 8, 15, 25, 44]
+        x = np.abs(d[pick]) % 1
+        quad = np.array([_polylog_re_quad(s, 2 * np.pi * min(v, 1 - v)) for v in x]) / special.zeta(s, 1)
+        np.testing.assert_allclose(got[pick], quad, rtol=0, atol=2e-11)
+    if nu >= 1:
+        k = np.arange(1, 400001.)
+        with np.errstate(over='ignore'):
+            direct = np.array([np.sum(np.cos(2 * np.pi * k * v) / k ** s) for v in d[::7]]) / special.zeta(s, 1)
+        np.testing.assert_allclose(got[::7], direct, rtol=0, atol=5e-12 if nu < 1.5 else 1e-13)       # (the truncated sum's own tail: N^-(s-1) / (s-1))
+    # the other entry points
+    x = rng.uniform(-3, 3, 600)
+    k = lgp.Zeta(nu=nu, scale=1.5, loc=0.2) * 2. + 0.25
+    ko = oracle.Zeta(nu=nu, scale=1.5, loc=0.2)
+    S = k.gram(x, x).to_host()
+    np.testing.assert_array_equal(S, S.T)
+    np.testing.assert_allclose(S, 2 * ko(x[:, None], x[None, :]) + 0.25, rtol=0, atol=4 * tol + 1e-13)
+    np.testing.assert_allclose(k.pairs(x[:100], x[100:200]).to_host(), 2 * ko(x[:100], x[100:200]) + 0.25, rtol=0, atol=4 * tol + 1e-13)
+    if nu in (0.5, 1):
+        xs = np.linspace(0, 2, 80); y = np.sin(2 * np.pi * xs)
+        post = {}
+        for mod in (lgp, oracle):
+            gp = mod.GP(mod.Zeta(nu=nu) + mod.White() * 1e-4, checkpos=False, checksym=False).addx(xs, 'a').addx(xs[:7] + 0.013, 'b')
+            post[mod] = gp.predfromdata({'a': y}, 'b', raw=True), gp.marginal_likelihood({'a': y})
+        np.testing.assert_allclose(post[lgp][0][0], post[oracle][0][0], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(post[lgp][0][1], post[oracle][0][1], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(post[lgp][1], post[oracle][1], rtol=1e-8)

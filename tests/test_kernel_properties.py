@@ -49,6 +49,7 @@ KERNELS = {
                + [dict(nu=nu + 0.5) for nu in range(5)], 'bessel', True, (-5, 5), 0),                       # ref :697-701
     'Color': ([dict(n=n) for n in (2, 3, 4, 5, 6, 20)], 1, True, (-5, 5), 0),            # ref :796-798
     'Pink': ([dict(dw=1), dict(dw=0.2), dict(dw=30)], 1, True, (-5, 5), 0),
+    'Zeta': ([dict(nu=nu) for nu in (0, 0.1, 1, 1.5, 4.9, 1000)], 1, True, (-5, 5), 0),     # ref :593-595
     'Wiener': ([{}], 1, False, (0, 5), 0),
     'WienerIntegral': ([{}], 1, False, (0, 5), 0),
     'OrnsteinUhlenbeck': ([{}], 1, False, (0, 5), 0),
@@ -153,7 +154,7 @@ def test_stationary_normalized_continuous(lgp, rng, name, kw):
     x = scalar_x(rng, name)
     var = k(x, x)
     util.assert_allclose(var, 1, rtol=1e-14, atol=1e-15)
-    discontinuous = ((name == 'Cauchy' and kw.get('alpha', 2) < 1) or (name == 'GammaExp' and kw.get('gamma', 1) < 1) or name == 'White' or (name == 'Matern' and kw['nu'] < 0.5)
+    discontinuous = ((name == 'Cauchy' and kw.get('alpha', 2) < 1) or (name == 'GammaExp' and kw.get('gamma', 1) < 1) or name == 'White' or (name == 'Matern' and kw['nu'] < 0.5) or (name == 'Zeta' and kw['nu'] < 0.5)
                      or (name == 'StationaryFracBrownian' and kw.get('H', 0.5) < 0.5))
     if not discontinuous:
         util.assert_allclose(k(np.zeros(1), np.full(1, 1e-15)), k(np.zeros(1), np.zeros(1)), rtol=1e-10)
