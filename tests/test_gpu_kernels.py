@@ -971,7 +971,8 @@ def test_bessel_kernel_against_scipy_jv(lgp, rng, nu):
     got = lgp.Bessel(nu=nu).gram(np.zeros(1), r).to_host()[0]
     ref = oracle.Bessel(nu=nu)(np.zeros((1, 1)), r[None, :])[0]
     assert got[0] == 1. and np.all(np.abs(got) <= 1 + 1e-13)
-    lost = (xs > 0) & ((xs / 2) ** nu < 1e-280)          # J_nu itself underflows there in the oracle's product: the limit, 1
+    from scipy import special
+    lost = (xs > 0) & ((xs / 2) ** nu / special.gamma(nu + 1) < 1e-290)      # J_nu itself underflows there in the oracle's product: the limit, 1
     np.testing.assert_allclose(got, np.where(lost, 1., ref), rtol=0, atol=5e-14)
     # several fields up to maxdim, one more refused; one-triangle grid; pairs; output operations; scale
     md = 2 * (int(np.floor(nu)) + 1)
