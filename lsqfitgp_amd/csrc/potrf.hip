@@ -666,9 +666,25 @@ static int potrf_lookahead_v1(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk,
 //   s0 (main)                  U2(k) = rest of block column k+1, U3(k) = everything right of it (the N^3/3 flops).
 // Against the round-1 driver (whole panel, all rows, on the chain stream; kept as potrf_lookahead_v1, LGP_POTRF=v1) the chain
 // loses the substitution and the update of up to N rows per block and the part of the block-column update below the square.
+static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *dblk, size_t nx, size_t row0, bool early);
+
 template <typename T>
 static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx) {
   ThinGuard thin_guard(ctx);
+  // The tail of a large factorisation is bound by the chain of diagonal blocks, not by the updates: once this few rows are left,
+  // the trailing matrix (already carrying every update) is handed to the chain-kernel driver, which factors it faster than the
+  // launch-per-block chain here.  Measured (tools/tail_sweep.sh, Cholesky alone): tail 8192 -> N = 32768 181.7 -> 180.9 ms, N = 20480
+  // 51.8 -> 50.5 ms; tail 4096: -0.2 / -0.8 ms; 12288: +0.2 / -0.6; 16384: +1.6 / +0.7 ms (the chain kernel keeps 16 CUs from updates that
+  // still bound the factorisation there).  Decided before anything is enqueued: the first use of the chain kernel in a context runs a
+  // handshake between its streams.
+  static const size_t tail_env = getenv("LGP_SPLIT_CHAIN_TAIL") ? (size_t)atol(getenv("LGP_SPLIT_CHAIN_TAIL")) : (size_t)8192;
+  size_t chain_tail = 0;
+  if constexpr (std::is_same<T, double>::value) {
+    if (tail_env >= 2048 && n > tail_env && n % LGP_DB == 0) {
+      const size_t cand = (tail_env < ctx->chain_max_n ? tail_env : ctx->chain_max_n) / LGP_NB * LGP_NB;
+      if (cand >= 2048 && lgp_chain_usable(ctx, cand, ldl)) chain_tail = cand;
+    }
+  }
   // chain-bound sizes: the trailing updates (sg) and the far rows (s3) run on CU-masked streams that leave a few CUs to the chain
   const bool reserve = ctx->stream_gm != nullptr && ctx->stream_fm != nullptr && n <= ctx->reserve_max_n;
   hipStream_t s0 = ctx->stream, s1 = ctx->stream2, s3 = reserve ? ctx->stream_fm : ctx->stream3, sg = reserve ? ctx->stream_gm : s0;
@@ -694,6 +710,18 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
   if (sg != s0) LGP_HIP(hipStreamWaitEvent(sg, E(EV_START), 0));
   bool have_u3 = false, have_far = false;
   for (size_t k0 = 0; k0 < n; k0 += NB) {
+    if constexpr (std::is_same<T, double>::value) {
+      if (chain_tail && k0 > 0 && n - k0 <= chain_tail && !reserve) {
+        // the trailing matrix has every update once U1 (s1) and U2 / U3 (s0, behind the far rows) of the previous panel are done
+        // (the square of this panel needs U1 alone, which is in s1's order: the chain kernel starts beside U3)
+        static const bool late = getenv("LGP_SPLIT_CHAIN_LATE") != nullptr;
+        if (late) {
+          LGP_HIP(hipEventRecord(E(EV_SQ), s1));
+          LGP_HIP(hipStreamWaitEvent(s0, E(EV_SQ), 0));
+        }
+        return potrf_chain(ctx, n - k0, L + k0 * ldl + k0, ldl, dblk + (k0 / LGP_DB) * (size_t)LGP_DBLK, nx, k0, !late);
+      }
+    }
     const size_t kb = (n - k0) < NB ? (n - k0) : NB;
     T *P = L + k0 * ldl + k0;
     T *Yk = dblk + (k0 / LGP_DB) * (size_t)LGP_DBLK;
@@ -782,7 +810,9 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
 //   s0 (main)        wait grp[k][*]  ->  U2(k) (block column k+1 below its square),  u2[k] := 1,  U3(k) (everything right of it),  u3[k] := 1
 // One stream for all the rows below was measured first: its 16 dependent launches per panel (8 x (37 + 52) us at N = 8192) were
 // slower than the chain (8 x 72 us) and the next square waited ~400 us for them; per group they overlap.
-static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *dblk, size_t nx) {
+// early (the hand-over from potrf_split): s1 already holds, in its own order, everything the FIRST square needs -- the chain kernel
+// is launched there without waiting for the caller's stream, i.e. beside the trailing update that is still running on it
+static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *dblk, size_t nx, size_t row0, bool early) {
   typedef double T;
   ThinGuard thin_guard(ctx);
   hipStream_t s0 = ctx->stream, s1 = ctx->stream2;
@@ -812,11 +842,18 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     return LGP_OK;
   };
   // the flag words are zeroed before any stream can look at them: every stream starts behind this point of s0
-  LGP_HIP(hipMemsetAsync(st, 0, lgp_chain_state_bytes(n), s0));
-  LGP_HIP(hipEventRecord(E(EV_START), s0));
-  LGP_HIP(hipStreamWaitEvent(s1, E(EV_START), 0));
+  if (early) {
+    LGP_HIP(hipMemsetAsync(st, 0, lgp_chain_state_bytes(n), s1));
+    LGP_HIP(hipEventRecord(E(EV_START), s1));
+    LGP_HIP(hipStreamWaitEvent(s0, E(EV_START), 0));
+    LGP_HIP(hipEventRecord(E(EV_START), s0));
+  } else {
+    LGP_HIP(hipMemsetAsync(st, 0, lgp_chain_state_bytes(n), s0));
+    LGP_HIP(hipEventRecord(E(EV_START), s0));
+    LGP_HIP(hipStreamWaitEvent(s1, E(EV_START), 0));
+  }
   for (int g = 0; g < MAXG; ++g) LGP_HIP(hipStreamWaitEvent(ctx->far_streams[(size_t)g], E(EV_START), 0));
-  LGP_CHECK(lgp_chain_launch(ctx, s1, n, L, ldl, dblk));
+  LGP_CHECK(lgp_chain_launch(ctx, s1, n, L, ldl, dblk, row0));
   LGP_HIP(hipEventRecord(E(EV_SQ), s1));
   const size_t npanels = (n + NB - 1) / NB;
   for (size_t k = 0; k < npanels; ++k) {
@@ -1001,7 +1038,7 @@ int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx)
   static const bool v1 = getenv("LGP_POTRF") != nullptr && strcmp(getenv("LGP_POTRF"), "v1") == 0;
   if (v1 || ctx->stream3 == nullptr) return potrf_lookahead_v1<T>(ctx, n, L, ldl, dblk, nx);
   if constexpr (std::is_same<T, double>::value) {
-    if (lgp_chain_usable(ctx, n, ldl) && n <= ctx->chain_max_n) return potrf_chain(ctx, n, L, ldl, dblk, nx);
+    if (lgp_chain_usable(ctx, n, ldl) && n <= ctx->chain_max_n) return potrf_chain(ctx, n, L, ldl, dblk, nx, 0, false);
   }
   return potrf_split<T>(ctx, n, L, ldl, dblk, nx);
 }

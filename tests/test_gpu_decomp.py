@@ -547,3 +547,37 @@ def test_gradient_large_and_repeatable(lgp, rng):
         assert v == outs[0][0]
         np.testing.assert_array_equal(np.asarray(g), np.asarray(outs[0][1]))
     np.testing.assert_allclose(np.asarray(outs[0][1]), gref, rtol=1e-9)
+
+
+def test_split_driver_hands_its_tail_to_the_chain_driver(lgp, driver_contexts):
+    """ above N = 16384 the launch-per-block driver factors the leading panels and hands the last <= 8192 rows (a multiple of 128,
+    here 137 x 128 = 17536 -> 7296 left after ten panels, so the chain kernel's last panel is ragged) to the chain-kernel
+    driver, whose first square starts beside the previous trailing update (csrc/potrf.hip, LGP_SPLIT_CHAIN_TAIL): against the
+    context that never uses the chain kernel, with 37 carried right-hand sides; and a bad pivot inside the tail is reported """
+    from lsqfitgp_amd._GP import _gemm
+    n, q = 17536, 37
+    rng = np.random.default_rng(17)
+    x = rng.uniform(0, n / 16, n)
+    ctx_launch, ctx_chain = driver_contexts
+    lib = __import__('lsqfitgp_amd')._lib.load()
+    B = rng.standard_normal((n, q))
+    V = rng.standard_normal((n, 3))
+    res = []
+    for ctx in (ctx_launch, ctx_chain):
+        K = lgp.ExpQuad().gram(x, x, ctx=ctx)
+        assert lib.lgp_add_diag_f64(ctx.handle, n, K.ptr, K.ld, None, ctypes.c_double(0.02)) == 0
+        d = lgp.Chol(K, ctx=ctx, rhs=B)
+        KV = _gemm(False, False, K, lgp.DeviceArray.from_host(V, ctx=ctx)).to_host() + d.eps * V
+        util.assert_close_matrices(d.correlate(d.back_correlate(V)), KV, rtol=1e-12)          # L L^T V = (K + eps) V
+        util.assert_close_matrices(d.correlate(d.solved()), B, rtol=1e-11)                     # L (L^-1 B) = B
+        res.append((d.solved(), d.back_correlate(V), d.minus_log_normal_density(B[:, 0], value=True)[0], d.eps))
+        del d, K
+    util.assert_close_matrices(res[1][0], res[0][0], rtol=1e-10)
+    util.assert_close_matrices(res[1][1], res[0][1], rtol=1e-12)
+    assert res[1][2] == pytest.approx(res[0][2], rel=1e-12) and res[1][3] == res[0][3]
+    K = lgp.ExpQuad().gram(x, x, ctx=ctx_chain)
+    assert lib.lgp_add_diag_f64(ctx_chain.handle, n, K.ptr, K.ld, None, ctypes.c_double(0.02)) == 0
+    Kh = K.block(15000, 15001, 15000, 15001)
+    Kh.assign(lgp.DeviceArray.from_host(np.array([[-1.0]]), ctx=ctx_chain))
+    with pytest.raises(np.linalg.LinAlgError):
+        lgp.Chol(K, ctx=ctx_chain, epsrel=0)
