@@ -49,8 +49,9 @@ struct lgp_ctx {
   size_t chain_trace_tasks = 0;
   const void *chain_trace_sched = nullptr;
   int chain_mode = 0;                 // 0 = not yet checked, 1 = off (env LGP_CHAIN=0, or the self-test failed), 2 = available
-  size_t chain_max_n = 16384;         // largest matrix factored this way (env LGP_CHAIN_MAX_N); beyond, the trailing update bounds the
-                                      // factorisation and the workers' CUs are worth more to it (N = 32768: 186 ms split driver, 204 ms chain)
+  size_t chain_max_n = 14336;         // largest matrix factored this way (env LGP_CHAIN_MAX_N); beyond, the trailing update bounds the
+                                      // factorisation and the workers' CUs are worth more to it (N = 32768: 186 ms split driver, 204 ms chain;
+                                      // N = 16384: 30.2-30.5 ms here against 28.9-29.3 for the split driver with a chain tail of 8192 rows, N = 14336 equal)
   size_t chain_hog_max_n = 8192;      // ... and largest matrix for which the workers keep other workgroups off their CUs
   int chain_workers = 16;             // resident worker workgroups = CUs taken from the trailing update (env LGP_CHAIN_WORKERS)
   int chain_lds_kb = 100;             // untouched dynamic LDS per worker that keeps other workgroups off its CU (env LGP_CHAIN_LDS_KB)
