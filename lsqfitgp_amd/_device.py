@@ -144,6 +144,9 @@ class _Graveyard:
         self.pending, self.nbytes = [], 0
         self.cache, self.cached_bytes = {}, 0
         self.enabled = os.environ.get('LGP_HOST_POOL', '1') != '0'
+        # blocks handed out and not yet buried; when the context object dies first (the garbage collector finalises the members of
+        # a reference cycle in no particular order) the library context is kept until the last of them comes back
+        self.live, self.closing = 0, False
         # `bury` runs from weakref finalizers, i.e. from the garbage collector in whatever thread triggers it
         self._lock = threading.RLock()
 
@@ -157,6 +160,17 @@ class _Graveyard:
             return blocks.pop()
 
     def bury(self, ptr, nbytes):
+        with self._lock:
+            self.live -= 1
+            last = self.closing and self.live <= 0
+            if self.closing:
+                self.pending.append(ptr)
+                self.nbytes += nbytes
+        if self.closing:
+            if last:
+                self.flush()
+                self.lib.lgp_ctx_destroy(self.handle)
+            return
         with self._lock:
             if self.enabled and nbytes <= self.BLOCK_BYTES and self.cached_bytes + nbytes <= self.CACHE_BYTES:
                 self.cache.setdefault(nbytes, []).append(ptr)
@@ -184,6 +198,10 @@ def _destroy_context(lib, handle, graveyard):
         _lib._on_enomem.remove(graveyard.flush)
     except ValueError:
         pass
+    with graveyard._lock:
+        if graveyard.live > 0:          # buffers of this context are still to be finalised: the last one destroys it (`bury`)
+            graveyard.closing = True
+            return
     graveyard.flush()
     lib.lgp_ctx_destroy(handle)
 
@@ -202,6 +220,8 @@ class _Buffer:
         self.ctx = ctx
         self.ptr = ptr.value
         self.nbytes = int(nbytes)
+        with ctx._graveyard._lock:
+            ctx._graveyard.live += 1
         self._finalizer = weakref.finalize(self, ctx._graveyard.bury, ptr.value, int(nbytes))
 
 
