@@ -984,8 +984,10 @@ class AR(_LagTable):
     def __init__(self, *, phi=None, gamma=None, maxlag=None, slnr=None, lnc=None, norm=False, scale=None, loc=None, dim=None):
         super().__init__(scale=scale, loc=loc, dim=dim)
         given = (phi is not None, gamma is not None, maxlag is not None, slnr is not None, lnc is not None)
-        if given not in ((True, False, True, False, False), (False, True, True, False, False), (False, False, False, True, True)):
-            raise ValueError('invalid set of specified parameters')                                   # _arma.py:164-170
+        self._invalid = given not in ((True, False, True, False, False), (False, True, True, False, False), (False, False, False, True, True))
+        if self._invalid:              # _arma.py:164-170: the reference's core raises when the kernel is evaluated, not when it is made
+            self._phi, self._gamma, self._maxlag = numpy.empty(0), numpy.ones(1), 0
+            return
         if slnr is not None:
             phi = self.phi_from_roots(slnr, lnc)
         elif phi is None:
@@ -1001,6 +1003,8 @@ class AR(_LagTable):
             self._fill = 0.     # never used: the table covers every lag of the inputs
 
     def _table(self, maxlag):
+        if self._invalid:
+            raise ValueError('invalid set of specified parameters')
         last = self._maxlag if self._maxlag is not None else maxlag
         return self.extend_gamma(self._gamma, self._phi, max(0, last + 1 - len(self._gamma)))[:last + 1]
 

@@ -627,7 +627,9 @@ class AR:
     def __new__(cls, *, phi=None, gamma=None, maxlag=None, slnr=None, lnc=None, norm=False, scale=None, loc=None, dim=None):
         given = (phi is not None, gamma is not None, maxlag is not None, slnr is not None, lnc is not None)
         if given not in ((True, False, True, False, False), (False, True, True, False, False), (False, False, False, True, True)):
-            raise ValueError('invalid set of specified parameters')
+            def invalid(delta):                               # (the reference's core runs, and raises, when the kernel is called)
+                raise ValueError('invalid set of specified parameters')
+            return Kernel(_stationary1d(invalid, 'abs'), scale=scale, loc=loc, dim=dim)
         if slnr is not None:
             slnr, lnc = cls._process_roots(slnr, lnc)
             ph = cls.phi_from_roots(slnr, lnc)
@@ -686,8 +688,9 @@ class AR:
             vals.append(float(sum(phi[k] * vals[-1 - k] for k in range(len(phi)))))
         return numpy.array(vals)
 
-    @staticmethod
-    def phi_from_roots(slnr, lnc):
+    @classmethod
+    def phi_from_roots(cls, slnr, lnc):
+        slnr, lnc = cls._process_roots(slnr, lnc)
         r = numpy.copysign(numpy.exp(-numpy.abs(slnr)), slnr)
         c = numpy.exp(-lnc)
         coef = numpy.atleast_1d(numpy.poly(numpy.sort(numpy.concatenate([r, c, c.conj()]))))
@@ -695,8 +698,21 @@ class AR:
 
     @staticmethod
     def _columns(slnr, lnc, lag):
-        """ the basis functions at the given lags (``_gamma_from_ampl_matmul``, without its per-column normalisation) """
+        """ the basis functions at the given lags, each divided by (about) its largest value over the lags 0 .. p
+        (``_gamma_from_ampl_matmul``, ``_arma.py:316-383``) """
         lag = numpy.asarray(lag, float)
+        p = len(slnr) + 2 * len(lnc)
+        lagnorm = float(p)
+
+        def logcol(root, lag, llag, repeat):
+            return -root * lag + (repeat * llag if repeat else 0.)
+
+        def lognorm(root, repeat):
+            with numpy.errstate(divide='ignore', invalid='ignore'):
+                maxnorm = repeat * (-1 + numpy.log(repeat / root)) if repeat else 0.
+                defnorm = logcol(root, lagnorm, numpy.log(lagnorm) if lagnorm else 0., repeat)
+                return maxnorm if (repeat / root if root else numpy.inf) <= lagnorm else defnorm
+
         cols = [numpy.where(lag, 0., 1.)]
         with numpy.errstate(divide='ignore'):
             llag = numpy.log(lag)
@@ -704,21 +720,28 @@ class AR:
         for root in slnr:
             repeat = repeat + 1 if root == prev else 0
             prev = root
-            lc = -abs(root) * lag + (repeat * llag if repeat else 0.)
-            cols.append(numpy.sign(root) ** lag * numpy.exp(lc))
+            aroot = abs(root)
+            cols.append(numpy.sign(root) ** lag * numpy.exp(logcol(aroot, lag, llag, repeat) - lognorm(aroot, repeat)))
         prev, repeat = None, 0
         for root in lnc:
             repeat = repeat + 1 if root == prev else 0
             prev = root
-            col = numpy.exp(-root * lag + (repeat * llag if repeat else 0.))
+            col = numpy.exp(logcol(root, lag, llag, repeat) - lognorm(root.real, repeat))
             cols.append(col.real)
-            cols.append(-col.imag if root.imag else col.real * lag)
+            if root.imag:
+                cols.append(-col.imag)
+            else:                                                     # a real "complex" root: a pair of identical real roots
+                repeat += 1
+                cols.append(col.real * lag)
         return numpy.stack(cols, axis=-1)
 
     @classmethod
     def ampl_from_roots(cls, slnr, lnc, gamma):
         mat = cls._columns(slnr, lnc, numpy.arange(len(gamma)))
-        return numpy.linalg.lstsq(mat, gamma, rcond=None)[0]
+        u, sv, vh = numpy.linalg.svd(mat)                             # ``_pseudo_solve``, ``_arma.py:306-312``
+        cut = sv[0] * numpy.finfo(float).eps * len(mat) if sv.size else 0.
+        inv = numpy.where(sv < cut, 0., 1. / numpy.where(sv, sv, 1.))
+        return vh.conj().T @ (inv * (u.conj().T @ gamma))
 
 
 _bow_regexp = re.compile('\\s|[!«»"“”‘’/()\'?¡¿„‚<>,;.\u003a-\u2013—]')      # ``_basic.py:270``; ':-–' there is a range (U+003A..U+2013)

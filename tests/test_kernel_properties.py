@@ -270,8 +270,9 @@ def test_ar_parametrisations_agree(lgp, rng):
     far = lgp.AR(phi=[0.5], maxlag=5)(np.array([0]), np.array([9]))
     assert np.isnan(far).all()
     for bad in (dict(phi=[0.5]), dict(phi=[0.5], gamma=[1, 0.5], maxlag=3), dict(slnr=[0.1]), dict()):
+        k = lgp.AR(**bad)                                             # (raised when the kernel is evaluated, as in the reference)
         with pytest.raises(ValueError):
-            lgp.AR(**bad)
+            k(np.array([1, 2, 3]), np.array([3, 2, 1]))
 
 
 def test_bag_of_words_counts(lgp):
