@@ -863,6 +863,21 @@ class Zeta(_Stationary1D):
         return out
 
 
+def _split_vector(v):
+    """ a 1-D array of hyperparameters, some of them possibly `_dual.Dual` (or one Dual array): ``(values, {key: tangents})`` """
+    if isinstance(v, _dual.Dual):
+        val = numpy.atleast_1d(numpy.asarray(v.value, float))
+        return val, {k: numpy.atleast_1d(v.tangent(k)).astype(float) for k in v.tangents}
+    items = list(v) if not isinstance(v, numpy.ndarray) else list(v.reshape(-1) if v.dtype != object else v)
+    val = numpy.array([float(e.value) if isinstance(e, _dual.Dual) else float(e) for e in items], float)
+    tan = {}
+    for i, e in enumerate(items):
+        if isinstance(e, _dual.Dual):
+            for k, t in e.tangents.items():
+                tan.setdefault(k, numpy.zeros(len(items)))[i] = float(t)
+    return val, tan
+
+
 class _LagTable(Kernel):
     """ stationary kernels of one INTEGER variable tabulated over the lag |x - y| (the reference's discrete-time kernels,
     ``_kernels/_arma.py``): the host computes the table, the device looks it up pair by pair (``lgp_gram_lagtable``) """
@@ -923,10 +938,13 @@ class _LagTable(Kernel):
         yd = xd if y is x else DeviceArray.from_host((y - base).astype(float)[None, :], ctx=ctx)
         return ctx, xd, yd, tab
 
-    def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
+    def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0), _table=None):
         if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
             raise NotImplementedError(f'derivatives of {type(self).__name__}')         # derivable=False
         ctx, xd, yd, (tab, ntab) = self._device_args(xs, ys, ctx)
+        if _table is not None:                          # (a tangent of the table: same look-up, other values)
+            host = numpy.ascontiguousarray(_table, float).reshape(-1)
+            tab, ntab = (DeviceArray.from_host(host, ctx=ctx) if host.size else None), host.size
         n, m = xd.shape[1], yd.shape[1]
         if out is None:
             out = DeviceArray.empty((n, m), numpy.float64, ctx)
@@ -937,6 +955,57 @@ class _LagTable(Kernel):
         _lib.check(f(ctx.handle, None if tab is None else tab.ptr, ntab, F(self._fill), xd.ptr, xd.ld, n, yd.ptr, yd.ld, m, 0, F(0), 0, F(1),
                      nops, codes, vals, int(xd is yd), out.ptr, out.ld), 'lgp_gram_lagtable')
         return out
+
+    # -- hyperparameters of the table as `_dual.Dual` (MA weights, AR coefficients): the tangent of the Gram matrix is the same
+    # look-up in the tangent of the table
+    _dtables = {}
+
+    def _table_tangents(self, maxlag):
+        """ ``{key: d table / d key}`` for the lags of `_table(maxlag)` """
+        return {}
+
+    def tangent_keys(self):
+        keys = super().tangent_keys()
+        for k in self._dkeys():
+            if k not in keys:
+                keys.append(k)
+        return keys
+
+    def _dkeys(self):
+        return []
+
+    def gram_tangents(self, xs, ys, *, ctx=None, deriv=(0, 0)):
+        keys = self.tangent_keys()
+        K = self.gram(xs, ys, ctx=ctx, deriv=deriv)
+        if not keys:
+            return K, {}
+        core = self._copy(_outops=(), _doutops=())
+        C = core.gram(xs, ys, ctx=ctx)
+        x = xs.parts[0] if isinstance(xs, _PointBundle) else self._ints(xs)
+        y = x if ys is xs else (ys.parts[0] if isinstance(ys, _PointBundle) else self._ints(ys))
+        maxlag = int(max(x.max() - y.min(), y.max() - x.min(), 0)) if x.size and y.size else 0
+        dtabs = self._table_tangents(maxlag)
+        a, b = _dual.Dual(1.), _dual.Dual(0.)
+        for (op, c), dc in zip(self._outops, self._doutops):
+            cd = _dual.Dual(float(c), dc)
+            if op == 'mul':
+                a, b = a * cd, b * cd
+            else:
+                b = b + cd
+        fa, F = _lib.fn('lgp_axpby', C.dtype)
+        fs, _ = _lib.fn('lgp_add_scalar', C.dtype)
+        tangents = {}
+        for k in keys:
+            da, db = float(a.tangents.get(k, 0.)), float(b.tangents.get(k, 0.))
+            dC = core.gram(xs, ys, ctx=ctx, _table=dtabs[k]) if k in dtabs else None
+            T = DeviceArray.empty(C.shape, C.dtype, C.ctx)
+            if C.size:
+                _lib.check(fa(C.ctx.handle, C.shape[0], C.shape[1], F(a.value), None if dC is None else dC.ptr, 0 if dC is None else dC.ld,
+                              F(da), C.ptr, C.ld, T.ptr, T.ld), 'lgp_axpby')
+                if db != 0.:
+                    _lib.check(fs(C.ctx.handle, C.shape[0], C.shape[1], T.ptr, T.ld, F(db)), 'lgp_add_scalar')
+            tangents[k] = T
+        return K, tangents
 
     def pairs(self, xs, ys, *, ctx=None):
         ctx, xd, yd, (tab, ntab) = self._device_args(xs, ys, ctx)
@@ -958,16 +1027,31 @@ class MA(_LagTable):
 
     def __init__(self, *, w=None, norm=False, scale=None, loc=None, dim=None):
         super().__init__(scale=scale, loc=loc, dim=dim)
-        w = numpy.asarray([] if w is None else w, float)
+        w, dw = _split_vector([] if w is None else w)
         assert w.ndim == 1
-        acov = numpy.correlate(w, w, 'full')[len(w) - 1:] if len(w) else numpy.zeros(0)     # lags 0 .. len(w) - 1
+
+        def acov_of(w, dw=None):
+            if not len(w):
+                return numpy.zeros(0)
+            if dw is None:
+                return numpy.correlate(w, w, 'full')[len(w) - 1:]        # lags 0 .. len(w) - 1
+            return (numpy.correlate(dw, w, 'full') + numpy.correlate(w, dw, 'full'))[len(w) - 1:]
+        acov = acov_of(w)
+        self._dacov = {k: acov_of(w, t) for k, t in dw.items()}
         if norm and len(w):
             with numpy.errstate(invalid='ignore', divide='ignore'):      # all-zero weights: not a number, as in the reference
+                self._dacov = {k: t / acov[0] - acov * t[0] / acov[0] ** 2 for k, t in self._dacov.items()}
                 acov = acov / acov[0]
         self._acov = acov
 
     def _table(self, maxlag):
         return self._acov                                              # beyond the last weight: 0 (`mode='fill', fill_value=0`)
+
+    def _dkeys(self):
+        return list(self._dacov)
+
+    def _table_tangents(self, maxlag):
+        return self._dacov
 
 
 class AR(_LagTable):
@@ -988,15 +1072,29 @@ class AR(_LagTable):
         if self._invalid:              # _arma.py:164-170: the reference's core raises when the kernel is evaluated, not when it is made
             self._phi, self._gamma, self._maxlag = numpy.empty(0), numpy.ones(1), 0
             return
+        self._dphi, self._dgamma = {}, {}
         if slnr is not None:
             phi = self.phi_from_roots(slnr, lnc)
         elif phi is None:
             phi = self.phi_from_gamma(gamma)
+        else:
+            phi, self._dphi = _split_vector(phi)          # coefficients as `_dual.Dual`: tangents of the autocovariance below
         if gamma is None:
             gamma = self.gamma_from_phi(phi)
+            if self._dphi:                                 # A(phi) gamma = e0, A[m, |m-k|] -= phi_k:  d gamma = A^-1 (sum_k dphi_k E_k) gamma
+                p = len(phi)
+                A = numpy.eye(p + 1)
+                for m in range(p + 1):
+                    for k in range(1, p + 1):
+                        A[m, abs(m - k)] -= phi[k - 1]
+                for key, dph in self._dphi.items():
+                    rhs = numpy.array([sum(dph[k - 1] * gamma[abs(m - k)] for k in range(1, p + 1)) for m in range(p + 1)])
+                    self._dgamma[key] = numpy.linalg.solve(A, rhs)
         gamma = numpy.asarray(gamma, float)
         self._phi = numpy.asarray(phi, float)
         with numpy.errstate(invalid='ignore', divide='ignore'):
+            if norm:
+                self._dgamma = {k: t / gamma[0] - gamma * t[0] / gamma[0] ** 2 for k, t in self._dgamma.items()}
             self._gamma = gamma / gamma[0] if norm else gamma
         self._maxlag = None if maxlag is None else int(maxlag)
         if slnr is not None:
@@ -1007,6 +1105,25 @@ class AR(_LagTable):
             raise ValueError('invalid set of specified parameters')
         last = self._maxlag if self._maxlag is not None else maxlag
         return self.extend_gamma(self._gamma, self._phi, max(0, last + 1 - len(self._gamma)))[:last + 1]
+
+    def _dkeys(self):
+        return list(self._dphi)
+
+    def _table_tangents(self, maxlag):
+        """ the recursion differentiated: d gamma_m = sum_k (dphi_k gamma_{m-k} + phi_k dgamma_{m-k}) """
+        if not self._dphi:
+            return {}
+        g = self._table(maxlag)
+        p = len(self._phi)
+        out = {}
+        for key, dph in self._dphi.items():
+            dg = numpy.zeros(len(g))
+            head = self._dgamma[key][:len(g)]
+            dg[:len(head)] = head
+            for i in range(len(self._gamma), len(g)):
+                dg[i] = sum(dph[k] * g[i - 1 - k] + self._phi[k] * dg[i - 1 - k] for k in range(p))
+            out[key] = dg
+        return out
 
     @staticmethod
     def phi_from_gamma(gamma):

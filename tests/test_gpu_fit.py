@@ -604,3 +604,55 @@ def test_fit_additional_loss(lgp, rng):
     assert abs(fit2.pmean['log(sdev)'] - loc) < abs(fit0.pmean['log(sdev)'] - loc)
     with pytest.raises(NotImplementedError):
         lgp.empbayes_fit(hp, gpfactory, {'x': data}, method='fisher', additional_loss=lambda _: 0.)
+
+
+def test_fit_of_an_autoregressive_coefficient(lgp, rng):
+    """ a discrete-time model through the fit driver: y an AR(1) series plus white noise, hyperparameters the coefficient (a bounded
+    copula variable) and the noise level.  The coefficient reaches `AR` as a `Dual`: the tangent of the autocovariance table (the
+    Yule-Walker system and the recursion differentiated on the host) gives the tangent of the Gram matrix by the same device
+    look-up, so the fit differentiates itself; with ``float(hp['phi'])`` the tangent is lost, the first gradient check notices
+    and the fit goes on by central differences -- same mode either way, the oracle's too, and where the data say """
+    import oracle
+    n, phi_true = 300, 0.7
+    e = rng.standard_normal(n + 200)
+    y = np.zeros(n + 200)
+    for i in range(1, len(y)):
+        y[i] = phi_true * y[i - 1] + e[i]
+    y = y[200:] + 0.3 * rng.standard_normal(n)
+    t = np.arange(n)
+    prior = {'phi': lgp.copula.uniform(-0.95, 0.95), 'log(s2)': (np.log(0.1), 1.)}
+    out = {}
+    for name, mod, conv in (('dual', lgp, lambda v: v), ('float', lgp, float), ('oracle', oracle, float)):
+        def makegp(hp, mod=mod, conv=conv):
+            k = mod.AR(phi=[conv(hp['phi'])], maxlag=n) + mod.White() * hp['s2']
+            return mod.GP(k, checkpos=False, checksym=False).addx(t, 'y')
+        out[name] = lgp.empbayes_fit(prior, makegp, {'y': y}, raises=False)
+    assert out['dual']._autodiff
+    z = out['dual'].zmean + 0.1
+    np.testing.assert_allclose(out['dual']._fun_and_jac(z)[1] - z, out['dual']._fd_gradient(z), rtol=1e-6, atol=1e-7)
+    assert out['float']._autodiff_checked and not out['float']._autodiff
+    assert abs(out['dual'].pmean['phi'] - phi_true) < 0.12
+    for other in ('float', 'oracle'):
+        assert out['dual'].pmean['phi'] == pytest.approx(out[other].pmean['phi'], abs=2e-4)
+        assert out['dual'].pmean['log(s2)'] == pytest.approx(out[other].pmean['log(s2)'], abs=5e-3)
+
+
+def test_tangents_of_the_discrete_time_kernels(lgp, rng):
+    """ MA weights and AR coefficients as `Dual`, with normalisation and output operations: against central differences """
+    x = rng.integers(0, 40, 60)
+    y = rng.integers(0, 40, 25)
+    h = 1e-6
+
+    def check(make, keys):
+        K, tan = make({k: 0. for k in keys}, True).gram_tangents(x, y)
+        assert sorted(tan) == sorted(keys)
+        for k in keys:
+            up = make({q: (h if q == k else 0.) for q in keys}, False).gram(x, y).to_host()
+            dn = make({q: (-h if q == k else 0.) for q in keys}, False).gram(x, y).to_host()
+            np.testing.assert_allclose(tan[k].to_host(), (up - dn) / (2 * h), rtol=0, atol=2e-8 * max(1., np.abs(K.to_host()).max()))
+
+    D = lambda v, k, dual: lgp.Dual(v, {k: 1.}) if dual else v
+    check(lambda d, dual: lgp.AR(phi=[D(0.5 + d['a'], 'a', dual), D(-0.2 + d['b'], 'b', dual)], maxlag=50) * D(1.5 + d['c'], 'c', dual) + 0.1, ['a', 'b', 'c'])
+    check(lambda d, dual: lgp.AR(phi=[D(0.6 + d['a'], 'a', dual)], maxlag=50, norm=True), ['a'])
+    check(lambda d, dual: lgp.MA(w=[1., D(0.5 + d['b'], 'b', dual), D(-0.3 + d['c'], 'c', dual)]), ['b', 'c'])
+    check(lambda d, dual: lgp.MA(w=[1., D(0.5 + d['b'], 'b', dual), -0.3], norm=True) * 2., ['b'])
