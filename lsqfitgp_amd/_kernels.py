@@ -502,7 +502,8 @@ class _Isotropic(Kernel):
         """ ``(K, dK/dscale)`` as two device matrices from one pass over the pairs (``lgp_gram_isotropic_dscale``): the
         tangent that ``jax.jacfwd`` of a reference gpfactory produces for a ``scale`` hyperparameter
         (``_Kernel/_ops.py:310-326`` through the core); with ``scale=None`` the derivative at scale = 1 """
-        if self._kind not in (_lib.LGP_KERNEL_EXPQUAD, _lib.LGP_KERNEL_MATERNP, _lib.LGP_KERNEL_GAMMAEXP, _lib.LGP_KERNEL_CAUCHY, _lib.LGP_KERNEL_MATERN):
+        if self._kind not in (_lib.LGP_KERNEL_EXPQUAD, _lib.LGP_KERNEL_MATERNP, _lib.LGP_KERNEL_GAMMAEXP, _lib.LGP_KERNEL_CAUCHY, _lib.LGP_KERNEL_MATERN,
+                              _lib.LGP_KERNEL_COLOR, _lib.LGP_KERNEL_PINK, _lib.LGP_KERNEL_BESSEL):
             raise NotImplementedError(f'derivative of {type(self).__name__} with respect to scale')
         xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
         n, m = xd.shape[1], yd.shape[1]

@@ -165,18 +165,21 @@ __device__ __forceinline__ T matern_real_of(const IsoArgs<T> &g, T r2, T *xdk) {
 // recurrence in complex arithmetic (92 steps at x = 2, 8 at x = 100).  The two agree to 4e-15 where they overlap (x in [1, 4],
 // n = 1 .. 50); psi(n) comes from the host.  (The reference switches between the closed form 8.19.7 and a 20-term asymptotic
 // series at a "knee" where both have lost digits -- 1e-4 at n = 20; the values here are good to the last few bits everywhere.)
+// (IM: the imaginary part instead -- d/dx Re E_n(-i x) = -Im E_{n-1}(-i x), the scale tangent of Color)
+template <bool IM = false>
 __device__ inline double expn_imag_re(int n, double psin, double x) {
   const int nm1 = n - 1;
   if (x <= 2.) {
     const double a = psin - log(x), b = 1.5707963267948966;
     const int r = nm1 & 3;
-    const double lead = r == 0 ? a : (r == 1 ? -b : (r == 2 ? -a : b));    // Re(i^(n-1) (a + i b))
-    double ans = nm1 == 0 ? lead : 1. / (double)nm1, fact = 1.;
+    // Re / Im of i^(n-1) (a + i b)
+    const double lead = IM ? (r == 0 ? b : (r == 1 ? a : (r == 2 ? -b : -a))) : (r == 0 ? a : (r == 1 ? -b : (r == 2 ? -a : b)));
+    double ans = nm1 == 0 ? lead : (IM ? 0. : 1. / (double)nm1), fact = 1.;
     for (int m = 1; m < 200; ++m) {
       fact *= x / (double)m;
       if (m == nm1) ans += lead * fact;
-      else if ((m & 1) == 0) ans -= ((m & 2) ? -fact : fact) / (double)(m - nm1);
-      if ((m & 1) == 0 && fact * (1. + fabs(lead)) < 1e-17 * fabs(ans)) break;
+      else if (((m & 1) != 0) == IM) ans -= ((m & 2) ? -fact : fact) / (double)(m - nm1);      // Re i^m = (-1)^(m/2), Im i^m = (-1)^((m-1)/2)
+      if (((m & 1) != 0) == IM && m > 1 && fact * (1. + fabs(lead)) < 1e-17 * (fabs(ans) + 1e-300)) break;
     }
     return ans;
   }
@@ -204,7 +207,7 @@ __device__ inline double expn_imag_re(int n, double psin, double x) {
   }
   double sn, cs;
   sincos(x, &sn, &cs);
-  return hr * cs - hi * sn;                                                  // Re(h e^(i x))
+  return IM ? hr * sn + hi * cs : hr * cs - hi * sn;                         // Im / Re of h e^(i x)
 }
 // Gamma(nu + 1) (x / 2)^-nu J_nu(x), real nu >= 0 (Bessel kernel, _kernels/_matern.py:102-119 through _special/_bessel.py:45-50): 1 at
 // x = 0.  Three regions: the power series sum_k (-x^2/4)^k / (k! (nu+1)_k) while it does not cancel (x^2 <= 8 (nu + 1), or x <= 3);
@@ -303,6 +306,25 @@ __device__ __forceinline__ T special_core(const IsoArgs<T> &g, T r2) {
     if (x * dw < (double)g.par[2]) return T(cos(x * (1. + 0.5 * dw)));
     return T((expn_imag_re(1, -0.5772156649015329, x) - expn_imag_re(1, -0.5772156649015329, x * (1. + dw))) / (double)g.par[1]);
   }
+}
+
+// -x k'(x) of the same cores, x the (transformed) distance: times 1 / scale it is dk / dscale (x = distance / scale)
+template <typename T>
+__device__ __forceinline__ T special_core_mxdk(const IsoArgs<T> &g, T r2) {
+  if (g.kernel == LGP_KERNEL_BESSEL) {                    // k_nu' = -X / (2 (nu + 1)) k_{nu+1}(X), X = s x: -x dk/dx = X^2 / (2 (nu + 1)) k_{nu+1}(X)
+    const double nu = (double)g.par[0], X2 = (double)g.twop1 * (double)r2;
+    return T(X2 / (2. * (nu + 1.)) * bessel_jmod(nu + 1., g.p + 1, (double)g.par[1] * (nu + 1.), (double)g.par[2], sqrt(X2)));
+  }
+  const double x = (double)sqrt(r2);
+  if (x == 0.) return T(0);
+  if (g.kernel == LGP_KERNEL_COLOR)                       // k' = -(n - 1) Im E_{n-1}(-i x); par[1] = psi(n - 1)
+    return T(x * (double)(g.p - 1) * expn_imag_re<true>(g.p - 1, (double)g.par[1], x));
+  if (g.kernel == LGP_KERNEL_PINK) {                      // Ci'(x) = cos x / x
+    const double dw = (double)g.par[0];
+    if (x * dw < (double)g.par[2]) return T(x * (1. + 0.5 * dw) * sin(x * (1. + 0.5 * dw)));
+    return T(-(cos(x * (1. + dw)) - cos(x)) / (double)g.par[1]);
+  }
+  return T(NAN);                                          // (PSeries: no tangent; refused by the launcher)
 }
 
 // d0: the signed difference of the (transformed) first coordinates, used by the derivative kernel only
@@ -636,6 +658,10 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
           const T kv = matern_real_of<T>(g, r2, &xdk);
           dk = g.has_scale ? xdk / g.scale : xdk;
           res[e] = g.ops.apply(kv);
+        } else if constexpr (CORE == CORE_SPECIAL) {
+          dk = special_core_mxdk<T>(g, r2);
+          if (g.has_scale) dk = dk / g.scale;
+          res[e] = g.ops.apply(special_core<T>(g, r2));
         } else {
           res[e] = g.ops.apply(iso_core_dscale<T>(g, r2, dk));
         }
@@ -813,7 +839,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
     g.flag = (p >> 4) & 1;
     g.p = p & 15;
   } else if (kernel == LGP_KERNEL_BESSEL) {              // hpar = {nu}
-    LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0) && hpar[0] <= T(100) && ddsc == nullptr, "Bessel takes {nu} in [0, 100]");   // _matern.py:117
+    LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0) && hpar[0] <= T(100), "Bessel takes {nu} in [0, 100]");   // _matern.py:117
     const double nu = (double)hpar[0];
     const int fl = (int)nu;
     LGP_REQUIRE(d <= 2 * (fl + 1), "Bessel(nu) is a kernel in at most 2 (floor(nu) + 1) dimensions");                                // _matern.py:97-99
@@ -821,12 +847,13 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
     g.par[0] = (T)nu; g.par[1] = (T)tgamma(nu + 1.); g.par[2] = (T)tgamma(1. + nu - (double)fl);
     g.twop1 = (T)((2. + nu / 2.) * (2. + nu / 2.));                                                                                   // _matern.py:118
   } else if (kernel == LGP_KERNEL_COLOR) {               // p = n
-    LGP_REQUIRE(npar == 0 && p >= 2 && ddsc == nullptr, "Color takes the integer n >= 2 as p, no real parameters");       // _spectral.py:110
+    LGP_REQUIRE(npar == 0 && p >= 2, "Color takes the integer n >= 2 as p, no real parameters");       // _spectral.py:110
     double psi = -0.5772156649015329;
-    for (int k = 1; k < p; ++k) psi += 1. / (double)k;
-    g.par[0] = (T)psi;
+    for (int k = 1; k < p - 1; ++k) psi += 1. / (double)k;
+    g.par[1] = (T)psi;                                   // psi(n - 1): the scale tangent
+    g.par[0] = (T)(psi + 1. / (double)(p - 1));          // psi(n)
   } else if (kernel == LGP_KERNEL_PINK) {                // hpar = {dw}
-    LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0) && hpar[0] < std::numeric_limits<T>::infinity() && ddsc == nullptr, "Pink takes {dw}, dw >= 0");
+    LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0) && hpar[0] < std::numeric_limits<T>::infinity(), "Pink takes {dw}, dw >= 0");
     g.par[0] = hpar[0]; g.par[1] = (T)log1p((double)hpar[0]); g.par[2] = (T)sqrt((double)std::numeric_limits<T>::epsilon());   // _spectral.py:62-66
   } else if (kernel == LGP_KERNEL_MATERN) {              // hpar = {nu}
     LGP_REQUIRE(npar == 1 && hpar != nullptr && hpar[0] >= T(0) && hpar[0] <= T(100), "Matern takes {nu} in [0, 100]");   // _matern.py:73
@@ -881,7 +908,14 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   LGP_REQUIRE(ntr * ntc < (1ull << 31), "gram grid too large");
   size_t shmem = (size_t)d * (GT_ROWS + GT_COLS) * sizeof(T);
   dim3 gd((unsigned)(ntr * ntc)), bd(GT_THREADS);
-  if (ddsc && kernel == LGP_KERNEL_MATERN) {
+  if (ddsc && core_of(kernel, p) == CORE_SPECIAL) {
+    switch (d) {
+      case 1: hipLaunchKernelGGL((gram_iso_kernel<T, 1, true, CORE_SPECIAL>), gd, bd, shmem, ctx->stream, g); break;
+      case 2: hipLaunchKernelGGL((gram_iso_kernel<T, 2, true, CORE_SPECIAL>), gd, bd, shmem, ctx->stream, g); break;
+      case 3: hipLaunchKernelGGL((gram_iso_kernel<T, 3, true, CORE_SPECIAL>), gd, bd, shmem, ctx->stream, g); break;
+      default: hipLaunchKernelGGL((gram_iso_kernel<T, 0, true, CORE_SPECIAL>), gd, bd, shmem, ctx->stream, g); break;
+    }
+  } else if (ddsc && kernel == LGP_KERNEL_MATERN) {
     switch (d) {
       case 1: hipLaunchKernelGGL((gram_iso_kernel<T, 1, true, CORE_MATERNNU>), gd, bd, shmem, ctx->stream, g); break;
       case 2: hipLaunchKernelGGL((gram_iso_kernel<T, 2, true, CORE_MATERNNU>), gd, bd, shmem, ctx->stream, g); break;

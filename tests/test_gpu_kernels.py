@@ -1054,3 +1054,26 @@ def test_zeta_kernel(lgp, rng, nu):
         np.testing.assert_allclose(post[lgp][0][0], post[oracle][0][0], rtol=0, atol=1e-8)
         np.testing.assert_allclose(post[lgp][0][1], post[oracle][0][1], rtol=0, atol=1e-8)
         np.testing.assert_allclose(post[lgp][1], post[oracle][1], rtol=1e-8)
+
+
+@pytest.mark.parametrize('make', [lambda m, s: m.Color(n=2, scale=s), lambda m, s: m.Color(n=3, scale=s), lambda m, s: m.Color(n=6, scale=s),
+                                  lambda m, s: m.Pink(dw=1., scale=s), lambda m, s: m.Pink(dw=1e-10, scale=s), lambda m, s: m.Pink(dw=40., scale=s),
+                                  lambda m, s: m.Bessel(nu=0, scale=s), lambda m, s: m.Bessel(nu=1.3, scale=s), lambda m, s: m.Bessel(nu=4.5, scale=s)],
+                         ids=['Color2', 'Color3', 'Color6', 'Pink1', 'Pink1e-10', 'Pink40', 'Bessel0', 'Bessel1.3', 'Bessel4.5'])
+def test_scale_tangents_of_the_special_function_kernels(lgp, rng, make):
+    """ dK/dscale of Color (-(n-1) Im E_{n-1}(-ix)), Pink (Ci' = cos x / x) and Bessel (k_nu' = -x / (2 (nu+1)) k_{nu+1}) in the same
+    pass as the matrix, against central differences of the oracle over the series / continued-fraction / recurrence regions, and
+    through `Dual` hyperparameters """
+    s, h = 0.8, 1e-6
+    x = np.concatenate([rng.uniform(-3, 3, 100), [0., 1e-9], 10. ** rng.uniform(-3, 1.5, 60)])      # (beyond, the differences' own error grows like h^2 x^3)
+    y = np.concatenate([[0.], rng.uniform(-3, 3, 40)])
+    K, dK = make(lgp, s).gram_dscale(x, y)
+    ref = make(oracle, s)(x[:, None], y[None, :])
+    # (differences of the device's own values, good to the last bits; the oracle's Color is 1e-9 off near its knee, which a
+    #  difference quotient magnifies; what is left is the quotient's truncation error, h^2 / 6 times a third derivative ~ x^3)
+    fd = (make(lgp, s + h).gram(x, y).to_host() - make(lgp, s - h).gram(x, y).to_host()) / (2 * h)
+    np.testing.assert_allclose(K.to_host(), ref, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(dK.to_host(), fd, rtol=0, atol=1e-6 * max(1., np.abs(fd).max()))
+    G, tan = (make(lgp, lgp.Dual(s, {'s': 1.})) * lgp.Dual(2., {'a': 1.})).gram_tangents(x, y)
+    np.testing.assert_allclose(tan['s'].to_host(), 2 * fd, rtol=0, atol=2e-6 * max(1., np.abs(fd).max()))
+    np.testing.assert_allclose(tan['a'].to_host(), ref, rtol=0, atol=1e-9)
