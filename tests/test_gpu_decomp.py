@@ -581,3 +581,26 @@ def test_split_driver_hands_its_tail_to_the_chain_driver(lgp, driver_contexts):
     Kh.assign(lgp.DeviceArray.from_host(np.array([[-1.0]]), ctx=ctx_chain))
     with pytest.raises(np.linalg.LinAlgError):
         lgp.Chol(K, ctx=ctx_chain, epsrel=0)
+
+
+@pytest.mark.parametrize('n,q', [(14464, 0), (15000, 3), (16512, 0), (18048, 5), (21120, 0)])
+def test_driver_selection_boundaries(lgp, n, q):
+    """ sizes around the switches between the drivers of the blocked factorisation (csrc/potrf.hip): 14464 = 113 x 128 just above
+    the chain-kernel driver's limit (split driver + chain tail of 6272 rows); 15000 is no multiple of 128 (no chain tail); 16512,
+    18048 and 21120 = 129, 141 and 165 x 128 (ragged tails of 8128, 7808 and 7808 rows); with and without carried right-hand sides:
+    L L^T V = (K + eps) V and L (L^-1 B) = B """
+    from lsqfitgp_amd._GP import _gemm
+    rng = np.random.default_rng(n)
+    x = rng.uniform(0, n / 16, n)
+    ctx = lgp.Context.default()
+    lib = __import__('lsqfitgp_amd')._lib.load()
+    K = lgp.ExpQuad().gram(x, x)
+    assert lib.lgp_add_diag_f64(ctx.handle, n, K.ptr, K.ld, None, ctypes.c_double(0.02)) == 0
+    B = rng.standard_normal((n, q)) if q else None
+    d = lgp.Chol(K, rhs=B)
+    V = rng.standard_normal((n, 2))
+    KV = _gemm(False, False, K, lgp.DeviceArray.from_host(V)).to_host() + d.eps * V
+    util.assert_close_matrices(d.correlate(d.back_correlate(V)), KV, rtol=1e-12)
+    util.assert_close_matrices(d.ginv_linear(KV), V, rtol=1e-9)
+    if q:
+        util.assert_close_matrices(d.correlate(d.solved()), B, rtol=1e-11)
