@@ -612,7 +612,9 @@ def main_multi(args, ctx, dist, rank, world):
                 'data': 'synthetic', 'config': {'workload': rcfg['name'], 'N': rcfg['n'], 'M': rcfg['m'], 'parallelism': replicas['parallelism']},
                 'roofline': None, 'cpu_baseline': None, 'sharded_path_error': err}
 
-    limit = float(os.environ.get('LGP_BENCH_SHARDED_TIMEOUT', 240 + 20 * (args.steps + args.warmup)))
+    # (a sharded C4 step is under a second on 2-8 GPUs; communicator set-up tens of seconds at most: a stalled attempt should not
+    #  hold the replicas line back for long)
+    limit = float(os.environ.get('LGP_BENCH_SHARDED_TIMEOUT', 120 + 10 * (args.steps + args.warmup)))
 
     def give_up():
         if rank == 0:
