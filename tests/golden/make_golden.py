@@ -123,9 +123,41 @@ def c5full():
                         evmin_Kxx=evmin, norm_mean_train=np.linalg.norm(mt))
 
 
+# one parameter set per kernel of the reference's public list (BART apart: c5small / c5full); the points of each kernel's domain
+KERNEL_CASES = {
+    'ExpQuad': {}, 'Maternp': dict(p=2), 'Matern': dict(nu=1.3), 'GammaExp': dict(gamma=1.3), 'Cauchy': dict(alpha=1.5, beta=2.5),
+    'Wendland': dict(k=1, alpha=2), 'CausalExpQuad': dict(alpha=1.5), 'Log': {}, 'Constant': {}, 'White': {}, 'Linear': {},
+    'Expon': {}, 'HoleEffect': {}, 'Periodic': dict(outerscale=0.7), 'Cos': {}, 'Sinc': {}, 'Celerite': dict(gamma=0.8, B=0.3),
+    'Harmonic': dict(Q=0.8), 'Circular': dict(tau=5, c=0.3), 'StationaryFracBrownian': dict(H=0.3), 'Wiener': {}, 'WienerIntegral': {},
+    'OrnsteinUhlenbeck': {}, 'BrownianBridge': {}, 'FracBrownian': dict(H=0.3, K=0.7), 'Decaying': dict(alpha=1.5), 'Taylor': {},
+    'NNKernel': dict(sigma0=0.7), 'Gibbs': {}, 'Rescaling': {}, 'Bessel': dict(nu=1.3), 'Color': dict(n=4), 'Pink': dict(dw=2.),
+    'Zeta': dict(nu=1.3), 'MA': dict(w=[1., 0.5, -0.25]), 'AR': dict(phi=[0.6, -0.2], maxlag=64),
+}
+KERNEL_DOMAIN = {'Wiener': (0, 5), 'WienerIntegral': (0, 5), 'OrnsteinUhlenbeck': (0, 5), 'BrownianBridge': (0, 1), 'Decaying': (0, 5), 'Taylor': (-2, 2)}
+
+
+def kernel_points(name):
+    rng = np.random.default_rng(sum(map(ord, name)))
+    if name in ('MA', 'AR'):
+        return rng.integers(0, 60, 24), rng.integers(0, 60, 16)
+    lo, hi = KERNEL_DOMAIN.get(name, (-4, 4))
+    return rng.uniform(lo, hi, 24), rng.uniform(lo, hi, 16)
+
+
+def kernels():
+    """ a 24 x 16 block of every kernel (scale 1.3 where the kernel takes one), frozen from the oracle: a change to a core of the
+    oracle or of the device is noticed whichever side it happens on """
+    out = {}
+    for name, kw in KERNEL_CASES.items():
+        x, y = kernel_points(name)
+        kwargs = dict(kw) if name in ('MA', 'AR') else dict(kw, scale=1.3)
+        out[name] = getattr(oracle, name)(**kwargs)(x[:, None], y[None, :])
+    np.savez_compressed(os.path.join(HERE, 'kernel_blocks.npz'), **out)
+
+
 if __name__ == '__main__':
     import sys as _sys
-    which = _sys.argv[1:] or ['c1', 'c2small', 'c3small', 'c5small', 'c5full']
+    which = _sys.argv[1:] or ['c1', 'c2small', 'c3small', 'c5small', 'c5full', 'kernels']
     for name in which:
         globals()[name]()
     print('written', sorted(f for f in os.listdir(HERE) if f.endswith('.npz')))
