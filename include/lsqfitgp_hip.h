@@ -158,6 +158,26 @@ int lgp_gram_isotropic_f32(lgp_ctx *ctx, int kernel, int p, int npar, const floa
                            int nops, const int *hops_code, const float *hops_val,
                            int symmetric, float *dout, size_t ldo);
 
+/* One block column of the REGULARISED Gram matrix, for the sharded factorisation (each rank builds its own block columns in place;
+ * _GP/_elements.py:554-579 + _linalg/_decomp.py:384-387 in one pass): dblock (n x w, ld ldb) receives the columns [c0, c0 + w) of
+ * tril(K~), K~ = (kernel(x, x) + diag(noise)) / s / s', zeros above the diagonal; dsvec (n) the scales s of ALL rows (every rank
+ * computes the same vector: K_ii = k(0) + noise_i needs the diagonal alone); dsums (w) the Gershgorin sums sum_i |K~_ij| of these
+ * columns over ALL n rows (the block column is evaluated in full for them: no other rank holds the mirrored entries).  Kernels:
+ * LGP_KERNEL_EXPQUAD, MATERNP, GAMMAEXP, CAUCHY, as lgp_gram_chol_factor_rhs.  noise: scalar, or dnoise (device, n).
+ * Block-cyclic storage in ONE launch (cyc_nb > 0, a multiple of the tile width 512 (f64) / 1024 (f32)): the w local columns are
+ * blocks of cyc_nb columns, local block q holding the global columns [c0 + q cyc_stride, c0 + q cyc_stride + cyc_nb) -- a rank's
+ * whole share of the matrix (c0 = rank nb, cyc_stride = nranks nb); cyc_nb = 0: the plain range [c0, c0 + w). */
+int lgp_gram_reg_cols_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d,
+                          const double *dx, size_t ldx, size_t n, size_t c0, size_t w, size_t cyc_nb, size_t cyc_stride,
+                          int has_loc, double loc, int has_scale, double scale,
+                          int nops, const int *hops_code, const double *hops_val,
+                          double noise, const double *dnoise, double *dblock, size_t ldb, double *dsvec, double *dsums);
+int lgp_gram_reg_cols_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int d,
+                          const float *dx, size_t ldx, size_t n, size_t c0, size_t w, size_t cyc_nb, size_t cyc_stride,
+                          int has_loc, float loc, int has_scale, float scale,
+                          int nops, const int *hops_code, const float *hops_val,
+                          float noise, const float *dnoise, float *dblock, size_t ldb, float *dsvec, float *dsums);
+
 /* Stationary kernels of one integer variable given by a table of their values (the reference's discrete-time kernels MA and AR,
  * _kernels/_arma.py:31-63 `cov.at[delta + len(w) - 1].get(mode='fill', fill_value=0)` and :180-189 `acf.at[delta].get(mode='fill',
  * fill_value=nan)`): out[i][j] = dtable[|x_i - y_j|] where the lag is below ntable, `fill` elsewhere.  dtable: DEVICE array.  The

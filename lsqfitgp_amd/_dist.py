@@ -267,27 +267,71 @@ class DistributedChol:
             nx = -(-mq // 128) * 128                     # whole 128-row tiles
             self._carry = (xs_c, y_c, mq)
         self.nx = nx
-        self.Lloc = DeviceArray.zeros((n + nx, L.local_cols), numpy.float64, self.ctx)
+        kdt = kernel_dtype(kernel, x)
+        # isotropic cores that the fused kernel covers: a block column is built ALREADY regularised (scaled lower triangle, zeros
+        # above, noise on the diagonal) together with the scales of every row and its Gershgorin sums -- one pass where the generic
+        # route below makes four (Gram, scales, scaling, column sums)
+        from ._kernels import _Isotropic
+        fused = (isinstance(kernel, _Isotropic) and kdt == numpy.float64 and os.environ.get('LGP_DIST_FUSED_GRAM', '1') != '0'
+                 and type(kernel).gram is _Isotropic.gram
+                 and kernel._kind in (_lib.LGP_KERNEL_EXPQUAD, _lib.LGP_KERNEL_MATERNP, _lib.LGP_KERNEL_GAMMAEXP, _lib.LGP_KERNEL_CAUCHY)
+                 and -(-n // nb) >= L.nranks)           # (every rank owns a block column: each writes the scales itself)
+        if fused and n % nb == 0:                        # (a ragged last block keeps zeros in its padding columns)
+            self.Lloc = DeviceArray.empty((n + nx, L.local_cols), numpy.float64, self.ctx)
+            if nx:
+                self.Lloc.rows(n, n + nx).fill_zero()
+        else:
+            self.Lloc = DeviceArray.zeros((n + nx, L.local_cols), numpy.float64, self.ctx)
         self.dblk_per_block = lib.lgp_chol_dblk_size(nb)
         self.dblk = DeviceArray.empty((max(L.nlocal, 1) * self.dblk_per_block,), numpy.float64, self.ctx)
         F = ctypes.c_double
         h = self.ctx.handle
         # ---- Gram build: every rank evaluates its own block columns in place, no communication; the points (replicated:
         # 8 d N bytes) go to the device once
-        kdt = kernel_dtype(kernel, x)
         xdev = kernel.prepare(x, ctx=self.ctx)
         xsdev = kernel.prepare(self._carry[0], ctx=self.ctx, dtype=xdev.dtype) if self._carry is not None else None
         ydev = DeviceArray.from_host(self._carry[1].reshape(1, n), ctx=self.ctx) if self._carry is not None else None
+        svec = DeviceArray.zeros((n,), numpy.float64, self.ctx)
+        sums = DeviceArray.zeros((L.local_cols,), numpy.float64, self.ctx)
+        if fused:
+            from ._kernels import _ops_arrays
+            d = xdev.array.shape[0]
+            nops, codes, vals = _ops_arrays(kernel._outops, F)
+            npar, hpar = kernel._par_args(F)
+        onecall = fused and nb % 512 == 0 and L.nlocal > 0
+        # the carried rows of all the rank's columns in one Gram launch and one copy (its points gathered in local column order)
+        batch_carry = self._carry is not None and n % nb == 0 and L.nlocal > 0 and kdt == numpy.float64
+        if batch_carry:
+            xs_c, y_c, mq = self._carry
+            cols = numpy.concatenate([numpy.arange(L.col0(b), L.col0(b) + L.width(b)) for b in L.owned()])
+            xloc = kernel.prepare(x[cols], ctx=self.ctx, dtype=xdev.dtype)
+            kernel.gram(xsdev, xloc, ctx=self.ctx, out=self.Lloc.block(n, n + mq - 1, 0, len(cols)))
+            self.Lloc.block(n + mq - 1, n + mq, 0, len(cols)).assign(DeviceArray.from_host(y_c[cols].reshape(1, -1), ctx=self.ctx))
+        if onecall:                                      # the rank's whole share in one launch: local block q = global block q nranks + rank
+            out = self.Lloc.block(0, n, 0, L.nlocal * nb)
+            _lib.check(lib.lgp_gram_reg_cols_f64(h, kernel._kind, int(kernel._p), npar, hpar, d, xdev.array.ptr, xdev.array.ld, n, L.rank * nb, L.nlocal * nb,
+                                                 nb, L.nranks * nb,
+                                                 int(kernel._loc is not None), F(kernel._loc or 0), int(kernel._scale is not None), F(kernel._scale or 1),
+                                                 nops, codes, vals, F(noise or 0.), None, out.ptr, out.ld, svec.ptr, sums.ptr),
+                       'lgp_gram_reg_cols')
         for b in L.owned():
             lb, w, c0 = L.local_index(b), L.width(b), L.col0(b)
             out = self.Lloc.block(0, n, lb * nb, lb * nb + w)
-            blk = kernel.gram(xdev, xdev.sub(c0, c0 + w), ctx=self.ctx, out=out if out.dtype == kdt else None)
-            if blk is not out:                           # float32 kernels: promoted into the float64 factor storage
-                out.assign(_astype(blk, numpy.float64))
-            if noise:
-                diag = self.Lloc.block(c0, c0 + w, lb * nb, lb * nb + w)
-                _lib.check(lib.lgp_add_diag_f64(h, w, diag.ptr, diag.ld, None, F(noise)), 'lgp_add_diag')
-            if self._carry is not None:                  # K(xs, x[block]) and y[block] below the matrix rows
+            if onecall:
+                pass
+            elif fused:
+                _lib.check(lib.lgp_gram_reg_cols_f64(h, kernel._kind, int(kernel._p), npar, hpar, d, xdev.array.ptr, xdev.array.ld, n, c0, w, 0, 0,
+                                                     int(kernel._loc is not None), F(kernel._loc or 0), int(kernel._scale is not None), F(kernel._scale or 1),
+                                                     nops, codes, vals, F(noise or 0.), None, out.ptr, out.ld, svec.ptr, sums.ptr + lb * nb * 8),
+                           'lgp_gram_reg_cols')
+            else:
+                blk = kernel.gram(xdev, xdev.sub(c0, c0 + w), ctx=self.ctx, out=out if out.dtype == kdt else None)
+                if blk is not out:                           # float32 kernels: promoted into the float64 factor storage
+                    out.assign(_astype(blk, numpy.float64))
+                if noise:
+                    diag = self.Lloc.block(c0, c0 + w, lb * nb, lb * nb + w)
+                    _lib.check(lib.lgp_add_diag_f64(h, w, diag.ptr, diag.ld, None, F(noise)), 'lgp_add_diag')
+            if self._carry is not None and not batch_carry:      # K(xs, x[block]) and y[block] below the matrix rows
                 xs_c, y_c, mq = self._carry
                 rows_k = self.Lloc.block(n, n + mq - 1, lb * nb, lb * nb + w)
                 kb = kernel.gram(xsdev, xdev.sub(c0, c0 + w), ctx=self.ctx, out=rows_k if rows_k.dtype == kdt else None)
@@ -296,12 +340,12 @@ class DistributedChol:
                 self.Lloc.block(n + mq - 1, n + mq, lb * nb, lb * nb + w).assign(ydev.block(0, 1, c0, c0 + w))
         mark('gram')
         # ---- s = diag_scale_pow2(K) (_decomp.py:356-361): own columns, then shared with one all-reduce
-        svec = DeviceArray.zeros((n,), numpy.float64, self.ctx)
-        for b in L.owned():
-            lb, w, c0 = L.local_index(b), L.width(b), L.col0(b)
-            diag = self.Lloc.block(c0, c0 + w, lb * nb, lb * nb + w)
-            _lib.check(lib.lgp_diag_scale_pow2_f64(h, w, diag.ptr, diag.ld, svec.ptr + c0 * 8), 'lgp_diag_scale_pow2')
-        _lib.check(lib.lgp_allreduce_sum_f64(h, svec.ptr, n), 'lgp_allreduce_sum')
+        if not fused:
+            for b in L.owned():
+                lb, w, c0 = L.local_index(b), L.width(b), L.col0(b)
+                diag = self.Lloc.block(c0, c0 + w, lb * nb, lb * nb + w)
+                _lib.check(lib.lgp_diag_scale_pow2_f64(h, w, diag.ptr, diag.ld, svec.ptr + c0 * 8), 'lgp_diag_scale_pow2')
+            _lib.check(lib.lgp_allreduce_sum_f64(h, svec.ptr, n), 'lgp_allreduce_sum')
         self.ctx.sync()
         s_host = svec.to_host()
         self._unit = bool(numpy.all(s_host == 1))
@@ -309,7 +353,8 @@ class DistributedChol:
             for b in L.owned():
                 lb, w, c0 = L.local_index(b), L.width(b), L.col0(b)
                 blk = self.Lloc.block(0, n, lb * nb, lb * nb + w)
-                _lib.check(lib.lgp_scale_rows_cols_f64(h, n, w, blk.ptr, blk.ld, svec.ptr, svec.ptr + c0 * 8, 1), 'lgp_scale_rows_cols')
+                if not fused:
+                    _lib.check(lib.lgp_scale_rows_cols_f64(h, n, w, blk.ptr, blk.ld, svec.ptr, svec.ptr + c0 * 8, 1), 'lgp_scale_rows_cols')
                 if nx:
                     ext = self.Lloc.block(n, n + nx, lb * nb, lb * nb + w)
                     _lib.check(lib.lgp_scale_rows_cols_f64(h, nx, w, ext.ptr, ext.ld, None, svec.ptr + c0 * 8, 1), 'lgp_scale_rows_cols')
@@ -320,11 +365,11 @@ class DistributedChol:
             epsrel = n * meps
         if isinstance(epsabs, str):
             epsabs = meps
-        sums = DeviceArray.zeros((L.local_cols,), numpy.float64, self.ctx)
-        for b in L.owned():
-            lb, w = L.local_index(b), L.width(b)
-            blk = self.Lloc.block(0, n, lb * nb, lb * nb + w)          # matrix rows only (not the carried rows)
-            _lib.check(lib.lgp_colabssum_f64(h, n, w, blk.ptr, blk.ld, sums.ptr + lb * nb * 8), 'lgp_colabssum')
+        if not fused:
+            for b in L.owned():
+                lb, w = L.local_index(b), L.width(b)
+                blk = self.Lloc.block(0, n, lb * nb, lb * nb + w)          # matrix rows only (not the carried rows)
+                _lib.check(lib.lgp_colabssum_f64(h, n, w, blk.ptr, blk.ld, sums.ptr + lb * nb * 8), 'lgp_colabssum')
         red = DeviceArray.zeros((1,), numpy.float64, self.ctx)
         if L.nlocal:
             _lib.check(lib.lgp_max_f64(h, L.nlocal * nb, sums.ptr, red.ptr), 'lgp_max')

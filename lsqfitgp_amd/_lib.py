@@ -120,6 +120,8 @@ def _signatures():
             'lgp_transpose_' + suf: (c_int, [c_void_p, _P, _S, _P, _S, _S, _S]),
             'lgp_gram_isotropic_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, _P, _S, _S, _P, _S, _S,
                                                  c_int, F, c_int, F, c_int, POINTER(c_int), POINTER(F), c_int, _P, _S]),
+            'lgp_gram_reg_cols_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, _P, _S, _S, _S, _S, _S, _S, c_int, F, c_int, F,
+                                                c_int, POINTER(c_int), POINTER(F), F, _P, _P, _S, _P, _P]),
             'lgp_gram_pseries_' + suf: (c_int, [c_void_p, c_int, c_int, _P, _S, POINTER(F), _P, _S, _S, _P, _S, _S, c_int, F, c_int, F,
                                                c_int, POINTER(c_int), POINTER(F), c_int, _P, _S]),
             'lgp_pairs_pseries_' + suf: (c_int, [c_void_p, c_int, c_int, _P, _S, POINTER(F), _P, _S, _P, _S, _S, c_int, F, c_int, F,

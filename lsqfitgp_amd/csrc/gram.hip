@@ -59,6 +59,8 @@ struct IsoArgs {
   int flag;        // GammaExp: gamma == 2;  Cauchy: alpha == 2  (the branches that act on r2 itself);  MaternpDiff: odd total order
   int xy;          // 0; 1: kernels of x and y themselves, one variable: the core receives y in place of r2 and x in place of d0; 2: d0 = sum_f x_f y_f
   int posabs;      // input='posabs' of the reference (_Kernel/_isotropic.py:67-78): per field (|x - y| + eps)^2, the core takes the root
+  int cbase;       // fused kernel, column-range mode: first column of the launch (the last is m - 1)
+  int cyc_nb, cyc_stride, wloc;   // ... block-cyclic columns: local block q (width cyc_nb) starts at global column cbase + q cyc_stride; wloc local columns
   const T *table;  // LagTable: device array of the values at the integer lags 0 .. ntable - 1, `fill` beyond
   int ntable;
   T fill;
@@ -790,6 +792,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.twop1 = (T)(2 * p + 1);
   g.par[0] = g.par[1] = g.par[2] = T(0);
   g.table = dtable; g.ntable = (int)ntable; g.fill = fill;
+  g.cbase = 0; g.cyc_nb = 0; g.cyc_stride = 0; g.wloc = 0;
   g.flag = 0;
   g.posabs = posabs ? 1 : 0;
   g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : ((kernel >= LGP_KERNEL_WIENER && kernel <= LGP_KERNEL_WIENERINTEGRAL) || kernel == LGP_KERNEL_TAYLOR ? 1 : (kernel == LGP_KERNEL_GIBBS ? 3 : 0));
@@ -995,7 +998,9 @@ __device__ __forceinline__ T pow2_scale(T d) {      // _decomp.py:356-361
 // whole multiples of the 128-row blocks).  So: tiles above: nothing; tiles below: column sums as before plus the sums along
 // their rows (per wave by lane shuffles, the four waves' partials added in fixed order) -> rpart[tile column][row]; tiles that
 // straddle the diagonal: evaluated in full as before, column sums only.  Gershgorin_j = sum_tr part[tr][j] + sum_tc rpart[tc][j].
-template <typename T, int D, int CORE>
+// COLS (the sharded factorisation, csrc/dist.hip / _dist.py): the block of the columns [g.cbase, g.m) only, every row -- a rank's own
+// block column evaluated in full (no other rank holds the mirrored entries), column sums only; svec for ALL rows
+template <typename T, int D, int CORE, bool COLS = false>
 __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g, T noise, const T *__restrict__ noisev, T *__restrict__ svec,
                                                               T *__restrict__ part, T *__restrict__ rpart) {
   constexpr int W = VecOf<T>::W;
@@ -1017,7 +1022,11 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
   // kinds of work: zeros alone 0.8 ms, evaluated tiles alone 1.9 ms, together 3.1 ms at N = 32768 on the same box).
   constexpr int RPB = GT_COLS / GR_ROWS;
   int tr, tc;
-  {
+  if (COLS) {
+    const int ntcl = (g.wloc + GT_COLS - 1) / GT_COLS;
+    tr = blockIdx.x / ntcl;
+    tc = blockIdx.x % ntcl;
+  } else {
     const long b = blockIdx.x;
     long G = (long)((sqrt(1.0 + 8.0 * (double)b / RPB) - 1.0) * 0.5);
     while (RPB * (G + 1) * (G + 2) / 2 <= b) ++G;
@@ -1026,11 +1035,18 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
     tr = (int)(G * RPB + rem / (G + 1));
     tc = (int)(rem % (G + 1));
   }
-  const int row0 = tr * GR_ROWS, col0 = tc * GT_COLS;
+  // COLS: local column lcol0 of the launch's storage -> global column col0 (block-cyclic: a tile lies within one block, GT_COLS
+  // divides the block width); cend: one past the last column this tile may touch
+  const int lcol0 = tc * GT_COLS;
+  const int cq = (COLS && g.cyc_nb) ? lcol0 / g.cyc_nb : 0;
+  const int row0 = tr * GR_ROWS, col0 = COLS ? g.cbase + (g.cyc_nb ? cq * g.cyc_stride + (lcol0 - cq * g.cyc_nb) : lcol0) : lcol0;
+  const int cblk_end = (COLS && g.cyc_nb) ? g.cbase + cq * g.cyc_stride + g.cyc_nb : g.m;
+  const int cend = COLS ? (cblk_end < n ? cblk_end : n) : n;
+  if (COLS && col0 >= cend) return;
   if (row0 >= n) return;                                 // (the last row group may be ragged)
   const int tid = threadIdx.x;
   const T k0 = g.ops.apply(iso_core_t<T, CORE>(g, T(0)));     // the kernel on its diagonal: r2 = 0 exactly, as for the pairs (i, i)
-  const bool below = col0 + GT_COLS - 1 < row0;         // every entry strictly below the diagonal: sums along the rows as well
+  const bool below = !COLS && col0 + GT_COLS - 1 < row0;   // every entry strictly below the diagonal: sums along the rows as well
   constexpr int TPR = GR_ROWS / W, RPR = GT_THREADS / TPR;     // zero rounds: threads per mirrored row, rows per round
   const bool zfull = ((g.ldo % W) == 0) && ((reinterpret_cast<uintptr_t>(g.out) % 16) == 0);
   auto zero_round = [&](int zr) {
@@ -1061,7 +1077,7 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
   for (int idx = tid; idx < d * GT_COLS; idx += GT_THREADS) {
     const int f = idx / GT_COLS, c = idx % GT_COLS;
     T v = T(0);
-    if (col0 + c < n) {
+    if (col0 + c < cend) {
       v = g.x[(long)f * g.ldx + col0 + c];
       if (g.has_loc) v = v - g.loc;
       if (g.has_scale) v = v / g.scale;
@@ -1071,7 +1087,9 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
   for (int r = tid; r < GR_ROWS; r += GT_THREADS) {
     const T nz = (row0 + r < n) ? (noisev ? noisev[row0 + r] : noise) : T(0);
     snz[r] = nz;
-    sinv[r] = T(1) / pow2_scale<T>(k0 + nz);
+    const T si = pow2_scale<T>(k0 + nz);
+    sinv[r] = T(1) / si;
+    if (COLS && tc == 0 && row0 + r < n) svec[row0 + r] = si;
   }
   __syncthreads();
 
@@ -1080,17 +1098,17 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
 #pragma unroll
   for (int e = 0; e < W; ++e) {
     const int j = col0 + c0 + e;
-    cnz[e] = (j < n) ? (noisev ? noisev[j] : noise) : T(0);
+    cnz[e] = (j < cend) ? (noisev ? noisev[j] : noise) : T(0);
     const T sj = pow2_scale<T>(k0 + cnz[e]);
     cinv[e] = T(1) / sj;
     acc[e] = T(0);
-    if (tr == RPB * tc && j < n) svec[j] = sj;        // the first tile row that holds this column block
+    if (!COLS && tr == RPB * tc && j < n) svec[j] = sj;        // the first tile row that holds this column block
     if (D > 0) {
 #pragma unroll
       for (int f = 0; f < D; ++f) vreg[f][e] = sv[f * GT_COLS + c0 + e];
     }
   }
-  const bool colfull = (col0 + c0 + W <= n) && ((g.ldo % W) == 0) && ((reinterpret_cast<uintptr_t>(g.out) % 16) == 0);
+  const bool colfull = (col0 + c0 + W <= cend) && ((g.ldo % W) == 0) && ((reinterpret_cast<uintptr_t>(g.out) % 16) == 0) && (!COLS || (g.cbase % W) == 0);
   const int rmax = (n - row0) < GR_ROWS ? (n - row0) : GR_ROWS;
   for (int r = 0; r < rmax; ++r) {
     const int i = row0 + r;
@@ -1117,7 +1135,7 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
       T v = g.ops.apply(iso_core_t<T, CORE>(g, r2));
       if (i == j) v = v + cnz[e];                       // Kxx + ycov (_compute.py:85), noise on the diagonal
       v = v * cinv[e] * rinv;                           // K / s / s[:, None] (:385): exact, s is a power of two
-      if (j < n) acc[e] += fabs(v);
+      if (j < cend) acc[e] += fabs(v);
       res[e] = (j <= i) ? v : T(0);
     }
     if (below) zero_round(r);
@@ -1130,7 +1148,7 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
       for (int off = 32; off >= 1; off >>= 1) rs += __shfl_xor(rs, off, 64);
       if ((tid & 63) == 0) srow[(tid >> 6) * GR_ROWS + r] = rs;
     }
-    T *po = g.out + (long)i * g.ldo + col0 + c0;
+    T *po = g.out + (long)i * g.ldo + lcol0 + c0;
     if (colfull) {
       vec_t v;
 #pragma unroll
@@ -1139,14 +1157,14 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
     } else {
 #pragma unroll
       for (int e = 0; e < W; ++e)
-        if (col0 + c0 + e < n) po[e] = res[e];
+        if (col0 + c0 + e < cend) po[e] = res[e];
     }
   }
   if (below)
     for (int zr = rmax; zr < GR_ROWS; ++zr) zero_round(zr);      // (ragged last tile row: the rounds its loop did not reach)
 #pragma unroll
   for (int e = 0; e < W; ++e)
-    if (col0 + c0 + e < n) part[(long)tr * n + col0 + c0 + e] = acc[e];
+    if (col0 + c0 + e < cend) part[(long)tr * (COLS ? g.wloc : n) + lcol0 + c0 + e] = acc[e];
   if (below) {
     __syncthreads();
     for (int r = tid; r < rmax; r += GT_THREADS)
@@ -1157,12 +1175,14 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
 template <typename T>
 int gram_reg_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, int d, const T *dx, size_t ldx, size_t n, int has_loc, T loc,
                     int has_scale, T scale, int nops, const int *hops_code, const T *hops_val, T noise, const T *dnoise, T *dL, size_t ldl, T *dsvec,
-                    T *dpart, T *drpart, size_t *ntr_out) {
-  LGP_REQUIRE(ctx != nullptr && dx != nullptr && dL != nullptr && dsvec != nullptr && dpart != nullptr && drpart != nullptr, "null pointer");
+                    T *dpart, T *drpart, size_t *ntr_out, bool cols = false, size_t c0 = 0, size_t w = 0, size_t cyc_nb = 0, size_t cyc_stride = 0) {
+  LGP_REQUIRE(ctx != nullptr && dx != nullptr && dL != nullptr && dsvec != nullptr && dpart != nullptr && (cols || drpart != nullptr), "null pointer");
+  LGP_REQUIRE(!cols || (w >= 1 && c0 < n && (cyc_nb || c0 + w <= n)), "column range outside the matrix");
+  LGP_REQUIRE(!cols || cyc_nb == 0 || (cyc_nb % (GT_THREADS * VecOf<T>::W) == 0 && cyc_stride >= cyc_nb), "block width: a multiple of the tile width");
   LGP_REQUIRE(kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_MATERNP || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY,
               "unknown isotropic kernel");
   LGP_REQUIRE(d >= 1 && d <= 64 && p >= 0 && p <= MAX_P && nops >= 0 && nops <= MAX_OPS, "bad kernel parameters");
-  LGP_REQUIRE(n >= 1 && n < (1u << 30) && ldx >= n && ldl >= n, "bad dimensions");
+  LGP_REQUIRE(n >= 1 && n < (1u << 30) && ldx >= n && ldl >= (cols ? w : n), "bad dimensions");
   LGP_REQUIRE(!has_scale || (scale > T(0) && scale < T(INFINITY)), "scale must be positive and finite");
   LGP_REQUIRE(!has_loc || (loc > T(-INFINITY) && loc < T(INFINITY)), "loc must be finite");
   DeviceGuard dg(ctx->device);
@@ -1179,6 +1199,7 @@ int gram_reg_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.posabs = 0;
   g.xy = 0;
   g.table = nullptr; g.ntable = 0; g.fill = T(0);
+  g.cbase = 0; g.cyc_nb = 0; g.cyc_stride = 0; g.wloc = 0;
   for (int f = 0; f < 8; ++f) g.dord[f] = 0;
   g.par[0] = g.par[1] = g.par[2] = T(0);
   g.flag = 0;
@@ -1204,6 +1225,33 @@ int gram_reg_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   LGP_REQUIRE(ntr * ntc < (1ull << 31), "gram grid too large");
   const size_t shmem = ((size_t)d * (GR_ROWS + GT_COLS) + 6 * GR_ROWS) * sizeof(T);
   constexpr size_t RPB = (size_t)GT_COLS / GR_ROWS;
+  if (cols) {
+    // a column range, every row (a rank's block column of the sharded factorisation): plain grid, every tile writes its partial sums
+    g.cbase = (int)c0;
+    g.m = (int)((cyc_nb ? n : c0 + w));
+    g.wloc = (int)w; g.cyc_nb = (int)cyc_nb; g.cyc_stride = (int)cyc_stride;
+    const size_t ntcl = (w + GT_COLS - 1) / GT_COLS;
+    LGP_REQUIRE(ntr * ntcl < (1ull << 31), "gram grid too large");
+    dim3 gdc((unsigned)(ntr * ntcl)), bdc(GT_THREADS);
+#define LGP_REGC_LAUNCH(DD, CC) hipLaunchKernelGGL((gram_reg_kernel<T, DD, CC, true>), gdc, bdc, shmem, ctx->stream, g, noise, dnoise, dsvec, dpart, drpart)
+#define LGP_REGC_BY_CORE(DD)                                   \
+    switch (core_of(kernel, p)) {                               \
+      case CORE_EXPQUAD: LGP_REGC_LAUNCH(DD, CORE_EXPQUAD); break;   \
+      case CORE_MATERN2: LGP_REGC_LAUNCH(DD, CORE_MATERN2); break;   \
+      default: LGP_REGC_LAUNCH(DD, CORE_GENERIC); break;             \
+    }
+    switch (d) {
+      case 1: LGP_REGC_BY_CORE(1); break;
+      case 2: LGP_REGC_BY_CORE(2); break;
+      case 3: LGP_REGC_BY_CORE(3); break;
+      default: LGP_REGC_BY_CORE(0); break;
+    }
+#undef LGP_REGC_BY_CORE
+#undef LGP_REGC_LAUNCH
+    LGP_LAUNCH_CHECK();
+    *ntr_out = ntr;
+    return LGP_OK;
+  }
   size_t tiles = 0;
   for (size_t tr = 0; tr < (ntr + RPB - 1) / RPB * RPB; ++tr) tiles += tr / RPB + 1;     // whole row groups (the kernel skips rows past n)
   dim3 gd((unsigned)tiles), bd(GT_THREADS);
@@ -1781,6 +1829,51 @@ extern "C" int lgp_pairs_lagtable_f32(lgp_ctx *ctx, const float *dtable, size_t 
                                       const float *hops_val, float *dout) {
   return gram_iso_launch<float>(ctx, LGP_KERNEL_LAGTABLE, 0, 0, nullptr, 1, dx, ldx, npairs, dy, ldy, npairs, has_loc, loc, has_scale, scale, nops, hops_code,
                                 hops_val, dout, npairs, true, nullptr, false, dtable, ntable, fill);
+}
+
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) regcols_reduce_kernel(size_t w, size_t ntr, const T *part, T *sums) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= w) return;
+  T acc = T(0);
+  for (size_t t = 0; t < ntr; ++t) acc += part[t * w + j];      // fixed order: deterministic
+  sums[j] = acc;
+}
+template <typename T>
+int gram_reg_cols_impl(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, int d, const T *dx, size_t ldx, size_t n, size_t c0, size_t w, size_t cyc_nb, size_t cyc_stride, int has_loc,
+                       T loc, int has_scale, T scale, int nops, const int *hops_code, const T *hops_val, T noise, const T *dnoise, T *dblock, size_t ldb,
+                       T *dsvec, T *dsums) {
+  LGP_REQUIRE(ctx != nullptr && dsums != nullptr, "null pointer");
+  if (n == 0 || w == 0) return LGP_OK;
+  const size_t ntr = (n + GR_ROWS - 1) / GR_ROWS;
+  T *part = nullptr;
+  LGP_CHECK(lgp_ws_alloc(ctx, ctx->stream, ntr * w * sizeof(T), reinterpret_cast<void **>(&part)));
+  WsGuard part_guard(ctx, ctx->stream, part);
+  LGP_HIP(hipMemsetAsync(part, 0, ntr * w * sizeof(T), ctx->stream));
+  size_t got = 0;
+  LGP_CHECK(gram_reg_launch<T>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, noise, dnoise, dblock, ldb,
+                               dsvec, part, nullptr, &got, true, c0, w, cyc_nb, cyc_stride));
+  // (columns of the padding behind a ragged last block: no tile wrote their partial sums)
+
+  hipLaunchKernelGGL((regcols_reduce_kernel<T>), dim3((unsigned)((w + 255) / 256)), dim3(256), 0, ctx->stream, w, ntr, part, dsums);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+}  // namespace
+
+extern "C" int lgp_gram_reg_cols_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d, const double *dx, size_t ldx, size_t n, size_t c0, size_t w,
+                                     size_t cyc_nb, size_t cyc_stride, int has_loc, double loc, int has_scale, double scale, int nops, const int *hops_code, const double *hops_val, double noise,
+                                     const double *dnoise, double *dblock, size_t ldb, double *dsvec, double *dsums) {
+  return gram_reg_cols_impl<double>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, c0, w, cyc_nb, cyc_stride, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, noise, dnoise, dblock,
+                                    ldb, dsvec, dsums);
+}
+
+extern "C" int lgp_gram_reg_cols_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int d, const float *dx, size_t ldx, size_t n, size_t c0, size_t w,
+                                     size_t cyc_nb, size_t cyc_stride, int has_loc, float loc, int has_scale, float scale, int nops, const int *hops_code, const float *hops_val, float noise,
+                                     const float *dnoise, float *dblock, size_t ldb, float *dsvec, float *dsums) {
+  return gram_reg_cols_impl<float>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, c0, w, cyc_nb, cyc_stride, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, noise, dnoise, dblock,
+                                   ldb, dsvec, dsums);
 }
 
 // ---- elementwise ("pairs") forms: out[i] = k(x_i, y_i) ------------------------------------------------
