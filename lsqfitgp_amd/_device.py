@@ -136,8 +136,8 @@ class _Graveyard:
 
     LIMIT_BYTES = 1 << 30
     LIMIT_COUNT = 256
-    CACHE_BYTES = 8 << 30
-    BLOCK_BYTES = 2 << 30
+    CACHE_BYTES = 40 << 30         # (of 288 GB: the matrices of a C3-sized step, 8.6 GB each, are reused instead of freed and mapped again)
+    BLOCK_BYTES = 16 << 30
 
     def __init__(self, lib, handle):
         self.lib, self.handle = lib, handle
