@@ -330,3 +330,42 @@ def test_distributed_composite_kernel(lgp, rng):
         c0 = d.layout.col0(b)
         full[c0:, c0:c0 + blk.shape[1]] = blk
     util.assert_close_matrices(full, o._L, rtol=1e-10)
+
+
+@pytest.mark.parametrize('n,nb,G,rank', [(3000, 512, 1, 0), (3000, 512, 3, 1), (2560, 1024, 2, 1), (1300, 512, 2, 0)])
+def test_fused_block_column_kernel(lgp, n, nb, G, rank):
+    """ ``lgp_gram_reg_cols``: a rank's block-cyclic share of the regularised Gram matrix in one launch -- the scaled lower triangle
+    of its columns (zeros above the diagonal), the scales of every row and the Gershgorin sums of its columns over all rows --
+    against numpy on the oracle's Gram matrix; ragged last blocks included """
+    import ctypes
+    from lsqfitgp_amd import _lib
+    from lsqfitgp_amd._kernels import _ops_arrays
+    rng = np.random.default_rng(n + G)
+    x = np.empty(n, [('a', float), ('b', float)])
+    x['a'] = rng.uniform(0, 30, n); x['b'] = rng.uniform(0, 30, n)
+    kd = lgp.Maternp(p=2, scale=1.7) * 37.0
+    K = (oracle.Maternp(p=2, scale=1.7) * 37.0)(x[:, None], x[None, :]) + 0.3 * np.eye(n)
+    s = 2.0 ** np.rint(0.5 * np.log2(np.diag(K)))
+    Kt = K / s[:, None] / s[None, :]
+    blocks = [b for b in range(-(-n // nb)) if b % G == rank]
+    cols = np.concatenate([np.arange(b * nb, min(n, (b + 1) * nb)) for b in blocks])
+    wloc = len(blocks) * nb
+    ctx = lgp.Context.default()
+    lib = _lib.load()
+    xdev = kd.prepare(x, ctx=ctx)
+    out = lgp.DeviceArray.zeros((n, wloc), np.float64, ctx)
+    svec = lgp.DeviceArray.zeros((n,), np.float64, ctx)
+    sums = lgp.DeviceArray.zeros((wloc,), np.float64, ctx)
+    F = ctypes.c_double
+    nops, codes, vals = _ops_arrays(kd._outops, F)
+    npar, hpar = kd._par_args(F)
+    _lib.check(lib.lgp_gram_reg_cols_f64(ctx.handle, kd._kind, int(kd._p), npar, hpar, 2, xdev.array.ptr, xdev.array.ld, n, rank * nb, wloc, nb, G * nb,
+                                         0, F(0), 1, F(1.7), nops, codes, vals, F(0.3), None, out.ptr, out.ld, svec.ptr, sums.ptr), 'lgp_gram_reg_cols')
+    got = out.to_host()
+    np.testing.assert_array_equal(svec.to_host(), s)
+    for q, b in enumerate(blocks):
+        c0, c1 = b * nb, min(n, (b + 1) * nb)
+        ref = np.tril(Kt, 0)[:, c0:c1]
+        np.testing.assert_allclose(got[:, q * nb:q * nb + (c1 - c0)], ref, rtol=0, atol=4e-15)
+        assert np.all(got[:c0, q * nb:q * nb + (c1 - c0)] == 0)
+        np.testing.assert_allclose(sums.to_host()[q * nb:q * nb + (c1 - c0)], np.abs(Kt[:, c0:c1]).sum(0), rtol=1e-13)
