@@ -120,7 +120,8 @@ def factor_tasks(layout, plan=None, nx=0):
         'SQ'     owner(b), i = 0: the diagonal square factored (the library records one event per 128-column block of it and
                  lets the rows below follow block by block; here the square is one operation)
         'SOLVE'  owner(b), i > 0: the rows solved against the square
-        'PACK'   owner(b), i > 0: the rows copied into panel slot b % nslots
+        'PACK'   owner(b), i > 0: the rows copied into panel slot b % nslots (for the broadcast: the owner's own updates read the rows
+                 where they lie, behind 'SOLVE')
         'BCAST'  every rank, i > 0: the piece broadcast from owner(b) (a collective: same order on every rank)
         'BULK'   every rank, i > 0: block columns ``extra`` (owned, >= b + 2) restricted to the rows of the piece
     """
@@ -152,7 +153,16 @@ def factor_tasks(layout, plan=None, nx=0):
         if b < nslots:
             return []
         s = b % nslots
-        return [('free_sc', s), ('free_l1', s)]
+        ev = [('free_sc', s), ('free_l1', s)]
+        prev = b - nslots                      # a panel of this rank's own is read in place by its updates: its slot by the broadcast alone
+        if L.owner(prev) == me and len(by_panel[prev]) > 1:
+            ev.append(('recv', prev, by_panel[prev][-1][1]))
+        return ev
+
+    def avail(b, i):
+        """ the event behind which the rows of piece i of panel b may be read by this rank's updates: solved (own panel, read in
+        the factor itself) or received (another rank's, read in its slot) """
+        return ('solved', b, i) if L.owner(b) == me else ('recv', b, i)
 
     mine = L.owned()
     for p in pieces:
@@ -161,7 +171,7 @@ def factor_tasks(layout, plan=None, nx=0):
         if L.owner(b) == me:
             if i == 0:
                 if b >= 1:          # U1 on the stream of the squares
-                    w = [('recv', b - 1, cover(b - 1, b * L.nb))]
+                    w = [avail(b - 1, cover(b - 1, b * L.nb))]
                     if b >= 2:
                         w.append(('bulk', b - 2, cover(b - 2, b * L.nb)))
                     push('s1', 'U', p, w)
@@ -170,7 +180,7 @@ def factor_tasks(layout, plan=None, nx=0):
                 if b >= 1:
                     rec['free_l1', (b - 1) % nslots] = t
             else:                   # (U2 of these rows: on the compute stream, with the piece of panel b - 1 that holds them, below)
-                push('s3', 'SOLVE', p, [('sq', b)] + ([('u2', b - 1, cover(b - 1, r0))] if b >= 1 else []))
+                rec['solved', b, i] = push('s3', 'SOLVE', p, [('sq', b)] + ([('u2', b - 1, cover(b - 1, r0))] if b >= 1 else []))
                 rec['ready', b, i] = push('s3', 'PACK', p, slot_events(b))
         if i == 0:
             continue
@@ -182,14 +192,14 @@ def factor_tasks(layout, plan=None, nx=0):
             if r2 < r1:
                 q = next(q for q in by_panel[b + 1] if q[2] == r2)
                 assert q[3] == r1 and q[1] >= 1
-                t = push('sc', 'U', q, [('recv', b, i), ('recv', b, cover(b, (b + 1) * L.nb))])
+                t = push('sc', 'U', q, [avail(b, i), avail(b, cover(b, (b + 1) * L.nb))])
             else:
-                t = push('sc', 'NOP', p, [('recv', b, i)])
+                t = push('sc', 'NOP', p, [avail(b, i)])
             rec['u2', b, i] = t
         cols = [c for c in mine if c >= b + 2 and c * L.nb < r1]
-        w = [('recv', b, i)]
+        w = [avail(b, i)]
         if cols:
-            w.append(('recv', b, cover(b, cols[0] * L.nb)))
+            w.append(avail(b, cover(b, cols[0] * L.nb)))
         t = push('sc', 'BULK', p, w, cols)
         rec['bulk', b, i] = t
         if last:

@@ -171,7 +171,7 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
     return v.size() - 1;
   };
   EventPool pool;
-  std::vector<std::vector<hipEvent_t>> ev_recv(nblocks), ev_ready(nblocks), ev_bulk(nblocks), ev_u2(nblocks);
+  std::vector<std::vector<hipEvent_t>> ev_recv(nblocks), ev_ready(nblocks), ev_bulk(nblocks), ev_u2(nblocks), ev_solved(nblocks);
   std::vector<hipEvent_t> ev_free_sc(nslots, nullptr), ev_free_l1(nslots, nullptr);
   std::vector<std::vector<hipEvent_t>> ev_blk(nblocks);       // per 128-column block of an owned square: factored, the square's rows solved
   bool ok = true;
@@ -185,8 +185,8 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
       for (size_t i = 0; i < np; ++i) make(ev_u2[b][i]);
     }
     if (owner(b) == me) {
-      ev_ready[b].resize(np);
-      for (size_t i = 0; i < np; ++i) make(ev_ready[b][i]);
+      ev_ready[b].resize(np); ev_solved[b].resize(np);
+      for (size_t i = 0; i < np; ++i) { make(ev_ready[b][i]); make(ev_solved[b][i]); }
       ev_blk[b].resize((width(b) + LGP_DB - 1) / LGP_DB);
       for (auto &e : ev_blk[b]) make(e);
     }
@@ -211,8 +211,20 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
     const size_t s = b % nslots;
     LGP_HIP(hipStreamWaitEvent(st, ev_free_sc[s], 0));
     LGP_HIP(hipStreamWaitEvent(st, ev_free_l1[s], 0));
+    // a panel of this rank's own is read by its updates IN PLACE (below): what still reads its slot is the broadcast
+    const size_t prev = b - nslots;
+    if (owner(prev) == me && pieces[prev].size() > 1) LGP_HIP(hipStreamWaitEvent(st, ev_recv[prev][pieces[prev].size() - 1], 0));
     return LGP_OK;
   };
+  // The rows of a panel as an update reads them: a panel this rank factored itself is read where it lies, in the factor (its rows
+  // are final once solved: `ev_solved`), so that neither the copy into the slot nor the broadcast stands between the solve and
+  // this rank's own updates; a panel of another rank from its slot, once received
+  auto prow = [&](size_t b, size_t r, size_t &ld) -> const double * {
+    if (owner(b) == me) { ld = ldl; return block(b) + (r - b * nb) * ldl; }
+    ld = ldp;
+    return panel_rows(b, r);
+  };
+  auto avail = [&](size_t b, size_t i) { return owner(b) == me ? ev_solved[b][i] : ev_recv[b][i]; };
 
   // ---- owner(b): update its piece of block column b with panel b - 1, factor / solve it, pack it
   auto lane = [&](const Piece &p) -> int {
@@ -222,10 +234,11 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
     if (b >= 1 && p.i == 0) {
       // U1: the square of block column b gets panel b - 1 here, on the stream that factors it (nothing else stands between the
       // arrival of those rows and the next square)
-      LGP_HIP(hipStreamWaitEvent(st, ev_recv[b - 1][cover(b - 1, b * nb)], 0));
+      LGP_HIP(hipStreamWaitEvent(st, avail(b - 1, cover(b - 1, b * nb)), 0));
       if (b >= 2) LGP_HIP(hipStreamWaitEvent(st, ev_bulk[b - 2][cover(b - 2, b * nb)], 0));   // ... and has every earlier update
-      const double *A = panel_rows(b - 1, b * nb);
-      LGP_CHECK(lgp_gemm_launch<double>(ctx, st, false, true, kb, kb, width(b - 1), -1.0, A, ldp, A, ldp, 1.0, C, ldl, true));
+      size_t lda = 0;
+      const double *A = prow(b - 1, b * nb, lda);
+      LGP_CHECK(lgp_gemm_launch<double>(ctx, st, false, true, kb, kb, width(b - 1), -1.0, A, lda, A, lda, 1.0, C, ldl, true));
     }
     // (U2, the rows below the square, was applied on the compute stream in front of the bulk update with the same piece of panel
     // b - 1, see `bulk`: the two do not share the CUs, as in the single-GPU driver)
@@ -242,6 +255,7 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
     if (b >= 1 && p.i == 0) LGP_HIP(hipEventRecord(ev_free_l1[(b - 1) % nslots], st));
     // the square itself stays at home: the trailing updates only read rows BELOW a panel's diagonal block
     if (p.i == 0) return LGP_OK;
+    LGP_HIP(hipEventRecord(ev_solved[b][p.i], st));
     LGP_CHECK(wait_slot_free(b, st));
     LGP_HIP(hipMemcpy2DAsync(panel_rows(b, p.r0), ldp * sizeof(double), C, ldl * sizeof(double), kb * sizeof(double), p.r1 - p.r0,
                              hipMemcpyDeviceToDevice, st));
@@ -262,13 +276,15 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   // ---- every rank: its block columns c >= b + 2, rows of the piece, in one staircase launch
   auto bulk = [&](const Piece &p) -> int {
     const size_t b = p.b;
-    LGP_HIP(hipStreamWaitEvent(sc, ev_recv[b][p.i], 0));
+    LGP_HIP(hipStreamWaitEvent(sc, avail(b, p.i), 0));
+    size_t ldq = 0;
+    (void)prow(b, p.r0, ldq);                              // the leading dimension of this panel's rows for this rank
     if (b + 1 < nblocks && owner(b + 1) == me) {
       // U2: the look-ahead column b + 1 below its square, rows of this piece, FIRST: its owner solves those rows next (s3)
       const size_t r2 = std::max(p.r0, std::min((b + 2) * nb, n));
       if (r2 < p.r1) {
-        LGP_HIP(hipStreamWaitEvent(sc, ev_recv[b][cover(b, (b + 1) * nb)], 0));
-        LGP_CHECK(lgp_gemm_launch<double>(ctx, sc, false, true, p.r1 - r2, width(b + 1), width(b), -1.0, panel_rows(b, r2), ldp, panel_rows(b, (b + 1) * nb), ldp,
+        LGP_HIP(hipStreamWaitEvent(sc, avail(b, cover(b, (b + 1) * nb)), 0));
+        LGP_CHECK(lgp_gemm_launch<double>(ctx, sc, false, true, p.r1 - r2, width(b + 1), width(b), -1.0, prow(b, r2, ldq), ldq, prow(b, (b + 1) * nb, ldq), ldq,
                                           1.0, block(b + 1) + (r2 - (b + 1) * nb) * ldl, ldl, false, 2));
       }
       LGP_HIP(hipEventRecord(ev_u2[b][p.i], sc));
@@ -278,16 +294,16 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
     if (c0 < nblocks) {
       const size_t rs = std::max(p.r0, c0 * nb);
       if (rs < p.r1) {
-        LGP_HIP(hipStreamWaitEvent(sc, ev_recv[b][cover(b, c0 * nb)], 0));                  // (arrived earlier: same stream order; explicit)
+        LGP_HIP(hipStreamWaitEvent(sc, avail(b, cover(b, c0 * nb)), 0));                    // (arrived earlier: same stream order; explicit)
         size_t ncols = 0;
         for (size_t c = c0; c < nblocks; c += G) ncols += width(c);
-        const double *A = panel_rows(b, rs), *B = panel_rows(b, c0 * nb);
+        const double *A = prow(b, rs, ldq), *B = prow(b, c0 * nb, ldq);
         double *C = block(c0) + (rs - c0 * nb) * ldl;
         // (late panels: the updates leave room on every CU for the latency-bound kernels of the look-ahead streams, as in potrf_split)
         const size_t left = n - std::min(n, (b + 1) * nb);
         ctx->gemm_thin_lds = left <= 6144 ? (size_t)70 * 1024 : (left <= 12288 ? (size_t)20 * 1024 : 0);
         if (nb % 128 == 0) {
-          const int st = lgp_gemm_launch<double>(ctx, sc, false, true, p.r1 - rs, ncols, width(b), -1.0, A, ldp, B, ldp, 1.0, C, ldl, true, 3, (int)nb,
+          const int st = lgp_gemm_launch<double>(ctx, sc, false, true, p.r1 - rs, ncols, width(b), -1.0, A, ldq, B, ldq, 1.0, C, ldl, true, 3, (int)nb,
                                                  (int)(G - 1), (int)(rs - c0 * nb));
           ctx->gemm_thin_lds = 0;
           LGP_CHECK(st);
@@ -297,7 +313,7 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
           for (size_t c = c0; c < nblocks; c += G) {
             const size_t rc = std::max(p.r0, c * nb);
             if (rc >= p.r1) continue;
-            LGP_CHECK(lgp_gemm_launch<double>(ctx, sc, false, true, p.r1 - rc, width(c), width(b), -1.0, panel_rows(b, rc), ldp, panel_rows(b, c * nb), ldp,
+            LGP_CHECK(lgp_gemm_launch<double>(ctx, sc, false, true, p.r1 - rc, width(c), width(b), -1.0, prow(b, rc, ldq), ldq, prow(b, c * nb, ldq), ldq,
                                               1.0, block(c) + (rc - c * nb) * ldl, ldl, true, 2, 0, 0, (int)(rc - c * nb)));
           }
         }

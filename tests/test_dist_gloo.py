@@ -47,10 +47,15 @@ class NumpyOps:
         self.blocks = {b: K[L.col0(b):, L.col0(b):L.col0(b) + L.width(b)].copy() for b in L.owned()}
         self.P = [np.full((self.rows_all, L.nb), np.nan) for _ in range(nslots)]
         self.tag = [np.full(self.rows_all, -1) for _ in range(nslots)]
+        self.solved = {b: np.zeros(self.rows_all, bool) for b in L.owned()}     # rows of an own panel that are final
         self.nslots = nslots
         self.log = []
 
     def _read(self, b, r0, r1):
+        if self.L.owner(b) == self.L.rank:          # an own panel is read where it lies, once its rows are solved
+            assert np.all(self.solved[b][r0:r1]), f'rows {r0}:{r1} of own panel {b} are not solved yet'
+            c0 = self.L.col0(b)
+            return self.blocks[b][r0 - c0:r1 - c0]
         slot = b % self.nslots
         assert np.all(self.tag[slot][r0:r1] == b), f'rows {r0}:{r1} of slot {slot} do not hold panel {b}'
         return self.P[slot][r0:r1, :self.L.width(b)]
@@ -79,6 +84,7 @@ class NumpyOps:
         c0, w = self.L.col0(b), self.L.width(b)
         blk = self.blocks[b]
         blk[r0 - c0:r1 - c0] = linalg.solve_triangular(blk[:w], blk[r0 - c0:r1 - c0].T, lower=True).T
+        self.solved[b][r0:r1] = True
 
     def pack(self, p, slot):
         b, i, r0, r1 = p
@@ -252,10 +258,10 @@ def test_schedule_single_rank():
     factor_schedule(L, ops)
     full = _gather(n, 0, nb, 1, lambda rank: ops.blocks)
     _check_factor(full, K, n)
-    # look-ahead: square 1 waits for the arrival of panel 0's rows only, not for the bulk update of the other block columns
-    # with panel 0 (which runs beside it on the compute stream)
+    # look-ahead: square 1 waits for panel 0's rows only -- an own panel: for their SOLVE, neither for the copy into the slot nor
+    # for the broadcast -- not for the bulk update of the other block columns with panel 0 (which runs beside it on the compute stream)
     u10 = next(t for t in tasks if t.kind == 'U' and t.piece[:2] == (1, 0))
-    assert [tasks[w].kind for w in u10.waits] == ['BCAST'] and u10.stream == 's1'
+    assert [tasks[w].kind for w in u10.waits] == ['SOLVE'] and u10.stream == 's1'
     bulk01 = next(t for t in tasks if t.kind == 'BULK' and t.piece[:2] == (0, 1))
     assert bulk01.stream == 'sc' and bulk01.extra == [2, 3, 4]
 
