@@ -256,9 +256,11 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
     // the square itself stays at home: the trailing updates only read rows BELOW a panel's diagonal block
     if (p.i == 0) return LGP_OK;
     LGP_HIP(hipEventRecord(ev_solved[b][p.i], st));
-    LGP_CHECK(wait_slot_free(b, st));
-    LGP_HIP(hipMemcpy2DAsync(panel_rows(b, p.r0), ldp * sizeof(double), C, ldl * sizeof(double), kb * sizeof(double), p.r1 - p.r0,
-                             hipMemcpyDeviceToDevice, st));
+    if (G > 1) {                                          // (without peers nobody reads the slot)
+      LGP_CHECK(wait_slot_free(b, st));
+      LGP_HIP(hipMemcpy2DAsync(panel_rows(b, p.r0), ldp * sizeof(double), C, ldl * sizeof(double), kb * sizeof(double), p.r1 - p.r0,
+                               hipMemcpyDeviceToDevice, st));
+    }
     LGP_HIP(hipEventRecord(ev_ready[b][p.i], st));
     return LGP_OK;
   };
