@@ -369,3 +369,23 @@ def test_fused_block_column_kernel(lgp, n, nb, G, rank):
         np.testing.assert_allclose(got[:, q * nb:q * nb + (c1 - c0)], ref, rtol=0, atol=4e-15)
         assert np.all(got[:c0, q * nb:q * nb + (c1 - c0)] == 0)
         np.testing.assert_allclose(sums.to_host()[q * nb:q * nb + (c1 - c0)], np.abs(Kt[:, c0:c1]).sum(0), rtol=1e-13)
+
+
+@pytest.mark.parametrize('n,nb,amp', [(2100, 512, 1.), (1536, 256, 37.), (3072, 1024, 0.003)])
+def test_fused_and_generic_gram_build_agree(lgp, rng, monkeypatch, n, nb, amp):
+    """ the two ways `DistributedChol` builds a rank's share (the fused block-column kernel for the isotropic cores it covers --
+    one launch when the block width is a multiple of 512, one per block otherwise -- and the generic kernel.gram + scaling +
+    column sums, ``LGP_DIST_FUSED_GRAM=0``): same jitter to rounding, same posterior; non-unit scales included (amp) """
+    x = rng.uniform(0, n / 16, n)
+    xs = rng.uniform(0, n / 16, 40)
+    y = np.sin(x) + 0.1 * rng.standard_normal(n)
+    from lsqfitgp_amd._dist import DistributedChol
+    kern = lgp.Maternp(p=2, scale=1.3) * amp
+    out = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('LGP_DIST_FUSED_GRAM', flag)
+        d = DistributedChol(kern, x, noise=0.01 * amp, nb=nb, carry=(xs, y))
+        out.append((d.eps, d.posterior(kern, x, xs, y)))
+    assert out[0][0] == pytest.approx(out[1][0], rel=1e-12)
+    for a, b in zip(out[0][1], out[1][1]):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * amp)
