@@ -332,7 +332,10 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   for (const Piece &p : plan) {
     if (failed == LGP_OK && owner(p.b) == me) failed = lane(p);
     if (p.i == 0) continue;                                // (squares are not sent, see `lane`)
-    int st = comm(p);
+    // (without peers nothing travels, and the communication stream stays empty: its event waits would sit in a hardware queue that
+    //  it shares with one of the other streams -- there are more streams than queues -- and hold that stream's kernels back: the
+    //  compute stream idled ~175 us per panel behind them, 5 ms of a C3 factorisation)
+    int st = G > 1 ? comm(p) : LGP_OK;
     if (failed == LGP_OK) failed = st;
     if (failed == LGP_OK) failed = bulk(p);
   }
