@@ -332,10 +332,11 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   for (const Piece &p : plan) {
     if (failed == LGP_OK && owner(p.b) == me) failed = lane(p);
     if (p.i == 0) continue;                                // (squares are not sent, see `lane`)
-    // (without peers nothing travels, and the communication stream stays empty: its event waits would sit in a hardware queue that
-    //  it shares with one of the other streams -- there are more streams than queues -- and hold that stream's kernels back: the
-    //  compute stream idled ~175 us per panel behind them, 5 ms of a C3 factorisation)
-    int st = G > 1 ? comm(p) : LGP_OK;
+    // (without peers nothing travels, and the communication stream stays empty.  Measured with one rank, LGP_DIST_FORCE_COMM: the
+    //  stream's event waits and records alone -- nothing reads what they order -- cost the factorisation 4.6-6.3 ms at C3, the
+    //  compute stream idling ~175 us per panel; neither GPU_MAX_HW_QUEUES = 8 / 16 nor a normal-priority stream changes that)
+    static const bool force_comm = getenv("LGP_DIST_FORCE_COMM") != nullptr;      // (experiments: the stream's traffic with one rank)
+    int st = (G > 1 || force_comm) ? comm(p) : LGP_OK;
     if (failed == LGP_OK) failed = st;
     if (failed == LGP_OK) failed = bulk(p);
   }
