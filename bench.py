@@ -13,10 +13,14 @@ One "step" = one full pass of the path over one batch of synthetic input (SURVEY
     c4  ExpQuad 1-D, N = 65536, M = 100, noise 0.01 I                     (default at --gpus N > 1, sharded)
     c5  BART p = 10 (fp32 Gram) on the first 4096 rows of the reference's bart-data.txt, through the GP / BART / Chol
         host classes: predict the 81 held-out rows + marginal likelihood
-With --gpus N > 1 (launched by torch.distributed.run, one process per GPU) the step is ONE C4 problem sharded by block
-columns over the ranks (lsqfitgp_amd._dist.DistributedChol: RCCL panel broadcasts over xGMI with look-ahead, "scaling":
-"strong"); N independent C3 replicas are timed afterwards and reported under "replicas" (no data-path collective).
-torch.distributed (gloo) is used only for the rendezvous, the barriers and the max-over-ranks of the timings.
+With --gpus N > 1 the step is ONE C4 problem sharded by block columns over N ranks, one process per GPU
+(lsqfitgp_amd._dist.DistributedChol: RCCL panel broadcasts over xGMI with look-ahead, "scaling": "strong"); N independent C3
+replicas are timed first and reported under "replicas" (no data-path collective).  The ranks come from either side:
+  * `python bench.py --gpus N` by itself: this process never touches the GPU, starts N fresh child processes
+    (RANK / LOCAL_RANK / WORLD_SIZE in their environment), relays rank 0's JSON line and exits non-zero if a child does;
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: the launcher's ranks are used as they are.
+Rendezvous, barriers and the max-over-ranks of the timings go through lsqfitgp_amd/_rendezvous.py (standard-library
+sockets on 127.0.0.1): bench.py imports no torch.
 
 Prints ONE JSON line (rank 0): whole-job throughput in TFLOP/s over the algorithmic flop count
 N^3/3 + N^2 (M+1) + N M^2, the roofline of the dominant kernel (syrk trailing update of the Cholesky,
@@ -519,36 +523,36 @@ def pmc_traffic(config):
         return None
 
 
-def init_transport(ctx, dist, rank, world):
+def init_transport(ctx, rdzv, rank, world):
     """ RCCL communicator over the ranks (one GPU each), or -- LGP_DIST_TRANSPORT=host -- panels staged through host memory and
-    gloo (lets several ranks rehearse the sharded path on ONE GPU).  Every rank learns whether every rank succeeded, so that a
-    failure can fall back to replicas instead of hanging in a collective.  Returns (ok, message). """
-    import torch
+    the rendezvous sockets (lets several ranks rehearse the sharded path on ONE GPU).  Every rank learns whether every rank
+    succeeded, so that a failure can fall back to replicas instead of hanging in a collective.  Returns (ok, message). """
     import lsqfitgp_amd as lgp
     err = ''
-    try:
-        if os.environ.get('LGP_DIST_TRANSPORT') == 'host':
-            def collective(op, arr, root):
-                t = torch.from_numpy(arr)
-                if op == 0:
-                    dist.broadcast(t, src=root)
-                else:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 1 else dist.ReduceOp.MAX)
-            ctx.comm_init_host(rank, world, collective)
-        else:
-            # every rank loads librccl first (lgp_comm_unique_id does): a missing library must not leave the others blocked
-            # inside ncclCommInitRank
-            probe = lgp.Context.comm_unique_id()
-            ok = torch.tensor([1.0])
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            uid = [probe if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(rank, world, uid[0])
-    except Exception as exc:
-        err = repr(exc)
-    flag = torch.tensor([0.0 if err else 1.0])
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    return bool(flag[0] > 0), err
+    if os.environ.get('LGP_DIST_TRANSPORT') == 'host':
+        try:
+            ctx.comm_init_host(rank, world, rdzv.collective)
+        except Exception as exc:
+            err = repr(exc)
+    else:
+        # every rank loads librccl first (lgp_comm_unique_id does): a missing library must not leave the others blocked inside
+        # ncclCommInitRank
+        uid = b''
+        try:
+            uid = lgp.Context.comm_unique_id()
+        except Exception as exc:
+            err = repr(exc)
+        loaded = rdzv.allreduce(0. if err else 1., 'min') > 0
+        uid = rdzv.broadcast_bytes(uid, 0)
+        if loaded:
+            try:
+                ctx.comm_init(rank, world, uid)
+            except Exception as exc:
+                err = repr(exc)
+        elif not err:
+            err = 'another rank could not load librccl'
+    ok = rdzv.allreduce(0. if err else 1., 'min') > 0
+    return ok, err
 
 
 def dist_step_factory(cfg, ctx):
@@ -573,44 +577,45 @@ def dist_step_factory(cfg, ctx):
     return step
 
 
-def timed(step, args, ctx, dist):
+def timed(step, args, sync, rdzv):
     """ W untimed + exactly K timed steps, bracketed by barrier + device sync on both sides; max over the ranks """
-    import torch
     for _ in range(args.warmup):
         step()
-    ctx.sync(); dist.barrier(); ctx.sync()
+    sync(); rdzv.barrier(); sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    ctx.sync(); dist.barrier(); ctx.sync()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t[0]), out
+    sync(); rdzv.barrier(); sync()
+    return rdzv.allreduce(time.perf_counter() - t0, 'max'), out
 
 
-def main_multi(args, ctx, dist, rank, world):
+METRIC_SHARDED = 'GP fit+predict fp64 throughput, one problem sharded over the GPUs (flops N^3/3 + N^2(M+1) + N M^2)'
+METRIC = 'GP fit+predict fp64 throughput (Gram build + Cholesky + solves; flops N^3/3 + N^2(M+1) + N M^2)'
+
+
+def main_multi(args, ctx, rdzv, rank, world):
     """ --gpus N > 1: N independent C3 replicas first (no data-path collective: always measurable), then BASELINE configuration C4
     (or --config) as ONE problem sharded by block columns over the N GPUs -- the headline line when it runs.  RCCL with more than
     one rank has never run on the builder's one-GPU boxes: the sharded attempt sits under a watchdog, so that a communicator that
-    hangs still leaves the replicas line (with the reason) instead of no line at all """
+    hangs still leaves the replicas line (with the reason) instead of no line at all -- and a NON-ZERO exit status, so that
+    nobody takes a stalled communicator for a success """
     import threading
     import lsqfitgp_amd as lgp
     lgp.Context._default = ctx
     cfg = CONFIGS[args.config if args.config_given else 'c4']
-    # replicas: every rank runs the single-GPU C3 step on its own GPU
-    rcfg = CONFIGS['c3']
+    # replicas: every rank runs the single-GPU step on its own GPU (C3; --replica-config for rehearsals on a shared GPU)
+    rcfg = CONFIGS[args.replica_config]
     wl = Workload(rcfg, ctx)
-    relapsed, _ = timed(lambda: wl.step(), args, ctx, dist)
+    relapsed, _ = timed(lambda: wl.step(), args, ctx.sync, rdzv)
     del wl
     replicas = {'workload': rcfg['name'], 'scaling': 'weak', 'value': flops_fit_predict(rcfg['n'], rcfg['m']) * args.steps * world / relapsed / 1e12,
                 'unit': 'TFLOP/s', 'ms_per_step': relapsed / args.steps * 1e3, 'parallelism': f'{world} independent replicas, one per GPU (no collective)'}
 
     def replicas_line(err):
-        return {'metric': 'GP fit+predict fp64 throughput (Gram build + Cholesky + solves; flops N^3/3 + N^2(M+1) + N M^2)',
-                'value': replicas['value'], 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        return {'metric': METRIC, 'value': replicas['value'], 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': replicas['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
                 'data': 'synthetic', 'config': {'workload': rcfg['name'], 'N': rcfg['n'], 'M': rcfg['m'], 'parallelism': replicas['parallelism']},
-                'roofline': None, 'cpu_baseline': None, 'sharded_path_error': err}
+                'roofline': None, 'cpu_baseline': None, 'rccl_ranks': None, 'sharded_path_error': err}
 
     # (a sharded C4 step is under a second on 2-8 GPUs; communicator set-up tens of seconds at most: a stalled attempt should not
     #  hold the replicas line back for long)
@@ -619,39 +624,120 @@ def main_multi(args, ctx, dist, rank, world):
     def give_up():
         if rank == 0:
             print(json.dumps(replicas_line(f'the sharded step did not finish within {limit:.0f} s (communicator or schedule stalled)')), flush=True)
-        os._exit(0)
+        os._exit(3)          # a process that has touched the GPU and is stuck in a collective: leave, and say it was not a success
 
     dog = threading.Timer(limit, give_up)
     dog.daemon = True
     dog.start()
-    ok, err = init_transport(ctx, dist, rank, world)
+    ok, err = init_transport(ctx, rdzv, rank, world)
     sharded = None
+    comm = (rank, 1, 'none')
     if ok:
         try:
-            elapsed, mll = timed(dist_step_factory(cfg, ctx), args, ctx, dist)
+            comm = ctx.comm_info()
+            elapsed, mll = timed(dist_step_factory(cfg, ctx), args, ctx.sync, rdzv)
             sharded = dict(elapsed=elapsed, mll=mll)
         except Exception as exc:             # (a rank that fails here leaves the others in a collective: reported, not hidden)
             err = repr(exc)
-    dog.cancel()
+    printed = threading.Event()
     if rank == 0:
-        transport = 'host-staged gloo' if os.environ.get('LGP_DIST_TRANSPORT') == 'host' else 'RCCL over xGMI'
+        transport = {'host': 'host-staged (rendezvous sockets)', 'rccl': 'RCCL over xGMI'}.get(comm[2], comm[2])
         if sharded is not None:
             n, m = cfg['n'], cfg['m']
-            out = {'metric': 'GP fit+predict fp64 throughput, one problem sharded over the GPUs (flops N^3/3 + N^2(M+1) + N M^2)',
+            out = {'metric': METRIC_SHARDED,
                    'value': flops_fit_predict(n, m) * args.steps / sharded['elapsed'] / 1e12, 'unit': 'TFLOP/s', 'n_gpus': world,
                    'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': sharded['elapsed'] / args.steps * 1e3,
                    'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                    'config': {'workload': cfg['name'], 'N': n, 'M': m,
                               'parallelism': f'1-D block-column-cyclic Cholesky over {world} GPUs, nb=1024, {transport} panel broadcast with look-ahead (lgp_chol_factor_dist)'},
+                   # what the communicator itself reports (ncclCommCount), None when the panels did not travel by RCCL
+                   'rccl_ranks': comm[1] if comm[2] == 'rccl' else None, 'transport': comm[2],
                    'log_marginal_likelihood': sharded['mll'], 'roofline': None, 'cpu_baseline': None, 'replicas': replicas}
         else:
             out = replicas_line(err)
         print(json.dumps(out), flush=True)
+    # the watchdog stays armed through the teardown: a rank stuck in the last barrier must not hang the job (the line is out
+    # already, so give_up only has to leave)
+    def leave():
+        os._exit(0 if sharded is not None else 3)
+    dog.cancel()
+    dog = threading.Timer(60., leave)
+    dog.daemon = True
+    dog.start()
     try:
-        dist.barrier()
-        dist.destroy_process_group()
+        rdzv.barrier()
+        rdzv.close()
     except Exception:
         pass
+    dog.cancel()
+    return 0 if sharded is not None else 3
+
+
+def main_stub(args, rdzv, rank, world):
+    """ LGP_BENCH_STUB=1: the launcher, the rendezvous and the timing protocol with a step that does not touch the GPU (the CPU test
+    of `--gpus N`; tests/test_bench_launcher.py) """
+    elapsed, _ = timed(lambda: time.sleep(0.01), args, lambda: None, rdzv)
+    pids = rdzv.allgather_bytes(str(os.getpid()).encode())
+    if rank == 0:
+        print(json.dumps({'metric': 'stub step (no GPU work): launcher + rendezvous + timing protocol', 'value': args.steps * world / elapsed, 'unit': 'steps/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+                          'scaling': 'weak', 'stub': True, 'rank_pids': [int(p) for p in pids], 'local_ranks_seen': world}), flush=True)
+    rdzv.barrier()
+    rdzv.close()
+    return 0
+
+
+def launch_ranks(args):
+    """ `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here.  This process makes no GPU call
+    (it imports nothing of the package), so the children are ordinary fresh processes, one per GPU; rank 0's standard output is
+    relayed, the others' goes to standard error; the exit status is non-zero if any rank's is, and a rank that outlives
+    LGP_BENCH_LAUNCH_TIMEOUT seconds (default 1500) is ended by its exact pid. """
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   LGP_RDZV_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs between processes on this image
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    deadline = time.monotonic() + float(os.environ.get('LGP_BENCH_LAUNCH_TIMEOUT', 1500))
+    grace = float(os.environ.get('LGP_BENCH_LAUNCH_GRACE', 90))
+    failed_at = None
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        now = time.monotonic()
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = now            # a rank has failed: the others get `grace` seconds (their own watchdogs print the fallback line)
+        if now > deadline or (failed_at is not None and now - failed_at > grace):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()           # the exact process this launcher started
+                    codes[i] = p.wait()
+            break
+        time.sleep(0.1)
+    th.join(timeout=10)
+    bad = [c for c in codes if c != 0]
+    if bad:
+        sys.stderr.write(f'bench.py: rank exit codes {codes}\n')
+        return bad[0] if bad[0] > 0 else 1
+    return 0
 
 
 def main():
@@ -664,30 +750,45 @@ def main():
     ap.add_argument('--no-sweep', action='store_true', help='skip the smaller-N / C2 / C4 / C5 runs reported under "vs_N"')
     ap.add_argument('--dist', action='store_true', default=os.environ.get('LGP_BENCH_DIST') == '1',
                     help='single process: run the sharded code path with one rank (the multi-rank default of --gpus N > 1)')
+    ap.add_argument('--replica-config', choices=sorted(CONFIGS), default='c3',
+                    help='--gpus N > 1: the single-GPU workload every rank runs as an independent replica (default c3)')
     args = ap.parse_args()
     args.config_given = args.config is not None
     if args.config is None:
         args.config = 'c3'
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args)           # no launcher around us: start the ranks; this process never touches the GPU
+
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist = None
+    if world != max(args.gpus, 1) and world > 1:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but the launcher started {world} ranks: reporting n_gpus = {world}\n')
+    rdzv = None
+    if os.environ.get('LGP_BENCH_STUB') == '1' and os.environ.get('LGP_BENCH_STUB_FAIL_RANK') == str(rank):
+        return 7                            # (test of the launcher: a rank that dies before the rendezvous)
     if world > 1 or args.dist:
-        import torch                       # plumbing only: rendezvous, barrier, max-over-ranks
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('gloo', rank=rank, world_size=world)       # rendezvous before any GPU call
-        os.environ.setdefault('LGP_DEVICE', str(local_rank))
+        from lsqfitgp_amd._rendezvous import Rendezvous       # standard-library sockets; before any GPU call
+        rdzv = Rendezvous(rank, world)
+        if os.environ.get('LGP_BENCH_STUB') == '1':
+            return main_stub(args, rdzv, rank, world)
 
     import lsqfitgp_amd as lgp              # fails loudly without the HIP library / a GPU
-    ctx = lgp.Context(int(os.environ.get('LGP_DEVICE', local_rank)))
+    device = os.environ.get('LGP_DEVICE')
+    if device is None:
+        device = local_rank
+        if os.environ.get('LGP_DIST_TRANSPORT') == 'host':      # rehearsal: more ranks than GPUs share what there is
+            cnt = ctypes.c_int()
+            from lsqfitgp_amd import _lib as _l
+            _l.load().lgp_device_count(ctypes.byref(cnt))
+            device = local_rank % max(cnt.value, 1)
+    ctx = lgp.Context(int(device))
     if args.config == 'c5':
         lgp.Context._default = ctx
         return main_c5(args, ctx)
-    if dist is not None:
-        return main_multi(args, ctx, dist, rank, world)
+    if rdzv is not None:
+        return main_multi(args, ctx, rdzv, rank, world)
     cfg = CONFIGS[args.config]
     lgp.Context._default = ctx
     wl = Workload(cfg, ctx)
@@ -715,7 +816,7 @@ def main():
     phases = np.array([[ctx.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in evs]).mean(axis=0)
     achieved = tot_fl.value / (tot_ms.value * 1e-3) / 1e12 if tot_ms.value > 0 else None
     out = {
-        'metric': 'GP fit+predict fp64 throughput (Gram build + Cholesky + solves; flops N^3/3 + N^2(M+1) + N M^2)',
+        'metric': METRIC,
         'value': total_flops / elapsed / 1e12,
         'unit': 'TFLOP/s',
         'n_gpus': 1,
@@ -776,4 +877,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

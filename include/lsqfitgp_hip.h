@@ -465,6 +465,12 @@ int lgp_mlnd_grad_f32(lgp_ctx *ctx, size_t n, const float *dL, size_t ldl, const
 int lgp_comm_unique_id(void *hid128);                                   /* ncclGetUniqueId on rank 0 */
 int lgp_comm_init(lgp_ctx *ctx, int rank, int nranks, const void *hid128);  /* ncclCommInitRank */
 int lgp_comm_destroy(lgp_ctx *ctx);
+/* Rank and number of ranks as the communicator itself reports them (ncclCommUserRank / ncclCommCount), and which
+ * transport the context's collectives use; 1 rank and LGP_TRANSPORT_NONE without a communicator. */
+#define LGP_TRANSPORT_NONE 0
+#define LGP_TRANSPORT_RCCL 1
+#define LGP_TRANSPORT_HOST 2
+int lgp_comm_info(lgp_ctx *ctx, int *rank, int *nranks, int *transport);
 /* Alternative transport (bring your own collective, e.g. MPI or gloo; also how the multi-rank schedule is tested on
  * a single GPU): lgp_bcast / lgp_allreduce_* then stage the buffer through host memory on the context's current
  * stream and call fn(user, op, host_buffer, count, root), op 0 = broadcast `count` bytes from `root`, 1 = all-reduce

@@ -96,6 +96,22 @@ class Diagonal:
         return a if dtype is None else a.astype(dtype)
 
 
+try:                                     # a fast non-cryptographic digest where there is one (10-20 GB/s), else the standard library's
+    import xxhash as _xxhash
+except ImportError:                      # pragma: no cover
+    _xxhash = None
+
+
+def _digest(arr):
+    """ digest of every byte of a host array (strided arrays are read in C order) """
+    a = numpy.ascontiguousarray(arr)
+    buf = a.view(numpy.uint8).reshape(-1) if a.dtype.names is None and a.dtype != object else a.tobytes()
+    if _xxhash is not None:
+        return _xxhash.xxh3_128_digest(buf)
+    import hashlib
+    return hashlib.blake2b(buf, digest_size=16).digest()
+
+
 def diag(values):
     """ ``lsqfitgp_amd.diag(v)``: see `Diagonal` """
     return Diagonal(values)
@@ -205,8 +221,9 @@ class GP:
     given a ``givencov`` (``_compute.py:55-58``), so ``predfromdata(given, key, givencov)`` followed by
     ``marginal_likelihood(given, givencov)`` -- the usual pair -- factors the same matrix twice.  Here the decomposition of the
     last such call is kept and serves the next call on the same object when the SAME ``givencov`` object is passed again with
-    the same keys and decomposition arguments (identity of the dictionary and of its blocks, their shapes, and a strided sample
-    of their values to notice in-place edits).  The numbers are those of the factorisation that was kept.
+    the same keys and decomposition arguments and the same CONTENT: a digest of every byte of its host blocks is compared, so an
+    in-place edit of any entry between the two calls is noticed (one pass over the blocks, 10-20 GB/s; the reference's calls make
+    several).  The numbers are those of the factorisation that was kept.
     """
 
     DefaultProcess = 'default'
@@ -991,19 +1008,19 @@ class GP:
 
     @staticmethod
     def _fingerprint(givencov):
-        """ identity of a ``givencov`` dictionary: the object, its blocks, their shapes and a strided sample of their values """
+        """ what a ``givencov`` dictionary holds: per block its pair, shape, dtype and a digest of EVERY byte of a host array (an
+        in-place edit of any entry changes it), or address, shape and write count of a device array (`DeviceArray.assign` /
+        `fill_zero` bump the count; stores made behind the class's back through the C-ABI are not seen) """
         if givencov is None or not hasattr(givencov, 'items'):
             return None
-        parts = [id(givencov)]
+        parts = []
         for pair, block in givencov.items():
             values = block.values if isinstance(block, Diagonal) else block
             if isinstance(values, DeviceArray):
-                parts.append((pair, id(block), values.shape, values.ptr))
+                parts.append((pair, type(block).__name__, values.shape, values.ptr, values.ld, values.writes))
                 continue
             arr = numpy.asarray(values)
-            flat = arr.reshape(-1)
-            step = max(1, flat.size // 257)
-            parts.append((pair, id(block), arr.shape, str(arr.dtype), flat[::step][:257].tobytes()))
+            parts.append((pair, type(block).__name__, arr.shape, str(arr.dtype), _digest(arr)))
         return tuple(parts)
 
     def _solver(self, keys, ycov=None, rhs_builder=None, **kw):
@@ -1246,7 +1263,8 @@ class GP:
         c = self._givencov_cache
         if not self._reuse_givencov or c is None or ycov is None:
             return None
-        if c[0] == tuple(keys) and c[2] == tuple(sorted(kw.items(), key=lambda kv: kv[0])) and c[1] == self._fingerprint(givencov):
+        # (the dictionary that was kept is held by the cache entry, c[4]: its address cannot be recycled for another object)
+        if c[4] is givencov and c[0] == tuple(keys) and c[2] == tuple(sorted(kw.items(), key=lambda kv: kv[0])) and c[1] == self._fingerprint(givencov):
             return c[3]
         return None
 
@@ -1257,7 +1275,7 @@ class GP:
                 hash(kwkey)
             except TypeError:
                 return
-            self._givencov_cache = (tuple(keys), self._fingerprint(givencov), kwkey, decomp)
+            self._givencov_cache = (tuple(keys), self._fingerprint(givencov), kwkey, decomp, givencov)
 
     def marginal_likelihood(self, given, givencov=None, **kw):
         """ Logarithm of the probability of the data (``_compute.py:383-422``) """

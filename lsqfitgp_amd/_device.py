@@ -118,6 +118,12 @@ class Context:
                    'lgp_comm_init_host')
         self.rank, self.nranks = int(rank), int(nranks)
 
+    def comm_info(self):
+        """ (rank, number of ranks, transport) as the communicator reports them; transport 'none' | 'rccl' | 'host' """
+        r, n, t = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self._lib.lgp_comm_info(self._handle, ctypes.byref(r), ctypes.byref(n), ctypes.byref(t)), 'lgp_comm_info')
+        return r.value, n.value, ('none', 'rccl', 'host')[t.value]
+
     @staticmethod
     def comm_unique_id():
         buf = ctypes.create_string_buffer(_lib.LGP_COMM_ID_BYTES)
@@ -146,7 +152,7 @@ class _Graveyard:
         self.enabled = os.environ.get('LGP_HOST_POOL', '1') != '0'
         # blocks handed out and not yet buried; when the context object dies first (the garbage collector finalises the members of
         # a reference cycle in no particular order) the library context is kept until the last of them comes back
-        self.live, self.closing = 0, False
+        self.live, self.closing, self.destroyed = 0, False, False
         # `bury` runs from weakref finalizers, i.e. from the garbage collector in whatever thread triggers it
         self._lock = threading.RLock()
 
@@ -160,35 +166,48 @@ class _Graveyard:
             return blocks.pop()
 
     def bury(self, ptr, nbytes):
+        """ one decision per block, taken inside one critical section: dropped (the library context is gone: its memory went with
+        it), freed with the context (closing), cached, or queued for lgp_free """
+        destroy = full = False
         with self._lock:
             self.live -= 1
-            last = self.closing and self.live <= 0
+            if self.destroyed:
+                return
             if self.closing:
                 self.pending.append(ptr)
                 self.nbytes += nbytes
-        if self.closing:
-            if last:
-                self.flush()
-                self.lib.lgp_ctx_destroy(self.handle)
-            return
-        with self._lock:
-            if self.enabled and nbytes <= self.BLOCK_BYTES and self.cached_bytes + nbytes <= self.CACHE_BYTES:
+                destroy = self.live <= 0
+                if destroy:
+                    self.destroyed = True            # nobody else may touch the handle from here on
+                    pending = self._take_all()
+            elif self.enabled and nbytes <= self.BLOCK_BYTES and self.cached_bytes + nbytes <= self.CACHE_BYTES:
                 self.cache.setdefault(nbytes, []).append(ptr)
                 self.cached_bytes += nbytes
-                return
-            self.pending.append(ptr)
-            self.nbytes += nbytes
-            full = self.nbytes > self.LIMIT_BYTES or len(self.pending) > self.LIMIT_COUNT
-        if full:
+            else:
+                self.pending.append(ptr)
+                self.nbytes += nbytes
+                full = self.nbytes > self.LIMIT_BYTES or len(self.pending) > self.LIMIT_COUNT
+        if destroy:
+            for p in pending:
+                self.lib.lgp_free(self.handle, ctypes.c_void_p(p))
+            self.lib.lgp_ctx_destroy(self.handle)
+        elif full:
             self.flush(cache=False)
+
+    def _take_all(self, cache=True):
+        """ (lock held) everything that waits for lgp_free, and the cache with it """
+        pending, self.pending, self.nbytes = self.pending, [], 0
+        if cache:
+            for blocks in self.cache.values():
+                pending.extend(blocks)
+            self.cache, self.cached_bytes = {}, 0
+        return pending
 
     def flush(self, cache=True):
         with self._lock:
-            pending, self.pending, self.nbytes = self.pending, [], 0
-            if cache:
-                for blocks in self.cache.values():
-                    pending.extend(blocks)
-                self.cache, self.cached_bytes = {}, 0
+            if self.destroyed:
+                return
+            pending = self._take_all(cache)
         for ptr in pending:
             self.lib.lgp_free(self.handle, ctypes.c_void_p(ptr))
 
@@ -199,10 +218,15 @@ def _destroy_context(lib, handle, graveyard):
     except ValueError:
         pass
     with graveyard._lock:
+        if graveyard.destroyed:
+            return
         if graveyard.live > 0:          # buffers of this context are still to be finalised: the last one destroys it (`bury`)
             graveyard.closing = True
             return
-    graveyard.flush()
+        graveyard.destroyed = True      # from here on `bury` drops what comes back and `take` finds nothing
+        pending = graveyard._take_all()
+    for ptr in pending:
+        lib.lgp_free(handle, ctypes.c_void_p(ptr))
     lib.lgp_ctx_destroy(handle)
 
 
@@ -322,7 +346,19 @@ class DeviceArray:
         return DeviceArray(self._buffer, self.ptr, shape, self.dtype, shape[-1] if len(shape) == 2 else 1)
 
     # ---- data movement
+    @property
+    def writes(self):
+        """ how often the buffer behind this array (or any view of it) was overwritten through `assign` / `fill_zero` """
+        return getattr(self._buffer, 'writes', 0)
+
+    def _written(self):
+        try:
+            self._buffer.writes = getattr(self._buffer, 'writes', 0) + 1
+        except AttributeError:            # a buffer object without attributes (foreign memory): nothing to count on
+            pass
+
     def fill_zero(self):
+        self._written()
         if self.contiguous:
             _lib.check(self.ctx._lib.lgp_memset(self.ctx.handle, self.ptr, 0, self.size * self.itemsize))
         else:
@@ -354,6 +390,7 @@ class DeviceArray:
         assert src.shape == self.shape and src.dtype == self.dtype, (src.shape, self.shape, src.dtype, self.dtype)
         if self.size == 0:
             return
+        self._written()
         rows, cols = (self.shape if self.ndim == 2 else (1, self.shape[0]))
         _lib.check(self.ctx._lib.lgp_copy2d(self.ctx.handle, self.ptr, max(self.ld, cols), src.ptr, max(src.ld, cols), rows, cols, self.itemsize), 'lgp_copy2d')
 

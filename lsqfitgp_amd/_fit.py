@@ -381,13 +381,19 @@ class empbayes_fit:
                 return None
             if not self._autodiff_checked:
                 # once per fit: a factory can lose a tangent without an error (numpy.full(n, hp[...]), math.exp(hp[...]) turn
-                # the hyperparameter into a plain number), so the first gradient is held against central differences
-                self._autodiff_checked = True
+                # the hyperparameter into a plain number), so the first gradient is held against central differences --
+                # component by component (a dropped tangent whose gradient is small beside the largest one must not pass),
+                # with the noise of the differences themselves as the absolute part of the tolerance.  The check only counts
+                # as done once the comparison has been made: a LinAlgError inside the differences leaves it for the next point
                 g = self._fd_gradient(z)
-                scale = max(float(numpy.max(numpy.abs(g), initial=0.)), 1e-8)
-                if not numpy.all(numpy.isfinite(res[1])) or numpy.max(numpy.abs(res[1] - g), initial=0.) > 1e-3 * scale + 1e-6:
+                self._autodiff_checked = True
+                value = abs(float(res[0]))
+                atol = 1e2 * numpy.finfo(float).eps * max(value, 1.) / self._fdstep + 1e-3 * self._fdstep ** 2 * max(value, 1.)
+                bad = ~numpy.isfinite(res[1]) | (numpy.abs(res[1] - g) > 1e-3 * numpy.abs(g) + atol)
+                if numpy.any(bad):
                     self._autodiff = False
-                    self._log(f'the tangents of the factory do not reproduce its finite differences ({res[1]} vs {g}): central differences', 1)
+                    self._log(f'the tangents of the factory do not reproduce its finite differences at components {numpy.flatnonzero(bad).tolist()} '
+                              f'({res[1]} vs {g}, tolerance 1e-3 relative + {atol:.1e}): central differences', 1)
                     return None
             return res
         return None

@@ -97,6 +97,7 @@ def _signatures():
         'lgp_comm_init': (c_int, [c_void_p, c_int, c_int, c_void_p]),
         'lgp_comm_init_host': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
         'lgp_comm_destroy': (c_int, [c_void_p]),
+        'lgp_comm_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
         'lgp_bcast': (c_int, [c_void_p, _P, _S, c_int]),
         'lgp_allreduce_sum_f64': (c_int, [c_void_p, _P, _S]),
         'lgp_allreduce_max_f64': (c_int, [c_void_p, _P, _S]),

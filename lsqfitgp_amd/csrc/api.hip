@@ -641,6 +641,8 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -666,6 +668,8 @@ int rccl_load() {
   LGP_SYM(GetUniqueId, "ncclGetUniqueId")
   LGP_SYM(CommInitRank, "ncclCommInitRank")
   LGP_SYM(CommDestroy, "ncclCommDestroy")
+  LGP_SYM(CommCount, "ncclCommCount")
+  LGP_SYM(CommUserRank, "ncclCommUserRank")
   LGP_SYM(Broadcast, "ncclBroadcast")
   LGP_SYM(AllReduce, "ncclAllReduce")
   LGP_SYM(GetErrorString, "ncclGetErrorString")
@@ -725,6 +729,23 @@ int lgp_comm_destroy(lgp_ctx *c) {
   c->hostuser = nullptr;
   c->rank = 0;
   c->nranks = 1;
+  return LGP_OK;
+}
+
+int lgp_comm_info(lgp_ctx *c, int *rank, int *nranks, int *transport) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  int r = c->rank, n = c->nranks, t = LGP_TRANSPORT_NONE;
+  if (c->comm) {          // what the communicator itself says, not what it was asked for
+    DeviceGuard dg(c->device);
+    LGP_NCCL(g_rccl.CommCount(static_cast<ncclComm_t>(c->comm), &n));
+    LGP_NCCL(g_rccl.CommUserRank(static_cast<ncclComm_t>(c->comm), &r));
+    t = LGP_TRANSPORT_RCCL;
+  } else if (c->hostfn) {
+    t = LGP_TRANSPORT_HOST;
+  }
+  if (rank) *rank = r;
+  if (nranks) *nranks = n;
+  if (transport) *transport = t;
   return LGP_OK;
 }
 

@@ -158,7 +158,7 @@ def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry, amp, slab):
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     m = 37
-    # separate interpreters (not torch.multiprocessing: torch must not be loaded into this process next to the library)
+    # separate interpreters, one per rank
     script = os.path.join(os.path.dirname(__file__), 'two_rank_worker.py')
     env = dict(os.environ, LGP_TEST_CARRY=str(carry), LGP_TEST_AMP=str(amp))        # carry = 1: [Kxxs | y] rides through the factorisation
     if slab is not None:
@@ -166,7 +166,7 @@ def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry, amp, slab):
     procs = [subprocess.Popen([sys.executable, script, str(rank), str(world), str(port), str(n), str(nb), str(m), str(tmp_path)],
                               cwd=os.path.dirname(os.path.dirname(__file__)), env=env) for rank in range(world)]
     for p in procs:
-        assert p.wait(timeout=900) == 0      # a first `import torch` on a fresh box can take minutes
+        assert p.wait(timeout=900) == 0
     rng = np.random.default_rng(7)
     x = rng.uniform(0, n / 16, n)
     xs = rng.uniform(0, n / 16, m)
@@ -389,3 +389,34 @@ def test_fused_and_generic_gram_build_agree(lgp, rng, monkeypatch, n, nb, amp):
     assert out[0][0] == pytest.approx(out[1][0], rel=1e-12)
     for a, b in zip(out[0][1], out[1][1]):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * amp)
+
+
+def test_bench_gpus_2_launches_two_ranks():
+    """ `python bench.py --gpus 2` by itself (no external launcher, no torch): two fresh rank processes sharing the one GPU through
+    the host-staged transport run the sharded step and rank 0's line says so (VERDICT r03 "next" 1).  RCCL with more than one
+    rank is NOT covered by this: one GPU per box. """
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'LGP_RDZV_PORT', 'LGP_DEVICE')}
+    env['LGP_DIST_TRANSPORT'] = 'host'
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--config', 'c2', '--replica-config', 'c2', '--steps', '1', '--warmup', '1',
+                          '--no-cpu-baseline', '--no-sweep'], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['transport'] == 'host' and out['rccl_ranks'] is None
+    assert out['config']['N'] == 8192 and out['steps'] == 1
+    assert out['replicas']['scaling'] == 'weak' and out['replicas']['value'] > 0
+    assert 'torch' not in res.stderr.lower()
+    # the sharded step computed the same log marginal likelihood as the single-GPU step of the same workload
+    sys.path.insert(0, root)
+    import bench
+    import lsqfitgp_amd as lgp
+    wl = bench.Workload(bench.CONFIGS['c2'], lgp.Context.default())
+    wl.step()
+    lgp.Context.default().sync()
+    assert abs(out['log_marginal_likelihood'] - wl.results['mll']) <= 1e-9 * abs(wl.results['mll'])

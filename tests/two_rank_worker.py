@@ -1,7 +1,7 @@
 """
 One rank of the two-rank on-device test of tests/test_gpu_dist.py (run as a script, one process per rank, both on
 the single GPU of the box): DistributedChol + posterior with panels exchanged through the host-callback transport
-(gloo), results written to <tmpdir>/rank<r>.npz.
+(standard-library sockets, lsqfitgp_amd/_rendezvous.py), results written to <tmpdir>/rank<r>.npz.
 """
 import os
 import sys
@@ -13,24 +13,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main(rank, world, port, n, nb, m, tmpdir):
     import os
-    import torch
-    import torch.distributed as dist
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lsqfitgp_amd._rendezvous import Rendezvous
+    dist = Rendezvous(rank, world, port=port)
     import lsqfitgp_amd as lgp
     from lsqfitgp_amd._dist import DistributedChol
     ctx = lgp.Context(0)                      # both ranks on the one GPU of the box
     lgp.Context._default = ctx
-
-    def collective(op, arr, root):
-        t = torch.from_numpy(arr)
-        if op == 0:
-            dist.broadcast(t, src=root)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 1 else dist.ReduceOp.MAX)
-
-    ctx.comm_init_host(rank, world, collective)
+    ctx.comm_init_host(rank, world, dist.collective)
+    assert ctx.comm_info() == (rank, world, 'host')
     rng = np.random.default_rng(7)
     x = rng.uniform(0, n / 16, n)
     xs = rng.uniform(0, n / 16, m)
@@ -77,13 +67,13 @@ def main(rank, world, port, n, nb, m, tmpdir):
         np.savez(os.path.join(tmpdir, f'rank{rank}.npz'), mean=mean, cov=cov, mlnd=mlnd, eps=d.eps, LZ=LZ, slab=d.slab,
                  owned=np.array(sorted(LtZ)), **{f'lt{b}': v for b, v in LtZ.items()}, **{f'dg{b}': v for b, v in diag.items()})
         dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
         return
     blocks = {b: blk for b, blk in d.local_factor().items()}
     np.savez(os.path.join(tmpdir, f'rank{rank}.npz'), mean=mean, cov=cov, mlnd=mlnd, eps=d.eps,
              owned=np.array(sorted(blocks)), **{f'b{b}': blk for b, blk in blocks.items()})
     dist.barrier()
-    dist.destroy_process_group()
+    dist.close()
 
 
 
