@@ -1,0 +1,92 @@
+// potf2_dev.h -- device pieces shared by the diagonal-block kernels (potf2m.hip) and the chain kernel (chainw.hip).
+#pragma once
+#include "chain.h"
+
+namespace {
+
+typedef Mma<double> MmaD;
+typedef MmaD::acc_t acc_t;
+
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  const long long bits = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)bits, lane), hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// 1 / sqrt(d): hardware estimate + two Newton steps, y <- y (1.5 - 0.5 d y^2)
+__device__ __forceinline__ double rsqrt_d(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * (1.5 - h * y * y);
+  y = y * (1.5 - h * y * y);
+  return y;
+}
+
+__device__ __forceinline__ int ut_idx(int j, int i) { return i * (i + 1) / 2 + j; }   // tile (block row j, block column i), j <= i
+
+// 1 / d to working accuracy with a short dependent chain: hardware estimate (~2^-24 relative) and ONE cubic step,
+// y (1 + e + e^2) with e = 1 - d y  (error e^3): rcp, fma, fma, fma
+__device__ __forceinline__ double rcp_chain(double d) {
+  const double y = __builtin_amdgcn_rcp(d);
+  const double e = __builtin_fma(-d, y, 1.0);
+  const double e2 = __builtin_fma(e, e, e);
+  return __builtin_fma(y, e2, y);
+}
+
+#ifdef LGP_POTF2_TRACE
+__device__ unsigned long long lgp_p4_trace[64];
+#define LGP_P4STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (threadIdx.x == 0) lgp_p4_trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LGP_P4STAMP(k) do { } while (0)
+#endif
+
+// pivot 4 r + G0 of a slab (register r of the tiles of a block row): w0 the diagonal tile's register, w1 / w2 the wave's own tiles'.
+// Rows g <= G0 of the slab are not touched (their multiplier stays zero); the last pivot of a slab eliminates nothing in it.
+template <int G0>
+__device__ __forceinline__ void p4_pivot(int r, double &w0, double &w1, double &w2, double &dg, double &dn, int n, int g, bool hasA, bool hasB) {
+  const int kk = 4 * r + G0;
+  const double d = readlane_d(w0, G0 * 16 + kk);
+  if constexpr (G0 < 3) {
+    // the pivot row, in every row: on the chain (the diagonal tile) by lane swaps; for the wave's own tiles, which nothing waits
+    // for inside the slab, through the LDS crossbar (one instruction per half instead of four; skipped for tiles it does not own)
+    const double rn0 = lgp_rowbcast(w0, G0);
+    const int arow = (G0 * 16 + n) * 4;
+    const double rn1 = hasA ? MmaD::bpermute(arow, w1) : 0.0, rn2 = hasB ? MmaD::bpermute(arow, w2) : 0.0;
+    // its entries at the columns 4 r + g of the slab's later rows g > G0: lane 4 r + g of the own row, by DPP moves that do not
+    // depend on one another (disjoint rows, zero elsewhere), then or-ed together
+    double c1 = 0.0, c2 = 0.0, c3 = 0.0;
+    switch (r) {                                        // (r is a constant after unrolling; the DPP lane has to be an immediate)
+      case 0:
+        if constexpr (G0 < 1) c1 = lgp_row_lane<1, 0x2>(0.0, rn0);
+        if constexpr (G0 < 2) c2 = lgp_row_lane<2, 0x4>(0.0, rn0);
+        c3 = lgp_row_lane<3, 0x8>(0.0, rn0);
+        break;
+      case 1:
+        if constexpr (G0 < 1) c1 = lgp_row_lane<5, 0x2>(0.0, rn0);
+        if constexpr (G0 < 2) c2 = lgp_row_lane<6, 0x4>(0.0, rn0);
+        c3 = lgp_row_lane<7, 0x8>(0.0, rn0);
+        break;
+      case 2:
+        if constexpr (G0 < 1) c1 = lgp_row_lane<9, 0x2>(0.0, rn0);
+        if constexpr (G0 < 2) c2 = lgp_row_lane<10, 0x4>(0.0, rn0);
+        c3 = lgp_row_lane<11, 0x8>(0.0, rn0);
+        break;
+      default:
+        if constexpr (G0 < 1) c1 = lgp_row_lane<13, 0x2>(0.0, rn0);
+        if constexpr (G0 < 2) c2 = lgp_row_lane<14, 0x4>(0.0, rn0);
+        c3 = lgp_row_lane<15, 0x8>(0.0, rn0);
+        break;
+    }
+    const double cf = __builtin_bit_cast(double, __builtin_bit_cast(long long, c1) | __builtin_bit_cast(long long, c2) | __builtin_bit_cast(long long, c3));
+    const double rc = rcp_chain(d);
+    const double cfm = -cf;
+    w0 = __builtin_fma(cfm * rn0, rc, w0);
+    const double cfs = cfm * rc;
+    if (hasA) w1 = __builtin_fma(cfs, rn1, w1);
+    if (hasB) w2 = __builtin_fma(cfs, rn2, w2);
+  }
+  dg = (g == G0) ? d : dg;
+  dn = (n == kk) ? d : dn;
+}
+
+}  // namespace
