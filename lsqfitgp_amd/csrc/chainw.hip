@@ -187,7 +187,11 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
   } else {
   // the workers of the dependent chain: the first `chainw` workgroups, or (samexcd) the first chainw of those that the hardware
   // places on XCD 0 (workgroup i runs on XCD i mod 8), so that what one of them writes the next finds in the same L2
-  bool on_chain = (int)blockIdx.x <= p.chainw;          // workers 1 .. chainw start on the NEAR list (thread 0's copy is the one that counts)
+  // the workers that start on the NEAR list (thread 0's copy is the one that counts): 1 .. chainw, or -- samexcd -- the workgroups
+  // 8, 16, .. 8 chainw, which the dispatcher places on the walker's XCD (workgroup i runs on XCD i mod 8): what the walker and
+  // they hand each other then stays in one L2 instead of crossing the fabric (a block handed over by another XCD takes ~4.5 us
+  // to arrive, cdna_hip_programming.md: 62-70 GB/s per block cross-XCD, 104-122 same-XCD)
+  bool on_chain = p.samexcd ? ((blockIdx.x & 7u) == 0u && (int)(blockIdx.x >> 3) <= p.chainw) : (int)blockIdx.x <= p.chainw;
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -464,10 +468,13 @@ int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size
   // workgroup 0 is the walker; of the workers (at least two: a task of one list may wait for a task of the other, which only
   // a worker that holds no task of the first can run) the first `chainw` start on the near list
   const int want = ctx->chain_workers < 3 ? 3 : ctx->chain_workers;
-  const int workers = want;
+  static const int samexcd_env = getenv("LGP_CHAIN_SAMEXCD") ? atoi(getenv("LGP_CHAIN_SAMEXCD")) : -1;
+  // near workers on the walker's XCD need workgroups 8, 16, 24: 25 resident workgroups at least
+  const bool samexcd = samexcd_env >= 0 ? samexcd_env != 0 : want >= 25;
+  const int workers = samexcd && want < 25 ? 25 : want;
   a.timeout = ctx->chain_timeout;
   a.chainw = workers >= 6 ? 3 : 1;
-  a.samexcd = 0;
+  a.samexcd = samexcd ? 1 : 0;
   // dynamic LDS: the walker's buffers (walker.inc), and -- untouched -- what keeps other workgroups off a worker's CU (no
   // trailing-update workgroup, 64 KB of LDS, fits beside 100 KB)
   size_t hog = n <= ctx->chain_hog_max_n ? (size_t)ctx->chain_lds_kb * 1024 : 0;
