@@ -65,7 +65,8 @@ def coefficients(nu):
     zs = zeta_real(s)
     m = int(round((s - 1) / 2))
     e = s - (2 * m + 1)                                   # s = 2 m + 1 + e
-    near = abs(e) < 1e-3 and m >= 1
+    near = abs(e) < 1e-3                                  # (m = 0, s -> 1+ included: both poles are there too; found by the reference's
+                                                          # golden values for s = 1 + 1e-15, tests/test_reference_special.py)
     c = numpy.zeros(NTERMS)
     for n in range(NTERMS):
         z = s - 2 * n
@@ -85,8 +86,11 @@ def coefficients(nu):
         A = -sign / f2m                                   # times log θ
         D = sign * numpy.sum(1. / numpy.arange(1, 2 * m + 1)) / f2m
     else:
-        u = (numpy.pi * e / 2) / numpy.sin(numpy.pi * e / 2)
+        xx = (numpy.pi * e / 2) ** 2
+        logu = xx / 6 + xx ** 2 / 180 + xx ** 3 / 2835 + xx ** 4 / 37800      # log(x / sin x), x = π e / 2: as the quotient it is 1 + 4e-9 at
+        u = numpy.exp(logu)                                                   # e = 1e-4 and its logarithm keeps 8 digits: 2.7e-13 in D, found
+                                                                              # by the reference's golden values (tests/test_reference_special.py)
         dl = sum(e ** (j + 1) * special.polygamma(j, 2 * m + 1.) / special.gamma(j + 2) for j in range(6))      # lgamma(2m+1+e) - lgamma(2m+1)
         A = -sign * u * numpy.exp(-dl) / (e * f2m)        # = π / (2 Γ(s) cos(πs/2))
-        D = sign / f2m * (-numpy.expm1(numpy.log(u) - dl) / e + _laurent_at_one(e))                               # = A + c_m
+        D = sign / f2m * (-numpy.expm1(logu - dl) / e + _laurent_at_one(e))                                      # = A + c_m
     return MODE_POWER, 1, c / zs, (A / zs, 2. * m, e, D / zs)

@@ -293,10 +293,13 @@ __device__ __forceinline__ T special_core(const IsoArgs<T> &g, T r2) {
     const double t2 = th * th;
     double acc = 0.;
     for (int n = g.ntable - 1; n >= 0; --n) acc = acc * t2 + (double)g.table[n];
+    const double A = (double)g.par[0], pw = (double)g.par[1], eps = (double)g.par[2];
     if (th > 0.) {
-      const double lt = log(th), A = (double)g.par[0], pw = (double)g.par[1], eps = (double)g.par[2];
+      const double lt = log(th);
       const double gl = g.flag ? (eps == 0. ? lt : expm1(eps * lt)) : 1.;
       acc += exp(pw * lt) * (A * gl + (double)g.par[3]);
+    } else if (pw == 0. && g.flag && eps > 0.) {
+      acc += (double)g.par[3] - A;                        // s -> 1+ (m = 0): theta^0 (A expm1(eps log 0) + D) = D - A = zeta(s) / zeta(s)
     }
     return T(acc);
   }

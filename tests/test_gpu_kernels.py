@@ -1077,3 +1077,32 @@ def test_scale_tangents_of_the_special_function_kernels(lgp, rng, make):
     G, tan = (make(lgp, lgp.Dual(s, {'s': 1.})) * lgp.Dual(2., {'a': 1.})).gram_tangents(x, y)
     np.testing.assert_allclose(tan['s'].to_host(), 2 * fd, rtol=0, atol=2e-6 * max(1., np.abs(fd).max()))
     np.testing.assert_allclose(tan['a'].to_host(), ref, rtol=0, atol=1e-9)
+
+
+class TestReferenceSpecialValues:
+    """ the device's Zeta and Color cores against golden values THE REFERENCE HOLDS (tests/golden/reference_special/: mpmath values
+    cached by its own tests, ``tests/test_special.py:190-226,415-424``); CPU counterpart: tests/test_reference_special.py """
+
+    def test_zeta_kernel_against_the_reference_values(self, lgp):
+        from . import reference_special as R
+        eps = np.finfo(float).eps
+        worst = 0.
+        for cid, x, s, z in R.periodic_zeta_cases():
+            for si, zi in zip(s, z):
+                want = zi.real
+                zs = want[0]                                   # x[0] = -1: F(integer, s) = zeta(s)
+                nu = (float(si) - 1) / 2
+                got = lgp.Zeta(nu=nu).gram(np.zeros(1), x).to_host()[0] * zs
+                err = np.max(np.abs(got - want)) / (eps * np.max(np.abs(want)))
+                worst = max(worst, err)
+                assert err < 150, (cid, si, err)              # the reference's own tolerance (``tests/test_special.py:222-226``)
+        assert worst < 60                                      # (measured on the CPU mirror of the same sum: 35)
+
+    def test_color_kernel_against_the_reference_values(self, lgp):
+        from . import reference_special as R
+        n, x, sol = R.expn_case()
+        for k, row in zip(n, sol):
+            got = lgp.Color(n=int(k)).gram(np.zeros(1), x).to_host()[0]
+            want = (k - 1) * row.real                          # Color(n)(d) = (n - 1) Re E_n(-i d)
+            # the reference holds its own evaluation to 1e-7 of the largest entry; the device's series / continued fraction to 1e-12
+            assert np.max(np.abs(got - want)) <= 1e-12 * max(np.max(np.abs(want)), 1.), (k, np.max(np.abs(got - want)))
