@@ -75,12 +75,14 @@ class CpuBackend:
         except Exception:
             pass
 
-    def gram(self, kernel, p, x, y, scale=None):
-        """ x: (d, n), y: (d, m) SoA covariates -> (n, m) """
+    def gram(self, kernel, p, x, y, scale=None, out=None):
+        """ x: (d, n), y: (d, m) SoA covariates -> (n, m); out: a C-contiguous (n, m) array to fill instead of a new one """
         x = np.ascontiguousarray(np.atleast_2d(x), float); y = np.ascontiguousarray(np.atleast_2d(y), float)
         d, n = x.shape
         m = y.shape[1]
-        out = np.empty((n, m))
+        if out is None:
+            out = np.empty((n, m))
+        assert out.shape == (n, m) and out.flags.c_contiguous and out.dtype == np.float64
         st = self.lib.lgp_gram_isotropic_f64(self.h, kernel, p, 0, None, d, _ptr(x), n, n, _ptr(y), m, m, 0, 0., int(scale is not None),
                                              float(scale or 1.), 0, None, None, 0, _ptr(out), m)
         assert st == 0, self.lib.lgp_last_error()
@@ -104,6 +106,23 @@ class CpuBackend:
         if info != 0:
             raise np.linalg.LinAlgError(f'cholesky decomposition not finite, probably matrix not pos def numerically (info {info})')
         return L, eps.value
+
+    def chol_inplace(self, L, n, epsrel='auto', epsabs=0.):
+        """ the same on ONE buffer (for matrices that fit the host only once): L is (n + q, n), rows 0 .. n-1 hold K on entry, the rows
+        below it rhs^T; on exit the factor and (L^-1 rhs)^T.  (chol_factor of cpu_backend.cpp reads a row of K before it writes that
+        row of L, and nothing else of K afterwards.) """
+        assert L.flags.c_contiguous and L.dtype == np.float64 and L.shape[1] == n and L.shape[0] >= n
+        q = L.shape[0] - n
+        flags = 0
+        if isinstance(epsrel, str):
+            flags |= 1; epsrel = 0.
+        if isinstance(epsabs, str):
+            flags |= 2; epsabs = 0.
+        eps = c_double()
+        info = self.lib.lgp_chol_factor_rhs_f64(self.h, n, _ptr(L), n, epsrel, epsabs, flags, _ptr(L), n, q, None, ctypes.byref(eps))
+        if info != 0:
+            raise np.linalg.LinAlgError(f'cholesky decomposition not finite, probably matrix not pos def numerically (info {info})')
+        return eps.value
 
     def trsm(self, L, B, trans=False):
         B = np.array(B, float, order='C', ndmin=2)

@@ -3,9 +3,10 @@ CPU tests of the host logic around the hot path's callers (SURVEY.md 8(f) ranks 
 transforms, value(sdev) formatting, sample packing -- and the fit driver itself, run here over the CPU ORACLE's GP (the
 driver only needs ``gp._prior_decomp`` and ``decomp.minus_log_normal_density``, which the oracle's classes provide too).
 
-Two of these are KNOWN-ANSWER tests against outputs of the reference stored in its user guide
-(``docs/userguide/hyper.rst:49-70`` and ``:124-156,252-257``): fits of the scale (and amplitude) of an ExpQuad GP to
-sin(x) on 11 points, printed by the reference as ``2.16(17)`` and ``log(sdev) 0.89(33)  log(scale) 1.051(77)``.  They
+Three of these are KNOWN-ANSWER tests against outputs of the reference stored in its user guide
+(``docs/userguide/hyper.rst:49-70``, ``:124-156,252-257`` and ``:406-447``): fits of the scale (and amplitude) of an ExpQuad
+GP, and of the period of a Periodic one, to sin(x) on 11 points, printed by the reference as ``2.16(17)``,
+``log(sdev) 0.89(33)  log(scale) 1.051(77)`` and ``log(period) 1.8373(29)  period 6.280(18)``.  They
 pin the oracle's Gram build + regularised Cholesky + marginal likelihood, through their argmax, to numbers produced by
 the reference itself.
 """
@@ -110,6 +111,30 @@ def fit_sdev_scale(mod, **kw):
     return empbayes_fit(hyperprior, makegp, {'sine': Y11}, raises=False, **kw)
 
 
+def fit_period(mod, **kw):
+    """ docs/userguide/hyper.rst:406-424: the same eleven values of sin(x) under a Periodic kernel whose period is the
+    hyperparameter; hyperprior log(period) = log(2 pi gvar(1, 1)), i.e. mean log 2 pi, standard deviation 1 """
+    def makegp(hp):
+        return mod.GP(mod.Periodic(scale=hp['period'] / (2 * np.pi))).addx(X11, 'sine')
+    hyperprior = {'log(period)': (np.log(2 * np.pi), 1.)}
+    return empbayes_fit(hyperprior, makegp, {'sine': Y11}, raises=False, **kw)
+
+
+def check_period(fit):
+    """ reference output (``docs/userguide/hyper.rst:441-447``): ``log(period) 1.8373(29)``, ``period 6.280(18)`` -- the mode to the
+    printed precision; the standard deviation from the curvature of the objective at the mode (the reference prints its BFGS
+    estimate, which is path dependent) """
+    assert abs(fit.pmean['log(period)'] - 1.8373) <= 0.00012
+    assert abs(fit.pmean['period'] - 6.280) <= 0.0012
+    z = fit.zmean
+    h = 1e-4
+    curv = (fit._fun(z + h) - 2 * fit._fun(z) + fit._fun(z - h)) / h ** 2
+    sd = 1 / np.sqrt(curv)                                    # z = log(period) - log(2 pi): unit prior standard deviation
+    assert abs(sd - 0.0029) <= 0.0004
+    assert str(UVal(fit.pmean['log(period)'], sd)) in ('1.8373(29)', '1.8373(28)', '1.8373(30)', '1.8372(29)', '1.8374(29)')
+    assert str(UVal(fit.pmean['period'], fit.pmean['period'] * sd)) in ('6.280(18)', '6.280(17)', '6.280(19)', '6.279(18)', '6.281(18)')
+
+
 def check_scale(fit):
     """ reference output ``2.16(17)``: the posterior mode to the printed precision; the standard deviation comes from the
     BFGS inverse-Hessian estimate (path dependent, ``covariance='auto'``), so it is compared loosely and, tightly, with the
@@ -153,6 +178,10 @@ def test_known_answer_scale_fit_oracle():
 
 def test_known_answer_sdev_scale_fit_oracle():
     check_sdev_scale(fit_sdev_scale(oracle))
+
+
+def test_known_answer_period_fit_oracle():
+    check_period(fit_period(oracle))
 
 
 def test_fit_options_on_oracle():

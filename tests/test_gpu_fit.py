@@ -11,7 +11,7 @@ from scipy import stats
 
 import oracle
 from . import util
-from .test_fit_host import X11, Y11, fit_scale, fit_sdev_scale, check_scale, check_sdev_scale
+from .test_fit_host import X11, Y11, fit_scale, fit_sdev_scale, check_scale, check_sdev_scale, fit_period, check_period
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +31,14 @@ def test_known_answer_scale_fit_device(lgp):
     check_scale(fit)
     ref = fit_scale(oracle)
     assert abs(fit.pmean['log(scale)'] - ref.pmean['log(scale)']) <= 2e-6
+
+
+def test_known_answer_period_fit_device(lgp):
+    """ ``docs/userguide/hyper.rst:406-447``: ``log(period) 1.8373(29)``, ``period 6.280(18)`` with every evaluation on the device,
+    and the same mode as the oracle's run of the same fit """
+    fit = fit_period(lgp)
+    check_period(fit)
+    assert abs(fit.pmean['log(period)'] - fit_period(oracle).pmean['log(period)']) <= 2e-6
 
 
 def test_known_answer_sdev_scale_fit_device(lgp):
