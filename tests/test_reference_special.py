@@ -77,7 +77,7 @@ def test_hurwitz_zeta_against_the_reference_values():
     s, a, z = R.hurwitz_case()
     half = a <= 0.5
     for si, zi in zip(s, z):
-        if si == 0 or abs(si - round(si)) < 2e-3:
+        if si == 0 or abs(si - round(si)) < 5e-3:
             continue                                           # (s1 = 0 is not reached by s > 1; next to integers: see periodic_zeta_real)
         want = zi[half] + zi[::-1][half]                       # a and 1 - a are both on the grid
         got = K.hurwitz_zeta_pair(float(si), a[half])
