@@ -397,6 +397,39 @@ def default_path(ctx, cfg_name='c2', reps=3):
     return out
 
 
+def small_n_latency(ctx):
+    """ the only numbers the reference publishes (docs/userguide/optim.rst:88-159, "unspecified laptop"): `doinference` =
+    GP(ExpQuad()).addx(x, 'data').addx(xplot, 'plot').predfromdata({'data': data}, 'plot', raw=True) + sqrt(diag(cov)), data =
+    zeros(N), x = linspace(0, 10, N), 100 plot points, N = 10 and 1000; there: 7.1 / 33.2 ms eager, 16.0 ms at N = 1000 without the
+    checks, 0.041 / 4.8 ms jitted (where the checks are off).  Here through the host classes, wall clock, best of 20. """
+    import lsqfitgp_amd as lgp
+
+    def doinference(data, **options):
+        x = np.linspace(0, 10, len(data))
+        xplot = np.linspace(0, 10, 100)
+        mean, cov = lgp.GP(lgp.ExpQuad(), ctx=ctx, **options).addx(x, 'data').addx(xplot, 'plot').predfromdata({'data': data}, 'plot', raw=True)
+        return mean, np.sqrt(np.diag(cov))
+
+    def best(n, **options):
+        data = np.zeros(n)
+        doinference(data, **options)
+        ts = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            doinference(data, **options)
+            ts.append(time.perf_counter() - t0)
+        return min(ts) * 1e3
+
+    out = {'workload': 'docs/userguide/optim.rst:88-159 doinference (ExpQuad, N data points on [0, 10], 100 plot points, raw=True), wall clock, best of 20',
+           'reference_published_ms': {'N=10 eager': 7.102, 'N=10 jit': 0.041, 'N=1000 eager': 33.204, 'N=1000 jit': 4.804,
+                                      'N=1000 eager, checkpos=False, checksym=False': 16.029, 'N=1000 jit, checks off': 5.010,
+                                      'hardware': 'unspecified laptop CPU (the reference states none)'}}
+    for n in (10, 1000):
+        out[f'N={n} default options ms'] = best(n)
+        out[f'N={n} checkpos=False, checksym=False ms'] = best(n, checkpos=False, checksym=False)
+    return out
+
+
 def c5_step(ctx, steps=3, warmup=1):
     """ configuration C5 on its real workload: the GP that bayestree.bart builds (``bayestree/_bart.py:187-205``) at the fixed
     hyperparameters of SURVEY.md 8(d) on the first 4096 rows of the reference's examples/bart-data.txt (p = 10, fp32 kernel,
@@ -872,6 +905,10 @@ def main():
             out['default_path'] = default_path(ctx, 'c2')
         except Exception as exc:
             out['default_path'] = {'error': repr(exc)}
+        try:
+            out['small_n_latency'] = small_n_latency(ctx)
+        except Exception as exc:
+            out['small_n_latency'] = {'error': repr(exc)}
     out['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(cfg)
     print(json.dumps(out), flush=True)
 

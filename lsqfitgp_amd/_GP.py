@@ -251,6 +251,7 @@ class GP:
         self._dtype = None
         decomp = self._getdecomp(solver)
         self._decomptype = decomp
+        self._decompkw = dict(kw)
         self._decompclass = lambda K, **kwargs: decomp(K, **kwargs, **kw)
         self._checkpos_cache = []
 
@@ -1135,6 +1136,11 @@ class GP:
         ylist, inkeys, ycovblocks = self._flatgiven(given, givencov)
         y = numpy.concatenate(ylist)
 
+        if fromdata and strip and len(inkeys) == 1:
+            fast = self._pred_one_call(inkeys[0], outkeys[0], y, ycovblocks)
+            if fast is not None:
+                return fast
+
         self._checkpos_keys(inkeys + outkeys)
 
         if tuple(inkeys) not in self._decompcache or ycovblocks is not None:
@@ -1229,6 +1235,91 @@ class GP:
             return meandict, covdict
         outkey, = outkeys                                                 # :301-305
         return mean.reshape(self._elements[outkey].shape), cov.reshape(2 * self._elements[outkey].shape)
+
+    def _pred_one_call(self, inkey, outkey, y, ycovblocks):
+        """ The plain question -- one set of points conditioned on, one predicted, one isotropic kernel the fused entry point covers,
+        no checks that need the assembled blocks -- in THREE calls of the library instead of fifteen: the cross blocks straight into
+        the rows carried below the factor, ``lgp_gram_chol_factor_rhs`` (Gram build + regularisation + factorisation, Kxx never
+        materialised), ``lgp_posterior_solved``.  Same arithmetic as the general path with ``fuse_solve`` (the kernels are the
+        same); what it saves is host work: at N = 1000 the general path spends more time in Python than the GPU in kernels
+        (the reference's own benchmark, ``docs/userguide/optim.rst:88-159``).  Returns None when the question is not of this kind. """
+        if self._checkpositive or self._checksym or not self._fuse_solve or self._decomptype is not Chol or self._decompkw:
+            return None
+        x, xs = self._elements.get(inkey), self._elements.get(outkey)
+        kernel = self._covfun
+        if not (isinstance(x, _Points) and isinstance(xs, _Points)) or x is xs or x.deriv or xs.deriv:
+            return None
+        if not isinstance(kernel, _kernels._Isotropic) or kernel._kind not in _kernels.FUSED_KINDS or kernel._dim is not None:
+            return None
+        if (inkey,) in self._decompcache:
+            return None
+        if not all(v is None or isinstance(v, (int, float, numpy.integer, numpy.floating)) for v in (kernel._scale, kernel._loc)) \
+                or any(not isinstance(c, (int, float, numpy.integer, numpy.floating)) for _, c in kernel._outops) or any(kernel._doutops):
+            return None                                   # (hyperparameters with tangents: the general path keeps them)
+        noise = None
+        if ycovblocks is not None:
+            if not isinstance(ycovblocks, Diagonal) or ycovblocks.dvalues:
+                return None                               # (a dense covariance of the data has to be uploaded and added: general path)
+            if numpy.any(ycovblocks.values):
+                noise = numpy.asarray(ycovblocks.values, float)
+        xa, xsa = x.x.reshape(-1), xs.x.reshape(-1)
+        n, m = xa.size, xsa.size
+        if n == 0 or m == 0 or n > 16384:
+            return None                                   # (large problems: the host work does not matter, and the blocks are kept for reuse)
+        cols = _kernels._leaf_columns(numpy.asarray(kernel._select(xa)))
+        colss = _kernels._leaf_columns(numpy.asarray(kernel._select(xsa)))
+        if len(cols) != len(colss):
+            return None
+        dtype = _kernels._float_dtype_of(cols + colss, kernel._scale, kernel._loc)
+        if numpy.dtype(dtype) != numpy.float64 or y.dtype.kind not in 'fiu':
+            return None
+        d = len(cols)
+        pts = numpy.empty((d, n + m))
+        for i in range(d):
+            pts[i, :n] = cols[i]
+            pts[i, n:] = colss[i]
+        if self._checkfinite:
+            # (finite points give finite values of these kernels; the blocks themselves are never assembled here)
+            if not numpy.all(numpy.isfinite(pts)):
+                return None
+            self._check_ymean(y)
+            if noise is not None and not numpy.all(numpy.isfinite(noise)):
+                return None
+        ctx = self.ctx
+        lib = _lib.load()
+        F = ctypes.c_double
+        P = DeviceArray.from_host(pts, ctx=ctx)                          # one upload: [x | xs], SoA
+        xd, xsd = P.block(0, d, 0, n), P.block(0, d, n, n + m)
+        nx = -(-(m + 1) // 128) * 128                                     # carried rows, padded to whole tiles
+        L = DeviceArray.empty((n + nx, n), numpy.float64, ctx)
+        if nx > m + 1:
+            L.block(n + m + 1, n + nx, 0, n).fill_zero()
+        nops, codes, vals = _kernels._ops_arrays(kernel._outops, F)
+        npar, hpar = kernel._par_args(F)
+        kargs = (int(kernel._loc is not None), F(kernel._loc or 0), int(kernel._scale is not None), F(kernel._scale or 1), nops, codes, vals)
+        top = L.block(n, n + m, 0, n)
+        _lib.check(lib.lgp_gram_isotropic_f64(ctx.handle, kernel._kind, int(kernel._p), npar, hpar, d, xsd.ptr, xsd.ld, m, xd.ptr, xd.ld, n,
+                                              *kargs, 0, top.ptr, top.ld), 'lgp_gram_isotropic')       # Kxxs^T into the carried rows
+        L.block(n + m, n + m + 1, 0, n).assign(DeviceArray.from_host(numpy.asarray(y, float).reshape(1, n), ctx=ctx))
+        Kss = DeviceArray.empty((m, m), numpy.float64, ctx)
+        _lib.check(lib.lgp_gram_isotropic_f64(ctx.handle, kernel._kind, int(kernel._p), npar, hpar, d, xsd.ptr, xsd.ld, m, xsd.ptr, xsd.ld, m,
+                                              *kargs, 1, Kss.ptr, Kss.ld), 'lgp_gram_isotropic')
+        dblk = DeviceArray.empty((lib.lgp_chol_dblk_size(n),), numpy.float64, ctx)
+        nz = None if noise is None else DeviceArray.from_host(noise, ctx=ctx)
+        eps = F()
+        info = _lib.check(lib.lgp_gram_chol_factor_rhs_f64(ctx.handle, kernel._kind, int(kernel._p), npar, hpar, d, xd.ptr, xd.ld, n, *kargs,
+                                                           F(0.), None if nz is None else nz.ptr, F(0.), F(0.), _lib.LGP_EPS_AUTO_REL,
+                                                           L.ptr, L.ld, nx, dblk.ptr, ctypes.byref(eps)), 'lgp_gram_chol_factor_rhs')
+        if info != 0:
+            raise numpy.linalg.LinAlgError('cholesky decomposition not finite, probably matrix not pos def numerically')
+        mean_d = DeviceArray.empty((m,), numpy.float64, ctx)
+        cov_d = DeviceArray.empty((m, m), numpy.float64, ctx)
+        Wt = L.block(n, n + m + 1, 0, n)
+        dens = F()
+        _lib.check(lib.lgp_posterior_solved_f64(ctx.handle, n, m, L.ptr, L.ld, Wt.ptr, Wt.ld, Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld,
+                                                ctypes.byref(dens)), 'lgp_posterior_solved')
+        mean, cov = mean_d.to_host(), cov_d.to_host()
+        return mean.reshape(xs.shape), cov.reshape(2 * xs.shape)
 
     def predfromfit(self, *args, **kw):
         """ Like `pred` with ``fromdata=False`` """

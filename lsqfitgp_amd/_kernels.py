@@ -367,6 +367,10 @@ class _Composite(Kernel):
         return self._finish(K0), tangents
 
 
+# kernels whose Gram build the library fuses with the regularisation and the factorisation (lgp_gram_chol_factor_rhs, csrc/gram.hip)
+FUSED_KINDS = (_lib.LGP_KERNEL_EXPQUAD, _lib.LGP_KERNEL_MATERNP, _lib.LGP_KERNEL_GAMMAEXP, _lib.LGP_KERNEL_CAUCHY)
+
+
 class _Isotropic(Kernel):
     """ ``_Kernel/_isotropic.py:61-81`` with input='squared' """
 

@@ -379,3 +379,57 @@ def test_decomposition_kept_for_the_same_givencov(lgp, rng):
     lo = go.marginal_likelihood({'d': y}, gc)
     assert np.linalg.norm(mean - mo) <= 1e-8 * np.linalg.norm(mo)
     assert abs(ml - lo) <= 1e-8 * abs(lo) + 1e-6 and abs(ml3 - lo) <= 1e-8 * abs(lo) + 1e-6
+
+
+@pytest.mark.parametrize('case', ['expquad1d', 'matern3d_noise', 'cauchy_ops'])
+def test_one_call_prediction_is_the_general_path(lgp, rng, monkeypatch, case):
+    """ `GP._pred_one_call` (three library calls for the plain question: one kernel, one point set given, one predicted, no checks
+    that need the blocks) against the general path of the same class and against the oracle """
+    n, m = 700, 37
+    if case == 'expquad1d':
+        x, xs = np.sort(rng.uniform(0, 10, n)), np.linspace(0, 10, m)
+        mk = lambda mod: mod.ExpQuad(scale=0.7)
+        gc = lambda mod: None
+    else:
+        dt = [('a', float), ('b', float), ('c', float)]
+        x = np.empty(n, dt); xs = np.empty(m, dt)
+        for f in 'abc':
+            x[f] = rng.uniform(0, 6, n); xs[f] = rng.uniform(0, 6, m)
+        if case == 'matern3d_noise':
+            mk = lambda mod: mod.Maternp(p=2, scale=1.3, loc=0.2)
+            noise = rng.uniform(0.01, 0.02, n)
+            gc = lambda mod: {('d', 'd'): (mod.diag(noise) if mod is lgp else np.diag(noise))}
+        else:
+            mk = lambda mod: mod.Cauchy(alpha=1.5, beta=3., scale=2.) * 1.7 + 0.25
+            gc = lambda mod: {('d', 'd'): (mod.diag(np.full(n, 0.05)) if mod is lgp else 0.05 * np.eye(n))}
+    # (smooth data for the noise-free case, whose matrix is numerically singular: white noise is not in its range)
+    y = np.sin(x) if case == 'expquad1d' else rng.standard_normal(n)
+    calls = []
+    orig = lgp.GP._pred_one_call
+    def counted(self, *a):
+        res = orig(self, *a)
+        calls.append(res is not None)
+        return res
+    monkeypatch.setattr(lgp.GP, '_pred_one_call', counted)
+
+    def run(mod, **kw):
+        gp = mod.GP(mk(mod), checkpos=False, checksym=False, **kw).addx(x, 'd').addx(xs, 't')
+        g = gc(mod)
+        return gp.predfromdata({'d': y}, 't', *(() if g is None else (g,)), raw=True)
+    mean, cov = run(lgp)
+    assert calls == [True]
+    mg, cg = run(lgp, fuse_solve=False)                    # the general path (the one-call path needs fuse_solve)
+    mo, co = run(oracle)
+    scale = np.linalg.norm(np.asarray(oracle.GP(mk(oracle), checkpos=False, checksym=False).addx(xs, 't').prior('t', raw=True)), 2)
+    # (the noise-free ExpQuad problem is numerically singular: two orders of the same arithmetic differ by the conditioning
+    #  floor measured in tests/test_gpu_gp.py::test_golden_c1, not by rounding)
+    loose = 2e-4 if case == 'expquad1d' else None
+    for a, b, tol in ((mean, mg, loose or 1e-9), (mean, mo, loose or 1e-8)):
+        assert np.linalg.norm(a - b) <= tol * max(np.linalg.norm(b), 1e-3), (case, np.linalg.norm(a - b) / np.linalg.norm(b))
+    for a, b, tol in ((cov, cg, loose or 1e-9), (cov, co, loose or 1e-8)):
+        assert np.linalg.norm(a - b, 2) <= tol * scale
+    # what the one-call path does not cover goes the general way and gives the same answer: checks on, two given keys
+    gp = lgp.GP(mk(lgp)).addx(x, 'd').addx(xs, 't')
+    g = gc(lgp)
+    m2, c2 = gp.predfromdata({'d': y}, 't', *(() if g is None else (g,)), raw=True)
+    assert calls == [True, False, False] and np.linalg.norm(m2 - mg) <= (loose or 1e-9) * max(np.linalg.norm(mg), 1e-3)
