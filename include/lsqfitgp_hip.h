@@ -244,6 +244,21 @@ int lgp_gram_bart_f64(lgp_ctx *ctx, int p, const int32_t *dix, size_t n, const i
                       int nops, const int *hops_code, const double *hops_val,
                       double *dout, size_t ldo);
 
+/* Gram block of a DERIVED kernel: d^ax/dx^ax d^by/dy^by k(x, y) along field fx of x and field fy of y (-1 with order 0), orders
+ * 0 .. 2 -- what `kernel.linop('diff', xderiv, yderiv)` evaluates through jax.grad of the core (_Kernel/_ops.py:115-211) when points
+ * are added with `deriv=` (_GP/_elements.py:158-242).  The core runs once in truncated Taylor arithmetic (csrc/gram_jet.hip).
+ * kernel: LGP_KERNEL_EXPQUAD, GAMMAEXP (gamma = 2), CAUCHY (alpha = 2; hpar = {alpha/2, beta, -beta/alpha}), MATERNP (hcoef: five
+ * rows of 24 Laurent coefficients of t^-7 .. t^16), CONSTANT, LINEAR, and of one variable (d = 1): COS, PERIODIC (hpar as
+ * lgp_gram_isotropic), SINC, CELERITE, HARMONIC, WENDLAND (hpar = {nu + k}, hcoef = the polynomial), CIRCULAR, DECAYING,
+ * WIENERINTEGRAL, FRACBROWNIAN (H = K = 1), STATIONARYFRACBROWNIAN (H = 1).  factor: product of the multiplicative output
+ * operations; the chain-rule factor 1 / scale^(ax + by) is applied by the library. */
+int lgp_gram_deriv_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int ncoef, const double *hcoef, int d,
+                       const double *dx, size_t ldx, size_t n, const double *dy, size_t ldy, size_t m, int has_loc, double loc,
+                       int has_scale, double scale, double factor, int fx, int ax, int fy, int by, double *dout, size_t ldo);
+int lgp_gram_deriv_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int ncoef, const float *hcoef, int d,
+                       const float *dx, size_t ldx, size_t n, const float *dy, size_t ldy, size_t m, int has_loc, float loc,
+                       int has_scale, float scale, float factor, int fx, int ax, int fy, int by, float *dout, size_t ldo);
+
 /* The isotropic Gram matrix together with its derivative with respect to `scale` (dout and ddscale: n x m, ld ldo): the
  * forward-mode tangent of `(x - loc) / scale` (_Kernel/_ops.py:310-326) through the cores and the output algops -- what
  * jax.jacfwd of a gpfactory with a `scale` hyperparameter produces in the reference's fit (_fit.py:679-690), here in the

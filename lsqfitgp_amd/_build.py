@@ -28,6 +28,7 @@ UNITS = [
     ('dist.hip', []),
     # the Gram kernels follow the reference's unfused square-then-add evaluation
     ('gram.hip', ['-ffp-contract=off']),
+    ('gram_jet.hip', ['-ffp-contract=off']),
 ]
 
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-Wno-pass-failed']

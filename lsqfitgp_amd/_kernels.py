@@ -431,6 +431,57 @@ class _Isotropic(Kernel):
             raise ValueError(f'negative derivative order {spec!r}')
         return orders
 
+    # ---- derivative observations (``_Kernel/_ops.py:115-211``) ------------------------------------------------------------
+    # how many times the PROCESS is derivable (the reference's ``derivable=`` of the kernel decorators: True = any order);
+    # None: no derivative core on the device yet
+    _derivable = 0
+
+    def _derivability(self):
+        return self._derivable
+
+    def _has_closed_form_diff(self, d):
+        """ ExpQuad (Hermite polynomials, any fields) and Maternp on one-dimensional points keep their closed forms (`_diff_call`);
+        everything else goes through the Taylor arithmetic of csrc/gram_jet.hip """
+        return self._kind == _lib.LGP_KERNEL_EXPQUAD or (self._kind == _lib.LGP_KERNEL_MATERNP and d == 1)
+
+    def _jet_pars(self):
+        """ (p, real parameters, coefficient table) of the derivative core """
+        return int(self._p), tuple(self._par), ()
+
+    def _gram_jet(self, xd, yd, dtype, ctx, d, da, db, out):
+        """ d^a/dx^a d^b/dy^b k along ONE field per side, a, b <= 2 (``lgp_gram_deriv``) """
+        deg = self._derivability()
+        name = type(self).__name__
+        if deg is None:
+            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, GammaExp(gamma=2), Cauchy(alpha=2), '
+                                      'Constant, Linear, Periodic, Cos, Sinc, Celerite, Harmonic, Wendland, Circular, Decaying, WienerIntegral, '
+                                      'FracBrownian(H=1, K=1), StationaryFracBrownian(H=1) have one)')
+        sides = []
+        for orders in (da, db):
+            nz = [(f, o) for f, o in enumerate(orders) if o]
+            if len(nz) > 1:
+                raise NotImplementedError(f'derivatives of {name} along more than one field of a point')
+            f, o = nz[0] if nz else (-1, 0)
+            if o > deg:
+                # the reference's error (``_Kernel/_ops.py:85-90``)
+                raise ValueError(f'Took {o} derivatives > limit {deg} on argument of a kernel ({name}).')
+            if o > 2:
+                raise NotImplementedError(f'derivatives of {name} above the second on one side')
+            sides.append((f, o))
+        factor = 1.
+        for op, c in self._outops:
+            if op == 'mul':
+                factor = factor * c
+        p, par, coef = self._jet_pars()
+        f, F = _lib.fn('lgp_gram_deriv', dtype)
+        hpar = (F * len(par))(*par) if par else None
+        hcoef = (F * len(coef))(*coef) if len(coef) else None
+        n, m = xd.shape[1], yd.shape[1]
+        _lib.check(f(ctx.handle, self._kind, p, len(par), hpar, len(coef), hcoef, d, xd.ptr, xd.ld, n, yd.ptr, yd.ld, m,
+                     int(self._loc is not None), F(self._loc or 0), int(self._scale is not None), F(self._scale or 1), F(factor),
+                     sides[0][0], sides[0][1], sides[1][0], sides[1][1], out.ptr, out.ld), 'lgp_gram_deriv')
+        return out
+
     def _diff_call(self, deriv, d):
         """
         ``(kernel id, p, real parameters, output operations)`` of the derived kernel ``kernel.linop('diff', dx, dy)``
@@ -491,9 +542,12 @@ class _Isotropic(Kernel):
         if out is None:
             out = DeviceArray.empty((n, m), dtype, ctx)
         assert out.shape == (n, m) and out.dtype == dtype
-        kind, order, par, outops = self._diff_call(deriv, d)
         if n == 0 or m == 0:
             return out
+        da, db = self._orders(deriv[0], d), self._orders(deriv[1], d)
+        if (any(da) or any(db)) and not self._has_closed_form_diff(d):
+            return self._gram_jet(xd, yd, dtype, ctx, d, da, db, out)
+        kind, order, par, outops = self._diff_call(deriv, d)
         f, F = _lib.fn('lgp_gram_isotropic', dtype)
         nops, codes, vals = _ops_arrays(outops, F)
         npar, hpar = (len(par), (F * len(par))(*par)) if par else (0, None)
@@ -582,6 +636,7 @@ class _Isotropic(Kernel):
 class ExpQuad(_Isotropic):
     """ Exponential quadratic kernel, k(r) = exp(-r²/2) (``_kernels/_basic.py:61-75``) """
     _kind = _lib.LGP_KERNEL_EXPQUAD
+    _derivable = float('inf')
 
     def __init__(self, *, scale=None, loc=None, dim=None):
         super().__init__(scale=scale, loc=loc, dim=dim)
@@ -598,6 +653,32 @@ class Maternp(_Isotropic):
             raise NotImplementedError('Maternp order above 16')
         super().__init__(scale=scale, loc=loc, dim=dim)
         self._p = int(p)
+
+    def _derivability(self):
+        return int(self._p) if self._kind == _lib.LGP_KERNEL_MATERNP else None      # (real order: no derivative core yet)
+
+    def _jet_pars(self):
+        """ k = f(s), s = (2p+1) r^2, t = sqrt(s): f^(k)(s) = exp(-t) R_k(t) with R_0 = P_p (``_special/_bessel.py:101-110``) and
+        R_(k+1) = (R_k' - R_k) / (2 t) -- Laurent polynomials in t (the division is exact up to the p-th derivative; beyond it
+        the negative powers meet powers of the distance in the chain rule), entry i of a row the coefficient of t^(i - 7) """
+        from fractions import Fraction
+        p = int(self._p)
+        # exact rational arithmetic: a rounding residue of 1e-17 in a coefficient of 1 / t is 1e-2 at a coincidence (t = 1e-15)
+        OFF, W = 7, 24
+        P = [Fraction(1)]                                              # ascending powers of t
+        for k in reversed(range(p)):
+            ck = Fraction(2 * (p - k), (2 * p - k) * (k + 1))
+            P = [Fraction(1)] + [ck * c for c in P]                    # 1 + ck t P
+        row = [Fraction(0)] * W
+        row[OFF:OFF + len(P)] = P
+        rows = [row]
+        for _ in range(4):
+            r = rows[-1]
+            d = [r[i + 1] * (i + 1 - OFF) for i in range(W - 1)] + [Fraction(0)]       # derivative: coefficient of t^(e - 1) -> slot of t^(e - 1)
+            q = [(di - ri) / 2 for di, ri in zip(d, r)]
+            assert q[0] == 0
+            rows.append(q[1:] + [Fraction(0)])                                          # divided by t
+        return p, (), tuple(float(v) for row in rows for v in row)
 
 
 class Matern(Maternp):
@@ -624,6 +705,7 @@ class Bessel(_Isotropic):
     """ Bessel kernel, k(r) = Γ(ν + 1) 2^ν (s r)^-ν J_ν(s r), s = 2 + ν/2, ν >= 0 (``_kernels/_matern.py:92-119``): usable in up to
     2 (⌊ν⌋ + 1) dimensions.  J_ν of real order on the device (power series, Miller's backward recurrence, Hankel's expansion) """
     _kind = _lib.LGP_KERNEL_BESSEL
+    _derivable = None
 
     def __init__(self, *, nu=0, scale=None, loc=None, dim=None):
         assert 0 <= nu < numpy.inf, nu                                     # _matern.py:117
@@ -651,6 +733,9 @@ class GammaExp(_Isotropic):
         self._gamma = gamma
         self._par = (float(gamma), float(gamma / 2))
 
+    def _derivability(self):
+        return float('inf') if self._gamma == 2 else 0              # _basic.py:94
+
 
 class Cauchy(_Isotropic):
     """ Generalized Cauchy kernel, k(r) = (1 + r^α/β)^(-β/α), α ∈ (0, 2], β > 0 (``_kernels/_basic.py:315-344``);
@@ -665,6 +750,12 @@ class Cauchy(_Isotropic):
         super().__init__(scale=scale, loc=loc, dim=dim)
         self._alpha, self._beta = alpha, beta
         self._par = (float(alpha), float(beta), float(-beta / alpha))
+
+    def _derivability(self):
+        return float('inf') if self._alpha == 2 else 0              # _basic.py:312-315
+
+    def _jet_pars(self):
+        return 0, (float(self._alpha / 2), float(self._beta), float(-self._beta / self._alpha)), ()
 
 
 class Wendland(_Isotropic):
@@ -682,6 +773,17 @@ class Wendland(_Isotropic):
         nu = k + alpha
         self._p = int(k)
         self._par = (float(nu + k),) + tuple(float(numpy.polyval(pj, nu)) for pj in self._POLY[k])
+
+    def _derivability(self):
+        return int(self._p)                                         # _wendland.py:25-26
+
+    def _jet_pars(self):
+        return int(self._p), (self._par[0],), tuple(self._par[1:])
+
+    def _gram_jet(self, xd, yd, dtype, ctx, d, da, db, out):
+        if d != 1:
+            raise NotImplementedError('derivatives of Wendland on one-dimensional points only')
+        return super()._gram_jet(xd, yd, dtype, ctx, d, da, db, out)
 
     def _prepare(self, xs, ys, ctx):
         out = super()._prepare(xs, ys, ctx)
@@ -711,6 +813,7 @@ class Log(_Isotropic):
 class Constant(_Isotropic):
     """ Constant kernel, k(x, y) = 1 (``_kernels/_basic.py:34-46``) """
     _kind = _lib.LGP_KERNEL_CONSTANT
+    _derivable = float('inf')
 
     def __init__(self, *, scale=None, loc=None, dim=None):
         super().__init__(scale=scale, loc=loc, dim=dim)
@@ -753,6 +856,7 @@ class Periodic(_Stationary1D):
     """ Periodic Gaussian kernel, k(Δ) = exp(-2 (sin(Δ/2) / outerscale)²): ``scale`` sets the period (2π at scale = 1),
     ``outerscale`` the correlation length (``_kernels/_basic.py:187-208``) """
     _kind = _lib.LGP_KERNEL_PERIODIC
+    _derivable = float('inf')
 
     def __init__(self, *, outerscale=1, scale=None, loc=None, dim=None):
         assert 0 < outerscale < numpy.inf, outerscale
@@ -763,12 +867,14 @@ class Periodic(_Stationary1D):
 class Cos(_Stationary1D):
     """ Cosine kernel, k(Δ) = cos(Δ) (``_kernels/_spectral.py:25-38``) """
     _kind = _lib.LGP_KERNEL_COS
+    _derivable = float('inf')
 
 
 class Sinc(_Stationary1D):
     """ Sinc kernel, k(Δ) = sin(πΔ) / (πΔ) (``_kernels/_spectral.py:113-122``; six Taylor terms below |Δ| = 0.1 as
     ``_special/_sinc.py:25-32``), input='posabs' """
     _kind = _lib.LGP_KERNEL_SINC
+    _derivable = float('inf')
 
 
 class StationaryFracBrownian(_Stationary1D):
@@ -780,6 +886,10 @@ class StationaryFracBrownian(_Stationary1D):
         assert 0 < H <= 1, H
         super().__init__(scale=scale, loc=loc, dim=dim)
         self._par = (float(2 * H),)
+        self._H = H
+
+    def _derivability(self):
+        return float('inf') if self._H == 1 else 0                  # _randomwalk.py:153-154
 
 
 class Color(_Stationary1D):
@@ -787,6 +897,7 @@ class Color(_Stationary1D):
     1/ω^n truncated below ω = 1 (``_kernels/_spectral.py:70-111``).  E_n on the device by its power series and its continued
     fraction (the reference's closed form and asymptotic series meet at a knee where both have lost digits, 1e-4 at n = 20) """
     _kind = _lib.LGP_KERNEL_COLOR
+    _derivable = None
 
     def __init__(self, *, n=2, scale=None, loc=None, dim=None):
         assert int(n) == n and n >= 2, n                                   # _spectral.py:110
@@ -798,6 +909,7 @@ class Pink(_Stationary1D):
     """ Pink noise kernel, k(Δ) = (Ci(Δ (1 + dw)) - Ci(Δ)) / log(1 + dw): a power spectrum 1/ω between 1 and 1 + dw
     (``_kernels/_spectral.py:41-66``); where Δ dw is below sqrt(eps), cos(Δ (1 + dw/2)) """
     _kind = _lib.LGP_KERNEL_PINK
+    _derivable = None
 
     def __init__(self, *, dw=1, scale=None, loc=None, dim=None):
         assert 0 <= dw < numpy.inf, dw
@@ -1191,11 +1303,15 @@ class Celerite(_Stationary1D):
         super().__init__(scale=scale, loc=loc, dim=dim)
         self._par = (float(gamma), float(B))
 
+    def _derivability(self):
+        return 1 if self._par[0] == self._par[1] else 0             # _celerite.py:26-32: B == gamma
+
 
 class Harmonic(_Stationary1D):
     """ Damped stochastically driven harmonic oscillator of quality factor Q (``_kernels/_celerite.py:54-121``): the four
     branches of the reference (Q < 1/2 in the cancellation-free form, Q < 1, Q = 1, Q > 1), chosen on the host """
     _kind = _lib.LGP_KERNEL_HARMONIC
+    _derivable = 1
 
     def __init__(self, *, Q=1, scale=None, loc=None, dim=None):
         assert 0 < Q < numpy.inf, Q
@@ -1215,6 +1331,7 @@ class Circular(_Stationary1D):
     """ Circular kernel of period 1, W_c(t) = (1 + τ t/c)(1 - t/c)_+^τ of the geodesic distance t, τ >= 4, c in (0, 1/2]
     (``_kernels/_wendland.py:88-113``) """
     _kind = _lib.LGP_KERNEL_CIRCULAR
+    _derivable = 1
 
     def __init__(self, *, tau=4, c=1 / 2, scale=None, loc=None, dim=None):
         assert tau >= 4, tau
@@ -1226,6 +1343,7 @@ class Circular(_Stationary1D):
 class Linear(_Isotropic):
     """ Dot product kernel, k(x, y) = sum_i x_i y_i (``_kernels/_basic.py:76-91``) """
     _kind = _lib.LGP_KERNEL_LINEAR
+    _derivable = float('inf')
 
     def __init__(self, *, scale=None, loc=None, dim=None):
         super().__init__(scale=scale, loc=loc, dim=dim)
@@ -1272,6 +1390,7 @@ class BrownianBridge(_OneVariable):
 class Decaying(_OneVariable):
     """ Decaying kernel, k(x, y) = 1 / (1 + x + y)^alpha, x, y, alpha >= 0 (``_kernels/_basic.py:362-379``) """
     _kind = _lib.LGP_KERNEL_DECAYING
+    _derivable = float('inf')
 
     def __init__(self, *, alpha=1, scale=None, loc=None, dim=None):
         assert alpha >= 0, alpha
@@ -1291,18 +1410,24 @@ class FracBrownian(_OneVariable):
         super().__init__(scale=scale, loc=loc, dim=dim)
         H2 = 2 * H
         self._par = (float(H2), float(K), float(1 / 2 ** K), float(H2 * K))
+        self._HK = (H, K)
+
+    def _derivability(self):
+        return float('inf') if self._HK == (1, 1) else 0            # _randomwalk.py:43-44
 
 
 class WienerIntegral(_OneVariable):
     """ Integral of the Wiener process, k(x, y) = a² (b - a / 3) / 2 with a = min(x, y), b = max(x, y), x, y >= 0
     (``_kernels/_randomwalk.py:93-110``) """
     _kind = _lib.LGP_KERNEL_WIENERINTEGRAL
+    _derivable = 1
 
 
 class Taylor(_OneVariable):
     """ Exponential-like power series kernel, k(x, y) = sum_k x^k y^k / k!^2 = I0(2 sqrt(x y)) (``_kernels/_basic.py:393-408``;
     J0 of the same argument where x y < 0) """
     _kind = _lib.LGP_KERNEL_TAYLOR
+    _derivable = None
     _domain = (-numpy.inf, numpy.inf)
 
 

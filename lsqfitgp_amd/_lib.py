@@ -134,6 +134,8 @@ def _signatures():
             'lgp_gram_bart_' + suf: (c_int, [c_void_p, c_int, _P, _S, _P, _S, POINTER(c_int32), POINTER(F),
                                             c_int, c_int, POINTER(F), F, _P, _P, _S,
                                             c_int, POINTER(c_int), POINTER(F), _P, _S]),
+            'lgp_gram_deriv_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, POINTER(F), c_int, _P, _S, _S, _P, _S, _S,
+                                      c_int, F, c_int, F, F, c_int, c_int, c_int, c_int, _P, _S]),
             'lgp_gram_isotropic_dscale_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, _P, _S, _S, _P, _S, _S,
                                                         c_int, F, c_int, F, c_int, POINTER(c_int), POINTER(F), _P, _P, _S]),
             'lgp_gram_bart_jvp_' + suf: (c_int, [c_void_p, c_int, _P, _S, _P, _S, POINTER(c_int32), POINTER(F),

@@ -1,0 +1,361 @@
+// gram_jet.hip -- Gram blocks of DERIVED kernels: d^a/dx^a d^b/dy^b k(x, y), a, b <= 2, along one field per side, for the kernels
+// of the reference whose core is an elementary expression.  Replaces what `kernel.linop('diff', xderiv, yderiv)` gives the
+// reference through jax.grad of the core (src/lsqfitgp/_Kernel/_ops.py:115-211) when points are added with `deriv=`
+// (_GP/_elements.py:158-242, 554-579).
+//
+// No closed forms per kernel and order: the core is evaluated ONCE in truncated Taylor arithmetic.  A value is a polynomial
+// sum_{i, j <= 2} c_ij u^i v^j in the two perturbations (u of the x side's field, v of the y side's), i.e. an element of
+// R[u, v] / (u^3, v^3); sums and products are those of the ring, an elementary function f acts through
+// f(a) = sum_{k <= 4} f^(k)(a_00) / k! (a - a_00)^k (the nilpotent part has no term of total degree 0, so its fifth power vanishes).
+// The derivative asked for is a! b! c_ab.  ExpQuad keeps its Hermite form (gram.hip, any fields, total order 4 per field) and
+// Maternp in one dimension its polynomial form; Maternp over several fields comes here, as a function of s = (2p+1) r^2 whose
+// derivatives e^-t R_k(t) the host derives (R_{k+1} = (R_k' - R_k) / (2 t), exact for k < p: no square root of a jet at r = 0).
+// One thread per pair: derivative blocks are the small blocks of a problem, not its N x N matrix.
+#include "common.h"
+
+namespace {
+
+constexpr int JD = 3;            // orders 0 .. 2 per side
+
+template <typename T>
+struct Jet {
+  T c[JD][JD];
+  __device__ __forceinline__ Jet() {}
+  __device__ __forceinline__ explicit Jet(T v) {
+#pragma unroll
+    for (int i = 0; i < JD; ++i)
+#pragma unroll
+      for (int j = 0; j < JD; ++j) c[i][j] = T(0);
+    c[0][0] = v;
+  }
+  __device__ __forceinline__ T val() const { return c[0][0]; }
+};
+
+template <typename T> __device__ __forceinline__ Jet<T> operator+(const Jet<T> &a, const Jet<T> &b) {
+  Jet<T> r;
+#pragma unroll
+  for (int i = 0; i < JD; ++i)
+#pragma unroll
+    for (int j = 0; j < JD; ++j) r.c[i][j] = a.c[i][j] + b.c[i][j];
+  return r;
+}
+template <typename T> __device__ __forceinline__ Jet<T> operator-(const Jet<T> &a, const Jet<T> &b) {
+  Jet<T> r;
+#pragma unroll
+  for (int i = 0; i < JD; ++i)
+#pragma unroll
+    for (int j = 0; j < JD; ++j) r.c[i][j] = a.c[i][j] - b.c[i][j];
+  return r;
+}
+template <typename T> __device__ __forceinline__ Jet<T> operator-(const Jet<T> &a) {
+  Jet<T> r;
+#pragma unroll
+  for (int i = 0; i < JD; ++i)
+#pragma unroll
+    for (int j = 0; j < JD; ++j) r.c[i][j] = -a.c[i][j];
+  return r;
+}
+template <typename T> __device__ __forceinline__ Jet<T> operator*(const Jet<T> &a, const Jet<T> &b) {
+  Jet<T> r(T(0));
+#pragma unroll
+  for (int i = 0; i < JD; ++i)
+#pragma unroll
+    for (int j = 0; j < JD; ++j)
+#pragma unroll
+      for (int k = 0; k + i < JD; ++k)
+#pragma unroll
+        for (int l = 0; l + j < JD; ++l) r.c[i + k][j + l] += a.c[i][j] * b.c[k][l];
+  return r;
+}
+template <typename T> __device__ __forceinline__ Jet<T> operator*(const Jet<T> &a, T s) {
+  Jet<T> r;
+#pragma unroll
+  for (int i = 0; i < JD; ++i)
+#pragma unroll
+    for (int j = 0; j < JD; ++j) r.c[i][j] = a.c[i][j] * s;
+  return r;
+}
+template <typename T> __device__ __forceinline__ Jet<T> operator*(T s, const Jet<T> &a) { return a * s; }
+template <typename T> __device__ __forceinline__ Jet<T> operator+(const Jet<T> &a, T s) { Jet<T> r = a; r.c[0][0] += s; return r; }
+template <typename T> __device__ __forceinline__ Jet<T> operator+(T s, const Jet<T> &a) { return a + s; }
+template <typename T> __device__ __forceinline__ Jet<T> operator-(const Jet<T> &a, T s) { return a + (-s); }
+template <typename T> __device__ __forceinline__ Jet<T> operator-(T s, const Jet<T> &a) { return (-a) + s; }
+
+// f(a) from the Taylor coefficients f[k] = f^(k)(a_00) / k!, k = 0 .. 4
+template <typename T> __device__ __forceinline__ Jet<T> compose(const Jet<T> &a, const T (&f)[5]) {
+  Jet<T> n = a;
+  n.c[0][0] = T(0);
+  Jet<T> r = f[4] * n;                 // Horner in the nilpotent part
+  r = (r + f[3]) * n;
+  r = (r + f[2]) * n;
+  r = (r + f[1]) * n;
+  return r + f[0];
+}
+template <typename T> __device__ __forceinline__ Jet<T> jexp(const Jet<T> &a) {
+  const T e = exp(a.val());
+  const T f[5] = {e, e, e / T(2), e / T(6), e / T(24)};
+  return compose(a, f);
+}
+template <typename T> __device__ __forceinline__ Jet<T> jsin(const Jet<T> &a) {
+  const T s = sin(a.val()), c = cos(a.val());
+  const T f[5] = {s, c, -s / T(2), -c / T(6), s / T(24)};
+  return compose(a, f);
+}
+template <typename T> __device__ __forceinline__ Jet<T> jcos(const Jet<T> &a) {
+  const T s = sin(a.val()), c = cos(a.val());
+  const T f[5] = {c, -s, -c / T(2), s / T(6), c / T(24)};
+  return compose(a, f);
+}
+template <typename T> __device__ __forceinline__ Jet<T> jcosh(const Jet<T> &a) {
+  const T s = sinh(a.val()), c = cosh(a.val());
+  const T f[5] = {c, s, c / T(2), s / T(6), c / T(24)};
+  return compose(a, f);
+}
+template <typename T> __device__ __forceinline__ Jet<T> jsinh(const Jet<T> &a) {
+  const T s = sinh(a.val()), c = cosh(a.val());
+  const T f[5] = {s, c, s / T(2), c / T(6), s / T(24)};
+  return compose(a, f);
+}
+// a^p, real p, a_00 > 0 (a_00 <= 0: zero, the continuation the kernels with a compact support want: (1 - t)_+^p)
+template <typename T> __device__ __forceinline__ Jet<T> jpow(const Jet<T> &a, T p) {
+  const T x = a.val();
+  if (!(x > T(0))) return Jet<T>(T(0));
+  const T v = pow(x, p), ix = T(1) / x;
+  T f[5];
+  f[0] = v;
+  f[1] = f[0] * p * ix;
+  f[2] = f[1] * (p - T(1)) * ix / T(2);
+  f[3] = f[2] * (p - T(2)) * ix / T(3);
+  f[4] = f[3] * (p - T(3)) * ix / T(4);
+  return compose(a, f);
+}
+template <typename T> __device__ __forceinline__ Jet<T> jrecip(const Jet<T> &a) {
+  const T ix = T(1) / a.val();
+  const T f[5] = {ix, -ix * ix, ix * ix * ix, -ix * ix * ix * ix, ix * ix * ix * ix * ix};
+  return compose(a, f);
+}
+// |a| as an even function continued from the right: sign(0) = +1 (the kernels that take |delta| and are derivable at 0 have
+// h'(0) = 0, so that d^2/d delta^2 h(|delta|) at 0 is h''(0+), which this gives; a sign that vanishes at 0 would give 0)
+template <typename T> __device__ __forceinline__ Jet<T> jabs(const Jet<T> &a) { return a.val() >= T(0) ? a : -a; }
+template <typename T> __device__ __forceinline__ Jet<T> jmin(const Jet<T> &a, const Jet<T> &b) { return a.val() <= b.val() ? a : b; }
+template <typename T> __device__ __forceinline__ Jet<T> jmax(const Jet<T> &a, const Jet<T> &b) { return a.val() <= b.val() ? b : a; }
+
+// sin(pi a) / (pi a) and its derivatives: the series of the even function below |pi x| = 1, sines and cosines above
+template <typename T> __device__ __forceinline__ Jet<T> jsinc(const Jet<T> &a) {
+  const T PI = T(3.141592653589793238462643383279502884);
+  const T z = PI * a.val();
+  T g[5];                                   // derivatives of sin(z) / z with respect to z, divided by k!
+  if (fabs(z) < T(1)) {
+    // sin z / z = sum_m (-1)^m z^(2m) / (2m+1)!;  k-th derivative term by term, 12 terms (z^24 / 25! = 6e-26)
+    const T z2 = z * z;
+    T d0 = T(0), d1 = T(0), d2 = T(0), d3 = T(0), d4 = T(0);
+    T c = T(1);                             // (-1)^m / (2m+1)!
+    T zp = T(1);                            // z^(2m)
+    for (int m = 0; m < 13; ++m) {
+      const T e = T(2 * m);
+      d0 += c * zp;
+      if (m >= 1) {
+        d1 += c * e * zp;                                   // times 1 / z below
+        d2 += c * e * (e - T(1)) * zp;                      // times 1 / z^2
+      }
+      if (m >= 2) {
+        d3 += c * e * (e - T(1)) * (e - T(2)) * zp;         // times 1 / z^3
+        d4 += c * e * (e - T(1)) * (e - T(2)) * (e - T(3)) * zp;
+      }
+      zp *= z2;
+      c = -c / (T(2 * m + 2) * T(2 * m + 3));
+    }
+    // (the divisions by powers of z: exact cancellation of the leading powers is avoided by dividing the accumulated sums, whose
+    //  lowest term is z^2 (d1, d2) or z^4 (d3, d4); at z = 0 the limits are -1/3 for d2 and 1/5 for d4, 0 for the odd ones)
+    if (z == T(0)) {
+      g[0] = T(1); g[1] = T(0); g[2] = T(-1) / T(6); g[3] = T(0); g[4] = T(1) / T(120);
+    } else {
+      g[0] = d0; g[1] = d1 / z; g[2] = d2 / (z * z) / T(2); g[3] = d3 / (z * z * z) / T(6); g[4] = d4 / (z * z * z * z) / T(24);
+    }
+  } else {
+    const T s = sin(z), c = cos(z), iz = T(1) / z;
+    // f = s / z; f' = (c - f) / z ... by the recurrence f_(k+1) = (d^k/dz^k cos-or-sin term - (k+1) f_k) / z from z f = sin z
+    const T t0 = s * iz;
+    const T t1 = (c - t0) * iz;
+    const T t2 = (-s - T(2) * t1) * iz;
+    const T t3 = (-c - T(3) * t2) * iz;
+    const T t4 = (s - T(4) * t3) * iz;
+    g[0] = t0; g[1] = t1; g[2] = t2 / T(2); g[3] = t3 / T(6); g[4] = t4 / T(24);
+  }
+  T f[5];
+  T pk = T(1);
+  for (int k = 0; k < 5; ++k) { f[k] = g[k] * pk; pk *= PI; }      // chain rule of z = pi a
+  return compose(a, f);
+}
+
+struct JetArgs {
+  int kernel, p, d, n, m;
+  int fx, fy, ax, by;          // field differentiated on each side (-1: none) and the orders (0 .. 2)
+  int has_loc, has_scale, xy, posabs;
+  double loc, scale, factor;   // factor: the product of the multiplicative output operations (added constants drop out of a derivative)
+  double par[8];
+  double coef[5][24];          // Maternp: R_k as Laurent polynomials in t, entry i the coefficient of t^(i - 7);  Wendland: row 0 = the
+                               // polynomial, highest power first
+  long ldx, ldy, ldo;
+};
+
+template <typename T, typename S>
+__device__ __forceinline__ S jet_core(const JetArgs &g, const S &r2, const S &X, const S &Y) {
+  // r2: squared distance over the fields (isotropic kernels); X, Y: the two (transformed) coordinates of one-variable kernels;
+  // stationary kernels of one variable take delta = X - Y
+  const int k = g.kernel;
+  if (k == LGP_KERNEL_EXPQUAD) return jexp(T(-0.5) * r2);
+  if (k == LGP_KERNEL_GAMMAEXP) return jexp(-r2);                                    // gamma = 2 only (the host refuses the others)
+  if (k == LGP_KERNEL_CAUCHY) return jpow(T(1) + r2 * T(1. / g.par[1]), T(g.par[2])); // alpha = 2: (1 + r2 / beta)^(-beta / 2)
+  if (k == LGP_KERNEL_MATERNP) {
+    // s = (2p+1) r2, t = sqrt(s): f^(k)(s) = e^-t R_k(t), R_k a Laurent polynomial (negative powers beyond the p-th derivative:
+    // they meet the matching powers of the nilpotent part, which carries delta^2 ~ t^2 per order, and the products stay finite)
+    const S s = T(2 * g.p + 1) * r2;
+    const T t = sqrt(s.val() + T(1e-30)), e = exp(-t), it = T(1) / t;
+    T f[5];
+    T fact = T(1);
+    for (int q = 0; q < 5; ++q) {
+      T poly = T(g.coef[q][23]);
+      for (int i = 22; i >= 7; --i) poly = poly * t + T(g.coef[q][i]);
+      T neg = T(0);
+      for (int i = 0; i < 7; ++i) neg = neg * it + T(g.coef[q][i]);     // t^-7 .. t^-1: Horner in 1 / t, lowest power first
+      f[q] = e * (poly + neg * it) / fact;
+      fact *= T(q + 1);
+    }
+    return compose(s, f);
+  }
+  if (k == LGP_KERNEL_CONSTANT) return S(T(1));
+  if (k == LGP_KERNEL_LINEAR) return r2;                                             // (r2 carries sum_f X_f Y_f for this kernel)
+  const S delta = X - Y;
+  if (k == LGP_KERNEL_COS) return jcos(delta);
+  if (k == LGP_KERNEL_PERIODIC) {
+    const S q = jsin(T(0.5) * delta) * T(1. / g.par[0]);
+    return jexp(T(-2) * (q * q));
+  }
+  if (k == LGP_KERNEL_SINC) return jsinc(delta);
+  if (k == LGP_KERNEL_CELERITE) {                                                    // B = gamma (derivable once)
+    const S a = jabs(delta);
+    return jexp(T(-g.par[0]) * a) * (jcos(a) + T(g.par[1]) * jsin(a));
+  }
+  if (k == LGP_KERNEL_HARMONIC) {
+    const S tau = jabs(delta), tauQ = tau * T(1. / g.par[0]);
+    if (g.p == 0) {
+      const S pexp = jexp(T(g.par[2]) * tauQ), mexp = jexp(T(-(1. + g.par[1])) * tauQ);
+      return T(0.5) * (pexp + mexp + (pexp - mexp) * T(1. / g.par[1]));
+    } else if (g.p == 1) {
+      const S et = T(g.par[1]) * tauQ;
+      return jexp(-tauQ) * (jcosh(et) + jsinh(et) * T(1. / g.par[1]));
+    } else if (g.p == 2) {
+      return (T(1) + tauQ) * jexp(-tauQ) + jexp(-tauQ) * (T(1. - g.par[0]) * (tau * tau) * (T(1) + tau * T(1. / 3.)));
+    } else {
+      const S et = T(g.par[1]) * tauQ;
+      return jexp(-tauQ) * (jcos(et) + jsin(et) * T(1. / g.par[1]));
+    }
+  }
+  if (k == LGP_KERNEL_WENDLAND) {                                                    // one-dimensional points: r = |delta| + eps
+    const S r = jabs(delta) + (sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-07f));
+    S poly(T(g.coef[0][0]));
+    for (int i = 1; i <= g.p; ++i) poly = poly * r + T(g.coef[0][i]);
+    return jpow(T(1) - r, T(g.par[0])) * poly;
+  }
+  if (k == LGP_KERNEL_CIRCULAR) {
+    const S a = jabs(delta) + (sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-07f));
+    const S x = a - floor(a.val());
+    const S t = jmin(x, T(1) - x);
+    return (T(1) + t * T(g.par[0] / g.par[1])) * jpow(T(1) - t * T(1. / g.par[1]), T(g.par[0]));
+  }
+  if (k == LGP_KERNEL_DECAYING) return jpow(X + Y + T(1), T(-g.par[0]));
+  if (k == LGP_KERNEL_WIENERINTEGRAL) {
+    const S a = jmin(X, Y), b = jmax(X, Y);
+    return T(0.5) * (a * a) * (b - a * T(1. / 3.));
+  }
+  if (k == LGP_KERNEL_FRACBROWNIAN) return X * Y;                                    // H = 1, K = 1: (x^2 + y^2 - (x - y)^2) / 2
+  if (k == LGP_KERNEL_STATIONARYFRACBROWNIAN) return S(T(1));                        // H = 1: ((d+1)^2 + (d-1)^2 - 2 d^2) / 2
+  return S(T(NAN));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gram_jet_kernel(const T *__restrict__ x, const T *__restrict__ y, T *out, JetArgs g) {
+  typedef Jet<T> S;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)g.n * g.m) return;
+  const int i = (int)(idx / g.m), j = (int)(idx % g.m);
+  const T sc = g.has_scale ? T(g.scale) : T(1), lc = g.has_loc ? T(g.loc) : T(0);
+  S r2(T(0)), X(T(0)), Y(T(0));
+  for (int f = 0; f < g.d; ++f) {
+    // the reference transforms each argument: (x - loc) / scale (_Kernel/_ops.py:292-326), true division
+    T xv = x[(long)f * g.ldx + i], yv = y[(long)f * g.ldy + j];
+    if (g.has_loc) { xv -= lc; yv -= lc; }
+    if (g.has_scale) { xv /= sc; yv /= sc; }
+    S xf(xv), yf(yv);
+    if (f == g.fx) xf.c[1][0] = T(1);            // u: the perturbation of x along its field (in transformed units)
+    if (f == g.fy) yf.c[0][1] = T(1);            // v: of y
+    if (g.xy == 2) {
+      r2 = r2 + xf * yf;
+    } else {
+      S df = xf - yf;
+      if (g.posabs) df = jabs(df) + (sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-07f));
+      r2 = r2 + df * df;
+    }
+    if (f == 0) { X = xf; Y = yf; }
+  }
+  const S v = jet_core<T, S>(g, r2, X, Y);
+  const T fact[3] = {T(1), T(1), T(2)};
+  // chain rule of the transformation: 1 / scale per derivative
+  T chain = T(g.factor);
+  for (int q = 0; q < g.ax + g.by; ++q) chain /= sc;
+  out[(long)i * g.ldo + j] = v.c[g.ax][g.by] * fact[g.ax] * fact[g.by] * chain;
+}
+
+template <typename T>
+int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, int ncoef, const T *hcoef, int d, const T *dx, size_t ldx, size_t n,
+                    const T *dy, size_t ldy, size_t m, int has_loc, T loc, int has_scale, T scale, T factor, int fx, int ax, int fy, int by, T *dout,
+                    size_t ldo) {
+  LGP_REQUIRE(ctx != nullptr && (n == 0 || m == 0 || (dx != nullptr && dy != nullptr && dout != nullptr)), "null pointer");
+  LGP_REQUIRE(d >= 1 && d <= 64 && npar >= 0 && npar <= 8 && (npar == 0 || hpar != nullptr), "bad kernel parameters");
+  LGP_REQUIRE(ax >= 0 && ax <= 2 && by >= 0 && by <= 2 && fx >= -1 && fx < d && fy >= -1 && fy < d, "derivative orders 0 .. 2 along one field per side");
+  LGP_REQUIRE((ax == 0 || fx >= 0) && (by == 0 || fy >= 0), "a derivative needs its field");
+  LGP_REQUIRE(!has_scale || (scale > T(0) && scale < T(INFINITY)), "scale must be positive and finite");
+  LGP_REQUIRE(ncoef >= 0 && ncoef <= 5 * 24 && (ncoef == 0 || hcoef != nullptr), "bad coefficient table");
+  const bool onevar = kernel == LGP_KERNEL_COS || kernel == LGP_KERNEL_PERIODIC || kernel == LGP_KERNEL_SINC || kernel == LGP_KERNEL_CELERITE ||
+                      kernel == LGP_KERNEL_HARMONIC || kernel == LGP_KERNEL_WENDLAND || kernel == LGP_KERNEL_CIRCULAR || kernel == LGP_KERNEL_DECAYING ||
+                      kernel == LGP_KERNEL_WIENERINTEGRAL || kernel == LGP_KERNEL_FRACBROWNIAN || kernel == LGP_KERNEL_STATIONARYFRACBROWNIAN;
+  const bool iso = kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY || kernel == LGP_KERNEL_MATERNP ||
+                   kernel == LGP_KERNEL_CONSTANT || kernel == LGP_KERNEL_LINEAR;
+  LGP_REQUIRE(onevar || iso, "no derivative core for this kernel");
+  LGP_REQUIRE(!onevar || d == 1, "a kernel of one variable takes one-dimensional points");
+  LGP_REQUIRE(kernel != LGP_KERNEL_MATERNP || (p >= 0 && p <= 16 && ncoef == 5 * 24), "Maternp: order 0 .. 16 and the five polynomials");
+  LGP_REQUIRE(kernel != LGP_KERNEL_WENDLAND || (p >= 0 && p <= 16 && ncoef >= p + 1), "Wendland: the polynomial");
+  if (n == 0 || m == 0) return LGP_OK;
+  LGP_REQUIRE(ldx >= n && ldy >= m && ldo >= m && n * m < (size_t(1) << 40), "bad dimensions");
+  DeviceGuard dg(ctx->device);
+  JetArgs g;
+  memset(&g, 0, sizeof(g));
+  g.kernel = kernel; g.p = p; g.d = d; g.n = (int)n; g.m = (int)m;
+  g.fx = ax ? fx : -1; g.fy = by ? fy : -1; g.ax = ax; g.by = by;
+  g.has_loc = has_loc; g.has_scale = has_scale; g.loc = (double)loc; g.scale = (double)scale; g.factor = (double)factor;
+  g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : 0;
+  g.posabs = 0;
+  for (int i = 0; i < npar; ++i) g.par[i] = (double)hpar[i];
+  for (int i = 0; i < ncoef; ++i) g.coef[i / 24][i % 24] = (double)hcoef[i];
+  g.ldx = (long)ldx; g.ldy = (long)ldy; g.ldo = (long)ldo;
+  const size_t total = n * m;
+  hipLaunchKernelGGL((gram_jet_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dx, dy, dout, g);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
+}  // namespace
+
+extern "C" int lgp_gram_deriv_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int ncoef, const double *hcoef, int d, const double *dx,
+                                  size_t ldx, size_t n, const double *dy, size_t ldy, size_t m, int has_loc, double loc, int has_scale, double scale,
+                                  double factor, int fx, int ax, int fy, int by, double *dout, size_t ldo) {
+  return gram_jet_launch<double>(ctx, kernel, p, npar, hpar, ncoef, hcoef, d, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, factor, fx, ax, fy, by,
+                                 dout, ldo);
+}
+extern "C" int lgp_gram_deriv_f32(lgp_ctx *ctx, int kernel, int p, int npar, const float *hpar, int ncoef, const float *hcoef, int d, const float *dx,
+                                  size_t ldx, size_t n, const float *dy, size_t ldy, size_t m, int has_loc, float loc, int has_scale, float scale,
+                                  float factor, int fx, int ax, int fy, int by, float *dout, size_t ldo) {
+  return gram_jet_launch<float>(ctx, kernel, p, npar, hpar, ncoef, hcoef, d, dx, ldx, n, dy, ldy, m, has_loc, loc, has_scale, scale, factor, fx, ax, fy, by,
+                                dout, ldo);
+}

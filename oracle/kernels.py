@@ -56,6 +56,11 @@ def sum_recurse_dtype(fun, x, y):
     return acc
 
 
+def _sp():
+    import sympy
+    return sympy
+
+
 # --------------------------------------------------------------------------
 # kernel objects
 
@@ -127,6 +132,11 @@ class Kernel:
         if not da and not db:
             return self
         kind = getattr(self._core, 'closed_form', None)
+        if kind == 'maternp' and (set(da) | set(db)) != {None}:
+            kind = None                                             # along named fields: the symbolic route (the closed form below is 1-D)
+        if kind is None and getattr(self._core, 'symbolic', None) is not None:
+            from .symdiff import symbolic_diff                      # sympy + mpmath: the cores with an elementary expression
+            return symbolic_diff(self, da, db, Kernel)
         if kind is None:
             raise NotImplementedError('derivatives in closed form for ExpQuad and Maternp only')
         scale = 1. if self._scale is None else self._scale
@@ -254,11 +264,15 @@ def ExpQuad(*, scale=None, loc=None, dim=None):
 
 
 def GammaExp(*, gamma=1, scale=None, loc=None, dim=None):
-    return Kernel(_isotropic(lambda r2: gammaexp_core(r2, gamma)), scale=scale, loc=loc, dim=dim)
+    core_ = _isotropic(lambda r2: gammaexp_core(r2, gamma))
+    core_.symbolic = ('iso', lambda r2: _sp().exp(-r2)) if gamma == 2 else None                    # derivable iff gamma = 2 (_basic.py:94)
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def Cauchy(*, alpha=2, beta=2, scale=None, loc=None, dim=None):
-    return Kernel(_isotropic(lambda r2: cauchy_core(r2, alpha, beta)), scale=scale, loc=loc, dim=dim)
+    core_ = _isotropic(lambda r2: cauchy_core(r2, alpha, beta))
+    core_.symbolic = ('iso', lambda r2: (1 + r2 / beta) ** (-_sp().Float(beta, 30) / 2)) if alpha == 2 else None       # derivable iff alpha = 2 (_basic.py:312-315)
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def Maternp(*, p=None, scale=None, loc=None, dim=None):
@@ -266,6 +280,15 @@ def Maternp(*, p=None, scale=None, loc=None, dim=None):
     core = _isotropic(lambda r2: maternp_core(r2, p))
     core.closed_form = 'maternp'
     core.p = p
+
+    def sym(r2):                                             # exp(-t) P_p(t), t = sqrt((2p+1) r2): along named fields (symdiff.py)
+        sp = _sp()
+        t = sp.sqrt((2 * p + 1) * r2)
+        poly = sp.Integer(1)
+        for k in reversed(range(p)):
+            poly = 1 + poly * sp.Rational(p - k, (2 * p - k) * (k + 1)) * 2 * t
+        return sp.exp(-t) * poly
+    core.symbolic = ('iso', sym)
     return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
@@ -332,6 +355,11 @@ def Wendland(*, k=0, alpha=1, scale=None, loc=None, dim=None):
         if x.dtype.names is not None and len(_leaf_columns_count(x.dtype)) > maxdim:
             raise ValueError(f'kernel called on type with dimensionality > maxdim={maxdim}')
         return inner(x, y)
+    def sym(a):                                              # one-dimensional points: r = |difference|
+        sp = _sp()
+        poly = sum(sp.Float(float(cf), 30) * a ** (len(coeffs) - 1 - i) for i, cf in enumerate(coeffs))
+        return (1 - a) ** sp.Float(nu + k, 30) * poly
+    checked.symbolic = ('abs', sym, 1.)
     return Kernel(checked, scale=scale, loc=loc, dim=dim)
 
 
@@ -350,6 +378,7 @@ def Constant(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:34-46`` """
     def core(x, y):
         return numpy.ones(numpy.broadcast_shapes(x.shape, y.shape))
+    core.symbolic = ('iso', lambda r2: _sp().Integer(1) + 0 * r2)
     return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
@@ -410,12 +439,16 @@ def HoleEffect(*, scale=None, loc=None, dim=None):
 def Periodic(*, outerscale=1, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:187-208`` """
     assert 0 < outerscale < numpy.inf
-    return Kernel(_stationary1d(lambda d: numpy.exp(-2 * (numpy.sin(d / 2) / outerscale) ** 2)), scale=scale, loc=loc, dim=dim)
+    core_ = _stationary1d(lambda d: numpy.exp(-2 * (numpy.sin(d / 2) / outerscale) ** 2))
+    core_.symbolic = ('delta', lambda d: _sp().exp(-2 * (_sp().sin(d / 2) / outerscale) ** 2))
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def Cos(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_spectral.py:25-38`` """
-    return Kernel(_stationary1d(numpy.cos), scale=scale, loc=loc, dim=dim)
+    core_ = _stationary1d(numpy.cos)
+    core_.symbolic = ('delta', lambda d: _sp().cos(d))
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def sinc(x):
@@ -429,20 +462,26 @@ def sinc(x):
 
 def Sinc(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_spectral.py:113-122`` """
-    return Kernel(_stationary1d(sinc, 'posabs'), scale=scale, loc=loc, dim=dim)
+    core_ = _stationary1d(sinc, 'posabs')
+    core_.symbolic = ('delta', lambda d: _sp().sin(_sp().pi * d) / (_sp().pi * d))
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def StationaryFracBrownian(*, H=1/2, scale=None, loc=None, dim=None):
     """ ``_kernels/_randomwalk.py:156-172`` """
     assert 0 < H <= 1, H
     H2 = 2 * H
-    return Kernel(_stationary1d(lambda d: 1/2 * (numpy.abs(d + 1) ** H2 + numpy.abs(d - 1) ** H2 - 2 * numpy.abs(d) ** H2)), scale=scale, loc=loc, dim=dim)
+    core_ = _stationary1d(lambda d: 1/2 * (numpy.abs(d + 1) ** H2 + numpy.abs(d - 1) ** H2 - 2 * numpy.abs(d) ** H2))
+    core_.symbolic = ('delta', lambda d: _sp().Integer(1) + 0 * d) if H == 1 else None
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def Celerite(*, gamma=1, B=0, scale=None, loc=None, dim=None):
     """ ``_kernels/_celerite.py:34-52`` """
     assert 0 <= gamma < numpy.inf and abs(B) <= gamma
-    return Kernel(_stationary1d(lambda d: numpy.exp(-gamma * d) * (numpy.cos(d) + B * numpy.sin(d)), 'abs'), scale=scale, loc=loc, dim=dim)
+    core_ = _stationary1d(lambda d: numpy.exp(-gamma * d) * (numpy.cos(d) + B * numpy.sin(d)), 'abs')
+    core_.symbolic = ('abs', lambda a: _sp().exp(-gamma * a) * (_sp().cos(a) + B * _sp().sin(a)))
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def Harmonic(*, Q=1, scale=None, loc=None, dim=None):
@@ -470,7 +509,25 @@ def Harmonic(*, Q=1, scale=None, loc=None, dim=None):
             tauQ = tau / Q
             etatau = etaQ * tauQ
             return numpy.exp(-tauQ) * (numpy.cos(etatau) + numpy.sin(etatau) / etaQ)
-    return Kernel(_stationary1d(core), scale=scale, loc=loc, dim=dim)
+
+    def sym(a):
+        sp = _sp()
+        Qs = sp.Float(Q, 30)
+        tq = a / Qs
+        if Q < 1/2:
+            e = sp.sqrt((1 - Qs) * (1 + Qs))
+            pexp, mexp = sp.exp((sp.sqrt(1 - Qs ** 2) - 1) * tq), sp.exp(-(1 + e) * tq)
+            return (pexp + mexp + (pexp - mexp) / e) / 2
+        if Q < 1:
+            e = sp.sqrt(1 - Qs ** 2)
+            return sp.exp(-tq) * (sp.cosh(e * tq) + sp.sinh(e * tq) / e)
+        if Q == 1:
+            return (1 + a) * sp.exp(-a)
+        e = sp.sqrt(Qs ** 2 - 1)
+        return sp.exp(-tq) * (sp.cos(e * tq) + sp.sin(e * tq) / e)
+    core_ = _stationary1d(core)
+    core_.symbolic = ('abs', sym)
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def Circular(*, tau=4, c=1/2, scale=None, loc=None, dim=None):
@@ -481,7 +538,9 @@ def Circular(*, tau=4, c=1/2, scale=None, loc=None, dim=None):
         x = delta % 1
         t = numpy.minimum(x, 1 - x)
         return (1 + tau * t / c) * numpy.maximum(1 - t / c, 0) ** tau
-    return Kernel(_stationary1d(core, 'posabs'), scale=scale, loc=loc, dim=dim)
+    core_ = _stationary1d(core, 'posabs')
+    core_.symbolic = ('circ', lambda t: (1 + tau * t / c) * (1 - t / c) ** _sp().Float(tau, 30), c)
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def Taylor(*, scale=None, loc=None, dim=None):
@@ -828,7 +887,9 @@ def NNKernel(*, sigma0=1, scale=None, loc=None, dim=None):
 
 def Linear(*, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:76-91`` """
-    return Kernel(lambda x, y: sum_recurse_dtype(lambda a, b: a * b, x, y), scale=scale, loc=loc, dim=dim)
+    core_ = lambda x, y: sum_recurse_dtype(lambda a, b: a * b, x, y)
+    core_.symbolic = ('xy', lambda X, Y, upper: X * Y)            # (derivatives along the variable of one-dimensional points)
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def _onevariable(core, lo=0., hi=numpy.inf):
@@ -862,7 +923,9 @@ def BrownianBridge(*, scale=None, loc=None, dim=None):
 def Decaying(*, alpha=1, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:362-379`` """
     assert alpha >= 0
-    return Kernel(_onevariable(lambda x, y: 1 / (x + y + 1) ** alpha), scale=scale, loc=loc, dim=dim)
+    core_ = _onevariable(lambda x, y: 1 / (x + y + 1) ** alpha)
+    core_.symbolic = ('xy', lambda X, Y, upper: (X + Y + 1) ** (-_sp().Float(alpha, 30)))
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def FracBrownian(*, H=1/2, K=1, scale=None, loc=None, dim=None):
@@ -870,7 +933,9 @@ def FracBrownian(*, H=1/2, K=1, scale=None, loc=None, dim=None):
     assert 0 < H <= 1 and 0 < K <= 1
     H2 = 2 * H
     core = lambda x, y: 1 / 2 ** K * ((numpy.abs(x) ** H2 + numpy.abs(y) ** H2) ** K - numpy.abs(x - y) ** (H2 * K))
-    return Kernel(_onevariable(core, -numpy.inf, numpy.inf), scale=scale, loc=loc, dim=dim)
+    core_ = _onevariable(core, -numpy.inf, numpy.inf)
+    core_.symbolic = ('xy', lambda X, Y, upper: X * Y) if (H, K) == (1, 1) else None      # (x^2 + y^2 - (x - y)^2) / 2
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def WienerIntegral(*, scale=None, loc=None, dim=None):
@@ -878,7 +943,9 @@ def WienerIntegral(*, scale=None, loc=None, dim=None):
     def core(x, y):
         a, b = numpy.minimum(x, y), numpy.maximum(x, y)
         return 1/2 * a ** 2 * (b - a / 3)
-    return Kernel(_onevariable(core), scale=scale, loc=loc, dim=dim)
+    core_ = _onevariable(core)
+    core_.symbolic = ('xy', lambda X, Y, upper: (X ** 2 * (Y - X / 3) / 2) if upper else (Y ** 2 * (X - Y / 3) / 2))
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 # --------------------------------------------------------------------------

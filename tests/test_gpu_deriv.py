@@ -74,8 +74,10 @@ def test_posterior_with_derivative_data_vs_oracle(lgp):
 
 def test_what_is_not_available_says_so(lgp):
     x = np.linspace(0, 1, 5)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                                             # not derivable: the reference's error (_Kernel/_ops.py:85-90)
         lgp.GP(lgp.GammaExp(gamma=1.2)).addx(x, 'a', deriv=1).prior('a', raw=True)
+    with pytest.raises(NotImplementedError):                                     # derivable in the reference, no derivative core here yet
+        lgp.GP(lgp.Matern(nu=2.3)).addx(x, 'a', deriv=1).prior('a', raw=True)
     with pytest.raises(ValueError):
         lgp.GP(lgp.Maternp(p=1)).addx(x, 'a', deriv=2).prior('a', raw=True)     # derivable p times on each side
     with pytest.raises(ValueError):
@@ -185,3 +187,100 @@ def test_addlintransf_on_the_device(lgp):
     gd.addlintransf(lambda u: u + 1, ['a'], 'affine', checklin=False)
     with pytest.raises(KeyError):
         gd.addlintransf(lambda u: u, ['zzz'], 'q')
+
+
+# ---- derivatives of the other derivable kernels (VERDICT r03 "missing" 2): the device evaluates the core in truncated Taylor
+# arithmetic (csrc/gram_jet.hip), the oracle differentiates its expression symbolically and evaluates in extended precision
+# (oracle/symdiff.py); nothing is shared between the two.
+
+def _jet_cases(mod):
+    return {
+        'periodic': mod.Periodic(outerscale=0.8, scale=1.3, loc=0.2) * 1.4 + 0.3,
+        'cos': mod.Cos(scale=0.7) * 0.9,
+        'sinc': mod.Sinc(scale=1.1),
+        'celerite': mod.Celerite(gamma=0.6, B=0.6, scale=1.5) * 2.,
+        'harmonic_q03': mod.Harmonic(Q=0.3), 'harmonic_q08': mod.Harmonic(Q=0.8, scale=0.9), 'harmonic_q1': mod.Harmonic(Q=1),
+        'harmonic_q17': mod.Harmonic(Q=1.7, scale=1.2),
+        'circular': mod.Circular(tau=5, c=0.4, scale=2.),
+        'wendland_k1': mod.Wendland(k=1, alpha=1.2, scale=2.5), 'wendland_k2': mod.Wendland(k=2, alpha=1.5, scale=2.5) * 1.1,
+        'decaying': mod.Decaying(alpha=1.5, scale=1.3),
+        'wienerintegral': mod.WienerIntegral(scale=0.8),
+        'cauchy2': mod.Cauchy(alpha=2, beta=3., scale=1.2) * 1.5,
+        'gammaexp2': mod.GammaExp(gamma=2, scale=0.9),
+        'constant': mod.Constant() * 2.,
+        'fracbrownian11': mod.FracBrownian(H=1, K=1),
+        'stationaryfracbrownian1': mod.StationaryFracBrownian(H=1),
+    }
+
+
+# kernel -> how often the PROCESS is derivable (the reference's `derivable=`): orders above it must be refused
+_ONCE = {'celerite', 'harmonic_q03', 'harmonic_q08', 'harmonic_q1', 'harmonic_q17', 'circular', 'wendland_k1', 'wienerintegral'}
+
+
+@pytest.mark.parametrize('name', sorted(_jet_cases(oracle)))
+def test_derived_gram_of_the_other_kernels_vs_oracle(lgp, name):
+    rng = np.random.default_rng(sum(map(ord, name)))
+    x = rng.uniform(0.1, 3, 23)
+    y = rng.uniform(0.1, 3, 31)
+    y[:6] = x[:6]                                              # coincident points: the diagonal of a derivative block
+    kd, ko = _jet_cases(lgp)[name], _jet_cases(oracle)[name]
+    # order 0 through the derivative core too: it restates the cores of csrc/gram.hip in Taylor arithmetic
+    orders = [(1, 0), (0, 1), (1, 1)] + ([] if name in _ONCE else [(2, 0), (2, 1), (1, 2), (2, 2)])
+    for a, b in orders:
+        got = kd.gram(x, y, deriv=(a, b)).to_host()
+        want = ko.diff(a, b)(x[:, None], y[None, :])
+        scale = max(np.abs(want).max(), 1e-3)
+        # (coincident points: the oracle takes the limit from an offset of 1e-10, 1e-12 at removable singularities)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-9 * scale, err_msg=f'{name} {(a, b)}')
+        far = np.abs(x[:, None] - y[None, :]) > 1e-6
+        np.testing.assert_allclose(got[far], want[far], rtol=0, atol=1e-12 * scale, err_msg=f'{name} {(a, b)} away from coincidences')
+    if name in _ONCE:
+        with pytest.raises(ValueError):
+            kd.gram(x, y, deriv=(2, 0))                        # _Kernel/_ops.py:85-90: more derivatives than the process has
+
+
+@pytest.mark.parametrize('p', [1, 2, 3])
+def test_maternp_derivatives_along_named_fields_vs_oracle(lgp, p):
+    """ Maternp over several fields, derived along named ones (one per side): `lgp_gram_deriv` with the host-derived Laurent
+    polynomials R_k against the oracle's symbolic route, coincident points included """
+    rng = np.random.default_rng(40 + p)
+    dt = [('a', float), ('b', float), ('c', float)]
+    x = np.empty(17, dt); y = np.empty(13, dt)
+    for f in 'abc':
+        x[f] = rng.uniform(0, 2, 17); y[f] = rng.uniform(0, 2, 13)
+    y[:4] = x[:4]
+    kd, ko = lgp.Maternp(p=p, scale=1.3) * 1.2, oracle.Maternp(p=p, scale=1.3) * 1.2
+    specs = [(('a', 1), ('b', 1)), (('a', 1), ('a', 1)), (('c', 1), None)]
+    if p >= 2:
+        specs += [(('a', 2), ('a', 2)), (('b', 2), ('c', 1)), (None, ('b', 2))]
+    for sx, sy in specs:
+        names = x.dtype.names
+        ox = tuple((sx[1] if sx and nm == sx[0] else 0) for nm in names)
+        oy = tuple((sy[1] if sy and nm == sy[0] else 0) for nm in names)
+        got = kd.gram(x, y, deriv=(ox, oy)).to_host()
+        want = ko.diff({sx[0]: sx[1]} if sx else 0, {sy[0]: sy[1]} if sy else 0)(x[:, None], y[None, :])
+        scale = max(np.abs(want).max(), 1e-3)
+        np.testing.assert_allclose(got, want, rtol=0, atol=3e-9 * scale, err_msg=f'p={p} {sx} {sy}')
+    with pytest.raises(ValueError):
+        kd.gram(x, y, deriv=((p + 1, 0, 0), (0, 0, 0)))             # derivable p times per side (_kernels/_matern.py:26-27)
+
+
+def test_posterior_with_derivative_data_of_a_periodic_process(lgp):
+    """ values and slopes of a periodic function observed together (GP.addx(..., deriv=1) with the Periodic kernel), the function
+    and its slope predicted: device against oracle """
+    rng = np.random.default_rng(8)
+    x = np.sort(rng.uniform(0, 2 * np.pi, 25))
+    xs = np.linspace(0, 2 * np.pi, 18)
+    y, dy = np.sin(x) + 0.5 * np.sin(2 * x), np.cos(x) + np.cos(2 * x)
+
+    def run(mod):
+        gp = (mod.GP(mod.Periodic(outerscale=1.2) * 1.5, checkpos=False, checksym=False)
+              .addx(x, 'f').addx(x, 'df', deriv=1).addx(xs, 'g').addx(xs, 'dg', deriv=1))
+        noise = {(a, b): (1e-4 * np.eye(25) if a == b else np.zeros((25, 25))) for a in ('f', 'df') for b in ('f', 'df')}
+        return gp.predfromdata({'f': y, 'df': dy}, ['g', 'dg'], noise, raw=True)
+    (md, cd), (mo, co) = run(lgp), run(oracle)
+    for k in mo:
+        np.testing.assert_allclose(md[k], mo[k], rtol=0, atol=1e-7)
+    for k in co:
+        np.testing.assert_allclose(cd[k], co[k], rtol=0, atol=1e-8)
+    assert np.max(np.abs(md['dg'] - (np.cos(xs) + np.cos(2 * xs)))) < 0.05         # it does predict the slope
