@@ -489,10 +489,22 @@ int lgp_comm_info(lgp_ctx *ctx, int *rank, int *nranks, int *transport);
 /* Alternative transport (bring your own collective, e.g. MPI or gloo; also how the multi-rank schedule is tested on
  * a single GPU): lgp_bcast / lgp_allreduce_* then stage the buffer through host memory on the context's current
  * stream and call fn(user, op, host_buffer, count, root), op 0 = broadcast `count` bytes from `root`, 1 = all-reduce
- * sum of `count` doubles, 2 = all-reduce max of `count` doubles; fn returns 0 on success. */
+ * sum of `count` doubles, 2 = all-reduce max of `count` doubles; fn returns 0 on success.  Only when asked to by
+ * lgp_comm_set_bcast(ctx, 2, .): op 5 = point to point, `count` bytes from rank (root & 0xffff) to rank (root >> 16); EVERY
+ * rank is called with every transfer, in the same order, and a rank that is neither end leaves hbuf alone. */
 int lgp_comm_init_host(lgp_ctx *ctx, int rank, int nranks, int (*fn)(void *user, int op, void *hbuf, size_t count, int root),
                        void *user);
-int lgp_bcast(lgp_ctx *ctx, void *dbuf, size_t bytes, int root);        /* ncclBroadcast on the ctx stream */
+/* Broadcast on the ctx stream.  With three or more ranks a large buffer travels as scatter + all-gather over the pairwise
+ * xGMI links: the root sends one of nranks - 1 chunks to each peer, the peers exchange them (two groups of ncclSend /
+ * ncclRecv), 2 S / ((G - 1) B_link) instead of the S / B_link of a broadcast that crosses one link per GPU.
+ * lgp_comm_set_bcast: algo 0 = auto (RCCL: as above from min_bytes on, default 1 MiB; host transport: its own op 0),
+ * 1 = always the transport's broadcast, 2 = always scatter + all-gather (>= 3 ranks).  Env LGP_BCAST_ALGO=auto|plain|scatter
+ * and LGP_BCAST_MIN_BYTES set a new context's values.  lgp_bcast_plan (host only): the transfers of such a broadcast, four
+ * values each (source, destination, byte offset, length), the *nscatter transfers of the first group first; returns their
+ * number (negative: error). */
+int lgp_bcast(lgp_ctx *ctx, void *dbuf, size_t bytes, int root);
+int lgp_comm_set_bcast(lgp_ctx *ctx, int algo, size_t min_bytes);
+long lgp_bcast_plan(size_t bytes, int nranks, int root, unsigned long long *xfers, size_t capacity, size_t *nscatter);
 int lgp_allreduce_sum_f64(lgp_ctx *ctx, double *dbuf, size_t count);
 int lgp_allreduce_max_f64(lgp_ctx *ctx, double *dbuf, size_t count);
 

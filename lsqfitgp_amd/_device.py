@@ -94,14 +94,16 @@ class Context:
         _lib.check(self._lib.lgp_comm_init(self._handle, int(rank), int(nranks), buf), 'lgp_comm_init')
         self.rank, self.nranks = int(rank), int(nranks)
 
-    def comm_init_host(self, rank, nranks, collective):
+    def comm_init_host(self, rank, nranks, collective, sendrecv=False):
         """ alternative transport: ``collective(op, array, root)`` performs the collective in place on a host numpy
-        view (op 0: broadcast of a uint8 array from ``root``; 1 / 2: all-reduce sum / max of a float64 array) """
+        view (op 0: broadcast of a uint8 array from ``root``; 1 / 2: all-reduce sum / max of a float64 array).
+        ``sendrecv=True``: the transport also moves bytes between two ranks (op 5: from rank ``root & 0xffff`` to rank
+        ``root >> 16``, called on every rank), and broadcasts travel as scatter + all-gather (`comm_set_bcast('scatter')`) """
         import numpy
 
         def trampoline(user, op, hbuf, count, root):
             try:
-                if op == 0:
+                if op in (0, 5):
                     arr = numpy.ctypeslib.as_array((ctypes.c_ubyte * count).from_address(hbuf))
                 else:
                     arr = numpy.ctypeslib.as_array((ctypes.c_double * count).from_address(hbuf))
@@ -117,6 +119,26 @@ class Context:
         _lib.check(self._lib.lgp_comm_init_host(self._handle, int(rank), int(nranks), ctypes.cast(self._hostcb, ctypes.c_void_p), None),
                    'lgp_comm_init_host')
         self.rank, self.nranks = int(rank), int(nranks)
+        if sendrecv:
+            self.comm_set_bcast('scatter')
+
+    def comm_set_bcast(self, algo='auto', min_bytes=1 << 20):
+        """ how `lgp_bcast` moves a buffer: 'auto' | 'plain' | 'scatter' (see include/lsqfitgp_hip.h) """
+        _lib.check(self._lib.lgp_comm_set_bcast(self._handle, {'auto': 0, 'plain': 1, 'scatter': 2}[algo], int(min_bytes)), 'lgp_comm_set_bcast')
+
+    @staticmethod
+    def bcast_plan(nbytes, nranks, root):
+        """ the transfers of a scatter + all-gather broadcast: (scatter, gather), lists of (src, dst, offset, length) """
+        import numpy
+        lib = _lib.load()
+        ns = ctypes.c_size_t()
+        cnt = lib.lgp_bcast_plan(int(nbytes), int(nranks), int(root), None, 0, ctypes.byref(ns))
+        if cnt < 0:
+            _lib.check(int(cnt), 'lgp_bcast_plan')
+        buf = numpy.zeros((max(cnt, 1), 4), numpy.uint64)
+        lib.lgp_bcast_plan(int(nbytes), int(nranks), int(root), buf.ctypes.data, int(cnt), ctypes.byref(ns))
+        rows = [tuple(int(v) for v in r) for r in buf[:cnt]]
+        return rows[:ns.value], rows[ns.value:]
 
     def comm_info(self):
         """ (rank, number of ranks, transport) as the communicator reports them; transport 'none' | 'rccl' | 'host' """

@@ -27,6 +27,8 @@ backend in ``tests/test_dist_gloo.py``).
 
 import ctypes
 
+import os
+
 import numpy
 
 from . import _lib
@@ -395,7 +397,8 @@ class DistributedChol:
         # ---- factorisation: the whole look-ahead schedule inside the library
         ldp = nb + self.PANEL_PAD
         _, nslots, self.slab = dist_plan(n, nb, nx, L.nranks)
-        self._panels = DeviceArray.empty((nslots * (n + nx) * ldp,), numpy.float64, self.ctx)
+        # (without peers nothing is packed or sent: the library takes no slots then)
+        self._panels = DeviceArray.empty((nslots * (n + nx) * ldp if L.nranks > 1 or os.environ.get('LGP_DIST_FORCE_COMM') else 1,), numpy.float64, self.ctx)
         info = ctypes.c_int()
         _lib.check(lib.lgp_chol_factor_dist_f64(h, n, nb, nx, self.Lloc.ptr, self.Lloc.ld, self.dblk.ptr, self._panels.ptr, ldp, nslots,
                                                 None if self._unit else svec.ptr, ctypes.byref(info)), 'lgp_chol_factor_dist')

@@ -96,6 +96,8 @@ def _signatures():
         'lgp_comm_unique_id': (c_int, [c_void_p]),
         'lgp_comm_init': (c_int, [c_void_p, c_int, c_int, c_void_p]),
         'lgp_comm_init_host': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+        'lgp_comm_set_bcast': (c_int, [c_void_p, c_int, c_size_t]),
+        'lgp_bcast_plan': (ctypes.c_long, [c_size_t, c_int, c_int, c_void_p, c_size_t, c_void_p]),
         'lgp_comm_destroy': (c_int, [c_void_p]),
         'lgp_comm_info': (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
         'lgp_bcast': (c_int, [c_void_p, _P, _S, c_int]),

@@ -26,7 +26,7 @@ import time
 import numpy
 
 _MAGIC = b'LGPRDZV1'
-OP_BCAST, OP_SUM, OP_MAX, OP_MIN, OP_GATHER = 0, 1, 2, 3, 4
+OP_BCAST, OP_SUM, OP_MAX, OP_MIN, OP_GATHER, OP_SENDRECV = 0, 1, 2, 3, 4, 5
 
 
 def free_port(addr='127.0.0.1'):
@@ -162,6 +162,10 @@ class Rendezvous:
         if self.rank == 0:
             parts = [payload] + [_recvmsg(self._peers[r]) for r in range(1, self.world)]
             out = combine(parts)
+            if isinstance(out, list):            # one answer per rank
+                for r in range(1, self.world):
+                    _sendall(self._peers[r], out[r])
+                return out[0]
             for r in range(1, self.world):
                 _sendall(self._peers[r], out)
             return out
@@ -195,11 +199,24 @@ class Rendezvous:
 
     def collective(self, op, arr, root):
         """ in place on the contiguous numpy array ``arr``: op 0 broadcast from ``root``, 1 sum, 2 max, 3 min.  The reductions are
-        done in rank order on rank 0, so every rank receives the same bits. """
+        done in rank order on rank 0, so every rank receives the same bits.  op 5: the bytes of rank ``root & 0xffff`` to rank
+        ``root >> 16`` (every rank calls; the others' arrays are left alone). """
         if not arr.flags.c_contiguous or not arr.flags.writeable:
             raise ValueError('collective needs a writeable contiguous array (it is modified in place)')
         flat = arr.reshape(-1)           # a view
         dt = flat.dtype
+        if op == OP_SENDRECV:
+            src, dst = root & 0xffff, root >> 16
+            if not (0 <= src < self.world and 0 <= dst < self.world) or src == dst:
+                raise ValueError(f'send/receive between ranks {src} and {dst} of {self.world}')
+            out = self._exchange(flat.tobytes() if self.rank == src else b'',
+                                 lambda parts: [parts[src] if r == dst else b'' for r in range(self.world)])
+            if self.rank == dst:
+                got = numpy.frombuffer(out, dtype=dt)
+                if got.size != flat.size:
+                    raise ValueError(f'send/receive: {got.size} elements arrived, {flat.size} expected')
+                flat[...] = got
+            return
 
         def combine(parts):
             if op == OP_BCAST:

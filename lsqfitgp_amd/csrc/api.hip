@@ -3,6 +3,8 @@
 #include "common.h"
 #include <cstdlib>
 #include <vector>
+#include <functional>
+#include <algorithm>
 #include <dlfcn.h>
 #include <cmath>
 #include <rccl/rccl.h>
@@ -170,6 +172,8 @@ int lgp_ctx_create(int device, lgp_ctx **out) {
     }
   }
   if (const char *m = getenv("LGP_RESERVE_MAX_N")) c->reserve_max_n = (size_t)strtoull(m, nullptr, 10);
+  if (const char *m = getenv("LGP_BCAST_ALGO")) c->bcast_algo = strcmp(m, "plain") == 0 ? 1 : (strcmp(m, "scatter") == 0 ? 2 : 0);
+  if (const char *m = getenv("LGP_BCAST_MIN_BYTES")) c->bcast_min = (size_t)strtoull(m, nullptr, 10);
   if (c->reserve_max_n > 0 && c->reserve_chain + c->reserve_far > 0 && c->cus > 64) {
     const int words = (c->cus + 31) / 32;
     std::vector<uint32_t> mg((size_t)words, 0u), mf((size_t)words, 0u);
@@ -227,6 +231,7 @@ int lgp_ctx_destroy(lgp_ctx *c) {
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->panel_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->dist_events) (void)hipEventDestroy(e);
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   for (hipStream_t s : c->far_streams)
     if (s != c->stream3) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
@@ -645,6 +650,10 @@ struct RcclApi {
   ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
@@ -672,6 +681,10 @@ int rccl_load() {
   LGP_SYM(CommUserRank, "ncclCommUserRank")
   LGP_SYM(Broadcast, "ncclBroadcast")
   LGP_SYM(AllReduce, "ncclAllReduce")
+  LGP_SYM(Send, "ncclSend")
+  LGP_SYM(Recv, "ncclRecv")
+  LGP_SYM(GroupStart, "ncclGroupStart")
+  LGP_SYM(GroupEnd, "ncclGroupEnd")
   LGP_SYM(GetErrorString, "ncclGetErrorString")
 #undef LGP_SYM
   g_rccl.handle = h;
@@ -686,6 +699,8 @@ int rccl_load() {
       return LGP_ECOMM;                                                                      \
     }                                                                                        \
   } while (0)
+
+struct lgp_xfer { int src, dst; size_t off, len; };
 }  // namespace
 
 extern "C" {
@@ -750,7 +765,7 @@ int lgp_comm_info(lgp_ctx *c, int *rank, int *nranks, int *transport) {
 }
 
 // host-staged transport: device -> host copy on the current stream, the caller's collective, host -> device copy
-static int host_collective(lgp_ctx *c, int op, void *dbuf, size_t count, size_t bytes, int root) {
+static int host_staged(lgp_ctx *c, void *dbuf, size_t bytes, const std::function<int(char *)> &body) {
   DeviceGuard dg(c->device);
   void *h = malloc(bytes);
   LGP_REQUIRE(h != nullptr, "out of host memory for the staged collective");
@@ -760,10 +775,7 @@ static int host_collective(lgp_ctx *c, int op, void *dbuf, size_t count, size_t 
   if (e != hipSuccess) {
     lgp_set_error("staged collective: %s", hipGetErrorString(e));
     rc = LGP_EHIP;
-  } else if (c->hostfn(c->hostuser, op, h, count, root) != 0) {
-    lgp_set_error("host collective callback failed (op %d)", op);
-    rc = LGP_ECOMM;
-  } else {
+  } else if ((rc = body(static_cast<char *>(h))) == LGP_OK) {
     e = hipMemcpyAsync(dbuf, h, bytes, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) {
@@ -773,6 +785,43 @@ static int host_collective(lgp_ctx *c, int op, void *dbuf, size_t count, size_t 
   }
   free(h);
   return rc;
+}
+
+static int host_collective(lgp_ctx *c, int op, void *dbuf, size_t count, size_t bytes, int root) {
+  return host_staged(c, dbuf, bytes, [&](char *h) {
+    if (c->hostfn(c->hostuser, op, h, count, root) == 0) return (int)LGP_OK;
+    lgp_set_error("host collective callback failed (op %d)", op);
+    return (int)LGP_ECOMM;
+  });
+}
+
+// ---- broadcast as scatter + all-gather.  The GPUs of a node are joined pairwise (xGMI: 7 links per GPU, no switch): a ring or
+// tree broadcast moves the whole buffer over ONE link of every GPU on the way, S / B_link, while six links idle.  Here the buffer
+// is cut into G - 1 chunks, one per peer of the root: the root sends chunk p to peer p (G - 1 links, S / (G - 1) each), then
+// every peer sends its chunk to every other peer (each link of each peer again carries S / (G - 1)):  2 S / ((G - 1) B_link).
+// The same table of transfers drives RCCL (grouped ncclSend / ncclRecv) and the host-staged transport (op 5 of the callback).
+static int lgp_bcast_xfers(size_t bytes, int nranks, int root, std::vector<lgp_xfer> &scatter, std::vector<lgp_xfer> &gather) {
+  scatter.clear();
+  gather.clear();
+  if (nranks < 2 || bytes == 0) return 0;
+  const size_t P = (size_t)nranks - 1;
+  size_t chunk = (bytes + P - 1) / P;
+  chunk = (chunk + 511) / 512 * 512;                       // (whole 512-byte runs: the rows of a panel slot start on them)
+  int used = 0;
+  for (size_t p = 0; p < P; ++p) {
+    const size_t off = p * chunk;
+    if (off >= bytes) break;
+    const size_t len = std::min(chunk, bytes - off);
+    const int holder = (root + 1 + (int)p) % nranks;
+    scatter.push_back({root, holder, off, len});
+    ++used;
+  }
+  for (int p = 0; p < used; ++p)
+    for (int q = 0; q < (int)P; ++q) {                     // (peers beyond the last chunk hold nothing but still receive everything)
+      const int dst = (root + 1 + q) % nranks;
+      if (dst != scatter[p].dst) gather.push_back({scatter[p].dst, dst, scatter[p].off, scatter[p].len});
+    }
+  return used;
 }
 
 int lgp_comm_init_host(lgp_ctx *c, int rank, int nranks, int (*fn)(void *, int, void *, size_t, int), void *user) {
@@ -787,14 +836,80 @@ int lgp_comm_init_host(lgp_ctx *c, int rank, int nranks, int (*fn)(void *, int, 
   return LGP_OK;
 }
 
+static bool bcast_scatters(const lgp_ctx *c, size_t bytes) {
+  if (c->nranks < 3 || c->bcast_algo == 1) return false;
+  if (c->bcast_algo == 2) return true;
+  return c->comm != nullptr && bytes >= c->bcast_min;      // auto: a host transport is only asked for op 5 when told so
+}
+
+int lgp_comm_set_bcast(lgp_ctx *c, int algo, size_t min_bytes) {
+  LGP_REQUIRE(c != nullptr, "null context");
+  LGP_REQUIRE(algo >= 0 && algo <= 2, "algo: 0 auto, 1 plain, 2 scatter + all-gather");
+  c->bcast_algo = algo;
+  c->bcast_min = min_bytes;
+  return LGP_OK;
+}
+
+long lgp_bcast_plan(size_t bytes, int nranks, int root, unsigned long long *xfers, size_t capacity, size_t *nscatter) {
+  if (nranks < 1 || root < 0 || root >= nranks) {
+    lgp_set_error("invalid argument: bad root");
+    return LGP_EINVAL;
+  }
+  std::vector<lgp_xfer> sc, ga;
+  lgp_bcast_xfers(bytes, nranks, root, sc, ga);
+  if (nscatter) *nscatter = sc.size();
+  size_t t = 0;
+  for (const auto *v : {&sc, &ga})
+    for (const lgp_xfer &x : *v) {
+      if (xfers != nullptr && t < capacity) {
+        xfers[4 * t] = (unsigned long long)x.src; xfers[4 * t + 1] = (unsigned long long)x.dst; xfers[4 * t + 2] = x.off; xfers[4 * t + 3] = x.len;
+      }
+      ++t;
+    }
+  return (long)t;
+}
+
 int lgp_bcast(lgp_ctx *c, void *dbuf, size_t bytes, int root) {
   LGP_REQUIRE(c != nullptr && (dbuf != nullptr || bytes == 0), "null pointer");
   LGP_REQUIRE(root >= 0 && root < c->nranks, "bad root");
-  if (bytes && c->hostfn) return host_collective(c, 0, dbuf, bytes, bytes, root);
+  const bool scatter = bytes != 0 && bcast_scatters(c, bytes);
+  std::vector<lgp_xfer> phase[2];
+  if (scatter) lgp_bcast_xfers(bytes, c->nranks, root, phase[0], phase[1]);
+  if (bytes && c->hostfn) {
+    if (!scatter) return host_collective(c, 0, dbuf, bytes, bytes, root);
+    // every rank walks the whole table (the callback decides who moves what): op 5, root = src | dst << 16
+    return host_staged(c, dbuf, bytes, [&](char *h) {
+      for (const auto &ph : phase)
+        for (const lgp_xfer &x : ph)
+          if (c->hostfn(c->hostuser, 5, h + x.off, x.len, x.src | (x.dst << 16)) != 0) {
+            lgp_set_error("host collective callback failed (op 5: %d -> %d)", x.src, x.dst);
+            return (int)LGP_ECOMM;
+          }
+      return (int)LGP_OK;
+    });
+  }
   if (bytes == 0 || (c->comm == nullptr && c->nranks == 1)) return LGP_OK;   // no communicator: single process
   LGP_REQUIRE(c->comm != nullptr, "communicator not initialised");
   DeviceGuard dg(c->device);
-  LGP_NCCL(g_rccl.Broadcast(dbuf, dbuf, bytes, ncclUint8, root, static_cast<ncclComm_t>(c->comm), c->stream));
+  ncclComm_t comm = static_cast<ncclComm_t>(c->comm);
+  if (!scatter) {
+    LGP_NCCL(g_rccl.Broadcast(dbuf, dbuf, bytes, ncclUint8, root, comm, c->stream));
+    return LGP_OK;
+  }
+  // two groups on the one stream: the second starts when this rank's chunk has arrived.  A group must be closed on every path
+  char *base = static_cast<char *>(dbuf);
+  for (const auto &ph : phase) {
+    LGP_NCCL(g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (const lgp_xfer &x : ph) {
+      if (r != ncclSuccess) break;
+      if (x.src == c->rank) r = g_rccl.Send(base + x.off, x.len, ncclUint8, x.dst, comm, c->stream);
+      else if (x.dst == c->rank) r = g_rccl.Recv(base + x.off, x.len, ncclUint8, x.src, comm, c->stream);
+    }
+    const ncclResult_t rend = g_rccl.GroupEnd();
+    LGP_NCCL(r);
+    LGP_NCCL(rend);
+  }
   return LGP_OK;
 }
 

@@ -24,6 +24,7 @@ struct lgp_ctx {
   int reserve_chain = 8, reserve_far = 8;      // env LGP_RESERVE="chain,far" (CUs; mask bit i is a CU of XCD i mod 8)
   size_t reserve_max_n = 0;                    // env LGP_RESERVE_MAX_N: largest matrix that reserves CUs (0: never, the default: measured slower)
   std::vector<hipEvent_t> panel_events;   // per 128-block of a panel: potf2 done, look-ahead rows solved, bulk done
+  std::vector<hipEvent_t> dist_events;    // the events of the sharded factorisation's schedule (dist.hip), kept between calls: several hundred per call
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   int *d_info = nullptr;              // pivot info word (0 = ok, else 1-based index), device
   void *d_scratch = nullptr;          // small reductions (>= 64 KiB)
@@ -34,6 +35,11 @@ struct lgp_ctx {
   int (*hostfn)(void *user, int op, void *hbuf, size_t count, int root) = nullptr;
   void *hostuser = nullptr;
   int rank = 0, nranks = 1;
+  // lgp_bcast: 0 = auto (RCCL: scatter + all-gather over the direct links for >= 3 ranks and >= bcast_min bytes; host transport:
+  // plain), 1 = always the transport's own broadcast, 2 = scatter + all-gather whenever there are >= 3 ranks (the host transport
+  // then needs op 5, see lgp_comm_init_host).  lgp_comm_set_bcast / env LGP_BCAST_ALGO=auto|plain|scatter, LGP_BCAST_MIN_BYTES
+  int bcast_algo = 0;
+  size_t bcast_min = (size_t)1 << 20;
   int cus = 256;
   int swapped = 0;                    // lgp_select_stream(1): `stream` and `stream2` exchanged
   int potf2_mode = 0;                 // diagonal-block kernel: 0 = auto, 1 = VALU, 2 = matrix cores (env LGP_POTF2=valu|mfma)

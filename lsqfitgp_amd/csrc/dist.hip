@@ -38,6 +38,7 @@ int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *P
                       const hipEvent_t *blk_events);                                                                               // potrf.hip
 int lgp_square_factor_f64(lgp_ctx *ctx, hipStream_t st, size_t kb, double *P, size_t ldl, double *Yk, size_t row0, bool use_chain,
                           const hipEvent_t *blk_events);                                                                           // potrf.hip
+int lgp_potrf_chain_tail_f64(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *dblk, size_t nx, size_t row0);                 // potrf.hip
 
 namespace {
 
@@ -87,16 +88,19 @@ void build_plan(size_t n, size_t nb, size_t nx, size_t slab, std::vector<Piece> 
 
 size_t plan_slots(size_t maxpieces) { return maxpieces / 2 + 2; }
 
+// the events of one schedule: taken from the context's store (a C3-sized call uses ~400: creating and destroying them every call
+// was 2-3 ms of host time in front of and behind the factorisation), which only grows
 struct EventPool {
-  std::vector<hipEvent_t> ev;
+  std::vector<hipEvent_t> &store;
+  size_t used = 0;
+  explicit EventPool(std::vector<hipEvent_t> &s) : store(s) {}
   hipEvent_t get() {
+    if (used < store.size()) return store[used++];
     hipEvent_t e = nullptr;
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    ev.push_back(e);
+    store.push_back(e);
+    ++used;
     return e;
-  }
-  ~EventPool() {
-    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
   }
 };
 
@@ -134,7 +138,8 @@ extern "C" long lgp_chol_dist_plan(size_t n, size_t nb, size_t nx, size_t nranks
 
 extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_t nx, double *dLloc, size_t ldl, double *ddblk,
                                         double *dpanels, size_t ldp, size_t nslots, const double *dsrow, int *hinfo) {
-  LGP_REQUIRE(ctx != nullptr && dLloc != nullptr && ddblk != nullptr && dpanels != nullptr, "null pointer");
+  LGP_REQUIRE(ctx != nullptr && dLloc != nullptr && ddblk != nullptr, "null pointer");
+  LGP_REQUIRE(dpanels != nullptr || ctx->nranks == 1, "null pointer: panel slots (only a single rank goes without)");
   LGP_REQUIRE(n >= 1 && nb >= 1 && nb <= n + nb, "bad sizes");
   LGP_REQUIRE(ldp >= nb, "ldp < nb");
   const size_t G = (size_t)ctx->nranks, me = (size_t)ctx->rank;
@@ -147,12 +152,26 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   size_t maxp = 0;
   build_plan(n, nb, nx, slab, plan, maxp);
   LGP_REQUIRE(nslots >= plan_slots(maxp), "too few panel slots: ask lgp_chol_dist_plan");
+  static const bool force_comm = getenv("LGP_DIST_FORCE_COMM") != nullptr;      // (experiments: the communication stream's traffic with one rank)
+  LGP_REQUIRE(dpanels != nullptr || !force_comm, "LGP_DIST_FORCE_COMM needs the panel slots");
   LGP_REQUIRE(ctx->stream2 != nullptr && ctx->stream3 != nullptr, "context without auxiliary streams");
   if (ctx->stream_comm == nullptr) LGP_HIP(hipStreamCreateWithPriority(&ctx->stream_comm, hipStreamNonBlocking, ctx->prio_hi));
   hipStream_t sc = ctx->stream, s1 = ctx->stream2, s3 = ctx->stream3, sx = ctx->stream_comm;
   const size_t rows_all = n + nx;
   const size_t dblk_per_block = lgp_chol_dblk_size(nb);
   ctx->potf2_small = n <= 8192;
+  // whether the squares go to the chain kernel is settled HERE: the first question of a context runs a self-test that
+  // synchronises the device, which must not happen between the broadcasts of a schedule that the peers are already inside
+  const bool chain_ok = nb >= 256 && lgp_chain_usable(ctx, nb, ldl);
+  // Without peers the end of the factorisation is what it is on the single-GPU driver (potrf_split): once this few rows are left
+  // the dependent chain of squares bounds the rest, and the trailing matrix goes to the chain driver in one piece -- the last
+  // eight panels of C3 in 6.3 ms instead of 10.4 (kernel trace, round 4).  With peers the trailing matrix is spread over them.
+  size_t chain_tail = 0;
+  if (G == 1 && slab == 0 && n % LGP_DB == 0 && nb % LGP_DB == 0 && lgp_chol_dblk_size(nb) == (nb / LGP_DB) * (size_t)LGP_DBLK) {
+    static const size_t tail_env = getenv("LGP_SPLIT_CHAIN_TAIL") ? (size_t)atol(getenv("LGP_SPLIT_CHAIN_TAIL")) : (size_t)8192;
+    const size_t cand = (tail_env < ctx->chain_max_n ? tail_env : ctx->chain_max_n) / LGP_NB * LGP_NB;
+    if (cand >= 2048 && n > cand && lgp_chain_usable(ctx, cand, ldl)) chain_tail = cand;
+  }
 
   auto owner = [&](size_t b) { return b % G; };
   auto width = [&](size_t b) { return (n - b * nb) < nb ? (n - b * nb) : nb; };
@@ -170,7 +189,7 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
       if (r >= v[i].r0 && r < v[i].r1) return i;
     return v.size() - 1;
   };
-  EventPool pool;
+  EventPool pool(ctx->dist_events);
   std::vector<std::vector<hipEvent_t>> ev_recv(nblocks), ev_ready(nblocks), ev_bulk(nblocks), ev_u2(nblocks), ev_solved(nblocks);
   std::vector<hipEvent_t> ev_free_sc(nslots, nullptr), ev_free_l1(nslots, nullptr);
   std::vector<std::vector<hipEvent_t>> ev_blk(nblocks);       // per 128-column block of an owned square: factored, the square's rows solved
@@ -194,16 +213,32 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   for (size_t s = 0; s < nslots; ++s) { make(ev_free_sc[s]); make(ev_free_l1[s]); }
   hipEvent_t ev_start = nullptr, ev_end1 = nullptr, ev_end3 = nullptr, ev_endx = nullptr;
   make(ev_start); make(ev_end1); make(ev_end3); make(ev_endx);
-  if (!ok) {
-    lgp_set_error("hipEventCreate failed");
-    return LGP_EHIP;
+  // From here on the peers may already be inside the broadcasts of this plan: a failure of this rank -- events, the first
+  // enqueues, anything in the middle -- still issues every broadcast of the plan (contents no longer matter) before it is reported
+  auto bare_broadcasts = [&](size_t from) {
+    if (G <= 1) return;
+    OnStream on(ctx, sx);
+    for (size_t t = from; t < plan.size(); ++t)
+      if (plan[t].i > 0) (void)lgp_bcast(ctx, panel_rows(plan[t].b, plan[t].r0), (plan[t].r1 - plan[t].r0) * ldp * sizeof(double), (int)owner(plan[t].b));
+    (void)hipStreamSynchronize(sx);
+  };
+  auto start = [&]() -> int {
+    if (!ok) {
+      lgp_set_error("hipEventCreate failed");
+      return LGP_EHIP;
+    }
+    LGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sc));
+    LGP_HIP(hipEventRecord(ev_start, sc));                               // (everything the caller enqueued on the compute stream)
+    LGP_HIP(hipStreamWaitEvent(s1, ev_start, 0));
+    LGP_HIP(hipStreamWaitEvent(s3, ev_start, 0));
+    LGP_HIP(hipStreamWaitEvent(sx, ev_start, 0));
+    return LGP_OK;
+  };
+  if (const int st0 = start(); st0 != LGP_OK) {
+    bare_broadcasts(0);
+    (void)hipStreamSynchronize(sc);
+    return st0;
   }
-
-  LGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), sc));
-  LGP_HIP(hipEventRecord(ev_start, sc));                                 // (everything the caller enqueued on the compute stream)
-  LGP_HIP(hipStreamWaitEvent(s1, ev_start, 0));
-  LGP_HIP(hipStreamWaitEvent(s3, ev_start, 0));
-  LGP_HIP(hipStreamWaitEvent(sx, ev_start, 0));
 
   // a slot is written by the owner's pack (s1 / s3) or by the arriving broadcast (comm stream): both behind its last readers
   auto wait_slot_free = [&](size_t b, hipStream_t st) -> int {
@@ -227,26 +262,29 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   auto avail = [&](size_t b, size_t i) { return owner(b) == me ? ev_solved[b][i] : ev_recv[b][i]; };
 
   // ---- owner(b): update its piece of block column b with panel b - 1, factor / solve it, pack it
+  // U1: the square of block column b gets panel b - 1, on the stream that factors it (nothing else stands between the arrival of
+  // those rows and the next square)
+  auto u1 = [&](size_t b) -> int {
+    if (b == 0) return LGP_OK;
+    const size_t kb = width(b);
+    LGP_HIP(hipStreamWaitEvent(s1, avail(b - 1, cover(b - 1, b * nb)), 0));
+    if (b >= 2) LGP_HIP(hipStreamWaitEvent(s1, ev_bulk[b - 2][cover(b - 2, b * nb)], 0));   // ... and has every earlier update
+    size_t lda = 0;
+    const double *A = prow(b - 1, b * nb, lda);
+    return lgp_gemm_launch<double>(ctx, s1, false, true, kb, kb, width(b - 1), -1.0, A, lda, A, lda, 1.0, block(b), ldl, true);
+  };
   auto lane = [&](const Piece &p) -> int {
     const size_t b = p.b, kb = width(b);
     hipStream_t st = p.i == 0 ? s1 : s3;
     double *C = block(b) + (p.r0 - b * nb) * ldl;
-    if (b >= 1 && p.i == 0) {
-      // U1: the square of block column b gets panel b - 1 here, on the stream that factors it (nothing else stands between the
-      // arrival of those rows and the next square)
-      LGP_HIP(hipStreamWaitEvent(st, avail(b - 1, cover(b - 1, b * nb)), 0));
-      if (b >= 2) LGP_HIP(hipStreamWaitEvent(st, ev_bulk[b - 2][cover(b - 2, b * nb)], 0));   // ... and has every earlier update
-      size_t lda = 0;
-      const double *A = prow(b - 1, b * nb, lda);
-      LGP_CHECK(lgp_gemm_launch<double>(ctx, st, false, true, kb, kb, width(b - 1), -1.0, A, lda, A, lda, 1.0, C, ldl, true));
-    }
+    if (p.i == 0) LGP_CHECK(u1(b));
     // (U2, the rows below the square, was applied on the compute stream in front of the bulk update with the same piece of panel
     // b - 1, see `bulk`: the two do not share the CUs, as in the single-GPU driver)
     if (b >= 1 && p.i >= 1) LGP_HIP(hipStreamWaitEvent(st, ev_u2[b - 1][cover(b - 1, p.r0)], 0));
     if (p.i == 0) {
       // the resident workers of the chain kernel take CUs from the trailing update: worth it once this rank's share of what is
       // left of the matrix is small enough for the squares to bound the factorisation (the single-GPU rule: N <= 16384)
-      const bool use_chain = (n - b * nb) / G <= ctx->chain_max_n;
+      const bool use_chain = chain_ok && (n - b * nb) / G <= ctx->chain_max_n;
       LGP_CHECK(lgp_square_factor_f64(ctx, st, kb, block(b), ldl, dblk(b), b * nb, use_chain, ev_blk[b].data()));
     } else {
       LGP_CHECK(lgp_far_rows_impl<double>(ctx, st, p.r1 - p.r0, kb, C, ldl, block(b), dblk(b), ev_blk[b].data()));
@@ -266,6 +304,9 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   };
   // ---- every rank: the piece travels
   auto comm = [&](const Piece &p) -> int {
+    // (tried in round 4: the owner's hand-over as a flag word -- hipStreamWriteValue32 behind the pack, one spinning lane of a
+    //  kernel on this stream instead of the event wait.  With one rank and LGP_DIST_FORCE_COMM the stream's traffic costs the same
+    //  4.5-5 ms at C3 either way, 195.8 vs 196.0 ms against 191.0 without the stream: it is not a polled barrier packet)
     if (owner(p.b) == me) LGP_HIP(hipStreamWaitEvent(sx, ev_ready[p.b][p.i], 0));
     else LGP_CHECK(wait_slot_free(p.b, sx));
     {
@@ -329,16 +370,29 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   // A failure in the middle must not leave the peers inside a collective: the broadcasts of the rest of the plan are still
   // issued (their contents no longer matter), every stream is drained, then the error is reported.
   int failed = LGP_OK;
-  for (const Piece &p : plan) {
+  for (size_t t = 0; t < plan.size(); ++t) {
+    const Piece &p = plan[t];
+    if (chain_tail != 0 && p.i == 0 && p.b >= 1 && n - p.b * nb <= chain_tail) {
+      // (everything of the earlier panels is enqueued: piece 1 of panel b - 1 sorts in front of the square of panel b)
+      failed = u1(p.b);
+      if (failed == LGP_OK) failed = lgp_potrf_chain_tail_f64(ctx, n - p.b * nb, block(p.b), ldl, dblk(p.b), nx, p.b * nb);
+      break;
+    }
     if (failed == LGP_OK && owner(p.b) == me) failed = lane(p);
     if (p.i == 0) continue;                                // (squares are not sent, see `lane`)
     // (without peers nothing travels, and the communication stream stays empty.  Measured with one rank, LGP_DIST_FORCE_COMM: the
     //  stream's event waits and records alone -- nothing reads what they order -- cost the factorisation 4.6-6.3 ms at C3, the
     //  compute stream idling ~175 us per panel; neither GPU_MAX_HW_QUEUES = 8 / 16 nor a normal-priority stream changes that)
-    static const bool force_comm = getenv("LGP_DIST_FORCE_COMM") != nullptr;      // (experiments: the stream's traffic with one rank)
-    int st = (G > 1 || force_comm) ? comm(p) : LGP_OK;
-    if (failed == LGP_OK) failed = st;
-    if (failed == LGP_OK) failed = bulk(p);
+    if (failed != LGP_OK) {                                // (the events of a broken schedule are not to be trusted: no more waits)
+      bare_broadcasts(t);
+      break;
+    }
+    failed = (G > 1 || force_comm) ? comm(p) : LGP_OK;
+    if (failed != LGP_OK) {                                // (this piece's broadcast may or may not have been issued: nothing sane is left
+      bare_broadcasts(t + 1);                              //  to do about that one; the rest of the plan is)
+      break;
+    }
+    failed = bulk(p);
   }
   if (failed == LGP_OK) {
     hipError_t e = hipEventRecord(ev_end1, s1);

@@ -1850,6 +1850,20 @@ int gram_reg_cols_impl(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar,
   LGP_REQUIRE(ctx != nullptr && dsums != nullptr, "null pointer");
   if (n == 0 || w == 0) return LGP_OK;
   const size_t ntr = (n + GR_ROWS - 1) / GR_ROWS;
+  if (c0 == 0 && w == n && (cyc_nb == 0 || cyc_stride == cyc_nb)) {
+    // the range is the whole matrix (the sharded path with one rank): the mirrored entries are all here, so the lower triangle
+    // alone is evaluated, as for the single-GPU factorisation -- its tiles add their sums along the rows to the columns' as well
+    const size_t ntc = (n + GT_THREADS * VecOf<T>::W - 1) / (GT_THREADS * VecOf<T>::W);
+    T *part = nullptr;
+    LGP_CHECK(lgp_ws_alloc(ctx, ctx->stream, (ntr + ntc) * n * sizeof(T), reinterpret_cast<void **>(&part)));
+    WsGuard part_guard(ctx, ctx->stream, part);
+    size_t got = 0;
+    LGP_CHECK(gram_reg_launch<T>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, noise, dnoise, dblock, ldb,
+                                 dsvec, part, part + ntr * n, &got));
+    hipLaunchKernelGGL((regcols_reduce_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, ntr + ntc, part, dsums);
+    LGP_LAUNCH_CHECK();
+    return LGP_OK;
+  }
   T *part = nullptr;
   LGP_CHECK(lgp_ws_alloc(ctx, ctx->stream, ntr * w * sizeof(T), reinterpret_cast<void **>(&part)));
   WsGuard part_guard(ctx, ctx->stream, part);

@@ -971,6 +971,12 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
   return LGP_OK;
 }
 
+// The end of the sharded factorisation when its rank has no peers: the trailing matrix (every update applied; U1 of its first
+// square in s1's order, U2 / U3 of the panel before on the context's stream) handed to the chain driver, as potrf_split does.
+int lgp_potrf_chain_tail_f64(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *dblk, size_t nx, size_t row0) {
+  return potrf_chain(ctx, n, L, ldl, dblk, nx, row0, true);
+}
+
 // ---- pieces of a panel for the sharded factorisation (dist.hip), the same kernels as the drivers above -----------------------
 // rows below a panel's diagonal square, solved against it: left-looking over the square's 128-column blocks, as the far rows
 // of potrf_split.  Pfar: the rows (column 0 of the panel), Psq: the square, Yk: its diagonal-block workspaces.  blk_events

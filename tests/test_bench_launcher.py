@@ -118,3 +118,64 @@ def test_rendezvous_times_out_instead_of_hanging():
         Rendezvous(1, 2, port=free_port(), timeout=0.5)
     with pytest.raises(TimeoutError):
         Rendezvous(0, 2, port=free_port(), timeout=0.5)
+
+
+# ---- the broadcast as scatter + all-gather (lgp_bcast_plan: host only; the transfers drive RCCL and the host transport alike)
+@pytest.mark.parametrize('world', [2, 3, 4, 8])
+@pytest.mark.parametrize('nbytes', [1, 511, 512, 4096 + 8, 1_000_003, 68_157_440])
+def test_bcast_plan_reaches_every_rank_over_direct_links(world, nbytes):
+    import lsqfitgp_amd as lgp
+    for root in {0, 1, world - 1}:
+        scatter, gather = lgp.Context.bcast_plan(nbytes, world, root)
+        have = {r: set() for r in range(world)}                 # chunk offsets each rank holds
+        chunks = {}
+        # first group: the root sends a different chunk to each peer, all at once
+        assert len({d for _, d, _, _ in scatter}) == len(scatter) <= world - 1
+        covered = 0
+        for src, dst, off, ln in scatter:
+            assert src == root and dst != root and off == covered and ln > 0
+            assert off % 512 == 0
+            covered += ln
+            have[dst].add(off); chunks[off] = ln
+        assert covered == nbytes
+        per_link = max(ln for *_, ln in scatter)
+        assert per_link <= -(-nbytes // (world - 1)) + 511        # 1 / (G - 1) of the buffer per link of the root
+        # second group: holders pass their chunk on, every pair of ranks at most once per direction
+        seen = set()
+        for src, dst, off, ln in gather:
+            assert off in have[src] and chunks[off] == ln and root not in (src, dst) and src != dst
+            assert (src, dst) not in seen
+            seen.add((src, dst))
+        for src, dst, off, ln in gather:
+            have[dst].add(off)
+        for r in range(world):
+            if r != root:
+                assert have[r] == set(chunks), (r, root)
+
+
+def test_bcast_plan_rejects_a_bad_root():
+    import lsqfitgp_amd as lgp
+    with pytest.raises(Exception):
+        lgp.Context.bcast_plan(100, 4, 4)
+
+
+@pytest.mark.parametrize('world', [3, 4, 6])
+def test_scatter_allgather_over_the_rendezvous(world):
+    """ op 5 of the host transport (bytes from one rank to another, called on every rank) executing the library's table of
+    transfers on host buffers: every rank ends with the root's bytes, and nothing else was touched on the way """
+    import lsqfitgp_amd as lgp
+    nbytes, root = 3_000_001, world - 2
+    truth = np.random.default_rng(5).integers(0, 256, nbytes, dtype=np.uint8)
+    scatter, gather = lgp.Context.bcast_plan(nbytes, world, root)
+
+    def fn(rz, r):
+        buf = truth.copy() if r == root else np.full(nbytes, r, np.uint8)
+        for phase in (scatter, gather):
+            for src, dst, off, ln in phase:
+                rz.collective(5, buf[off:off + ln], src | dst << 16)
+        mid = np.full(10, 77, np.uint8)
+        rz.collective(5, mid, 0 | (world - 1) << 16)             # (rank 0 to the last: the others' arrays are left alone)
+        return buf, mid
+    for r, (buf, mid) in enumerate(_run_world(world, fn)):
+        np.testing.assert_array_equal(buf, truth)
+        assert (mid == 77).all()

@@ -145,11 +145,13 @@ def test_distributed_posterior_single_rank(lgp, rng):
     assert abs(-mlnd - lo) <= 1e-8 * abs(lo) + 1e-6
 
 
-@pytest.mark.parametrize('n,nb,world,carry,amp,slab', [(1500, 256, 2, 0, 1, 512), (2600, 1024, 2, 1, 1, None), (2900, 256, 3, 1, 1, 768), (1700, 256, 2, 1, 37, 256),
-                                                        (4100, 128, 4, 1, 1, 1024)])
-def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry, amp, slab):
-    """ world size 2 and 3 on the device: real kernels, real stream/event choreography of the panel look-ahead, panels
-    exchanged through the host-callback transport; factor, posterior and likelihood against the oracle """
+@pytest.mark.parametrize('n,nb,world,carry,amp,slab,bcast', [(1500, 256, 2, 0, 1, 512, 'plain'), (2600, 1024, 2, 1, 1, None, 'plain'), (2900, 256, 3, 1, 1, 768, 'scatter'),
+                                                              (1700, 256, 2, 1, 37, 256, 'scatter'), (4100, 128, 4, 1, 1, 1024, 'scatter'), (2900, 256, 3, 0, 1, 512, 'plain'),
+                                                              (3300, 256, 5, 1, 1, 512, 'scatter')])
+def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry, amp, slab, bcast):
+    """ world size 2 to 5 on the device: real kernels, real stream/event choreography of the panel look-ahead, panels
+    exchanged through the host-callback transport -- as one broadcast ('plain') or as scatter + all-gather between the
+    ranks (`lgp_bcast`, three ranks or more; with two it is the same thing); factor, posterior and likelihood against the oracle """
     import os
     import socket
     import subprocess
@@ -161,6 +163,7 @@ def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry, amp, slab):
     # separate interpreters, one per rank
     script = os.path.join(os.path.dirname(__file__), 'two_rank_worker.py')
     env = dict(os.environ, LGP_TEST_CARRY=str(carry), LGP_TEST_AMP=str(amp))        # carry = 1: [Kxxs | y] rides through the factorisation
+    env['LGP_TEST_SENDRECV'] = '1' if bcast == 'scatter' else '0'
     if slab is not None:
         env['LGP_DIST_SLAB'] = str(slab)                                            # (default for several ranks: 8 nb)
     procs = [subprocess.Popen([sys.executable, script, str(rank), str(world), str(port), str(n), str(nb), str(m), str(tmp_path)],

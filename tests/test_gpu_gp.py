@@ -381,6 +381,34 @@ def test_decomposition_kept_for_the_same_givencov(lgp, rng):
     assert abs(ml - lo) <= 1e-8 * abs(lo) + 1e-6 and abs(ml3 - lo) <= 1e-8 * abs(lo) + 1e-6
 
 
+@pytest.mark.parametrize('where', ['interior', 'last', 'random', 'diagonal_block'])
+def test_an_edit_of_any_entry_of_givencov_factors_again(lgp, rng, where):
+    """ the kept decomposition is keyed on every byte of the blocks: one entry changed in place between two calls, anywhere in
+    the block (a sampled fingerprint would miss most of them), gives the numbers of the new matrix, those of the oracle """
+    n = 300
+    x = rng.uniform(0, 20, n)
+    y = np.sin(x) + 0.1 * rng.standard_normal(n)
+    if where == 'diagonal_block':
+        block = lgp.diag(np.full(n, 0.01)); i = j = 123
+        dense = lambda: np.diag(block.values)
+    else:
+        block = 0.01 * np.eye(n)
+        i, j = {'interior': (157, 157), 'last': (n - 1, n - 1), 'random': tuple(rng.integers(1, n - 1, 2))}[where]
+        dense = lambda: block
+    gc = {('d', 'd'): block}
+    gp = lgp.GP(lgp.ExpQuad(), checkpos=False, checksym=False).addx(x, 'd')
+    ml = gp.marginal_likelihood({'d': y}, gc)
+    if where == 'diagonal_block':
+        block.values[i] = 0.5
+    else:
+        block[i, j] += 0.004; block[j, i] = block[i, j]
+    ml2 = gp.marginal_likelihood({'d': y}, gc)
+    go = oracle.GP(oracle.ExpQuad(), checkpos=False, checksym=False).addx(x, 'd')
+    lo2 = go.marginal_likelihood({'d': y}, {('d', 'd'): np.array(dense())})
+    assert ml2 != ml
+    assert abs(ml2 - lo2) <= 1e-8 * abs(lo2) + 1e-6
+
+
 @pytest.mark.parametrize('case', ['expquad1d', 'matern3d_noise', 'cauchy_ops'])
 def test_one_call_prediction_is_the_general_path(lgp, rng, monkeypatch, case):
     """ `GP._pred_one_call` (three library calls for the plain question: one kernel, one point set given, one predicted, no checks

@@ -19,7 +19,7 @@ def main(rank, world, port, n, nb, m, tmpdir):
     from lsqfitgp_amd._dist import DistributedChol
     ctx = lgp.Context(0)                      # both ranks on the one GPU of the box
     lgp.Context._default = ctx
-    ctx.comm_init_host(rank, world, dist.collective)
+    ctx.comm_init_host(rank, world, dist.collective, sendrecv=os.environ.get('LGP_TEST_SENDRECV', '1' if world >= 3 else '0') == '1')
     assert ctx.comm_info() == (rank, world, 'host')
     rng = np.random.default_rng(7)
     x = rng.uniform(0, n / 16, n)
