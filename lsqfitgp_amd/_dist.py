@@ -124,7 +124,8 @@ def factor_tasks(layout, plan=None, nx=0):
         'SOLVE'  owner(b), i > 0: the rows solved against the square
         'PACK'   owner(b), i > 0: the rows copied into panel slot b % nslots (for the broadcast: the owner's own updates read the rows
                  where they lie, behind 'SOLVE')
-        'BCAST'  every rank, i > 0: the piece broadcast from owner(b) (a collective: same order on every rank)
+        'BCAST'  every rank, i > 0: the piece broadcast from owner(b) (a collective: same order on every rank); the owner issues it
+                 on 's3' behind 'PACK', the others on 'sx' 
         'BULK'   every rank, i > 0: block columns ``extra`` (owned, >= b + 2) restricted to the rows of the piece
     """
     L, me = layout, layout.rank
@@ -186,7 +187,8 @@ def factor_tasks(layout, plan=None, nx=0):
                 rec['ready', b, i] = push('s3', 'PACK', p, slot_events(b))
         if i == 0:
             continue
-        rec['recv', b, i] = push('sx', 'BCAST', p, [('ready', b, i)] if L.owner(b) == me else slot_events(b))
+        # (the owner sends from the stream that packed, in its order: no event between the two; the others on the broadcast stream)
+        rec['recv', b, i] = push('s3', 'BCAST', p, []) if L.owner(b) == me else push('sx', 'BCAST', p, slot_events(b))
         if b + 1 < L.nblocks and L.owner(b + 1) == me:
             # U2: the rows of this piece below the square of the look-ahead column b + 1 = one piece of panel b + 1
             r2 = max(r0, min((b + 2) * L.nb, L.n))

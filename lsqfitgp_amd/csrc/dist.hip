@@ -23,7 +23,8 @@
 //                                 of the other block columns only read rows below a panel's diagonal block
 //     owner(b), piece i>0   [s3]  (behind U2 of those rows, below) substitution against square b (left-looking over its 128-column blocks, each behind the
 //                                 event of that block of the square), pack, ready(b, i)
-//     every rank            [comm] broadcast piece (b, i) from owner(b) into panel slot b % nslots; recv(b, i)
+//     owner(b), piece i>0   [s3]  ... and sent: its broadcast is issued right there, in stream order (see `comm`)
+//     every other rank      [comm] broadcast piece (b, i) from owner(b) into panel slot b % nslots; recv(b, i)
 //     owner(b+1)            [sc]  U2: the look-ahead column b + 1 below its square, rows of the piece -- in FRONT of:
 //     every rank            [sc]  its block columns c >= b + 2, rows of the piece: one staircase MFMA launch (row offset =
 //                                 the piece's first row below the diagonal of the first of them); bulk(b, i)
@@ -153,6 +154,7 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   build_plan(n, nb, nx, slab, plan, maxp);
   LGP_REQUIRE(nslots >= plan_slots(maxp), "too few panel slots: ask lgp_chol_dist_plan");
   static const bool force_comm = getenv("LGP_DIST_FORCE_COMM") != nullptr;      // (experiments: the communication stream's traffic with one rank)
+  static const bool owner_sends_in_order = !(getenv("LGP_DIST_OWNER_COMM") != nullptr && strcmp(getenv("LGP_DIST_OWNER_COMM"), "stream") == 0);
   LGP_REQUIRE(dpanels != nullptr || !force_comm, "LGP_DIST_FORCE_COMM needs the panel slots");
   LGP_REQUIRE(ctx->stream2 != nullptr && ctx->stream3 != nullptr, "context without auxiliary streams");
   if (ctx->stream_comm == nullptr) LGP_HIP(hipStreamCreateWithPriority(&ctx->stream_comm, hipStreamNonBlocking, ctx->prio_hi));
@@ -299,21 +301,27 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
       LGP_HIP(hipMemcpy2DAsync(panel_rows(b, p.r0), ldp * sizeof(double), C, ldl * sizeof(double), kb * sizeof(double), p.r1 - p.r0,
                                hipMemcpyDeviceToDevice, st));
     }
-    LGP_HIP(hipEventRecord(ev_ready[b][p.i], st));
+    if (!owner_sends_in_order) LGP_HIP(hipEventRecord(ev_ready[b][p.i], st));
     return LGP_OK;
   };
   // ---- every rank: the piece travels
   auto comm = [&](const Piece &p) -> int {
-    // (tried in round 4: the owner's hand-over as a flag word -- hipStreamWriteValue32 behind the pack, one spinning lane of a
-    //  kernel on this stream instead of the event wait.  With one rank and LGP_DIST_FORCE_COMM the stream's traffic costs the same
-    //  4.5-5 ms at C3 either way, 195.8 vs 196.0 ms against 191.0 without the stream: it is not a polled barrier packet)
-    if (owner(p.b) == me) LGP_HIP(hipStreamWaitEvent(sx, ev_ready[p.b][p.i], 0));
-    else LGP_CHECK(wait_slot_free(p.b, sx));
+    // A piece of this rank's own is sent from the stream that solved and packed it (s3), in stream order.  Handing it to the
+    // communication stream through an event (rounds 2-3) cost ~170 us per panel, 5.5 ms at C3, measured with one rank
+    // (LGP_DIST_FORCE_COMM; LGP_DIST_OWNER_COMM=stream brings it back): the one wait that sits on the otherwise idle stream until
+    // the rows are solved delays the dispatches of the compute stream behind ITS event waits (U2 by ~80 us, the large update by
+    // ~50 us in the kernel trace), whether the wait is an event or a lane spinning on a flag word, with 4 or 8 hardware queues.
+    // What the communication stream keeps are the pieces of the OTHER ranks' panels: their slot has long been free when they are
+    // enqueued, and the receiving kernel itself waits for the data.  (One communicator on two streams: RCCL orders the kernels of
+    // a communicator in issue order through its own stream, whatever streams they were issued on.)
+    hipStream_t sq = (owner(p.b) == me && owner_sends_in_order) ? s3 : sx;
+    if (owner(p.b) != me) LGP_CHECK(wait_slot_free(p.b, sx));
+    else if (sq == sx) LGP_HIP(hipStreamWaitEvent(sx, ev_ready[p.b][p.i], 0));
     {
-      OnStream on(ctx, sx);
+      OnStream on(ctx, sq);
       LGP_CHECK(lgp_bcast(ctx, panel_rows(p.b, p.r0), (p.r1 - p.r0) * ldp * sizeof(double), (int)owner(p.b)));
     }
-    LGP_HIP(hipEventRecord(ev_recv[p.b][p.i], sx));
+    LGP_HIP(hipEventRecord(ev_recv[p.b][p.i], sq));
     return LGP_OK;
   };
   // ---- every rank: its block columns c >= b + 2, rows of the piece, in one staircase launch
@@ -380,9 +388,7 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
     }
     if (failed == LGP_OK && owner(p.b) == me) failed = lane(p);
     if (p.i == 0) continue;                                // (squares are not sent, see `lane`)
-    // (without peers nothing travels, and the communication stream stays empty.  Measured with one rank, LGP_DIST_FORCE_COMM: the
-    //  stream's event waits and records alone -- nothing reads what they order -- cost the factorisation 4.6-6.3 ms at C3, the
-    //  compute stream idling ~175 us per panel; neither GPU_MAX_HW_QUEUES = 8 / 16 nor a normal-priority stream changes that)
+    // (without peers nothing travels; LGP_DIST_FORCE_COMM issues the -- empty -- broadcasts all the same, see `comm`)
     if (failed != LGP_OK) {                                // (the events of a broken schedule are not to be trusted: no more waits)
       bare_broadcasts(t);
       break;

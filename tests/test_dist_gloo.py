@@ -157,9 +157,15 @@ def simulate(world, n, nb, nx, slab, seed):
         queues = {}
         for t in tasks:
             queues.setdefault(t.stream, []).append(t)
-        ranks.append(dict(ops=NumpyOps(L, K, nslots), tasks=tasks, queues=queues, pos={s: 0 for s in queues}, done=set(), nslots=nslots))
+        # the broadcasts of a rank in issue order: the communicator runs them in that order whatever stream they were issued on
+        # (the owner of a panel sends from the stream that packed it, 's3'; the others receive on 'sx')
+        ranks.append(dict(ops=NumpyOps(L, K, nslots), tasks=tasks, queues=queues, pos={s: 0 for s in queues}, done=set(), nslots=nslots,
+                          bcasts=[t.index for t in tasks if t.kind == 'BCAST'], bpos=0))
+        for t in tasks:
+            if t.kind == 'BCAST':
+                assert t.stream == ('s3' if L.owner(t.piece[0]) == r else 'sx')
     # every rank issues the same broadcasts in the same order
-    order = [[t.piece for t in rk['queues'].get('sx', [])] for rk in ranks]
+    order = [[t.piece for t in rk['tasks'] if t.kind == 'BCAST'] for rk in ranks]
     assert all(o == order[0] for o in order)
     remaining = sum(len(rk['tasks']) for rk in ranks)
     steps = 0
@@ -172,7 +178,7 @@ def simulate(world, n, nb, nx, slab, seed):
                     if all(w in rk['done'] for w in t.waits):
                         ready.append((r, s, t))
         # a collective needs every rank
-        heads = [(r, s, t) for r, s, t in ready if t.kind == 'BCAST']
+        heads = [(r, s, t) for r, s, t in ready if t.kind == 'BCAST' and ranks[r]['bcasts'][ranks[r]['bpos']] == t.index]
         runnable = [(r, s, t) for r, s, t in ready if t.kind != 'BCAST']
         if len(heads) == world:
             assert len({t.piece for _, _, t in heads}) == 1
@@ -193,7 +199,8 @@ def simulate(world, n, nb, nx, slab, seed):
                 rk['ops'].P[slot][r0:r1, :w] = data
                 rk['ops'].tag[slot][r0:r1] = b
                 rk['done'].add(tt.index)
-                rk['pos']['sx'] += 1
+                rk['pos'][ss] += 1
+                rk['bpos'] += 1
                 remaining -= 1
         else:
             rk = ranks[r]
