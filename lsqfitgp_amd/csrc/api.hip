@@ -45,10 +45,20 @@ static void ws_trim(lgp_ctx *c, size_t keep) {
   }
 }
 
+// LGP_WS_ASYNC=1 (diagnosis only, tools/malloc_async_probe.hip and DESIGN.md): the stream-ordered allocator of the runtime instead
+static bool ws_async() {
+  static const bool on = getenv("LGP_WS_ASYNC") != nullptr && atoi(getenv("LGP_WS_ASYNC")) != 0;
+  return on;
+}
+
 int lgp_ws_alloc(lgp_ctx *c, hipStream_t stream, size_t bytes, void **out) {
   *out = nullptr;
   if (bytes == 0) bytes = 256;
   bytes = (bytes + 255) / 256 * 256;
+  if (ws_async()) {
+    LGP_HIP(hipMallocAsync(out, bytes, stream));
+    return LGP_OK;
+  }
   size_t best = (size_t)-1;
   for (size_t i = 0; i < c->ws_blocks.size(); ++i) {
     const auto &b = c->ws_blocks[i];
@@ -81,6 +91,10 @@ int lgp_ws_alloc(lgp_ctx *c, hipStream_t stream, size_t bytes, void **out) {
 
 int lgp_ws_free(lgp_ctx *c, hipStream_t stream, void *ptr) {
   if (ptr == nullptr) return LGP_OK;
+  if (ws_async()) {
+    LGP_HIP(hipFreeAsync(ptr, stream));
+    return LGP_OK;
+  }
   for (auto &b : c->ws_blocks)
     if (b.ptr == ptr) {
       b.busy = false;
