@@ -547,7 +547,7 @@ def pmc_traffic(config):
     """ HBM bytes per trailing-update launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
     x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, collected in their own runs of this same
     command); counters cannot be read live from inside the process, so None when no committed pass matches """
-    path = next((q for q in (os.path.join(ROOT, 'profiles', f'{tag}_{config}_pmc_traffic.json') for tag in ('r03', 'r02', 'r01')) if os.path.exists(q)), '')
+    path = next((q for q in (os.path.join(ROOT, 'profiles', f'{tag}_{config}_pmc_traffic.json') for tag in ('r04', 'r03', 'r02', 'r01')) if os.path.exists(q)), '')
     try:
         with open(path) as f:
             d = json.load(f)
