@@ -453,7 +453,7 @@ class _Isotropic(Kernel):
         deg = self._derivability()
         name = type(self).__name__
         if deg is None:
-            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, GammaExp(gamma=2), Cauchy(alpha=2), '
+            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, GammaExp(gamma=2), Cauchy(alpha=2), '
                                       'Constant, Linear, Periodic, Cos, Sinc, Celerite, Harmonic, Wendland, Circular, Decaying, WienerIntegral, '
                                       'FracBrownian(H=1, K=1), StationaryFracBrownian(H=1) have one)')
         sides = []
@@ -655,13 +655,17 @@ class Maternp(_Isotropic):
         self._p = int(p)
 
     def _derivability(self):
-        return int(self._p) if self._kind == _lib.LGP_KERNEL_MATERNP else None      # (real order: no derivative core yet)
+        if self._kind == _lib.LGP_KERNEL_MATERNP:
+            return int(self._p)
+        return int(max(0, numpy.ceil(self._nu) - 1))              # real order: _matern.py:51-53
 
     def _jet_pars(self):
         """ k = f(s), s = (2p+1) r^2, t = sqrt(s): f^(k)(s) = exp(-t) R_k(t) with R_0 = P_p (``_special/_bessel.py:101-110``) and
         R_(k+1) = (R_k' - R_k) / (2 t) -- Laurent polynomials in t (the division is exact up to the p-th derivative; beyond it
         the negative powers meet powers of the distance in the chain rule), entry i of a row the coefficient of t^(i - 7) """
         from fractions import Fraction
+        if self._kind != _lib.LGP_KERNEL_MATERNP:       # real order: the library derives its constants from nu (csrc/bessel_k_dev.h)
+            return 0, tuple(self._par), ()
         p = int(self._p)
         # exact rational arithmetic: a rounding residue of 1e-17 in a coefficient of 1 / t is 1e-2 at a coincidence (t = 1e-15)
         OFF, W = 7, 24

@@ -15,6 +15,7 @@
 // This file is compiled with -ffp-contract=off: the reference evaluates square-then-add without fused
 // multiply-add and the entries are compared to a few ulp.
 #include "common.h"
+#include "bessel_k_dev.h"
 #include <limits>
 
 namespace {
@@ -72,82 +73,16 @@ template <typename T> struct VecOf;
 template <> struct VecOf<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int W = 2; };
 template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int W = 4; };
 
-// Matern of real order (_kernels/_matern.py:56-76 through _special/_bessel.py:72-82): 2 / Gamma(nu) (x / 2)^nu K_nu(x), x = sqrt(2 nu r2),
-// 1 at x = 0.  K_nu by Temme's method (N. M. Temme, J. Comput. Phys. 19 (1975) 324): nu = mu + nl, |mu| <= 1/2; K_mu and K_{mu+1}
-// from the series in x^2/4 for x < 2 and from Steed's continued fraction otherwise, then nl steps of the upward recurrence (stable
-// for K).  The constants that depend on nu alone (1/Gamma(1 +- mu), the two Temme combinations of them, pi mu / sin(pi mu),
-// 2/Gamma(nu)) come from the host.  Also returns x K_{nu-1}(x) in units of K's prefactor: dk/dx = -c (x/2)^nu K_{nu-1}(x).
-struct MaternNu { double nu, mu, gampl, gammi, gam1, gam2, fact, c2; int nl; };
-__device__ inline double matern_real(const MaternNu &c, double x, double *xdk) {
-  const double eps = 1e-16;
-  const double mu2 = c.mu * c.mu, xi = 1. / x, xi2 = 2. * xi;
-  double kmu, k1, lhalf;                                 // lhalf = log(x / 2)
-  if (x < 2.) {
-    const double d = log(xi2);
-    lhalf = -d;
-    double e = c.mu * d;
-    const double sh = fabs(e) < eps ? 1. : sinh(e) / e;
-    double ff = c.fact * (c.gam1 * cosh(e) + c.gam2 * sh * d);
-    double sum = ff;
-    e = exp(e);
-    double p = 0.5 * e / c.gampl, q = 0.5 / (e * c.gammi), cc = 1., sum1 = p;
-    const double q4 = 0.25 * x * x;
-    for (int i = 1; i < 500; ++i) {
-      ff = (i * ff + p + q) / (i * i - mu2);
-      cc *= q4 / i;
-      p /= i - c.mu;
-      q /= i + c.mu;
-      const double del = cc * ff;
-      sum += del;
-      sum1 += cc * (p - i * ff);
-      if (fabs(del) < fabs(sum) * eps) break;
-    }
-    kmu = sum;
-    k1 = sum1 * xi2;
-  } else {
-    lhalf = log(0.5 * x);
-    double b = 2. * (1. + x), d = 1. / b, h = d, delh = d, q1 = 0., q2 = 1.;
-    const double a1 = 0.25 - mu2;
-    double q = a1, cc = a1, a = -a1, s = 1. + q * delh;
-    for (int i = 2; i < 500; ++i) {
-      a -= 2 * (i - 1);
-      cc = -a * cc / i;
-      const double qnew = (q1 - b * q2) / a;
-      q1 = q2; q2 = qnew;
-      q += cc * qnew;
-      b += 2.;
-      d = 1. / (b + a * d);
-      delh = (b * d - 1.) * delh;
-      h += delh;
-      const double dels = q * delh;
-      s += dels;
-      if (fabs(dels / s) < eps) break;
-    }
-    h = a1 * h;
-    kmu = sqrt(1.5707963267948966 / x) * exp(-x) / s;
-    k1 = kmu * (c.mu + x + 0.5 - h) * xi;
-  }
-  double km1 = k1 - 2. * c.mu * xi * kmu;                // K_{mu-1} = K_{1-mu} = K_{mu+1} - (2 mu / x) K_mu, used when nl == 0
-  for (int i = 1; i <= c.nl; ++i) {
-    const double kn = (c.mu + i) * xi2 * k1 + kmu;
-    km1 = kmu; kmu = k1; k1 = kn;
-  }
-  // 2/Gamma(nu) and (x/2)^nu are both tiny where K_nu is huge (and the power huge where K_nu is tiny): pair the factors so that
-  // no intermediate product leaves the normal range
-  const double pw = exp(c.nu * lhalf);
-  *xdk = (km1 > 1. ? (c.c2 * km1) * pw : (c.c2 * pw) * km1) * x;
-  return kmu > 1. ? (c.c2 * kmu) * pw : (c.c2 * pw) * kmu;
-}
 template <typename T>
 __device__ __forceinline__ T matern_real_of(const IsoArgs<T> &g, T r2, T *xdk) {
   if (g.flag) { *xdk = T(0); return r2 == T(0) ? T(1) : T(0); }          // nu = 0: _matern.py:74 "the correct limit is white"
   const double x = sqrt((double)g.twop1 * (double)r2);
   double dk = 0., k = 1.;
   if (x > 0.) {
-    MaternNu c;
+    lgp_bessel::MaternNu c;
     c.nu = (double)g.coef[0]; c.mu = (double)g.coef[1]; c.gampl = (double)g.coef[2]; c.gammi = (double)g.coef[3];
     c.gam1 = (double)g.coef[4]; c.gam2 = (double)g.coef[5]; c.fact = (double)g.coef[6]; c.c2 = (double)g.coef[7]; c.nl = g.p;
-    k = matern_real(c, x, &dk);
+    k = lgp_bessel::matern_real(c, x, &dk);
     if (!(k <= 1.)) {
       // x so small that K_nu overflows (x < 0.06 at nu = 100, 1e-8 at nu = 33, 1e-76 at nu = 4): the series
       // sum_k (-x^2/4)^k / (k! (nu-1) ... (nu-k)); its companion in x^(2 nu) is far below the last bit there
@@ -866,23 +801,10 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
     const double nu = (double)hpar[0];
     g.flag = nu == 0.;
     g.twop1 = (T)(2. * (nu == 0. ? 1. : nu));            // _matern.py:74
-    const int nl = (int)(nu + 0.5);
-    const double mu = nu - nl, mu2 = mu * mu;
-    // 1 / Gamma(1 + z) = sum_k c_k z^(k-1) (Abramowitz & Stegun 6.1.34); Temme's gam2 and gam1 are its even and (minus its) odd part
-    static const double rg[26] = {1.0000000000000000, 0.5772156649015329, -0.6558780715202538, -0.0420026350340952, 0.1665386113822915,
-      -0.0421977345555443, -0.0096219715278770, 0.0072189432466630, -0.0011651675918591, -0.0002152416741149, 0.0001280502823882,
-      -0.0000201348547807, -0.0000012504934821, 0.0000011330272320, -0.0000002056338417, 0.0000000061160950, 0.0000000050020075,
-      -0.0000000011812746, 0.0000000001043427, 0.0000000000077823, -0.0000000000036968, 0.0000000000005100, -0.0000000000000206,
-      -0.0000000000000054, 0.0000000000000014, 0.0000000000000001};
-    double gam1 = 0., gam2 = 0.;
-    for (int k = 25; k >= 1; k -= 2) gam1 = gam1 * mu2 + rg[k];
-    for (int k = 24; k >= 0; k -= 2) gam2 = gam2 * mu2 + rg[k];
-    gam1 = -gam1;
-    const double pimu = 3.141592653589793238462643383279502884 * mu;
-    g.p = nl;
-    g.coef[0] = (T)nu; g.coef[1] = (T)mu; g.coef[2] = (T)(gam2 - mu * gam1); g.coef[3] = (T)(gam2 + mu * gam1);
-    g.coef[4] = (T)gam1; g.coef[5] = (T)gam2; g.coef[6] = (T)(fabs(pimu) < 1e-16 ? 1. : pimu / sin(pimu));
-    g.coef[7] = (T)(nu == 0. ? 0. : 2. / tgamma(nu));
+    const lgp_bessel::MaternNu c = lgp_bessel::matern_nu_constants(nu);
+    g.p = c.nl;
+    g.coef[0] = (T)c.nu; g.coef[1] = (T)c.mu; g.coef[2] = (T)c.gampl; g.coef[3] = (T)c.gammi;
+    g.coef[4] = (T)c.gam1; g.coef[5] = (T)c.gam2; g.coef[6] = (T)c.fact; g.coef[7] = (T)c.c2;
   } else if (kernel == LGP_KERNEL_GAMMAEXP) {            // hpar = {gamma, gamma / 2}
     LGP_REQUIRE(npar == 2 && hpar != nullptr, "GammaExp takes {gamma, gamma/2}");
     LGP_REQUIRE(hpar[0] > T(0) && hpar[0] <= T(2), "gamma must be in (0, 2]");                 // _basic.py:109-110

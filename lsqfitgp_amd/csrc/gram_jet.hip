@@ -12,6 +12,7 @@
 // derivatives e^-t R_k(t) the host derives (R_{k+1} = (R_k' - R_k) / (2 t), exact for k < p: no square root of a jet at r = 0).
 // One thread per pair: derivative blocks are the small blocks of a problem, not its N x N matrix.
 #include "common.h"
+#include "bessel_k_dev.h"
 
 namespace {
 
@@ -224,6 +225,29 @@ __device__ __forceinline__ S jet_core(const JetArgs &g, const S &r2, const S &X,
     }
     return compose(s, f);
   }
+  if (k == LGP_KERNEL_MATERN) {
+    // real order: G(q) = c2 (x/2)^nu K_nu(x), x^2 = 2 nu q, has G^(k)(q) = (-nu / 2)^k F_k(x) (bessel_k_dev.h); at q = 0 the limits
+    // c2 (-nu / 2)^k Gamma(nu - k) / 2 from the host (row 1 of the table; 0 beyond the orders that exist: they meet powers of a
+    // vanishing distance, and the host has refused the derivatives that the process does not have)
+    const double q = (double)r2.val();
+    T f[5];
+    if (q > 0.) {
+      lgp_bessel::MaternNu c;
+      c.nu = g.coef[0][0]; c.mu = g.coef[0][1]; c.gampl = g.coef[0][2]; c.gammi = g.coef[0][3];
+      c.gam1 = g.coef[0][4]; c.gam2 = g.coef[0][5]; c.fact = g.coef[0][6]; c.c2 = g.coef[0][7]; c.nl = g.p;
+      double F[5];
+      lgp_bessel::matern_ladder(c, sqrt(2. * c.nu * q), F);
+      double fk = 1., fact = 1.;
+      for (int i = 0; i < 5; ++i) {
+        f[i] = T(F[i] * fk / fact);
+        fk *= -0.5 * c.nu;
+        fact *= (double)(i + 1);
+      }
+    } else {
+      for (int i = 0; i < 5; ++i) f[i] = T(g.coef[1][i]);
+    }
+    return compose(r2, f);
+  }
   if (k == LGP_KERNEL_CONSTANT) return S(T(1));
   if (k == LGP_KERNEL_LINEAR) return r2;                                             // (r2 carries sum_f X_f Y_f for this kernel)
   const S delta = X - Y;
@@ -321,7 +345,7 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
                       kernel == LGP_KERNEL_HARMONIC || kernel == LGP_KERNEL_WENDLAND || kernel == LGP_KERNEL_CIRCULAR || kernel == LGP_KERNEL_DECAYING ||
                       kernel == LGP_KERNEL_WIENERINTEGRAL || kernel == LGP_KERNEL_FRACBROWNIAN || kernel == LGP_KERNEL_STATIONARYFRACBROWNIAN;
   const bool iso = kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY || kernel == LGP_KERNEL_MATERNP ||
-                   kernel == LGP_KERNEL_CONSTANT || kernel == LGP_KERNEL_LINEAR;
+                   kernel == LGP_KERNEL_CONSTANT || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_MATERN;
   LGP_REQUIRE(onevar || iso, "no derivative core for this kernel");
   LGP_REQUIRE(!onevar || d == 1, "a kernel of one variable takes one-dimensional points");
   LGP_REQUIRE(kernel != LGP_KERNEL_MATERNP || (p >= 0 && p <= 16 && ncoef == 5 * 24), "Maternp: order 0 .. 16 and the five polynomials");
@@ -338,6 +362,20 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.posabs = 0;
   for (int i = 0; i < npar; ++i) g.par[i] = (double)hpar[i];
   for (int i = 0; i < ncoef; ++i) g.coef[i / 24][i % 24] = (double)hcoef[i];
+  if (kernel == LGP_KERNEL_MATERN) {                     // hpar = {nu}: the constants of the Bessel evaluation and the limits at r = 0
+    LGP_REQUIRE(npar == 1 && hpar[0] > T(0) && hpar[0] <= T(100), "Matern takes {nu} in (0, 100]");
+    const double nu = (double)hpar[0];
+    const lgp_bessel::MaternNu c = lgp_bessel::matern_nu_constants(nu);
+    g.p = c.nl;
+    g.coef[0][0] = c.nu; g.coef[0][1] = c.mu; g.coef[0][2] = c.gampl; g.coef[0][3] = c.gammi;
+    g.coef[0][4] = c.gam1; g.coef[0][5] = c.gam2; g.coef[0][6] = c.fact; g.coef[0][7] = c.c2;
+    double fk = 1., fact = 1.;
+    for (int i = 0; i < 5; ++i) {
+      g.coef[1][i] = nu - i > 0. ? 0.5 * (c.c2 * tgamma(nu - i)) * fk / fact : 0.;
+      fk *= -0.5 * nu;
+      fact *= (double)(i + 1);
+    }
+  }
   g.ldx = (long)ldx; g.ldy = (long)ldy; g.ldo = (long)ldo;
   const size_t total = n * m;
   hipLaunchKernelGGL((gram_jet_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dx, dy, dout, g);

@@ -302,7 +302,17 @@ def Matern(*, nu=None, scale=None, loc=None, dim=None):
         with numpy.errstate(invalid='ignore', divide='ignore', over='ignore'):
             val = 2 ** (1 - nu) / special.gamma(nu) * x ** nu * special.kv(nu, x)
         return numpy.where(x == 0, 1., val)
-    return Kernel(_isotropic(core), scale=scale, loc=loc, dim=dim)
+    inner = _isotropic(core)
+
+    def sym(r2):                                             # derivative observations (symdiff.py): sympy differentiates K_nu itself
+        sp = _sp()
+        v = sp.Rational(float(nu))                           # the double, exactly
+        x = sp.sqrt(2 * v * r2)
+        return 2 ** (1 - v) / sp.gamma(v) * x ** v * sp.besselk(v, x)
+    # ceil(nu) - 1 times derivable (_matern.py:51-53).  The derivatives at a coincidence are limits of sums of terms up to
+    # x^-(nu + 4) in size that approach them like x^(2 (nu - order)): far smaller an offset, far more digits, than the elementary cores
+    inner.symbolic = ('iso', sym, None, dict(dps=400, offset='1e-40')) if nu > 1 else None
+    return Kernel(inner, scale=scale, loc=loc, dim=dim)
 
 
 def Bessel(*, nu=0, scale=None, loc=None, dim=None):

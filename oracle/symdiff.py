@@ -10,7 +10,8 @@ A core announces its expression through ``core.symbolic = (kind, builder)``:
     'circ'   builder(t): a function of the distance t of |difference| to the nearest integer;
     'xy'     builder(x, y, upper): of the two points themselves; upper: the branch x <= y;
     'iso'    builder(r2): of the squared distance over the fields;
-an optional third entry is the radius of a compact support (the expression is then the one inside it).
+an optional third entry is the radius of a compact support (the expression is then the one inside it), a fourth a dictionary
+``dps`` / ``offset``: working digits and the offset from which the limit at coincident points is taken (default 120, 1e-10).
 """
 
 import numpy
@@ -22,6 +23,7 @@ def symbolic_diff(kernel, da, db, Kernel):
     import sympy as sp
     kind, build = kernel._core.symbolic[:2]
     support = kernel._core.symbolic[2] if len(kernel._core.symbolic) > 2 else None       # compact support: zero for arguments >= support
+    opts = kernel._core.symbolic[3] if len(kernel._core.symbolic) > 3 else {}            # working precision / offset at coincidences
     scale = float(kernel._scale if kernel._scale is not None else 1.)
     factor = 1.
     for op, c in kernel._outops:
@@ -105,13 +107,15 @@ def symbolic_diff(kernel, da, db, Kernel):
         shape = numpy.broadcast_shapes(*(c[0].shape for c in cols.values()), *(c[1].shape for c in cols.values()))
         bc = {k: (numpy.broadcast_to(v[0], shape), numpy.broadcast_to(v[1], shape)) for k, v in cols.items()}
         out = numpy.empty(shape)
-        with mpmath.workdps(120):
-            for idx in numpy.ndindex(shape):
-                rest = sum((bc[k][0][idx] - bc[k][1][idx]) ** 2 for k in bc if k not in (f1, f2))
-                u, v = bc[f1][0][idx], bc[f1][1][idx]
-                args = [u, v] + ([bc[f2][0][idx], bc[f2][1][idx]] if f2 is not None else []) + [rest]
-                if rest == 0 and u == v and (f2 is None or args[2] == args[3]):
-                    args[0] = mpmath.mpf(float(u)) + mpmath.mpf('1e-10')    # a coincidence: the limit, from a small offset (error ~ 1e-10) in extended precision
+        for idx in numpy.ndindex(shape):
+            rest = sum((bc[k][0][idx] - bc[k][1][idx]) ** 2 for k in bc if k not in (f1, f2))
+            u, v = bc[f1][0][idx], bc[f1][1][idx]
+            args = [u, v] + ([bc[f2][0][idx], bc[f2][1][idx]] if f2 is not None else []) + [rest]
+            coincide = rest == 0 and u == v and (f2 is None or args[2] == args[3])
+            # a coincidence: the limit, from a small offset (error ~ the offset) in extended precision
+            with mpmath.workdps(opts.get('dps', 120) if coincide else 120):
+                if coincide:
+                    args[0] = mpmath.mpf(float(u)) + mpmath.mpf(opts.get('offset', '1e-10'))
                 out[idx] = float(fn(*args))
         return out
     return Kernel(core, scale=kernel._scale, loc=kernel._loc, outops=(('mul', factor),))

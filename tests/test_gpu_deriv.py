@@ -77,7 +77,11 @@ def test_what_is_not_available_says_so(lgp):
     with pytest.raises(ValueError):                                             # not derivable: the reference's error (_Kernel/_ops.py:85-90)
         lgp.GP(lgp.GammaExp(gamma=1.2)).addx(x, 'a', deriv=1).prior('a', raw=True)
     with pytest.raises(NotImplementedError):                                     # derivable in the reference, no derivative core here yet
-        lgp.GP(lgp.Matern(nu=2.3)).addx(x, 'a', deriv=1).prior('a', raw=True)
+        lgp.GP(lgp.Bessel(nu=2.3)).addx(x, 'a', deriv=1).prior('a', raw=True)
+    with pytest.raises(ValueError):                                             # ceil(nu) - 1 times derivable (_kernels/_matern.py:51-53)
+        lgp.GP(lgp.Matern(nu=1.7)).addx(x, 'a', deriv=2).prior('a', raw=True)
+    with pytest.raises(ValueError):
+        lgp.GP(lgp.Matern(nu=0.8)).addx(x, 'a', deriv=1).prior('a', raw=True)
     with pytest.raises(ValueError):
         lgp.GP(lgp.Maternp(p=1)).addx(x, 'a', deriv=2).prior('a', raw=True)     # derivable p times on each side
     with pytest.raises(ValueError):
@@ -263,6 +267,55 @@ def test_maternp_derivatives_along_named_fields_vs_oracle(lgp, p):
         np.testing.assert_allclose(got, want, rtol=0, atol=3e-9 * scale, err_msg=f'p={p} {sx} {sy}')
     with pytest.raises(ValueError):
         kd.gram(x, y, deriv=((p + 1, 0, 0), (0, 0, 0)))             # derivable p times per side (_kernels/_matern.py:26-27)
+
+
+@pytest.mark.parametrize('nu', [1.2, 1.9, 2.3, 3.75, 7.1])
+def test_matern_of_real_order_derivatives_vs_oracle(lgp, nu):
+    """ Matern(nu), ceil(nu) - 1 times derivable (_kernels/_matern.py:51-76): the derivative core evaluates K of the orders nu - k on
+    the device (csrc/bessel_k_dev.h) and uses the exact limits at coincident points; the oracle differentiates K_nu symbolically and
+    evaluates in extended precision.  One- and three-dimensional points. """
+    rng = np.random.default_rng(int(100 * nu))
+    x = rng.uniform(0.1, 3, 14); y = rng.uniform(0.1, 3, 11)
+    y[:4] = x[:4]
+    y[4] = x[4] + 1e-7; y[5] = x[5] - 3e-5                       # nearly coincident: large negative orders times small powers
+    kd, ko = lgp.Matern(nu=nu, scale=1.3, loc=0.1) * 1.2, oracle.Matern(nu=nu, scale=1.3, loc=0.1) * 1.2
+    deg = int(np.ceil(nu) - 1)
+    orders = [(a, b) for a in range(min(deg, 2) + 1) for b in range(min(deg, 2) + 1) if a + b]
+    for a, b in orders:
+        got = kd.gram(x, y, deriv=(a, b)).to_host()
+        want = ko.diff(a, b)(x[:, None], y[None, :])
+        scale = max(np.abs(want).max(), 1e-3)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-9 * scale, err_msg=f'nu={nu} {(a, b)}')
+        far = np.abs(x[:, None] - y[None, :]) > 1e-3
+        np.testing.assert_allclose(got[far], want[far], rtol=0, atol=1e-11 * scale, err_msg=f'nu={nu} {(a, b)} away from coincidences')
+    with pytest.raises(ValueError):
+        kd.gram(x, y, deriv=(deg + 1, 0))
+    # along named fields of three-dimensional points
+    dt = [('a', float), ('b', float), ('c', float)]
+    X = np.empty(9, dt); Y = np.empty(7, dt)
+    for f in 'abc':
+        X[f] = rng.uniform(0, 2, 9); Y[f] = rng.uniform(0, 2, 7)
+    Y[:3] = X[:3]
+    for sx, sy in [(('a', 1), ('b', 1)), (('c', 1), ('c', 1))] + ([(('b', 2), ('b', 2))] if deg >= 2 else []):
+        ox = tuple((sx[1] if nm == sx[0] else 0) for nm in X.dtype.names)
+        oy = tuple((sy[1] if nm == sy[0] else 0) for nm in X.dtype.names)
+        got = kd.gram(X, Y, deriv=(ox, oy)).to_host()
+        want = ko.diff({sx[0]: sx[1]}, {sy[0]: sy[1]})(X[:, None], Y[None, :])
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-9 * max(np.abs(want).max(), 1e-3), err_msg=f'nu={nu} {sx} {sy}')
+
+
+def test_matern_of_real_order_derivatives_meet_the_half_integer_closed_form(lgp):
+    """ nu -> p + 1/2: the derivative core of real order next to Maternp's own (Laurent polynomials, another code path), nu = 2.5
+    approached from both sides; and its exact values at a coincidence, 3 nu^2 / ((nu - 1)(nu - 2)) for order (2, 2) """
+    x = np.array([0.3, 0.9, 1.4, 2.2]); y = np.array([0.3, 0.5, 1.4, 3.1])
+    ref = lgp.Maternp(p=2).gram(x, y, deriv=(2, 2)).to_host()
+    for nu in (2.5 - 1e-7, 2.5 + 1e-7):
+        got = lgp.Matern(nu=nu).gram(x, y, deriv=(2, 2)).to_host()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=3e-5 * np.abs(ref).max())           # (d/dnu of the values times 1e-7)
+        assert abs(got[0, 0] - 3 * nu ** 2 / ((nu - 1) * (nu - 2))) <= 1e-12 * got[0, 0]
+    for nu, a, b, exact in [(1.3, 1, 1, 1.3 / 0.3), (3.3, 1, 1, 3.3 / 2.3), (3.3, 2, 0, -3.3 / 2.3)]:
+        got = lgp.Matern(nu=nu).gram(x, y, deriv=(a, b)).to_host()
+        assert abs(got[0, 0] - exact) <= 1e-12 * abs(exact) and abs(got[2, 2] - exact) <= 1e-12 * abs(exact)
 
 
 def test_posterior_with_derivative_data_of_a_periodic_process(lgp):
