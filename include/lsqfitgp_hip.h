@@ -573,6 +573,13 @@ int lgp_update_nt_slab_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, con
                            double *dC, size_t ldc, size_t nb, size_t nranks, size_t roff);
 /* dout[0] = max_i dx[i] (NaN if any element is NaN, like jnp.max): the Gershgorin bound over a rank's column sums */
 int lgp_max_f64(lgp_ctx *ctx, size_t n, const double *dx, double *dout);
+/* `steps` Lanczos iterations on the symmetric n x n device matrix dK from the unit host vector hq0 (n doubles), entirely on the
+ * device: halpha, hbeta (steps values each, host) are the diagonal and the off-diagonal of the tridiagonal matrix whose
+ * eigenvalues lie inside the spectrum of K; hbeta[j] = 0 marks an invariant subspace (cut the matrix there).  Three-term
+ * recurrence, vectors and sums in double for both matrix types.  Replaces the two LOBPCG iterations on a host copy behind
+ * GP(checkpos=True) (_GP/_elements.py:651-668).  Synchronises. */
+int lgp_lanczos_f64(lgp_ctx *ctx, size_t n, const double *dK, size_t ldk, size_t steps, const double *hq0, double *halpha, double *hbeta);
+int lgp_lanczos_f32(lgp_ctx *ctx, size_t n, const float *dK, size_t ldk, size_t steps, const double *hq0, double *halpha, double *hbeta);
 /* A_ij <- A_ij / drow_i / dcol_j (divide != 0) or * drow_i * dcol_j: the power-of-two scaling of a locally owned block
  * column and its undoing on the factor (_decomp.py:385,392); drow / dcol may be NULL */
 int lgp_scale_rows_cols_f64(lgp_ctx *ctx, size_t rows, size_t cols, double *dA, size_t lda,

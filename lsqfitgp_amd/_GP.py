@@ -926,8 +926,8 @@ class GP:
     def _extreme_eigenvalues(self, cov, steps=24):
         """ estimates of the smallest and largest eigenvalue of a symmetric device matrix.  The reference runs two LOBPCG
         iterations from one random vector on the host copy (``_elements.py:651-668``); here: exact for small matrices,
-        otherwise `steps` Lanczos iterations with the matrix-vector products on the device (the Krylov basis, n x steps
-        numbers, lives on the host and is fully reorthogonalised).  Like LOBPCG's, the Ritz values bracket from inside:
+        otherwise `steps` Lanczos iterations entirely on the device (``lgp_lanczos``: two launches per step, no host round
+        trip; the host only diagonalises the steps x steps tridiagonal matrix).  Like LOBPCG's, the Ritz values bracket from inside:
         the estimate of the minimum is an upper bound of it. """
         n = cov.shape[0]
         if n <= 256:
@@ -936,18 +936,13 @@ class GP:
         rng = numpy.random.default_rng(0x5eed)
         q = rng.standard_normal(n)
         q /= numpy.linalg.norm(q)
-        Q = [q]
-        alpha, beta = [], []
-        for j in range(min(steps, n)):
-            v = _gemm(False, False, cov, DeviceArray.from_host(Q[-1].reshape(n, 1), dtype=cov.dtype, ctx=self.ctx)).to_host()[:, 0].astype(float)
-            alpha.append(float(Q[-1] @ v))
-            for qq in Q:                                   # full reorthogonalisation
-                v -= (qq @ v) * qq
-            nb = float(numpy.linalg.norm(v))
-            if nb <= 1e-14 * max(1., abs(alpha[0])):
-                break
-            beta.append(nb)
-            Q.append(v / nb)
+        steps = min(steps, n)
+        alpha, beta = numpy.zeros(steps), numpy.zeros(steps)
+        f, _ = _lib.fn('lgp_lanczos', cov.dtype)
+        _lib.check(f(self.ctx.handle, n, cov.ptr, cov.ld, steps, q.ctypes.data, alpha.ctypes.data, beta.ctypes.data), 'lgp_lanczos')
+        stop = numpy.flatnonzero(beta == 0)                # an invariant subspace: the recurrence ended there
+        if len(stop):
+            alpha, beta = alpha[:stop[0] + 1], beta[:stop[0] + 1]
         k = len(alpha)
         T = numpy.diag(alpha) + numpy.diag(beta[:k - 1], 1) + numpy.diag(beta[:k - 1], -1)
         w = numpy.linalg.eigvalsh(T)

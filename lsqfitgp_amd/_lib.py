@@ -115,6 +115,8 @@ def _signatures():
         'lgp_chol_dist_plan': (ctypes.c_long, [_S, _S, _S, _S, _S, _P, _S, POINTER(c_size_t), POINTER(c_size_t)]),
         'lgp_update_nt_slab_f64': (c_int, [c_void_p, _S, _S, _S, _P, _S, _P, _S, _P, _S, _S, _S, _S]),
         'lgp_max_f64': (c_int, [c_void_p, _S, _P, _P]),
+        'lgp_lanczos_f64': (c_int, [c_void_p, _S, _P, _S, _S, _P, _P, _P]),
+        'lgp_lanczos_f32': (c_int, [c_void_p, _S, _P, _S, _S, _P, _P, _P]),
         'lgp_scale_rows_cols_f64': (c_int, [c_void_p, _S, _S, _P, _S, _P, _P, c_int]),
         'lgp_diag_scale_pow2_f64': (c_int, [c_void_p, _S, _P, _S, _P]),
     }

@@ -621,3 +621,87 @@ extern "C" int lgp_max_f64(lgp_ctx *ctx, size_t n, const double *dx, double *dou
   LGP_LAUNCH_CHECK();
   return LGP_OK;
 }
+
+// ---- extreme eigenvalues of a symmetric matrix by Lanczos iterations, entirely on the device (GP(checkpos=True),
+// _GP/_elements.py:651-668: the reference runs two LOBPCG iterations on a host copy).  Two launches per step, no host round trip:
+//   matvec   w = K q_j - beta_{j-1} q_{j-1}           one wave per row, the vectors in double whatever the matrix's type
+//   step     alpha_j = q_j . w;  w -= alpha_j q_j;  beta_j = |w|;  q_{j+1} = w / beta_j     one workgroup, sums in fixed order
+// The three-term recurrence without reorthogonalisation: the Ritz values stay inside the spectrum (what the check needs; copies of
+// converged ones may appear among 24 steps, which does not move the extremes).
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) lanczos_matvec_kernel(size_t n, const T *__restrict__ K, size_t ldk, const double *__restrict__ q,
+                                                            const double *__restrict__ qprev, const double *bprev, double *__restrict__ w) {
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const T *kr = K + row * ldk;
+  double acc = 0.;
+  for (size_t c = lane; c < n; c += 64) acc += (double)kr[c] * q[c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) w[row] = qprev != nullptr ? acc - bprev[0] * qprev[row] : acc;
+}
+
+__device__ __forceinline__ double block_sum_1024(double v, double *sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();                                       // (sh may still be read from the previous sum)
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.;
+  for (int i = 0; i < 16; ++i) t += sh[i];
+  return t;
+}
+
+__global__ void __launch_bounds__(1024) lanczos_step_kernel(size_t n, const double *__restrict__ q, double *__restrict__ w, double *alpha, double *beta,
+                                                           const double *alpha0) {
+  __shared__ double sh[16];
+  double acc = 0.;
+  for (size_t i = threadIdx.x; i < n; i += 1024) acc += q[i] * w[i];
+  const double a = block_sum_1024(acc, sh);
+  acc = 0.;
+  for (size_t i = threadIdx.x; i < n; i += 1024) {
+    const double v = w[i] - a * q[i];
+    w[i] = v;
+    acc += v * v;
+  }
+  const double b = sqrt(block_sum_1024(acc, sh));
+  // an invariant subspace: the recurrence ends (the host cuts the tridiagonal matrix at the first such beta); later steps see q = 0
+  const double ref = fabs(alpha0 != nullptr ? alpha0[0] : a);
+  const double inv = b > 1e-14 * (ref > 1. ? ref : 1.) ? 1. / b : 0.;
+  for (size_t i = threadIdx.x; i < n; i += 1024) w[i] *= inv;
+  if (threadIdx.x == 0) { alpha[0] = a; beta[0] = inv != 0. ? b : 0.; }
+}
+
+template <typename T>
+int lanczos_impl(lgp_ctx *ctx, size_t n, const T *dK, size_t ldk, size_t steps, const double *hq0, double *halpha, double *hbeta) {
+  LGP_REQUIRE(ctx != nullptr && dK != nullptr && hq0 != nullptr && halpha != nullptr && hbeta != nullptr, "null pointer");
+  LGP_REQUIRE(n >= 1 && ldk >= n && steps >= 1 && steps <= 1024, "bad sizes");
+  DeviceGuard dg(ctx->device);
+  hipStream_t st = ctx->stream;
+  double *ws = nullptr;
+  LGP_CHECK(lgp_ws_alloc(ctx, st, (3 * n + 2 * steps) * sizeof(double), reinterpret_cast<void **>(&ws)));
+  WsGuard guard(ctx, st, ws);
+  double *buf[3] = {ws, ws + n, ws + 2 * n}, *dalpha = ws + 3 * n, *dbeta = dalpha + steps;
+  LGP_HIP(hipMemcpyAsync(buf[0], hq0, n * sizeof(double), hipMemcpyHostToDevice, st));
+  for (size_t j = 0; j < steps; ++j) {
+    double *q = buf[j % 3], *w = buf[(j + 1) % 3], *qprev = j ? buf[(j + 2) % 3] : nullptr;
+    hipLaunchKernelGGL((lanczos_matvec_kernel<T>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, n, dK, ldk, q, qprev, j ? dbeta + (j - 1) : nullptr, w);
+    LGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lanczos_step_kernel, dim3(1), dim3(1024), 0, st, n, q, w, dalpha + j, dbeta + j, j ? dalpha : nullptr);
+    LGP_LAUNCH_CHECK();
+  }
+  LGP_HIP(hipMemcpyAsync(halpha, dalpha, steps * sizeof(double), hipMemcpyDeviceToHost, st));
+  LGP_HIP(hipMemcpyAsync(hbeta, dbeta, steps * sizeof(double), hipMemcpyDeviceToHost, st));
+  LGP_HIP(hipStreamSynchronize(st));
+  return LGP_OK;
+}
+}  // namespace
+
+extern "C" int lgp_lanczos_f64(lgp_ctx *ctx, size_t n, const double *dK, size_t ldk, size_t steps, const double *hq0, double *halpha, double *hbeta) {
+  return lanczos_impl<double>(ctx, n, dK, ldk, steps, hq0, halpha, hbeta);
+}
+extern "C" int lgp_lanczos_f32(lgp_ctx *ctx, size_t n, const float *dK, size_t ldk, size_t steps, const double *hq0, double *halpha, double *hbeta) {
+  return lanczos_impl<float>(ctx, n, dK, ldk, steps, hq0, halpha, hbeta);
+}

@@ -461,3 +461,30 @@ def test_one_call_prediction_is_the_general_path(lgp, rng, monkeypatch, case):
     g = gc(lgp)
     m2, c2 = gp.predfromdata({'d': y}, 't', *(() if g is None else (g,)), raw=True)
     assert calls == [True, False, False] and np.linalg.norm(m2 - mg) <= (loose or 1e-9) * max(np.linalg.norm(mg), 1e-3)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_extreme_eigenvalues_by_device_lanczos(lgp, rng, dtype):
+    """ `lgp_lanczos` behind GP(checkpos=True) (_GP/_elements.py:651-668): the Ritz values lie inside the spectrum, find a separated
+    extreme eigenvalue at once, and a matrix with one clearly negative eigenvalue is refused """
+    n = 700
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.concatenate([[-0.5], rng.uniform(0.1, 2., n - 2), [40.]])
+    A = (Qm * lam) @ Qm.T
+    A = (A + A.T) / 2
+    gp = lgp.GP(lgp.ExpQuad())
+    lo, hi = gp._extreme_eigenvalues(lgp.DeviceArray.from_host(A.astype(dtype)))
+    eps = np.finfo(dtype).eps
+    assert -0.5 - 100 * eps * 40 <= lo <= -0.5 + 1e-3 and 40 - 1e-3 <= hi <= 40 + 100 * eps * 40
+    with pytest.raises(np.linalg.LinAlgError):
+        lgp.GP(checksym=False).addcov(A.astype(dtype), 'a').prior('a', raw=True)
+    # positive definite with a cluster at the bottom: accepted, the minimum estimated from above
+    lam[0] = 0.1
+    B = (Qm * lam) @ Qm.T
+    B = (B + B.T) / 2
+    lo, hi = gp._extreme_eigenvalues(lgp.DeviceArray.from_host(B.astype(dtype)))
+    assert 0.1 - 100 * eps * 40 <= lo <= 0.2 and abs(hi - 40) <= 1e-3
+    lgp.GP().addcov(B.astype(dtype), 'a').prior('a', raw=True)
+    # an invariant subspace: the identity stops after one step
+    lo, hi = gp._extreme_eigenvalues(lgp.DeviceArray.from_host(np.eye(n, dtype=dtype) * 3))
+    assert abs(lo - 3) <= 1e-6 and abs(hi - 3) <= 1e-6
