@@ -741,11 +741,25 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
         LGP_HIP(hipStreamWaitEvent(s3, E(EV_BLK + bi), 0));
         // left-looking: column block j of the far rows receives the update of all earlier blocks in one product (K = j0: half the
         // memory traffic of eight K = 128 updates of all the remaining columns), then is solved
-        if (j0 > 0 && !right_looking)
+        // (LGP_FAR_RECURSIVE: 0 = left-looking K = 128 j products of 128 columns; 1 = recursive order, the default: C3 189.9 -> 189.3 ms,
+        //  N = 20480 50.7 -> 50.3 ms; 2 = the same on 128-tiles where they fill the GPU: equal)
+        static const int far_rec_env = getenv("LGP_FAR_RECURSIVE") ? atoi(getenv("LGP_FAR_RECURSIVE")) : 1;
+        const int far_rec = kb % LGP_DB == 0 ? far_rec_env : 0;          // (a ragged last panel keeps the left-looking order)
+        if (j0 > 0 && !right_looking && !far_rec)
           LGP_CHECK(lgp_gemm_launch<T>(ctx, s3, false, true, far, jb, j0, T(-1), Pfar, ldl, P + j0 * ldl, ldl, T(1), Pfar + j0, ldl, false, 2));
         LGP_CHECK(subst(s3, w, jb, Pfar + j0, far));
         if (wc > 0 && right_looking)
           LGP_CHECK(lgp_gemm_launch<T>(ctx, s3, false, true, far, wc, jb, T(-1), Pfar + j0, ldl, Xsq, ldl, T(1), Pfar + (j0 + jb), ldl, false));
+        if (far_rec && !right_looking) {
+          // recursive order: after block b the columns [c, c + s) get blocks [c - s, c), c = b + 1, s = its lowest set bit -- the same
+          // flops as the left-looking K = 128 j products of 128 columns, 16 of 28 units of them in ONE 512 x 512 product
+          const size_t c = (size_t)bi + 1, sbit = c & (~c + 1), nq = kb / LGP_DB;
+          if (c < nq) {
+            const size_t ncol = (c + sbit <= nq ? sbit : nq - c) * LGP_DB, kk = sbit * LGP_DB;
+            LGP_CHECK(lgp_gemm_launch<T>(ctx, s3, false, true, far, ncol, kk, T(-1), Pfar + (c - sbit) * LGP_DB, ldl, P + (c * LGP_DB) * ldl + (c - sbit) * LGP_DB, ldl,
+                                         T(1), Pfar + c * LGP_DB, ldl, false, far_rec == 1 ? 2 : 0));
+          }
+        }
       }
       if (wc > 0) LGP_CHECK(lgp_gemm_launch<T>(ctx, s1, false, true, below, wc, jb, T(-1), Xsq, ldl, Xsq, ldl, T(1), P + (j0 + jb) * ldl + (j0 + jb), ldl, true));
     }
@@ -894,14 +908,24 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
       // of the next in the late panels of N = 8192, where right-looking rows (every block followed by a K = 128 update of all
       // the remaining columns: 37 + 52 us per step against the chain's 68) fell 20 us further behind per block (~390 us).
       // (The early panels wait for the previous panel's updates instead: their far rows cannot start before U2.)
+      static const int far_rec = getenv("LGP_CHAIN_FAR_RECURSIVE") ? atoi(getenv("LGP_CHAIN_FAR_RECURSIVE")) : 0;
       for (size_t j = 0; j < nq; ++j) {
         const size_t j0 = j * LGP_DB;
-        if (j >= 1) {
+        if (j >= 1 && !far_rec) {
           LGP_HIP(wait_ge(sg, word(k, LGP_CH_READY) + (j - 1), (unsigned)(1 + 2 * nq - 2 * (j - 1) - 2)));
           LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_g, LGP_DB, j0, T(-1), Pg, ldl, P + j0 * ldl, ldl, T(1), Pg + j0, ldl, false, 2));
         }
         LGP_HIP(wait_ge(sg, word(k, LGP_CH_FLAGP) + j, 1));
         LGP_CHECK(subst(sg, Yk + j * (size_t)LGP_DBLK, Pg + j0, rows_g));
+        if (far_rec) {   // recursive order (as potrf_split): after block j the columns [c, c + s) get blocks [c - s, c), once the square's rows below block j are solved
+          const size_t c = j + 1, sbit = c & (~c + 1);
+          if (c < nq) {
+            const size_t ncol = (c + sbit <= nq ? sbit : nq - c) * LGP_DB, kk = sbit * LGP_DB;
+            LGP_HIP(wait_ge(sg, word(k, LGP_CH_READY) + j, (unsigned)(1 + 2 * nq - 2 * j - 2)));
+            LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_g, ncol, kk, T(-1), Pg + (c - sbit) * LGP_DB, ldl, P + (c * LGP_DB) * ldl + (c - sbit) * LGP_DB, ldl,
+                                         T(1), Pg + c * LGP_DB, ldl, false, far_rec == 1 ? 2 : 0));
+          }
+        }
       }
       LGP_HIP(hipStreamWriteValue32(sg, word(k, LGP_CH_GRP + g), 1, 0));
     }
@@ -992,10 +1016,13 @@ template <typename T>
 int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *Pfar, size_t ldl, const T *Psq, const T *Yk,
                       const hipEvent_t *blk_events) {
   if (rows == 0) return LGP_OK;
+  static const int far_rec = getenv("LGP_FAR_RECURSIVE") ? atoi(getenv("LGP_FAR_RECURSIVE")) : 1;     // (as in potrf_split)
+  const bool recursive = far_rec != 0 && kb % LGP_DB == 0;
+  const size_t nq = (kb + LGP_DB - 1) / LGP_DB;
   size_t j = 0;
   for (size_t j0 = 0; j0 < kb; j0 += LGP_DB, ++j) {
     const size_t jb = (kb - j0) < (size_t)LGP_DB ? (kb - j0) : (size_t)LGP_DB;
-    if (j0 > 0) {
+    if (j0 > 0 && !recursive) {
       if (blk_events) LGP_HIP(hipStreamWaitEvent(st, blk_events[j - 1], 0));
       LGP_CHECK(lgp_gemm_launch<T>(ctx, st, false, true, rows, jb, j0, T(-1), Pfar, ldl, Psq + j0 * ldl, ldl, T(1), Pfar + j0, ldl, false, 2));
     }
@@ -1003,6 +1030,14 @@ int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *P
     hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((rows + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, st,
                        Yk + (j0 / LGP_DB) * (size_t)LGP_DBLK, (int)jb, Pfar + j0, (long)ldl, (long)rows);
     LGP_LAUNCH_CHECK();
+    if (recursive) {     // after block j the columns [c, c + s) get blocks [c - s, c), c = j + 1, s = its lowest set bit (behind event j: the square's rows of those blocks are final)
+      const size_t c = j + 1, sbit = c & (~c + 1);
+      if (c < nq) {
+        const size_t ncol = (c + sbit <= nq ? sbit : nq - c) * LGP_DB, kk = sbit * LGP_DB;
+        LGP_CHECK(lgp_gemm_launch<T>(ctx, st, false, true, rows, ncol, kk, T(-1), Pfar + (c - sbit) * LGP_DB, ldl, Psq + (c * LGP_DB) * ldl + (c - sbit) * LGP_DB, ldl,
+                                     T(1), Pfar + c * LGP_DB, ldl, false, far_rec == 1 ? 2 : 0));
+      }
+    }
   }
   return LGP_OK;
 }
