@@ -238,6 +238,7 @@ int lgp_ctx_destroy(lgp_ctx *c) {
     (void)hipFree(c->chain_trace);
   }
   if (c->chain_state) (void)hipFree(c->chain_state);
+  if (c->chain_scratch) (void)hipFree(c->chain_scratch);
   for (const auto &e : c->chain_sched) (void)hipFree(e.tasks);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);

@@ -52,6 +52,8 @@ struct ChainArgs {
   unsigned long long timeout;  // wall_clock64 ticks a worker waits for one input before it abandons the launch
   long row0;                   // global index of the matrix's first row (pivot indices of the info word)
   int samexcd;                 // chain workers all on XCD 0 (experiment, env LGP_CHAIN_SAMEXCD)
+  int tailwg;                  // two-workgroup mode: index of the tail workgroup (walker.inc, wk_tail), 0 = the single walker does it all
+  double *scratch;             // ... its hand-over buffers: 2 x 36 tiles of published block rows, 2 x 36 tiles of the next block
 };
 
 __device__ __forceinline__ unsigned ch_peek(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -184,6 +186,8 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
   const int npanels = (p.n + LGP_NB - 1) / LGP_NB;
   if (blockIdx.x == 0) {
 #include "walker_body.inc"
+  } else if (p.tailwg != 0 && (int)blockIdx.x == p.tailwg) {
+#include "tail_body.inc"
   } else {
   // the workers of the dependent chain: the first `chainw` workgroups, or (samexcd) the first chainw of those that the hardware
   // places on XCD 0 (workgroup i runs on XCD i mod 8), so that what one of them writes the next finds in the same L2
@@ -191,7 +195,8 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
   // 8, 16, .. 8 chainw, which the dispatcher places on the walker's XCD (workgroup i runs on XCD i mod 8): what the walker and
   // they hand each other then stays in one L2 instead of crossing the fabric (a block handed over by another XCD takes ~4.5 us
   // to arrive, cdna_hip_programming.md: 62-70 GB/s per block cross-XCD, 104-122 same-XCD)
-  bool on_chain = p.samexcd ? ((blockIdx.x & 7u) == 0u && (int)(blockIdx.x >> 3) <= p.chainw) : (int)blockIdx.x <= p.chainw;
+  const int widx = (int)blockIdx.x - (p.tailwg != 0 && (int)blockIdx.x > p.tailwg ? 1 : 0);     // (workers count from 1, the tail workgroup left out)
+  bool on_chain = p.samexcd ? ((blockIdx.x & 7u) == 0u && (int)(blockIdx.x >> 3) <= p.chainw) : widx <= p.chainw;
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -475,6 +480,23 @@ int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size
   a.timeout = ctx->chain_timeout;
   a.chainw = workers >= 6 ? 3 : 1;
   a.samexcd = samexcd ? 1 : 0;
+  // two-workgroup mode (walker.inc, wk_tail; LGP_CHAIN_TAIL_WG=1, off by default): one more workgroup, on the walker's XCD when
+  // the launch has nine (workgroup i runs on XCD i mod 8).  Measured in round 4: correct, and NO faster -- 1.24 / 2.50 / 6.52 ms at
+  // N = 2048 / 4096 / 8192 against 1.27 / 2.50 / 6.50.  The first block of a square, whose rows nobody has to deliver, goes from 75 to
+  // 58 us; every other block waits ~27 us into the potf2 for the workers to bring the rows of block j + 1 up to date (their
+  // substitution against block j - 1, 19 us, and its tile updates, 9.5 us, start when THAT block is factored), after which solve and
+  // update still take their 31-41 us: the dependency that bounds the chain runs through the workers, not through the walker.
+  static const int tail_env = getenv("LGP_CHAIN_TAIL_WG") ? atoi(getenv("LGP_CHAIN_TAIL_WG")) : 0;
+  a.tailwg = 0;
+  a.scratch = nullptr;
+  int nblocks = workers;
+  if (tail_env != 0 && !samexcd) {
+    if (ctx->chain_scratch == nullptr) LGP_HIP(hipMalloc(&ctx->chain_scratch, (size_t)4 * 36 * 256 * sizeof(double)));
+    a.scratch = static_cast<double *>(ctx->chain_scratch);
+    nblocks = workers + 1;
+    a.tailwg = tail_env > 1 ? tail_env : (nblocks > 8 ? 8 : 1);
+    if (a.tailwg >= nblocks) a.tailwg = 1;
+  }
   // dynamic LDS: the walker's buffers (walker.inc), and -- untouched -- what keeps other workgroups off a worker's CU (no
   // trailing-update workgroup, 64 KB of LDS, fits beside 100 KB)
   size_t hog = n <= ctx->chain_hog_max_n ? (size_t)ctx->chain_lds_kb * 1024 : 0;
@@ -483,7 +505,7 @@ int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size
     LGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     ctx->chain_attr_set = true;
   }
-  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)workers), dim3(256), hog, stream, a);
+  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)nblocks), dim3(256), hog, stream, a);
   LGP_LAUNCH_CHECK();
   return LGP_OK;
 }
