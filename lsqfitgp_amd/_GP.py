@@ -102,14 +102,27 @@ except ImportError:                      # pragma: no cover
     _xxhash = None
 
 
+_DIGEST_POOL = None
+
+
 def _digest(arr):
-    """ digest of every byte of a host array (strided arrays are read in C order) """
+    """ digest of every byte of a host array (strided arrays are read in C order).  Large arrays are hashed in chunks on a few
+    threads (xxhash releases the interpreter lock): the 512 MB of a dense N = 8192 block in ~3 ms instead of ~20 """
     a = numpy.ascontiguousarray(arr)
-    buf = a.view(numpy.uint8).reshape(-1) if a.dtype.names is None and a.dtype != object else a.tobytes()
-    if _xxhash is not None:
+    buf = a.view(numpy.uint8).reshape(-1) if a.dtype.names is None and a.dtype != object else numpy.frombuffer(a.tobytes(), numpy.uint8)
+    if _xxhash is None:
+        import hashlib
+        return hashlib.blake2b(buf, digest_size=16).digest()
+    if buf.size < (8 << 20):
         return _xxhash.xxh3_128_digest(buf)
-    import hashlib
-    return hashlib.blake2b(buf, digest_size=16).digest()
+    global _DIGEST_POOL
+    if _DIGEST_POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _DIGEST_POOL = ThreadPoolExecutor(max_workers=max(2, min(8, os.cpu_count() or 2)), thread_name_prefix='lgp-digest')
+    step = 4 << 20
+    parts = _DIGEST_POOL.map(lambda off: _xxhash.xxh3_128_digest(buf[off:off + step]), range(0, buf.size, step))
+    return _xxhash.xxh3_128_digest(b''.join(parts))
 
 
 def diag(values):
@@ -1132,7 +1145,7 @@ class GP:
         y = numpy.concatenate(ylist)
 
         if fromdata and strip and len(inkeys) == 1:
-            fast = self._pred_one_call(inkeys[0], outkeys[0], y, ycovblocks)
+            fast = self._pred_one_call(inkeys[0], outkeys[0], y, ycovblocks, givencov)
             if fast is not None:
                 return fast
 
@@ -1231,7 +1244,7 @@ class GP:
         outkey, = outkeys                                                 # :301-305
         return mean.reshape(self._elements[outkey].shape), cov.reshape(2 * self._elements[outkey].shape)
 
-    def _pred_one_call(self, inkey, outkey, y, ycovblocks):
+    def _pred_one_call(self, inkey, outkey, y, ycovblocks, givencov=None):
         """ The plain question -- one set of points conditioned on, one predicted, one isotropic kernel the fused entry point covers,
         no checks that need the assembled blocks -- in THREE calls of the library instead of fifteen: the cross blocks straight into
         the rows carried below the factor, ``lgp_gram_chol_factor_rhs`` (Gram build + regularisation + factorisation, Kxx never
@@ -1257,6 +1270,8 @@ class GP:
                 return None                               # (a dense covariance of the data has to be uploaded and added: general path)
             if numpy.any(ycovblocks.values):
                 noise = numpy.asarray(ycovblocks.values, float)
+            if noise is not None and self._cached_given([inkey], givencov, True, {}) is not None:
+                return None                               # (factored by an earlier call with this very givencov: the general path reuses it)
         xa, xsa = x.x.reshape(-1), xs.x.reshape(-1)
         n, m = xa.size, xsa.size
         if n == 0 or m == 0 or n > 16384:
@@ -1314,6 +1329,21 @@ class GP:
         _lib.check(lib.lgp_posterior_solved_f64(ctx.handle, n, m, L.ptr, L.ld, Wt.ptr, Wt.ld, Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld,
                                                 ctypes.byref(dens)), 'lgp_posterior_solved')
         mean, cov = mean_d.to_host(), cov_d.to_host()
+        # the factorisation stays, as on the general path: a `marginal_likelihood` of the same data (with the same givencov) finds it,
+        # with the density of y that came out of this solve; another question solves against it
+        def matrix(kernel=kernel, xa=xa, nz=nz):
+            K = kernel.gram(xa, xa, ctx=ctx)
+            if nz is not None:
+                _lib.check(lib.lgp_add_diag_f64(ctx.handle, n, K.ptr, K.ld, nz.ptr, F(0.)), 'lgp_add_diag')
+            return K
+        solver = Chol._adopt(L.block(0, n, 0, n), dblk, eps.value, solved=L.block(n, n + m + 1, 0, n), matrix=matrix)
+        ymean = numpy.asarray(y)
+        solver._solved_key = ((outkey,), ymean.dtype.str, ymean.tobytes())
+        solver._density_memo = (numpy.array(ymean, copy=True), numpy.float64(dens.value))
+        if noise is None:
+            self._decompcache[(inkey,)] = solver
+        else:
+            self._keep_given([inkey], givencov, {}, solver)
         return mean.reshape(xs.shape), cov.reshape(2 * xs.shape)
 
     def predfromfit(self, *args, **kw):

@@ -192,6 +192,23 @@ class Chol(Decomposition):
         self._dblk = dblk
         self._eps = self._dtype.type(eps.value)                        # :393
 
+    @classmethod
+    def _adopt(cls, L, dblk, eps, *, solved=None, matrix=None):
+        """ a decomposition around a factor that the library has already computed (the fused Gram + factorisation entry point never
+        materialises K): ``L`` (n, n) device block, ``dblk`` its diagonal-block workspace, ``solved`` (q, n) the rows carried
+        through the factorisation, ``matrix`` a callable that builds K on the device if somebody asks for it """
+        self = cls.__new__(cls)
+        self._K = None
+        self._K_builder = matrix
+        self._ctx = L.ctx
+        self._dtype = L.dtype
+        self._L = L
+        self._dblk = dblk
+        self._eps = self._dtype.type(eps)
+        self._solved = solved
+        self._solved_for = True if solved is not None else None
+        return self
+
     def solved(self, *, device=False):
         """ ``L^-1 rhs`` for the ``rhs`` given at construction, shape (n, q) """
         if self._solved is None:
@@ -263,6 +280,8 @@ class Chol(Decomposition):
 
     def matrix(self):
         """ The input matrix (``:395-396``), device resident """
+        if self._K is None and getattr(self, '_K_builder', None) is not None:
+            self._K = self._K_builder()
         return self._K
 
     def factor(self):

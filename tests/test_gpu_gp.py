@@ -488,3 +488,42 @@ def test_extreme_eigenvalues_by_device_lanczos(lgp, rng, dtype):
     # an invariant subspace: the identity stops after one step
     lo, hi = gp._extreme_eigenvalues(lgp.DeviceArray.from_host(np.eye(n, dtype=dtype) * 3))
     assert abs(lo - 3) <= 1e-6 and abs(hi - 3) <= 1e-6
+
+
+@pytest.mark.parametrize('noise', [False, True])
+def test_one_call_prediction_keeps_its_factorisation(lgp, rng, noise):
+    """ `GP._pred_one_call` leaves its decomposition where the general path would (the cache of the prior, or the one kept for
+    the same givencov): `marginal_likelihood` of the same data factors nothing, another question solves against the kept factor,
+    and the numbers are the oracle's """
+    n, m = 900, 41
+    x = np.sort(rng.uniform(0, 30, n)); xs = rng.uniform(0, 30, m); xt = rng.uniform(0, 30, 17)
+    y = np.sin(x) + 0.1 * rng.standard_normal(n)
+    gc = {('d', 'd'): lgp.diag(np.full(n, 0.02))} if noise else None
+    gco = {('d', 'd'): 0.02 * np.eye(n)} if noise else None
+    kern = lambda mod: mod.Maternp(p=2, scale=1.7) * 1.3
+    calls = []
+    orig = lgp.Chol.__init__
+
+    def counting(self, *a, **k):
+        calls.append(1)
+        return orig(self, *a, **k)
+    lgp.Chol.__init__ = counting
+    try:
+        gp = lgp.GP(kern(lgp), checkpos=False, checksym=False).addx(x, 'd').addx(xs, 't').addx(xt, 'u')
+        mean, cov = gp.predfromdata({'d': y}, 't', gc, raw=True)
+        ml = gp.marginal_likelihood({'d': y}, gc)
+        mean_u, cov_u = gp.predfromdata({'d': y}, 'u', gc, raw=True)
+        assert len(calls) == 0                       # (the fused entry point factored once; nothing was factored again)
+        K = gp._solver(('d',)).matrix() if not noise else None
+    finally:
+        lgp.Chol.__init__ = orig
+    go = oracle.GP(kern(oracle), checkpos=False, checksym=False).addx(x, 'd').addx(xs, 't').addx(xt, 'u')
+    mo, co = go.predfromdata({'d': y}, 't', gco, raw=True)
+    mu, cu = go.predfromdata({'d': y}, 'u', gco, raw=True)
+    lo = go.marginal_likelihood({'d': y}, gco)
+    tol = 1e-8 if noise else 2e-4                    # (without noise the problem is singular: test_one_call_prediction_is_the_general_path)
+    assert np.linalg.norm(mean - mo) <= tol * np.linalg.norm(mo) and np.linalg.norm(mean_u - mu) <= tol * np.linalg.norm(mu)
+    assert np.linalg.norm(cov - co, 2) <= 1e-8 * np.linalg.norm(go.prior('t', raw=True), 2)
+    assert abs(ml - lo) <= (1e-8 if noise else 1e-5) * abs(lo) + 1e-6
+    if K is not None:                                # the matrix is built when somebody asks for it
+        np.testing.assert_allclose(K.to_host(), go.prior('d', raw=True), rtol=0, atol=1e-13)
