@@ -453,7 +453,7 @@ class _Isotropic(Kernel):
         deg = self._derivability()
         name = type(self).__name__
         if deg is None:
-            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, GammaExp(gamma=2), Cauchy(alpha=2), '
+            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, Bessel, GammaExp(gamma=2), Cauchy(alpha=2), '
                                       'Constant, Linear, Periodic, Cos, Sinc, Celerite, Harmonic, Wendland, Circular, Decaying, WienerIntegral, '
                                       'FracBrownian(H=1, K=1), StationaryFracBrownian(H=1) have one)')
         sides = []
@@ -709,7 +709,9 @@ class Bessel(_Isotropic):
     """ Bessel kernel, k(r) = Γ(ν + 1) 2^ν (s r)^-ν J_ν(s r), s = 2 + ν/2, ν >= 0 (``_kernels/_matern.py:92-119``): usable in up to
     2 (⌊ν⌋ + 1) dimensions.  J_ν of real order on the device (power series, Miller's backward recurrence, Hankel's expansion) """
     _kind = _lib.LGP_KERNEL_BESSEL
-    _derivable = None
+
+    def _derivability(self):
+        return int(self._par[0] // 2)                                      # _matern.py:92-94
 
     def __init__(self, *, nu=0, scale=None, loc=None, dim=None):
         assert 0 <= nu < numpy.inf, nu                                     # _matern.py:117

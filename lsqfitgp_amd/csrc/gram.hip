@@ -146,69 +146,11 @@ __device__ inline double expn_imag_re(int n, double psin, double x) {
   sincos(x, &sn, &cs);
   return IM ? hr * sn + hi * cs : hr * cs - hi * sn;                         // Im / Re of h e^(i x)
 }
-// Gamma(nu + 1) (x / 2)^-nu J_nu(x), real nu >= 0 (Bessel kernel, _kernels/_matern.py:102-119 through _special/_bessel.py:45-50): 1 at
-// x = 0.  Three regions: the power series sum_k (-x^2/4)^k / (k! (nu+1)_k) while it does not cancel (x^2 <= 8 (nu + 1), or x <= 3);
-// Hankel's asymptotic expansion above max(30, nu^2); between them Miller's backward recurrence from an even order N > x down to the
-// fractional order mu = nu - floor(nu), normalised by (x/2)^mu = sum_k (mu + 2k) Gamma(mu + k) / k! J_{mu+2k}(x).  Against scipy's
-// jv: <= 1e-14 absolute for nu in [0, 30], x in [0, 3000].
-__device__ inline double bessel_jmod(double nu, int n, double gnu1, double gmu1, double x) {
-  if (x == 0.) return 1.;
-  if (x * x <= 8. * (nu + 1.) || x <= 3.) {
-    const double q = -0.25 * x * x;
-    double term = 1., sum = 1.;
-    for (int k = 1; k < 300; ++k) {
-      term *= q / ((double)k * (nu + (double)k));
-      sum += term;
-      if (fabs(term) < 1e-17 * fabs(sum)) break;
-    }
-    return sum;
-  }
-  if (x > fmax(30., nu * nu)) {
-    const double mu4 = 4. * nu * nu;
-    double P = 1., Q = 0., t = 1.;
-    for (int k = 1; k < 60; ++k) {
-      const double odd = (double)(2 * k - 1);
-      const double tn = t * (mu4 - odd * odd) / ((double)k * 8. * x);
-      if (fabs(tn) > fabs(t) && (double)k > nu) break;
-      t = tn;
-      const bool neg = ((k >> 1) & 1) != 0;
-      if (k & 1) Q += neg ? -t : t;
-      else P += neg ? -t : t;
-      if (fabs(t) < 1e-17) break;
-    }
-    double sn, cs;
-    sincos(x - (0.5 * nu + 0.25) * 3.141592653589793238462643383279502884, &sn, &cs);
-    const double J = sqrt(0.6366197723675814 / x) * (P * cs - Q * sn);
-    return gnu1 * exp(-nu * log(0.5 * x)) * J;
-  }
-  const double mu = nu - (double)n, big = fmax(x, nu);
-  int N = (int)(big + 25. + 8. * cbrt(big));
-  N += N & 1;
-  const int K = N >> 1;
-  double ck = exp(lgamma(mu + (double)K) - lgamma((double)K + 1.)) * (mu + 2. * (double)K);
-  double fp = 0., f = 1e-300, S = 0., fn = 0.;
-  const double tox = 2. / x;
-  for (int j = N; j >= 0; --j) {
-    if ((j & 1) == 0) {
-      const int k = j >> 1;
-      S += ck * f;
-      if (k >= 2) ck = ck * (mu + (double)(2 * k - 2)) / (mu + (double)(2 * k)) * (double)k / (mu + (double)(k - 1));
-      else if (k == 1) ck = gmu1;
-    }
-    if (j == n) fn = f;
-    if (j > 0) {
-      const double fm = (mu + (double)j) * tox * f - fp;
-      fp = f; f = fm;
-      if (fabs(f) > 1e250) { f *= 1e-250; fp *= 1e-250; S *= 1e-250; fn *= 1e-250; }
-    }
-  }
-  return gnu1 * exp(-(double)n * log(0.5 * x)) * fn / S;
-}
 // the cores that need loops of their own (one compile-time core, CORE_SPECIAL, for all of them)
 template <typename T>
 __device__ __forceinline__ T special_core(const IsoArgs<T> &g, T r2) {
   if (g.kernel == LGP_KERNEL_BESSEL)                     // par = {nu, Gamma(nu + 1), Gamma(1 + nu - floor(nu))}, p = floor(nu), twop1 = (2 + nu/2)^2
-    return T(bessel_jmod((double)g.par[0], g.p, (double)g.par[1], (double)g.par[2], sqrt((double)g.twop1 * (double)r2)));
+    return T(lgp_bessel::bessel_jmod((double)g.par[0], g.p, (double)g.par[1], (double)g.par[2], sqrt((double)g.twop1 * (double)r2)));
   const double x = (double)sqrt(r2);                      // one variable: sqrt(d^2) = |d| exactly
   if (g.kernel == LGP_KERNEL_PSERIES) {
     // even 1-periodic functions of the difference given by host-computed coefficients (Zeta kernel, _kernels/_zeta.py:37-70):
@@ -253,7 +195,7 @@ template <typename T>
 __device__ __forceinline__ T special_core_mxdk(const IsoArgs<T> &g, T r2) {
   if (g.kernel == LGP_KERNEL_BESSEL) {                    // k_nu' = -X / (2 (nu + 1)) k_{nu+1}(X), X = s x: -x dk/dx = X^2 / (2 (nu + 1)) k_{nu+1}(X)
     const double nu = (double)g.par[0], X2 = (double)g.twop1 * (double)r2;
-    return T(X2 / (2. * (nu + 1.)) * bessel_jmod(nu + 1., g.p + 1, (double)g.par[1] * (nu + 1.), (double)g.par[2], sqrt(X2)));
+    return T(X2 / (2. * (nu + 1.)) * lgp_bessel::bessel_jmod(nu + 1., g.p + 1, (double)g.par[1] * (nu + 1.), (double)g.par[2], sqrt(X2)));
   }
   const double x = (double)sqrt(r2);
   if (x == 0.) return T(0);

@@ -248,6 +248,19 @@ __device__ __forceinline__ S jet_core(const JetArgs &g, const S &r2, const S &X,
     }
     return compose(r2, f);
   }
+  if (k == LGP_KERNEL_BESSEL) {
+    // k_nu(x) = Gamma(nu + 1) (x / 2)^-nu J_nu(x), x^2 = s^2 q: k_nu' = -x / (2 (nu + 1)) k_{nu+1} makes
+    // G^(k)(q) = (-s^2 / 4)^k / ((nu + 1) .. (nu + k)) k_{nu+k}(x), an entire function of q (1 at x = 0 for every order)
+    const double nu = g.par[0], s2 = g.par[3], x = sqrt(s2 * fmax((double)r2.val(), 0.));
+    T f[5];
+    double c = 1., gn = g.par[1];
+    for (int i = 0; i < 5; ++i) {
+      f[i] = T(c * lgp_bessel::bessel_jmod(nu + i, g.p + i, gn, g.par[2], x));
+      gn *= nu + i + 1.;
+      c *= -0.25 * s2 / ((nu + i + 1.) * (double)(i + 1));
+    }
+    return compose(r2, f);
+  }
   if (k == LGP_KERNEL_CONSTANT) return S(T(1));
   if (k == LGP_KERNEL_LINEAR) return r2;                                             // (r2 carries sum_f X_f Y_f for this kernel)
   const S delta = X - Y;
@@ -345,7 +358,7 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
                       kernel == LGP_KERNEL_HARMONIC || kernel == LGP_KERNEL_WENDLAND || kernel == LGP_KERNEL_CIRCULAR || kernel == LGP_KERNEL_DECAYING ||
                       kernel == LGP_KERNEL_WIENERINTEGRAL || kernel == LGP_KERNEL_FRACBROWNIAN || kernel == LGP_KERNEL_STATIONARYFRACBROWNIAN;
   const bool iso = kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY || kernel == LGP_KERNEL_MATERNP ||
-                   kernel == LGP_KERNEL_CONSTANT || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_MATERN;
+                   kernel == LGP_KERNEL_CONSTANT || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_MATERN || kernel == LGP_KERNEL_BESSEL;
   LGP_REQUIRE(onevar || iso, "no derivative core for this kernel");
   LGP_REQUIRE(!onevar || d == 1, "a kernel of one variable takes one-dimensional points");
   LGP_REQUIRE(kernel != LGP_KERNEL_MATERNP || (p >= 0 && p <= 16 && ncoef == 5 * 24), "Maternp: order 0 .. 16 and the five polynomials");
@@ -362,6 +375,14 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.posabs = 0;
   for (int i = 0; i < npar; ++i) g.par[i] = (double)hpar[i];
   for (int i = 0; i < ncoef; ++i) g.coef[i / 24][i % 24] = (double)hcoef[i];
+  if (kernel == LGP_KERNEL_BESSEL) {                     // hpar = {nu}: as the value core (gram.hip), par = {nu, Gamma(nu + 1), Gamma(1 + nu - floor(nu)), (2 + nu / 2)^2}
+    LGP_REQUIRE(npar == 1 && hpar[0] >= T(0) && hpar[0] <= T(96), "Bessel takes {nu} in [0, 96]");
+    const double nu = (double)hpar[0];
+    const int fl = (int)nu;
+    LGP_REQUIRE(d <= 2 * (fl + 1), "Bessel(nu) is a kernel in at most 2 (floor(nu) + 1) dimensions");       // _matern.py:97-99
+    g.p = fl;
+    g.par[0] = nu; g.par[1] = tgamma(nu + 1.); g.par[2] = tgamma(1. + nu - (double)fl); g.par[3] = (2. + nu / 2.) * (2. + nu / 2.);
+  }
   if (kernel == LGP_KERNEL_MATERN) {                     // hpar = {nu}: the constants of the Bessel evaluation and the limits at r = 0
     LGP_REQUIRE(npar == 1 && hpar[0] > T(0) && hpar[0] <= T(100), "Matern takes {nu} in (0, 100]");
     const double nu = (double)hpar[0];

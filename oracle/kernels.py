@@ -331,6 +331,13 @@ def Bessel(*, nu=0, scale=None, loc=None, dim=None):
         if x.dtype.names is not None and len(_leaf_columns_count(x.dtype)) > maxdim:
             raise ValueError(f'kernel called on type with dimensionality > maxdim={maxdim}')
         return inner(x, y)
+
+    def sym(r2):                                             # derivative observations (symdiff.py); int(nu // 2) times derivable (_matern.py:92-94)
+        sp = _sp()
+        v = sp.Rational(float(nu))
+        x = sp.sqrt(r2) * (2 + v / 2)
+        return sp.gamma(v + 1) * (x / 2) ** (-v) * sp.besselj(v, x)
+    checked.symbolic = ('iso', sym, None, dict(dps=200, offset='1e-20')) if nu >= 2 else None
     return Kernel(checked, scale=scale, loc=loc, dim=dim)
 
 

@@ -77,7 +77,7 @@ def test_what_is_not_available_says_so(lgp):
     with pytest.raises(ValueError):                                             # not derivable: the reference's error (_Kernel/_ops.py:85-90)
         lgp.GP(lgp.GammaExp(gamma=1.2)).addx(x, 'a', deriv=1).prior('a', raw=True)
     with pytest.raises(NotImplementedError):                                     # derivable in the reference, no derivative core here yet
-        lgp.GP(lgp.Bessel(nu=2.3)).addx(x, 'a', deriv=1).prior('a', raw=True)
+        lgp.GP(lgp.Color(n=6)).addx(x, 'a', deriv=1).prior('a', raw=True)
     with pytest.raises(ValueError):                                             # ceil(nu) - 1 times derivable (_kernels/_matern.py:51-53)
         lgp.GP(lgp.Matern(nu=1.7)).addx(x, 'a', deriv=2).prior('a', raw=True)
     with pytest.raises(ValueError):
@@ -302,6 +302,37 @@ def test_matern_of_real_order_derivatives_vs_oracle(lgp, nu):
         got = kd.gram(X, Y, deriv=(ox, oy)).to_host()
         want = ko.diff({sx[0]: sx[1]}, {sy[0]: sy[1]})(X[:, None], Y[None, :])
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-9 * max(np.abs(want).max(), 1e-3), err_msg=f'nu={nu} {sx} {sy}')
+
+
+@pytest.mark.parametrize('nu', [2.5, 4.3, 6.])
+def test_bessel_kernel_derivatives_vs_oracle(lgp, nu):
+    """ Bessel(nu), int(nu // 2) times derivable (_kernels/_matern.py:92-119): G^(k)(r^2) = (-s^2/4)^k / ((nu+1)..(nu+k)) k_{nu+k}(s r), the
+    J of the five orders evaluated on the device; the oracle differentiates J_nu symbolically """
+    rng = np.random.default_rng(int(10 * nu))
+    x = rng.uniform(0.1, 3, 13); y = rng.uniform(0.1, 3, 11)
+    y[:4] = x[:4]
+    y[4] = x[4] + 1e-7
+    x[5] = 9.5; y[5] = 0.2                                       # (argument s r ~ 40: the recurrence / the asymptotic region)
+    kd, ko = lgp.Bessel(nu=nu, scale=1.3) * 1.2, oracle.Bessel(nu=nu, scale=1.3) * 1.2
+    deg = int(nu // 2)
+    orders = [(a, b) for a in range(min(deg, 2) + 1) for b in range(min(deg, 2) + 1) if a + b]
+    for a, b in orders:
+        got = kd.gram(x, y, deriv=(a, b)).to_host()
+        want = ko.diff(a, b)(x[:, None], y[None, :])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-11 * max(np.abs(want).max(), 1e-3), err_msg=f'nu={nu} {(a, b)}')
+    with pytest.raises(ValueError):
+        kd.gram(x, y, deriv=(deg + 1, 0))
+    s2 = (2 + nu / 2) ** 2 / 1.3 ** 2
+    got = kd.gram(x, y, deriv=(1, 1)).to_host()
+    assert abs(got[0, 0] - 1.2 * 2 * s2 / (4 * (nu + 1))) <= 1e-12 * got[0, 0]          # the exact value at a coincidence
+    dt = [('a', float), ('b', float)]
+    X = np.empty(9, dt); Y = np.empty(7, dt)
+    for f in 'ab':
+        X[f] = rng.uniform(0, 2, 9); Y[f] = rng.uniform(0, 2, 7)
+    Y[:3] = X[:3]
+    got = kd.gram(X, Y, deriv=((1, 0), (0, 1))).to_host()
+    want = ko.diff({'a': 1}, {'b': 1})(X[:, None], Y[None, :])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-11 * np.abs(want).max())
 
 
 def test_matern_of_real_order_derivatives_meet_the_half_integer_closed_form(lgp):
