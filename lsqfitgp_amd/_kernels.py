@@ -453,7 +453,7 @@ class _Isotropic(Kernel):
         deg = self._derivability()
         name = type(self).__name__
         if deg is None:
-            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, Bessel, GammaExp(gamma=2), Cauchy(alpha=2), '
+            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, Bessel, GammaExp(gamma=2), Cauchy(alpha=2), CausalExpQuad(alpha=0), Taylor, '
                                       'Constant, Linear, Periodic, Cos, Sinc, Celerite, Harmonic, Wendland, Circular, Decaying, WienerIntegral, '
                                       'FracBrownian(H=1, K=1), StationaryFracBrownian(H=1) have one)')
         sides = []
@@ -806,6 +806,12 @@ class CausalExpQuad(_Isotropic):
         assert alpha >= 0, alpha
         super().__init__(scale=scale, loc=loc, dim=dim)
         self._par = (float(alpha / 4),)
+
+    def _derivability(self):
+        return float('inf') if self._par[0] == 0 else 0                    # _basic.py:346
+
+    def _jet_pars(self):
+        return 0, (), ()
 
 
 class Log(_Isotropic):
@@ -1433,7 +1439,7 @@ class Taylor(_OneVariable):
     """ Exponential-like power series kernel, k(x, y) = sum_k x^k y^k / k!^2 = I0(2 sqrt(x y)) (``_kernels/_basic.py:393-408``;
     J0 of the same argument where x y < 0) """
     _kind = _lib.LGP_KERNEL_TAYLOR
-    _derivable = None
+    _derivable = float('inf')                                              # _basic.py:393
     _domain = (-numpy.inf, numpy.inf)
 
 

@@ -261,6 +261,7 @@ __device__ __forceinline__ S jet_core(const JetArgs &g, const S &r2, const S &X,
     }
     return compose(r2, f);
   }
+  if (k == LGP_KERNEL_CAUSALEXPQUAD) return jexp(T(-0.5) * r2);                       // alpha = 0 only (the host refuses the others): r2 of the softened distances
   if (k == LGP_KERNEL_CONSTANT) return S(T(1));
   if (k == LGP_KERNEL_LINEAR) return r2;                                             // (r2 carries sum_f X_f Y_f for this kernel)
   const S delta = X - Y;
@@ -305,6 +306,44 @@ __device__ __forceinline__ S jet_core(const JetArgs &g, const S &r2, const S &X,
   if (k == LGP_KERNEL_WIENERINTEGRAL) {
     const S a = jmin(X, Y), b = jmax(X, Y);
     return T(0.5) * (a * a) * (b - a * T(1. / 3.));
+  }
+  if (k == LGP_KERNEL_TAYLOR) {
+    // h(w) = I0(2 sqrt(w)) = sum_j w^j / j!^2 (J0 of the same argument where w = x y < 0): h^(m)(w) = sum_j w^j / (j! (j + m)!) =
+    // |w|^(-m/2) I_m or J_m (2 sqrt|w|).  The series while it neither overflows the patience nor cancels (|w| <= 30); beyond, the
+    // library's I0, I1 with the recurrence upwards (harmless at arguments >= 11 for four orders) and its J_m
+    const S w = X * Y;
+    const double w0 = (double)w.val(), aw = fabs(w0);
+    T f[5];
+    if (aw <= 30.) {
+      double mfact = 1.;
+      for (int m = 0; m < 5; ++m) {
+        double term = 1. / mfact, sum = term;                       // j = 0: 1 / (0! m!)
+        for (int j = 1; j < 200; ++j) {
+          term *= w0 / ((double)j * (double)(j + m));
+          sum += term;
+          if (fabs(term) < 1e-18 * fabs(sum)) break;
+        }
+        f[m] = T(sum / mfact);                                      // h^(m) / m!
+        mfact *= (double)(m + 1);
+      }
+    } else {
+      const double z = 2. * sqrt(aw), iz = 1. / z;
+      double b[5];
+      if (w0 > 0.) {
+        b[0] = cyl_bessel_i0(z); b[1] = cyl_bessel_i1(z);
+        for (int m = 1; m < 4; ++m) b[m + 1] = b[m - 1] - 2. * (double)m * iz * b[m];
+      } else {
+        for (int m = 0; m < 5; ++m) b[m] = jn(m, z);
+      }
+      double pw = 1., mfact = 1.;
+      const double isq = 2. * iz;                                   // 1 / sqrt|w|
+      for (int m = 0; m < 5; ++m) {
+        f[m] = T(b[m] * pw / mfact);
+        pw *= isq;
+        mfact *= (double)(m + 1);
+      }
+    }
+    return compose(w, f);
   }
   if (k == LGP_KERNEL_FRACBROWNIAN) return X * Y;                                    // H = 1, K = 1: (x^2 + y^2 - (x - y)^2) / 2
   if (k == LGP_KERNEL_STATIONARYFRACBROWNIAN) return S(T(1));                        // H = 1: ((d+1)^2 + (d-1)^2 - 2 d^2) / 2
@@ -356,9 +395,11 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   LGP_REQUIRE(ncoef >= 0 && ncoef <= 5 * 24 && (ncoef == 0 || hcoef != nullptr), "bad coefficient table");
   const bool onevar = kernel == LGP_KERNEL_COS || kernel == LGP_KERNEL_PERIODIC || kernel == LGP_KERNEL_SINC || kernel == LGP_KERNEL_CELERITE ||
                       kernel == LGP_KERNEL_HARMONIC || kernel == LGP_KERNEL_WENDLAND || kernel == LGP_KERNEL_CIRCULAR || kernel == LGP_KERNEL_DECAYING ||
-                      kernel == LGP_KERNEL_WIENERINTEGRAL || kernel == LGP_KERNEL_FRACBROWNIAN || kernel == LGP_KERNEL_STATIONARYFRACBROWNIAN;
+                      kernel == LGP_KERNEL_WIENERINTEGRAL || kernel == LGP_KERNEL_FRACBROWNIAN || kernel == LGP_KERNEL_STATIONARYFRACBROWNIAN ||
+                      kernel == LGP_KERNEL_TAYLOR;
   const bool iso = kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY || kernel == LGP_KERNEL_MATERNP ||
-                   kernel == LGP_KERNEL_CONSTANT || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_MATERN || kernel == LGP_KERNEL_BESSEL;
+                   kernel == LGP_KERNEL_CONSTANT || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_MATERN || kernel == LGP_KERNEL_BESSEL ||
+                   kernel == LGP_KERNEL_CAUSALEXPQUAD;
   LGP_REQUIRE(onevar || iso, "no derivative core for this kernel");
   LGP_REQUIRE(!onevar || d == 1, "a kernel of one variable takes one-dimensional points");
   LGP_REQUIRE(kernel != LGP_KERNEL_MATERNP || (p >= 0 && p <= 16 && ncoef == 5 * 24), "Maternp: order 0 .. 16 and the five polynomials");
@@ -372,7 +413,7 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.fx = ax ? fx : -1; g.fy = by ? fy : -1; g.ax = ax; g.by = by;
   g.has_loc = has_loc; g.has_scale = has_scale; g.loc = (double)loc; g.scale = (double)scale; g.factor = (double)factor;
   g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : 0;
-  g.posabs = 0;
+  g.posabs = kernel == LGP_KERNEL_CAUSALEXPQUAD ? 1 : 0;           // input='posabs' (_Kernel/_isotropic.py:67-78)
   for (int i = 0; i < npar; ++i) g.par[i] = (double)hpar[i];
   for (int i = 0; i < ncoef; ++i) g.coef[i / 24][i % 24] = (double)hcoef[i];
   if (kernel == LGP_KERNEL_BESSEL) {                     // hpar = {nu}: as the value core (gram.hip), par = {nu, Gamma(nu + 1), Gamma(1 + nu - floor(nu)), (2 + nu / 2)^2}

@@ -383,7 +383,10 @@ def Wendland(*, k=0, alpha=1, scale=None, loc=None, dim=None):
 def CausalExpQuad(*, alpha=1, scale=None, loc=None, dim=None):
     """ ``_kernels/_basic.py:346-360`` """
     assert alpha >= 0
-    return Kernel(_isotropic_posabs(lambda r: special.erfc(alpha / 4 * r) * numpy.exp(-1/2 * numpy.square(r))), scale=scale, loc=loc, dim=dim)
+    core = _isotropic_posabs(lambda r: special.erfc(alpha / 4 * r) * numpy.exp(-1/2 * numpy.square(r)))
+    # derivable iff alpha = 0 (_basic.py:346): then exp(-r^2/2) of the softened distance (|d| + eps per field: not seen at 1e-9)
+    core.symbolic = ('iso', lambda r2: _sp().exp(-r2 / 2)) if alpha == 0 else None
+    return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 
 def Log(*, scale=None, loc=None, dim=None):
@@ -566,7 +569,10 @@ def Taylor(*, scale=None, loc=None, dim=None):
         mul = x * y
         val = 2 * numpy.sqrt(numpy.abs(mul))
         return numpy.where(mul >= 0, special.i0(val), special.j0(val))
-    return Kernel(_onevariable(core, -numpy.inf, numpy.inf), scale=scale, loc=loc, dim=dim)
+    core_ = _onevariable(core, -numpy.inf, numpy.inf)
+    # I0(2 sqrt(w)) = 0F1(; 1; w), w = x y, J0 where w < 0: one entire function of w, derivable any number of times (_basic.py:393)
+    core_.symbolic = ('xy', lambda X, Y, upper: _sp().hyper((), (1,), X * Y))
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def exp1_imag(x):

@@ -335,6 +335,28 @@ def test_bessel_kernel_derivatives_vs_oracle(lgp, nu):
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-11 * np.abs(want).max())
 
 
+def test_taylor_and_causal_expquad_derivatives_vs_oracle(lgp):
+    """ Taylor (I0(2 sqrt(x y)), J0 where x y < 0: the series of h^(m)(w) below |w| = 30, the library's I_m / J_m beyond) and
+    CausalExpQuad(alpha=0), the two remaining kernels of _kernels/_basic.py that the reference marks derivable """
+    rng = np.random.default_rng(77)
+    x = np.concatenate([rng.uniform(-3, 3, 14), [7., -8., 9.5, 0.]])
+    y = np.concatenate([rng.uniform(-3, 3, 9), [9., 6., -7.5, 0.]])
+    y[:3] = x[:3]
+    kd, ko = lgp.Taylor(scale=1.1) * 0.9, oracle.Taylor(scale=1.1) * 0.9
+    for a, b in [(1, 0), (0, 1), (1, 1), (2, 0), (2, 1), (1, 2), (2, 2)]:
+        got = kd.gram(x, y, deriv=(a, b)).to_host()
+        want = ko.diff(a, b)(x[:, None], y[None, :])
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-12 * np.abs(want).max(), err_msg=f'Taylor {(a, b)}')
+    x = rng.uniform(0, 3, 15); y = rng.uniform(0, 3, 12); y[:4] = x[:4]
+    kd, ko = lgp.CausalExpQuad(alpha=0, scale=0.8) * 1.3, oracle.CausalExpQuad(alpha=0, scale=0.8) * 1.3
+    for a, b in [(1, 0), (1, 1), (2, 1), (2, 2)]:
+        got = kd.gram(x, y, deriv=(a, b)).to_host()
+        want = ko.diff(a, b)(x[:, None], y[None, :])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * np.abs(want).max(), err_msg=f'CausalExpQuad {(a, b)}')
+    with pytest.raises(ValueError):
+        lgp.CausalExpQuad(alpha=0.5).gram(x, y, deriv=(1, 0))
+
+
 def test_matern_of_real_order_derivatives_meet_the_half_integer_closed_form(lgp):
     """ nu -> p + 1/2: the derivative core of real order next to Maternp's own (Laurent polynomials, another code path), nu = 2.5
     approached from both sides; and its exact values at a coincidence, 3 nu^2 / ((nu - 1)(nu - 2)) for order (2, 2) """
