@@ -453,7 +453,7 @@ class _Isotropic(Kernel):
         deg = self._derivability()
         name = type(self).__name__
         if deg is None:
-            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, Bessel, GammaExp(gamma=2), Cauchy(alpha=2), CausalExpQuad(alpha=0), Taylor, '
+            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, Bessel, GammaExp(gamma=2), Cauchy(alpha=2), CausalExpQuad(alpha=0), Taylor, Color, '
                                       'Constant, Linear, Periodic, Cos, Sinc, Celerite, Harmonic, Wendland, Circular, Decaying, WienerIntegral, '
                                       'FracBrownian(H=1, K=1), StationaryFracBrownian(H=1) have one)')
         sides = []
@@ -909,7 +909,12 @@ class Color(_Stationary1D):
     1/ω^n truncated below ω = 1 (``_kernels/_spectral.py:70-111``).  E_n on the device by its power series and its continued
     fraction (the reference's closed form and asymptotic series meet at a knee where both have lost digits, 1e-4 at n = 20) """
     _kind = _lib.LGP_KERNEL_COLOR
-    _derivable = None
+
+    def _derivability(self):
+        return int(self._p) // 2 - 1                                        # _spectral.py:70-71
+
+    def _jet_pars(self):
+        return int(self._p), (), ()
 
     def __init__(self, *, n=2, scale=None, loc=None, dim=None):
         assert int(n) == n and n >= 2, n                                   # _spectral.py:110

@@ -95,57 +95,6 @@ __device__ __forceinline__ T matern_real_of(const IsoArgs<T> &g, T r2, T *xdk) {
   return T(k);
 }
 
-// Re E_n(-i x), x > 0, n >= 1: the generalised exponential integral on the imaginary axis (Color: (n - 1) Re E_n(-i x),
-// _kernels/_spectral.py:73-111; Pink through Ci(x) = -Re E_1(-i x), :41-66).  For x <= 2 the power series of E_n (DLMF 8.19.8 /
-// 6.6.6 for n = 1): sum_{m != n-1} -(i x)^m / ((m - n + 1) m!) + (i x)^(n-1) / (n-1)! (psi(n) - ln x + i pi/2), real part; above,
-// the continued fraction e^(-z) / (z + n - 1 n / (z + n + 2 - 2 (n + 1) / (z + n + 4 - ...))) at z = -i x by the modified Lentz
-// recurrence in complex arithmetic (92 steps at x = 2, 8 at x = 100).  The two agree to 4e-15 where they overlap (x in [1, 4],
-// n = 1 .. 50); psi(n) comes from the host.  (The reference switches between the closed form 8.19.7 and a 20-term asymptotic
-// series at a "knee" where both have lost digits -- 1e-4 at n = 20; the values here are good to the last few bits everywhere.)
-// (IM: the imaginary part instead -- d/dx Re E_n(-i x) = -Im E_{n-1}(-i x), the scale tangent of Color)
-template <bool IM = false>
-__device__ inline double expn_imag_re(int n, double psin, double x) {
-  const int nm1 = n - 1;
-  if (x <= 2.) {
-    const double a = psin - log(x), b = 1.5707963267948966;
-    const int r = nm1 & 3;
-    // Re / Im of i^(n-1) (a + i b)
-    const double lead = IM ? (r == 0 ? b : (r == 1 ? a : (r == 2 ? -b : -a))) : (r == 0 ? a : (r == 1 ? -b : (r == 2 ? -a : b)));
-    double ans = nm1 == 0 ? lead : (IM ? 0. : 1. / (double)nm1), fact = 1.;
-    for (int m = 1; m < 200; ++m) {
-      fact *= x / (double)m;
-      if (m == nm1) ans += lead * fact;
-      else if (((m & 1) != 0) == IM) ans -= ((m & 2) ? -fact : fact) / (double)(m - nm1);      // Re i^m = (-1)^(m/2), Im i^m = (-1)^((m-1)/2)
-      if (((m & 1) != 0) == IM && m > 1 && fact * (1. + fabs(lead)) < 1e-17 * (fabs(ans) + 1e-300)) break;
-    }
-    return ans;
-  }
-  // complex Lentz: b = z + n, c = 1 / tiny, d = 1 / b, h = d; a_i = -i (n - 1 + i), b += 2
-  double br = (double)n, bi = -x;
-  double den = br * br + bi * bi;
-  double dr = br / den, di = -bi / den;
-  double cr = 1e300, ci = 0.;
-  double hr = dr, hi = di;
-  for (int i = 1; i < 400; ++i) {
-    const double ai = -(double)i * (double)(nm1 + i);
-    br += 2.;
-    // d = 1 / (a d + b)
-    const double tr = ai * dr + br, ti = ai * di + bi;
-    den = tr * tr + ti * ti;
-    dr = tr / den; di = -ti / den;
-    // c = b + a / c
-    den = cr * cr + ci * ci;
-    const double qr = br + ai * cr / den, qi = bi - ai * ci / den;
-    cr = qr; ci = qi;
-    const double er = cr * dr - ci * di, ei = cr * di + ci * dr;             // del = c d
-    const double nr = hr * er - hi * ei, ni = hr * ei + hi * er;
-    hr = nr; hi = ni;
-    if (fabs(er - 1.) + fabs(ei) < 1e-16) break;
-  }
-  double sn, cs;
-  sincos(x, &sn, &cs);
-  return IM ? hr * sn + hi * cs : hr * cs - hi * sn;                         // Im / Re of h e^(i x)
-}
 // the cores that need loops of their own (one compile-time core, CORE_SPECIAL, for all of them)
 template <typename T>
 __device__ __forceinline__ T special_core(const IsoArgs<T> &g, T r2) {
@@ -182,11 +131,11 @@ __device__ __forceinline__ T special_core(const IsoArgs<T> &g, T r2) {
   }
   if (g.kernel == LGP_KERNEL_COLOR) {                     // par = {psi(n)}, p = n
     if (x == 0.) return T(1);
-    return T((double)(g.p - 1) * expn_imag_re(g.p, (double)g.par[0], x));
+    return T((double)(g.p - 1) * lgp_bessel::expn_imag_re(g.p, (double)g.par[0], x));
   } else {                                                // Pink: par = {dw, log1p(dw), sqrt(eps)}
     const double dw = (double)g.par[0];
     if (x * dw < (double)g.par[2]) return T(cos(x * (1. + 0.5 * dw)));
-    return T((expn_imag_re(1, -0.5772156649015329, x) - expn_imag_re(1, -0.5772156649015329, x * (1. + dw))) / (double)g.par[1]);
+    return T((lgp_bessel::expn_imag_re(1, -0.5772156649015329, x) - lgp_bessel::expn_imag_re(1, -0.5772156649015329, x * (1. + dw))) / (double)g.par[1]);
   }
 }
 
@@ -200,7 +149,7 @@ __device__ __forceinline__ T special_core_mxdk(const IsoArgs<T> &g, T r2) {
   const double x = (double)sqrt(r2);
   if (x == 0.) return T(0);
   if (g.kernel == LGP_KERNEL_COLOR)                       // k' = -(n - 1) Im E_{n-1}(-i x); par[1] = psi(n - 1)
-    return T(x * (double)(g.p - 1) * expn_imag_re<true>(g.p - 1, (double)g.par[1], x));
+    return T(x * (double)(g.p - 1) * lgp_bessel::expn_imag_re<true>(g.p - 1, (double)g.par[1], x));
   if (g.kernel == LGP_KERNEL_PINK) {                      // Ci'(x) = cos x / x
     const double dw = (double)g.par[0];
     if (x * dw < (double)g.par[2]) return T(x * (1. + 0.5 * dw) * sin(x * (1. + 0.5 * dw)));

@@ -271,6 +271,27 @@ __device__ __forceinline__ S jet_core(const JetArgs &g, const S &r2, const S &X,
     return jexp(T(-2) * (q * q));
   }
   if (k == LGP_KERNEL_SINC) return jsinc(delta);
+  if (k == LGP_KERNEL_COLOR) {
+    // k(x) = (n - 1) Re E_n(-i x), x = |delta|: E_n' = -E_{n-1} makes d^m/dx^m E_n(-i x) = i^m E_{n-m}(-i x); psi(n - m) from the host
+    // (par[m]); at x = 0, E_k = 1 / (k - 1).  Orders with n - m < 2 only meet derivatives the host has refused.
+    const S a = jabs(delta);
+    const double x = (double)a.val();
+    T f[5];
+    double fact = 1.;
+    for (int m = 0; m < 5; ++m) {
+      const int kk = g.p - m;
+      double v = 0.;
+      if (kk >= 2 || (kk >= 1 && x > 0.)) {
+        const bool im = (m & 1) != 0;
+        if (x == 0.) v = im ? 0. : 1. / (double)(kk - 1);
+        else v = im ? lgp_bessel::expn_imag_re<true>(kk, g.par[m], x) : lgp_bessel::expn_imag_re<false>(kk, g.par[m], x);
+        if (m == 1 || m == 2) v = -v;                    // Re(i E) = -Im E, Re(-E) = -Re E, Re(-i E) = Im E, Re(E)
+      }
+      f[m] = T((double)(g.p - 1) * v / fact);
+      fact *= (double)(m + 1);
+    }
+    return compose(a, f);
+  }
   if (k == LGP_KERNEL_CELERITE) {                                                    // B = gamma (derivable once)
     const S a = jabs(delta);
     return jexp(T(-g.par[0]) * a) * (jcos(a) + T(g.par[1]) * jsin(a));
@@ -396,7 +417,7 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   const bool onevar = kernel == LGP_KERNEL_COS || kernel == LGP_KERNEL_PERIODIC || kernel == LGP_KERNEL_SINC || kernel == LGP_KERNEL_CELERITE ||
                       kernel == LGP_KERNEL_HARMONIC || kernel == LGP_KERNEL_WENDLAND || kernel == LGP_KERNEL_CIRCULAR || kernel == LGP_KERNEL_DECAYING ||
                       kernel == LGP_KERNEL_WIENERINTEGRAL || kernel == LGP_KERNEL_FRACBROWNIAN || kernel == LGP_KERNEL_STATIONARYFRACBROWNIAN ||
-                      kernel == LGP_KERNEL_TAYLOR;
+                      kernel == LGP_KERNEL_TAYLOR || kernel == LGP_KERNEL_COLOR;
   const bool iso = kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY || kernel == LGP_KERNEL_MATERNP ||
                    kernel == LGP_KERNEL_CONSTANT || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_MATERN || kernel == LGP_KERNEL_BESSEL ||
                    kernel == LGP_KERNEL_CAUSALEXPQUAD;
@@ -416,6 +437,14 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.posabs = kernel == LGP_KERNEL_CAUSALEXPQUAD ? 1 : 0;           // input='posabs' (_Kernel/_isotropic.py:67-78)
   for (int i = 0; i < npar; ++i) g.par[i] = (double)hpar[i];
   for (int i = 0; i < ncoef; ++i) g.coef[i / 24][i % 24] = (double)hcoef[i];
+  if (kernel == LGP_KERNEL_COLOR) {                      // p = n: psi(n - m), m = 0 .. 4, for the series of E_{n-m}
+    LGP_REQUIRE(npar == 0 && p >= 2, "Color takes the integer n >= 2 as p");
+    for (int m = 0; m < 5; ++m) {
+      double psi = -0.5772156649015329;
+      for (int j = 1; j < p - m; ++j) psi += 1. / (double)j;
+      g.par[m] = psi;
+    }
+  }
   if (kernel == LGP_KERNEL_BESSEL) {                     // hpar = {nu}: as the value core (gram.hip), par = {nu, Gamma(nu + 1), Gamma(1 + nu - floor(nu)), (2 + nu / 2)^2}
     LGP_REQUIRE(npar == 1 && hpar[0] >= T(0) && hpar[0] <= T(96), "Bessel takes {nu} in [0, 96]");
     const double nu = (double)hpar[0];

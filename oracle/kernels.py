@@ -606,7 +606,13 @@ def expn_imag(n, x):
 def Color(*, n=2, scale=None, loc=None, dim=None):
     """ ``_kernels/_spectral.py:73-111`` """
     assert int(n) == n and n >= 2, n
-    return Kernel(_stationary1d(lambda delta: (n - 1) * expn_imag(n, delta).real, 'abs'), scale=scale, loc=loc, dim=dim)
+    core_ = _stationary1d(lambda delta: (n - 1) * expn_imag(n, delta).real, 'abs')
+    # n // 2 - 1 times derivable (_spectral.py:70-71); the real part written as the mean of the two conjugate values (symdiff.py)
+    def sym(a):
+        sp = _sp()
+        return (n - 1) * (sp.expint(n, -sp.I * a) + sp.expint(n, sp.I * a)) / 2
+    core_.symbolic = ('abs', sym) if n >= 4 else None
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def Pink(*, dw=1, scale=None, loc=None, dim=None):

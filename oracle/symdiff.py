@@ -67,7 +67,7 @@ def symbolic_diff(kernel, da, db, Kernel):
                             sgn = sgn * (1. if fr <= 0.5 else -1.)
                             arg = min(fr, 1 - fr)
                         val = 0. if (support is not None and arg >= support) else fn(arg if arg > 0 else 1e-12) * sgn ** q
-                    out[idx] = float(val) * (-1.) ** b                 # d/dy of a function of x - y
+                    out[idx] = float(mpmath.re(val)) * (-1.) ** b      # d/dy of a function of x - y (real expressions written with complex parts: Color)
             return out
         return Kernel(core, scale=kernel._scale, loc=kernel._loc, outops=(('mul', factor),))
 

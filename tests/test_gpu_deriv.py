@@ -77,7 +77,7 @@ def test_what_is_not_available_says_so(lgp):
     with pytest.raises(ValueError):                                             # not derivable: the reference's error (_Kernel/_ops.py:85-90)
         lgp.GP(lgp.GammaExp(gamma=1.2)).addx(x, 'a', deriv=1).prior('a', raw=True)
     with pytest.raises(NotImplementedError):                                     # derivable in the reference, no derivative core here yet
-        lgp.GP(lgp.Color(n=6)).addx(x, 'a', deriv=1).prior('a', raw=True)
+        lgp.GP(lgp.Pink()).addx(x, 'a', deriv=1).prior('a', raw=True)
     with pytest.raises(ValueError):                                             # ceil(nu) - 1 times derivable (_kernels/_matern.py:51-53)
         lgp.GP(lgp.Matern(nu=1.7)).addx(x, 'a', deriv=2).prior('a', raw=True)
     with pytest.raises(ValueError):
@@ -333,6 +333,30 @@ def test_bessel_kernel_derivatives_vs_oracle(lgp, nu):
     got = kd.gram(X, Y, deriv=((1, 0), (0, 1))).to_host()
     want = ko.diff({'a': 1}, {'b': 1})(X[:, None], Y[None, :])
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-11 * np.abs(want).max())
+
+
+@pytest.mark.parametrize('n', [4, 5, 6, 9])
+def test_color_kernel_derivatives_vs_oracle(lgp, n):
+    """ Color(n) = (n - 1) Re E_n(-i |delta|), n // 2 - 1 times derivable (_kernels/_spectral.py:70-111): d^m/dx^m E_n(-i x) =
+    i^m E_{n-m}(-i x), real and imaginary parts of the exponential integral of the lower orders on the device (series below x = 2,
+    continued fraction above); the oracle differentiates expint symbolically """
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-4, 4, 14); y = rng.uniform(-4, 4, 12)
+    y[:4] = x[:4]
+    x[4] = 11.; y[5] = -9.                                      # (arguments in the continued-fraction region)
+    kd, ko = lgp.Color(n=n, scale=1.2) * 1.1, oracle.Color(n=n, scale=1.2) * 1.1
+    deg = n // 2 - 1
+    orders = [(a, b) for a in range(min(deg, 2) + 1) for b in range(min(deg, 2) + 1) if a + b]
+    for a, b in orders:
+        got = kd.gram(x, y, deriv=(a, b)).to_host()
+        want = ko.diff(a, b)(x[:, None], y[None, :])
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-9 * max(np.abs(want).max(), 1e-3), err_msg=f'n={n} {(a, b)}')
+        far = np.abs(x[:, None] - y[None, :]) > 1e-6
+        np.testing.assert_allclose(got[far], want[far], rtol=0, atol=1e-12 * max(np.abs(want).max(), 1e-3), err_msg=f'n={n} {(a, b)} away from coincidences')
+    got = kd.gram(x, y, deriv=(1, 1)).to_host()
+    assert abs(got[0, 0] - 1.1 * (n - 1) / (n - 3) / 1.2 ** 2) <= 1e-12 * got[0, 0]       # -k''(0) = (n - 1) E_{n-2}(0)
+    with pytest.raises(ValueError):
+        kd.gram(x, y, deriv=(deg + 1, 0))
 
 
 def test_taylor_and_causal_expquad_derivatives_vs_oracle(lgp):
