@@ -453,7 +453,7 @@ class _Isotropic(Kernel):
         deg = self._derivability()
         name = type(self).__name__
         if deg is None:
-            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, Bessel, GammaExp(gamma=2), Cauchy(alpha=2), CausalExpQuad(alpha=0), Taylor, Color, '
+            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, Bessel, GammaExp(gamma=2), Cauchy(alpha=2), CausalExpQuad(alpha=0), Taylor, Color, Pink, '
                                       'Constant, Linear, Periodic, Cos, Sinc, Celerite, Harmonic, Wendland, Circular, Decaying, WienerIntegral, '
                                       'FracBrownian(H=1, K=1), StationaryFracBrownian(H=1) have one)')
         sides = []
@@ -926,7 +926,7 @@ class Pink(_Stationary1D):
     """ Pink noise kernel, k(Δ) = (Ci(Δ (1 + dw)) - Ci(Δ)) / log(1 + dw): a power spectrum 1/ω between 1 and 1 + dw
     (``_kernels/_spectral.py:41-66``); where Δ dw is below sqrt(eps), cos(Δ (1 + dw/2)) """
     _kind = _lib.LGP_KERNEL_PINK
-    _derivable = None
+    _derivable = 1                                                          # _spectral.py:41
 
     def __init__(self, *, dw=1, scale=None, loc=None, dim=None):
         assert 0 <= dw < numpy.inf, dw

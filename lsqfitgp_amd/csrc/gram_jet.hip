@@ -13,6 +13,7 @@
 // One thread per pair: derivative blocks are the small blocks of a problem, not its N x N matrix.
 #include "common.h"
 #include "bessel_k_dev.h"
+#include <limits>
 
 namespace {
 
@@ -292,6 +293,38 @@ __device__ __forceinline__ S jet_core(const JetArgs &g, const S &r2, const S &X,
     }
     return compose(a, f);
   }
+  if (k == LGP_KERNEL_PINK) {
+    // k(x) = (Ci(a x) - Ci(x)) / L, a = 1 + dw, L = log1p(dw), x = |delta|; derivable once: Ci' = cos / x makes k' and k'' elementary
+    // (their series in x below 1e-2, where the closed forms cancel); where x dw < sqrt(eps), cos(x (1 + dw / 2)) as the value core does
+    const S a = jabs(delta);
+    const double x = (double)a.val(), dw = g.par[0], L = g.par[1], aa = 1. + dw;
+    double k0, k1, k2;
+    if (x * dw < g.par[2]) {
+      const double m = 1. + 0.5 * dw;
+      k0 = cos(x * m); k1 = -m * sin(x * m); k2 = -m * m * k0;
+    } else {
+      k0 = (lgp_bessel::expn_imag_re(1, -0.5772156649015329, x) - lgp_bessel::expn_imag_re(1, -0.5772156649015329, x * aa)) / L;
+      if (x < 1e-2) {
+        // cos(a x) - cos x = sum_j (-1)^j (a^(2j) - 1) x^(2j) / (2j)!
+        double t1 = 0., t2 = 0., a2j = 1., x2j2 = 1., fac = 1.;          // x^(2j-2), (2j)!
+        for (int j = 1; j < 8; ++j) {
+          a2j *= aa * aa;
+          fac *= (double)(2 * j - 1) * (double)(2 * j);
+          const double c = ((j & 1) ? -1. : 1.) * (a2j - 1.) / fac;
+          t1 += c * x2j2 * x;
+          t2 += c * (double)(2 * j - 1) * x2j2;
+          x2j2 *= x * x;
+        }
+        k1 = t1 / L; k2 = t2 / L;
+      } else {
+        const double ca = cos(aa * x), c1 = cos(x), ix = 1. / x;
+        k1 = (ca - c1) * ix / L;
+        k2 = ((-aa * sin(aa * x) + sin(x)) * ix - (ca - c1) * ix * ix) / L;
+      }
+    }
+    const T f[5] = {T(k0), T(k1), T(0.5 * k2), T(0), T(0)};
+    return compose(a, f);
+  }
   if (k == LGP_KERNEL_CELERITE) {                                                    // B = gamma (derivable once)
     const S a = jabs(delta);
     return jexp(T(-g.par[0]) * a) * (jcos(a) + T(g.par[1]) * jsin(a));
@@ -417,7 +450,7 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   const bool onevar = kernel == LGP_KERNEL_COS || kernel == LGP_KERNEL_PERIODIC || kernel == LGP_KERNEL_SINC || kernel == LGP_KERNEL_CELERITE ||
                       kernel == LGP_KERNEL_HARMONIC || kernel == LGP_KERNEL_WENDLAND || kernel == LGP_KERNEL_CIRCULAR || kernel == LGP_KERNEL_DECAYING ||
                       kernel == LGP_KERNEL_WIENERINTEGRAL || kernel == LGP_KERNEL_FRACBROWNIAN || kernel == LGP_KERNEL_STATIONARYFRACBROWNIAN ||
-                      kernel == LGP_KERNEL_TAYLOR || kernel == LGP_KERNEL_COLOR;
+                      kernel == LGP_KERNEL_TAYLOR || kernel == LGP_KERNEL_COLOR || kernel == LGP_KERNEL_PINK;
   const bool iso = kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY || kernel == LGP_KERNEL_MATERNP ||
                    kernel == LGP_KERNEL_CONSTANT || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_MATERN || kernel == LGP_KERNEL_BESSEL ||
                    kernel == LGP_KERNEL_CAUSALEXPQUAD;
@@ -437,6 +470,10 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.posabs = kernel == LGP_KERNEL_CAUSALEXPQUAD ? 1 : 0;           // input='posabs' (_Kernel/_isotropic.py:67-78)
   for (int i = 0; i < npar; ++i) g.par[i] = (double)hpar[i];
   for (int i = 0; i < ncoef; ++i) g.coef[i / 24][i % 24] = (double)hcoef[i];
+  if (kernel == LGP_KERNEL_PINK) {                       // hpar = {dw}: par = {dw, log1p(dw), sqrt(eps)} as the value core (_spectral.py:62-66)
+    LGP_REQUIRE(npar == 1 && hpar[0] >= T(0) && hpar[0] < std::numeric_limits<T>::infinity(), "Pink takes {dw}, dw >= 0");
+    g.par[0] = (double)hpar[0]; g.par[1] = log1p((double)hpar[0]); g.par[2] = sqrt((double)std::numeric_limits<T>::epsilon());
+  }
   if (kernel == LGP_KERNEL_COLOR) {                      // p = n: psi(n - m), m = 0 .. 4, for the series of E_{n-m}
     LGP_REQUIRE(npar == 0 && p >= 2, "Color takes the integer n >= 2 as p");
     for (int m = 0; m < 5; ++m) {

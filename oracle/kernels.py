@@ -622,7 +622,16 @@ def Pink(*, dw=1, scale=None, loc=None, dim=None):
             l = special.sici(delta)[1]
             r = special.sici(delta * (1 + dw))[1]
             return numpy.where(delta * dw < numpy.sqrt(numpy.finfo(float).eps), numpy.cos(delta * (1 + dw / 2)), (r - l) / numpy.log1p(dw))
-    return Kernel(_stationary1d(core, 'abs'), scale=scale, loc=loc, dim=dim)
+    core_ = _stationary1d(core, 'abs')
+    # derivable once (_spectral.py:41).  Below delta dw = sqrt(eps) the reference's core IS cos(delta (1 + dw / 2)), and jax
+    # differentiates the branch taken: the variance of the derivative at a point is (1 + dw / 2)^2, not the limit of the other branch
+    def sym(a):
+        sp = _sp()
+        v = sp.Rational(float(dw))
+        return (sp.Ci(a * (1 + v)) - sp.Ci(a)) / sp.log(1 + v)
+    tol = numpy.sqrt(numpy.finfo(float).eps)
+    core_.symbolic = ('abs', sym, None, dict(small=(tol / dw, lambda a: _sp().cos(a * (1 + _sp().Rational(float(dw)) / 2))))) if dw > 1e-6 else None
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def _eta_borwein(z, n=40):

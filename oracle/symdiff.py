@@ -50,6 +50,8 @@ def symbolic_diff(kernel, da, db, Kernel):
         z = sp.Symbol('z', positive=True) if kind != 'delta' else sp.Symbol('z', real=True)
         q = a + b
         fn = mp_eval(sp.diff(build(z), z, q) if q else build(z), [z])
+        small = opts.get('small')                              # (threshold, builder): the branch the reference's core takes below it
+        fn_small = mp_eval(sp.diff(small[1](z), z, q) if q else small[1](z), [z]) if small else None
 
         def core(x, y):
             d = column(x) - column(y)
@@ -66,7 +68,10 @@ def symbolic_diff(kernel, da, db, Kernel):
                             fr = arg - numpy.floor(arg)
                             sgn = sgn * (1. if fr <= 0.5 else -1.)
                             arg = min(fr, 1 - fr)
-                        val = 0. if (support is not None and arg >= support) else fn(arg if arg > 0 else 1e-12) * sgn ** q
+                        if small is not None and arg < small[0]:
+                            val = fn_small(arg) * sgn ** q
+                        else:
+                            val = 0. if (support is not None and arg >= support) else fn(arg if arg > 0 else 1e-12) * sgn ** q
                     out[idx] = float(mpmath.re(val)) * (-1.) ** b      # d/dy of a function of x - y (real expressions written with complex parts: Color)
             return out
         return Kernel(core, scale=kernel._scale, loc=kernel._loc, outops=(('mul', factor),))

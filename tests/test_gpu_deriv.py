@@ -77,7 +77,7 @@ def test_what_is_not_available_says_so(lgp):
     with pytest.raises(ValueError):                                             # not derivable: the reference's error (_Kernel/_ops.py:85-90)
         lgp.GP(lgp.GammaExp(gamma=1.2)).addx(x, 'a', deriv=1).prior('a', raw=True)
     with pytest.raises(NotImplementedError):                                     # derivable in the reference, no derivative core here yet
-        lgp.GP(lgp.Pink()).addx(x, 'a', deriv=1).prior('a', raw=True)
+        lgp.GP(lgp.Zeta(nu=2.5)).addx(x, 'a', deriv=1).prior('a', raw=True)
     with pytest.raises(ValueError):                                             # ceil(nu) - 1 times derivable (_kernels/_matern.py:51-53)
         lgp.GP(lgp.Matern(nu=1.7)).addx(x, 'a', deriv=2).prior('a', raw=True)
     with pytest.raises(ValueError):
@@ -357,6 +357,26 @@ def test_color_kernel_derivatives_vs_oracle(lgp, n):
     assert abs(got[0, 0] - 1.1 * (n - 1) / (n - 3) / 1.2 ** 2) <= 1e-12 * got[0, 0]       # -k''(0) = (n - 1) E_{n-2}(0)
     with pytest.raises(ValueError):
         kd.gram(x, y, deriv=(deg + 1, 0))
+
+
+@pytest.mark.parametrize('dw', [1., 0.2, 3.5])
+def test_pink_kernel_derivatives_vs_oracle(lgp, dw):
+    """ Pink(dw) = (Ci((1 + dw) x) - Ci(x)) / log1p(dw), derivable once (_kernels/_spectral.py:41-66): k' and k'' in closed form, by
+    their series where those cancel """
+    rng = np.random.default_rng(int(10 * dw))
+    x = rng.uniform(-4, 4, 14); y = rng.uniform(-4, 4, 12)
+    y[:4] = x[:4]
+    y[4] = x[4] + 3e-3; y[5] = x[5] - 1e-5                      # (the series region)
+    kd, ko = lgp.Pink(dw=dw, scale=1.2) * 1.1, oracle.Pink(dw=dw, scale=1.2) * 1.1
+    for a, b in [(1, 0), (0, 1), (1, 1)]:
+        got = kd.gram(x, y, deriv=(a, b)).to_host()
+        want = ko.diff(a, b)(x[:, None], y[None, :])
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-9 * max(np.abs(want).max(), 1e-3), err_msg=f'dw={dw} {(a, b)}')
+    got = kd.gram(x, y, deriv=(1, 1)).to_host()
+    # at a coincidence the reference differentiates the branch its core takes there, cos(delta (1 + dw / 2)) (_spectral.py:62-66)
+    assert abs(got[0, 0] - 1.1 * (1 + dw / 2) ** 2 / 1.2 ** 2) <= 1e-12 * got[0, 0]
+    with pytest.raises(ValueError):
+        kd.gram(x, y, deriv=(2, 0))
 
 
 def test_taylor_and_causal_expquad_derivatives_vs_oracle(lgp):
