@@ -453,7 +453,7 @@ class _Isotropic(Kernel):
         deg = self._derivability()
         name = type(self).__name__
         if deg is None:
-            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, Bessel, GammaExp(gamma=2), Cauchy(alpha=2), CausalExpQuad(alpha=0), Taylor, Color, Pink, '
+            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, Bessel, GammaExp(gamma=2), Cauchy(alpha=2), CausalExpQuad(alpha=0), Taylor, Color, Pink, NNKernel, '
                                       'Constant, Linear, Periodic, Cos, Sinc, Celerite, Harmonic, Wendland, Circular, Decaying, WienerIntegral, '
                                       'FracBrownian(H=1, K=1), StationaryFracBrownian(H=1) have one)')
         sides = []
@@ -1591,6 +1591,20 @@ class Gibbs(_Isotropic):
         return self._kind, 0, (), self._outops
 
 
+class _NNJet(_Isotropic):
+    """ the derivative core of `NNKernel` (``LGP_KERNEL_NNKERNEL``, only through ``lgp_gram_deriv``): derivable any number of times
+    (``_kernels/_basic.py:122``) """
+    _kind = _lib.LGP_KERNEL_NNKERNEL
+    _derivable = float('inf')
+
+    def __init__(self, q, *, scale=None, loc=None, dim=None):
+        super().__init__(scale=scale, loc=loc, dim=dim)
+        self._par = (float(q),)
+
+    def _has_closed_form_diff(self, d):
+        return False
+
+
 class NNKernel(Kernel):
     """ Neural network kernel, k(x, y) = 2/π asin(2 (q + x·y) / ((1 + 2 (q + x·x)) (1 + 2 (q + y·y)))), q = sigma0²
     (``_kernels/_basic.py:122-154``): the argument is `Linear` + q times an outer product of per-point factors, a composite of
@@ -1608,6 +1622,7 @@ class NNKernel(Kernel):
                 xx = sum(numpy.sum(numpy.square(x[nm]), axis=tuple(range(x.ndim, x[nm].ndim))) for nm in x.dtype.names)
             return 1 / (1 + 2 * (q + xx))
         self._inner = (Linear(scale=scale, loc=loc, dim=dim) + q) * Rescaling(stdfun=inv_norm, scale=scale, loc=loc, dim=dim) * 2.
+        self._jet = _NNJet(q, scale=scale, loc=loc, dim=dim)          # derivative observations: the whole expression in Taylor arithmetic
 
     def _result_dtype(self, x, y):
         return numpy.dtype(numpy.float64)
@@ -1623,7 +1638,8 @@ class NNKernel(Kernel):
 
     def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
         if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
-            raise NotImplementedError('derivatives of NNKernel')
+            jet = self._jet._copy(_outops=tuple(self._outops), _doutops=tuple({} for _ in self._outops))     # (scalar factors of this kernel multiply the derivative)
+            return jet.gram(xs, ys, ctx=ctx, out=out, deriv=deriv)
         return self._outer(self._inner.gram(xs, ys, ctx=ctx, out=out))
 
     def pairs(self, xs, ys, *, ctx=None):

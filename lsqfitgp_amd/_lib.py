@@ -58,6 +58,7 @@ LGP_KERNEL_COLOR = 31
 LGP_KERNEL_PINK = 32
 LGP_KERNEL_BESSEL = 33
 LGP_KERNEL_PSERIES = 34
+LGP_KERNEL_NNKERNEL = 35
 LGP_OP_MUL = 0
 LGP_OP_ADD = 1
 LGP_EPS_AUTO_REL = 1

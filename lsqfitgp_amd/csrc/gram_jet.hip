@@ -136,6 +136,12 @@ template <typename T> __device__ __forceinline__ Jet<T> jrecip(const Jet<T> &a) 
   const T f[5] = {ix, -ix * ix, ix * ix * ix, -ix * ix * ix * ix, ix * ix * ix * ix * ix};
   return compose(a, f);
 }
+// asin(a), |a_00| < 1
+template <typename T> __device__ __forceinline__ Jet<T> jasin(const Jet<T> &a) {
+  const T t = a.val(), u = T(1) / (T(1) - t * t), r = sqrt(u);        // u = 1 / (1 - t^2)
+  const T f[5] = {asin(t), r, t * r * u / T(2), (T(1) + T(2) * t * t) * r * u * u / T(6), (T(9) * t + T(6) * t * t * t) * r * u * u * u / T(24)};
+  return compose(a, f);
+}
 // |a| as an even function continued from the right: sign(0) = +1 (the kernels that take |delta| and are derivable at 0 have
 // h'(0) = 0, so that d^2/d delta^2 h(|delta|) at 0 is h''(0+), which this gives; a sign that vanishes at 0 would give 0)
 template <typename T> __device__ __forceinline__ Jet<T> jabs(const Jet<T> &a) { return a.val() >= T(0) ? a : -a; }
@@ -263,6 +269,11 @@ __device__ __forceinline__ S jet_core(const JetArgs &g, const S &r2, const S &X,
     return compose(r2, f);
   }
   if (k == LGP_KERNEL_CAUSALEXPQUAD) return jexp(T(-0.5) * r2);                       // alpha = 0 only (the host refuses the others): r2 of the softened distances
+  if (k == LGP_KERNEL_NNKERNEL) {                        // r2 carries x.y, X carries x.x, Y carries y.y (all fields); par = {q}
+    const T q = T(g.par[0]);
+    const S denom = (T(1) + T(2) * (X + q)) * (T(1) + T(2) * (Y + q));
+    return T(0.63661977236758134308) * jasin(T(2) * (r2 + q) * jrecip(denom));
+  }
   if (k == LGP_KERNEL_CONSTANT) return S(T(1));
   if (k == LGP_KERNEL_LINEAR) return r2;                                             // (r2 carries sum_f X_f Y_f for this kernel)
   const S delta = X - Y;
@@ -420,14 +431,18 @@ __global__ void __launch_bounds__(256) gram_jet_kernel(const T *__restrict__ x, 
     S xf(xv), yf(yv);
     if (f == g.fx) xf.c[1][0] = T(1);            // u: the perturbation of x along its field (in transformed units)
     if (f == g.fy) yf.c[0][1] = T(1);            // v: of y
-    if (g.xy == 2) {
+    if (g.xy == 3) {                                 // the three dot products over the fields
+      r2 = r2 + xf * yf;
+      X = X + xf * xf;
+      Y = Y + yf * yf;
+    } else if (g.xy == 2) {
       r2 = r2 + xf * yf;
     } else {
       S df = xf - yf;
       if (g.posabs) df = jabs(df) + (sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-07f));
       r2 = r2 + df * df;
     }
-    if (f == 0) { X = xf; Y = yf; }
+    if (f == 0 && g.xy != 3) { X = xf; Y = yf; }
   }
   const S v = jet_core<T, S>(g, r2, X, Y);
   const T fact[3] = {T(1), T(1), T(2)};
@@ -453,7 +468,7 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
                       kernel == LGP_KERNEL_TAYLOR || kernel == LGP_KERNEL_COLOR || kernel == LGP_KERNEL_PINK;
   const bool iso = kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY || kernel == LGP_KERNEL_MATERNP ||
                    kernel == LGP_KERNEL_CONSTANT || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_MATERN || kernel == LGP_KERNEL_BESSEL ||
-                   kernel == LGP_KERNEL_CAUSALEXPQUAD;
+                   kernel == LGP_KERNEL_CAUSALEXPQUAD || kernel == LGP_KERNEL_NNKERNEL;
   LGP_REQUIRE(onevar || iso, "no derivative core for this kernel");
   LGP_REQUIRE(!onevar || d == 1, "a kernel of one variable takes one-dimensional points");
   LGP_REQUIRE(kernel != LGP_KERNEL_MATERNP || (p >= 0 && p <= 16 && ncoef == 5 * 24), "Maternp: order 0 .. 16 and the five polynomials");
@@ -466,10 +481,11 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.kernel = kernel; g.p = p; g.d = d; g.n = (int)n; g.m = (int)m;
   g.fx = ax ? fx : -1; g.fy = by ? fy : -1; g.ax = ax; g.by = by;
   g.has_loc = has_loc; g.has_scale = has_scale; g.loc = (double)loc; g.scale = (double)scale; g.factor = (double)factor;
-  g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : 0;
+  g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : (kernel == LGP_KERNEL_NNKERNEL ? 3 : 0);
   g.posabs = kernel == LGP_KERNEL_CAUSALEXPQUAD ? 1 : 0;           // input='posabs' (_Kernel/_isotropic.py:67-78)
   for (int i = 0; i < npar; ++i) g.par[i] = (double)hpar[i];
   for (int i = 0; i < ncoef; ++i) g.coef[i / 24][i % 24] = (double)hcoef[i];
+  LGP_REQUIRE(kernel != LGP_KERNEL_NNKERNEL || (npar == 1 && hpar[0] > T(0)), "NNKernel takes {sigma0^2}");
   if (kernel == LGP_KERNEL_PINK) {                       // hpar = {dw}: par = {dw, log1p(dw), sqrt(eps)} as the value core (_spectral.py:62-66)
     LGP_REQUIRE(npar == 1 && hpar[0] >= T(0) && hpar[0] < std::numeric_limits<T>::infinity(), "Pink takes {dw}, dw >= 0");
     g.par[0] = (double)hpar[0]; g.par[1] = log1p((double)hpar[0]); g.par[2] = sqrt((double)std::numeric_limits<T>::epsilon());

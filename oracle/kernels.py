@@ -920,6 +920,8 @@ def NNKernel(*, sigma0=1, scale=None, loc=None, dim=None):
     def core(x, y):
         denom = (1 + 2 * (q + dot(x, x))) * (1 + 2 * (q + dot(y, y)))
         return 2 / numpy.pi * numpy.arcsin(2 * (q + dot(x, y)) / denom)
+    # derivable any number of times (_basic.py:122): a function of the three dot products x.y, x.x, y.y over the fields (symdiff.py)
+    core.symbolic = ('dots', lambda xy, xx, yy: 2 / _sp().pi * _sp().asin(2 * (_sp().Float(q, 30) + xy) / ((1 + 2 * (_sp().Float(q, 30) + xx)) * (1 + 2 * (_sp().Float(q, 30) + yy)))))
     return Kernel(core, scale=scale, loc=loc, dim=dim)
 
 

@@ -10,6 +10,7 @@ A core announces its expression through ``core.symbolic = (kind, builder)``:
     'circ'   builder(t): a function of the distance t of |difference| to the nearest integer;
     'xy'     builder(x, y, upper): of the two points themselves; upper: the branch x <= y;
     'iso'    builder(r2): of the squared distance over the fields;
+    'dots'   builder(xy, xx, yy): of the three dot products x.y, x.x, y.y over the fields;
 an optional third entry is the radius of a compact support (the expression is then the one inside it), a fourth a dictionary
 ``dps`` / ``offset``: working digits and the offset from which the limit at coincident points is taken (default 120, 1e-10).
 """
@@ -86,6 +87,37 @@ def symbolic_diff(kernel, da, db, Kernel):
             with mpmath.workdps(40):
                 for idx in numpy.ndindex(x.shape):
                     out[idx] = float(exprs[bool(x[idx] <= y[idx])](x[idx], y[idx]))
+            return out
+        return Kernel(core, scale=kernel._scale, loc=kernel._loc, outops=(('mul', factor),))
+
+    if kind == 'dots':
+        # U: the x side's differentiated coordinate (field f), Z: the y side's (field g); every other coordinate enters as a number.
+        # f = g (or one side only): x.y = U Z + Rxy;  f != g: x.y = U Vf + Xg Z + Rxy with Vf = y_f, Xg = x_g;  x.x = U^2 + Rxx, y.y = Z^2 + Ryy
+        U, Z, Vf, Xg, Rxy, Rxx, Ryy = sp.symbols('U Z Vf Xg Rxy Rxx Ryy', real=True)
+        split = bool(a and b and xf != yf)
+        expr = build((U * Vf + Xg * Z + Rxy) if split else (U * Z + Rxy), U ** 2 + Rxx, Z ** 2 + Ryy)
+        fn = mp_eval(sp.diff(expr, *([U] * a + [Z] * b)) if a + b else expr, [U, Z, Vf, Xg, Rxy, Rxx, Ryy])
+
+        def core(x, y):
+            x = numpy.asarray(x); y = numpy.asarray(y)
+            names = x.dtype.names
+            if names is None:
+                cols = {None: (numpy.asarray(x, float), numpy.asarray(y, float))}
+            else:
+                cols = {nm: (numpy.asarray(x[nm], float), numpy.asarray(y[nm], float)) for nm in names}
+            fa = xf if a else (yf if b else next(iter(cols)))          # the field U stands for
+            fb = yf if split else fa                                     # ... and Z
+            shape = numpy.broadcast_shapes(*(c[0].shape for c in cols.values()), *(c[1].shape for c in cols.values()))
+            bc = {k: (numpy.broadcast_to(v[0], shape), numpy.broadcast_to(v[1], shape)) for k, v in cols.items()}
+            out = numpy.empty(shape)
+            with mpmath.workdps(60):
+                for idx in numpy.ndindex(shape):
+                    u, z = bc[fa][0][idx], bc[fb][1][idx]
+                    vf, xg = (bc[fa][1][idx], bc[fb][0][idx]) if split else (0., 0.)
+                    rxy = sum(bc[k][0][idx] * bc[k][1][idx] for k in bc if k not in (fa, fb))
+                    rxx = sum(bc[k][0][idx] ** 2 for k in bc if k != fa)
+                    ryy = sum(bc[k][1][idx] ** 2 for k in bc if k != fb)
+                    out[idx] = float(fn(u, z, vf, xg, rxy, rxx, ryy))
             return out
         return Kernel(core, scale=kernel._scale, loc=kernel._loc, outops=(('mul', factor),))
 

@@ -379,6 +379,41 @@ def test_pink_kernel_derivatives_vs_oracle(lgp, dw):
         kd.gram(x, y, deriv=(2, 0))
 
 
+def test_nnkernel_derivatives_vs_oracle(lgp):
+    """ NNKernel (_kernels/_basic.py:122-154), a function of the dot products x.y, x.x, y.y over the fields: the whole expression in
+    Taylor arithmetic on the device (LGP_KERNEL_NNKERNEL), sympy on the same three dot products in the oracle; one-dimensional
+    points and named fields, the same and different fields on the two sides """
+    rng = np.random.default_rng(31)
+    x = rng.uniform(-2, 2, 13); y = rng.uniform(-2, 2, 11); y[:3] = x[:3]
+    kd, ko = lgp.NNKernel(sigma0=0.7, scale=1.3, loc=0.1) * 1.2, oracle.NNKernel(sigma0=0.7, scale=1.3, loc=0.1) * 1.2
+    for a, b in [(1, 0), (0, 1), (1, 1), (2, 0), (2, 1), (2, 2)]:
+        got = kd.gram(x, y, deriv=(a, b)).to_host()
+        want = ko.diff(a, b)(x[:, None], y[None, :])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12 * np.abs(want).max(), err_msg=f'NNKernel {(a, b)}')
+    dt = [('a', float), ('b', float), ('c', float)]
+    X = np.empty(9, dt); Y = np.empty(7, dt)
+    for f in 'abc':
+        X[f] = rng.uniform(-1, 1, 9); Y[f] = rng.uniform(-1, 1, 7)
+    Y[:3] = X[:3]
+    for sx, sy in [(('a', 1), ('b', 1)), (('c', 2), ('c', 1)), (('b', 2), None), (None, ('a', 1)), (('a', 2), ('c', 2))]:
+        ox = tuple((sx[1] if sx and nm == sx[0] else 0) for nm in X.dtype.names)
+        oy = tuple((sy[1] if sy and nm == sy[0] else 0) for nm in X.dtype.names)
+        got = kd.gram(X, Y, deriv=(ox, oy)).to_host()
+        want = ko.diff({sx[0]: sx[1]} if sx else 0, {sy[0]: sy[1]} if sy else 0)(X[:, None], Y[None, :])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12 * np.abs(want).max(), err_msg=f'NNKernel {sx} {sy}')
+    # the posterior of a process observed through its slope: device against oracle
+    xs = np.linspace(-1.5, 1.5, 9)
+    yv = np.tanh(2 * x)
+    nf = len(x)
+    gc = {('f', 'f'): 1e-4 * np.eye(nf), ('df', 'df'): 1e-4 * np.eye(5), ('f', 'df'): np.zeros((nf, 5)), ('df', 'f'): np.zeros((5, nf))}
+    for mod, kk in ((lgp, kd), (oracle, ko)):
+        gp = mod.GP(kk, checkpos=False, checksym=False).addx(x, 'f').addx(x[:5], 'df', deriv=1).addx(xs, 'out')
+        m, c = gp.predfromdata({'f': yv, 'df': 2 / np.cosh(2 * x[:5]) ** 2}, 'out', gc, raw=True)
+        if mod is lgp:
+            md, cd = m, c
+    assert np.linalg.norm(md - m) <= 1e-7 * np.linalg.norm(m) and np.linalg.norm(cd - c, 2) <= 1e-7 * max(np.linalg.norm(c, 2), 1e-6)
+
+
 def test_taylor_and_causal_expquad_derivatives_vs_oracle(lgp):
     """ Taylor (I0(2 sqrt(x y)), J0 where x y < 0: the series of h^(m)(w) below |w| = 30, the library's I_m / J_m beyond) and
     CausalExpQuad(alpha=0), the two remaining kernels of _kernels/_basic.py that the reference marks derivable """
