@@ -131,7 +131,7 @@ int lgp_profile_end(lgp_ctx *ctx, size_t *launches, double *total_ms, double *to
 #define LGP_KERNEL_COLOR 31       /* _kernels/_spectral.py:73-111  (n - 1) Re E_n(-i |x - y|), integer n >= 2 passed as p: power spectrum 1/omega^n above omega = 1.  E_n by its power series (|x - y| <= 2) and its continued fraction.  Has a scale tangent (-(n - 1) Im E_{n-1}) */
 #define LGP_KERNEL_PINK 32        /* _kernels/_spectral.py:41-66   (Ci(D (1 + dw)) - Ci(D)) / log(1 + dw), D = |x - y|; cos(D (1 + dw/2)) where D dw < sqrt(eps): hpar = {dw}.  Has a scale tangent (Ci' = cos x / x) */
 #define LGP_KERNEL_BESSEL 33      /* _kernels/_matern.py:102-119   Gamma(nu + 1) (s r / 2)^-nu J_nu(s r), s = 2 + nu / 2, real nu in [0, 100]: hpar = {nu}; at most 2 (floor(nu) + 1) fields.  J_nu by series / Miller's recurrence / Hankel's expansion.  Has a scale tangent (through the kernel of order nu + 1) */
-#define LGP_KERNEL_NNKERNEL 35    /* _kernels/_basic.py:122-154  2/pi asin(2 (q + x.y) / ((1 + 2 (q + x.x)) (1 + 2 (q + y.y)))), q = sigma0^2: hpar = {q}.  Only through lgp_gram_deriv (the values are a composite of Linear and per-point factors on the host side) */
+#define LGP_KERNEL_NNKERNEL 35    /* _kernels/_basic.py:122-154  2/pi asin(2 (q + x.y) / ((1 + 2 (q + x.x)) (1 + 2 (q + y.y)))), q = sigma0^2: hpar = {q}.  Derivative entry points only, lgp_gram_deriv_f64 / lgp_gram_deriv_f32: the values are a composite of Linear and per-point factors on the host side */
 #define LGP_KERNEL_PSERIES 34     /* even 1-periodic functions of |x - y| from host-computed coefficients (the Zeta kernel, _kernels/_zeta.py:37-70): only through lgp_gram_pseries / lgp_pairs_pseries */
 #define LGP_OP_MUL 0           /* kernel * c  (_Kernel/_alg.py:58-82)  */
 #define LGP_OP_ADD 1           /* kernel + c  (_Kernel/_alg.py:32-56)  */
