@@ -24,6 +24,8 @@ UNITS = [
     # the chain kernel (walker + workers): a unit of its own (with the walker's phases inlined into one loop body ROCm 7.2's AGPR
     # rewrite pass crashed on the spills of this unit; they are functions of their own now, csrc/walker.inc)
     ('chainw.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form=1']),
+    # the chain kernel of round 3 (task graph): the default (chaint.hip says why)
+    ('chaint.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form=1']),
     ('elementwise.hip', []),
     ('dist.hip', []),
     # the Gram kernels follow the reference's unfused square-then-add evaluation

@@ -1,12 +1,14 @@
-// chainw.hip -- the dependent chain of the whole blocked factorisation as ONE launch of resident workgroups (fp64): the walker
-// (walker.inc) and the workers of the diagonal squares, their schedule and the launch.  Replaces, on the squares, the LAPACK
-// potrf that jlinalg.cholesky lowers to (src/lsqfitgp/_linalg/_decomp.py:388); the driver around it is potrf_chain (potrf.hip).
+// chaint.hip -- the chain kernel of round 3: the diagonal squares of all panels factored by resident worker workgroups as a task graph
+// (P: factor a diagonal block, S: substitution of 64 rows, G: update of a 64 x 64 tile).  Round 4 built a replacement whose first
+// workgroup keeps the diagonal block on chip (chainw.hip, walker.inc); measured side by side on one box it is 9 % SLOWER up to
+// N = 4096 (1.28 vs 1.17 ms at N = 2048, 2.57 vs 2.35 at 4096, 6.43 vs 6.23 at 8192; equal from 16384 on), so this kernel is
+// the default again and the walker an option (LGP_CHAIN_IMPL=walker).  Both obey the same flag words (common.h, LGP_CH_*) and
+// are driven by the same potrf_chain (potrf.hip).
 #include "potf2_dev.h"
 #include <algorithm>
 #include <cstdlib>
 
 namespace {
-
 // ------------------------------------------------------------------------------------------------
 // The dependent chain of the WHOLE factorisation as one launch: resident worker workgroups that own their CUs.
 //
@@ -23,7 +25,7 @@ namespace {
 //     G(k, r, c, j)  A(r, c) -= X(r, j) X(c, j)^T, a 64 x 64 tile with K = 128, c a unit right of block j, r >= c
 // with  S(r, j) <- P(j), G(r, 2j | 2j+1, i < j);  G(r, c, j) <- S(r, j), S(c, j), G(r, c, j - 1);  P(j) <- G(2j | 2j+1, 2j | 2j+1, j - 1),
 // kept as flags and per-tile step counters in device memory.  Workers take tasks from a list in topological order
-// (lgp_chainw_schedule: every block's chain first, the other rows of the square lagging behind) with an atomic counter, wait
+// (lgp_chaint_schedule: every block's chain first, the other rows of the square lagging behind) with an atomic counter, wait
 // for the task's inputs (agent-scope acquire), run it, publish it (release).  A task is only ever held by a running
 // workgroup and only waits for tasks earlier in the list, which have all been taken: the earliest unfinished task can always
 // run -- no deadlock, whatever the dispatch order.
@@ -52,8 +54,6 @@ struct ChainArgs {
   unsigned long long timeout;  // wall_clock64 ticks a worker waits for one input before it abandons the launch
   long row0;                   // global index of the matrix's first row (pivot indices of the info word)
   int samexcd;                 // chain workers all on XCD 0 (experiment, env LGP_CHAIN_SAMEXCD)
-  int tailwg;                  // two-workgroup mode: index of the tail workgroup (walker.inc, wk_tail), 0 = the single walker does it all
-  double *scratch;             // ... its hand-over buffers: 2 x 36 tiles of published block rows, 2 x 36 tiles of the next block
 };
 
 __device__ __forceinline__ unsigned ch_peek(unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -75,28 +75,6 @@ __device__ __forceinline__ bool ch_wait(unsigned *p, unsigned need, unsigned *st
     }
   }
   return true;
-}
-
-// wave 0 of a workgroup, lanes 0 .. count-1: spin until every word (lane i: ptrs laid out by the caller) has reached `need`.  One
-// poll round trips for all the words together (polled one after the other, seven words cost seven L2 round trips: 3-5 us).
-// Returns false when the launch is being abandoned.  Call with the whole wave.
-__device__ __forceinline__ bool ch_wait_lanes(unsigned *mine, bool active, unsigned need, unsigned *state, unsigned long long timeout) {
-  unsigned spins = 0;
-  unsigned long long t0 = 0;
-  for (;;) {
-    const bool ok = !active || ch_peek(mine) >= need;
-    if (__builtin_amdgcn_ballot_w64(!ok) == 0) return true;
-    __builtin_amdgcn_s_sleep(2);
-    if ((++spins & 63u) == 0) {
-      if (ch_peek(state + LGP_CH_ABORT) != 0) return false;
-      const unsigned long long now = wall_clock64();
-      if (t0 == 0) t0 = now;
-      if (now - t0 > timeout) {
-        __hip_atomic_store(state + LGP_CH_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return false;
-      }
-    }
-  }
 }
 
 // G(r, c, j): the 64 x 64 tile at (64 r, 64 c) of the panel -= X(r, j) X(c, j)^T.  Four waves, 32 x 32 each; both operands are
@@ -175,28 +153,16 @@ __device__ __forceinline__ void ch_update_tile(double *P, long ldp, int j, int r
     }
 }
 
-#include "walker.inc"
-
-// Workgroup 0 is the walker (walker.inc); the others are workers that take the S and G tasks of the two lists.
 __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
-  extern __shared__ double wk_lds[];
+  __shared__ double rowbuf[P4_ROWBUF];
+  __shared__ double diagbuf[4 * 64];
   __shared__ int s_task;
   __builtin_amdgcn_s_setprio(LGP_CHAIN_PRIO);
   unsigned *const st = p.state;
   const int npanels = (p.n + LGP_NB - 1) / LGP_NB;
-  if (blockIdx.x == 0) {
-#include "walker_body.inc"
-  } else if (p.tailwg != 0 && (int)blockIdx.x == p.tailwg) {
-#include "tail_body.inc"
-  } else {
   // the workers of the dependent chain: the first `chainw` workgroups, or (samexcd) the first chainw of those that the hardware
   // places on XCD 0 (workgroup i runs on XCD i mod 8), so that what one of them writes the next finds in the same L2
-  // the workers that start on the NEAR list (thread 0's copy is the one that counts): 1 .. chainw, or -- samexcd -- the workgroups
-  // 8, 16, .. 8 chainw, which the dispatcher places on the walker's XCD (workgroup i runs on XCD i mod 8): what the walker and
-  // they hand each other then stays in one L2 instead of crossing the fabric (a block handed over by another XCD takes ~4.5 us
-  // to arrive, cdna_hip_programming.md: 62-70 GB/s per block cross-XCD, 104-122 same-XCD)
-  const int widx = (int)blockIdx.x - (p.tailwg != 0 && (int)blockIdx.x > p.tailwg ? 1 : 0);     // (workers count from 1, the tail workgroup left out)
-  bool on_chain = p.samexcd ? ((blockIdx.x & 7u) == 0u && (int)(blockIdx.x >> 3) <= p.chainw) : widx <= p.chainw;
+  bool on_chain = p.samexcd ? ((blockIdx.x & 7u) == 0u && (int)(blockIdx.x >> 3) < p.chainw) : (int)blockIdx.x < p.chainw;          // (thread 0's copy is the one that counts)
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -230,7 +196,13 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
     // ---- inputs
     if (threadIdx.x == 0) {
       bool ok = true;
-      if (type == CH_TYPE_S) {
+      if (type == CH_TYPE_P) {
+        if (j == 0) {
+          if (k > 0) ok = ch_wait(pst + LGP_CH_U1, 1, st, p.timeout);
+        } else {
+          ok = ch_wait(cnt + 16 * (2 * j) + 2 * j, j, st, p.timeout) && ch_wait(cnt + 16 * (2 * j + 1) + 2 * j, j, st, p.timeout) && ch_wait(cnt + 16 * (2 * j + 1) + 2 * j + 1, j, st, p.timeout);
+        }
+      } else if (type == CH_TYPE_S) {
         ok = ch_wait(flagP + j, 1, st, p.timeout);
         if (j > 0) ok = ok && ch_wait(cnt + 16 * r + 2 * j, j, st, p.timeout) && ch_wait(cnt + 16 * r + 2 * j + 1, j, st, p.timeout);
       } else {
@@ -247,21 +219,35 @@ __global__ void __launch_bounds__(256) chain_kernel(ChainArgs p) {
     double *const P = p.L + ((long)LGP_NB * k) * (p.ldl + 1);              // top left of panel k's square
     double *const pdblk = p.dblk + (size_t)(8 * k) * LGP_DBLK;
     const int kb = (p.n - LGP_NB * k) < LGP_NB ? (p.n - LGP_NB * k) : LGP_NB;
-    if (type == CH_TYPE_S) {
+    if (type == CH_TYPE_P) {
+      double *const A = P + (128L * j) * p.ldl + 128 * j, *const dblk = pdblk + (size_t)j * LGP_DBLK;
+      const long lda = p.ldl, row0 = p.row0 + (long)LGP_NB * k + 128 * j;
+      constexpr int nb = 128;
+      int *const info = p.info;
+      // the block is published as soon as its fragment image is out: the substitutions read nothing else
+#define P4_FRAGMENTS_OUT                                                                                              \
+      __syncthreads();                                                                                                \
+      if (threadIdx.x == 0) {                                                                                         \
+        __hip_atomic_store(flagP + j, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);                                \
+        __hip_atomic_fetch_add(pst + LGP_CH_READY + j, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);              \
+        if (p.trace) p.trace[4 * t + 3] = wall_clock64();                                                             \
+      }
+#include "potf2m4_block.inc"
+#undef P4_FRAGMENTS_OUT
+    } else if (type == CH_TYPE_S) {
       subst_right_wave<double>(pdblk + (size_t)j * LGP_DBLK, 128, P + 128 * j, p.ldl, (long)kb, 64L * r + 16 * (threadIdx.x >> 6));
     } else {
       ch_update_tile(P, p.ldl, j, r, c);
     }
     // ---- publish: the workgroup's stores, then the flag; ready[k][j] counts P(k, j) and the S(k, ., j) for the far-row stream
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && type != CH_TYPE_P) {         // (P published itself above)
       unsigned *f = type == CH_TYPE_S ? flagS + 8 * r + j : cnt + 16 * r + c;
       __hip_atomic_store(f, type == CH_TYPE_G ? (unsigned)(j + 1) : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (type == CH_TYPE_S) __hip_atomic_fetch_add(pst + LGP_CH_READY + j, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       if (p.trace) p.trace[4 * t + 3] = wall_clock64();
     }
   }
-  }      // workers
   if (threadIdx.x == 0 && ch_peek(st + LGP_CH_ABORT) != 0) {
     // nobody may be left waiting for this launch: release every stream-side wait, then report
     // (ready[k][j] and flagP[k][j] are the two families of words the far-row streams poll, potrf.hip potrf_chain; the
@@ -289,37 +275,34 @@ __global__ void chain_selftest_mark(unsigned *words) { words[3] = 1u; }
 
 }  // namespace
 
-// ---- the schedule (host).  Per panel and block j of its square:
-//   W(j)          the walker (workgroup 0, not a list task; published as type P for the host-side checks): potf2 of block j,
-//                 the two row units of block j + 1 solved against it, block j + 1 updated with them;
-//   S(r, j)       r >= 2 j + 4: the other row units of the square solved against block j;
-//   G(r, c, j)    r >= 2 j + 4, 2 j + 2 <= c <= r: their tiles updated (the tiles of block j + 1 itself belong to the walker).
-// The NEAR list = the tasks of the rows of block j + 2 (units 2 j + 4, 2 j + 5): what the walker reads one block later (those
-// rows to solve, that block to update and factor) -- they have the time of one potf2, and workers of their own, so that they
-// never queue behind the ~100 tile updates of a step that nothing is waiting for (round 2: the next potf2 started 18-66 us late
-// with one list).  The rest (BULK) is taken in step order: everything in it is ready soon after W(j).  Both lists and the
-// walker's own steps are subsequences of ONE topological order (`out`), each has a workgroup that holds no task of another:
-// the earliest unfinished task can always run.
-constexpr unsigned CH_ON_CHAIN = 0x80u;     // bit of the type byte in the published schedule: the task is on the near list
+// ---- the schedule (host).  Inside a panel: step by step (block j), P, then the substitutions (nearest rows first), then the
+// tile updates column by column (the columns of the next diagonal block first) -- every task after the tasks it waits for.
+// The tasks ON the dependent chain (P(j), the two row units of block j + 1 solved, its three tiles updated) form a list of
+// their own with workers of their own: in one list they queued behind ~100 updates of step j that nothing was waiting for
+// (trace of N = 2048: the next potf2 started 18-66 us late).  The rest is taken in step order: everything in it is ready
+// soon after P(j), so a worker that takes the next task rarely holds it idle (an order that let far rows lag behind, so as to
+// favour near ones, made workers sit on tasks of later steps while earlier, ready ones waited: 30-40 us stalls of the chain).
+constexpr unsigned CH_ON_CHAIN = 0x80u;     // bit of the type byte in the published schedule: the task is on the chain list
 
-// out: one topological order of all tasks (what lgp_chainw_schedule publishes); chain / bulk: the two lists the workers take
-// from, each a subsequence of `out`; walk: the walker's steps, in order
-static void chain_build(size_t n, std::vector<uint2> &out, std::vector<uint2> *chain = nullptr, std::vector<uint2> *bulk = nullptr,
-                        std::vector<uint2> *walk = nullptr) {
-  struct Item { long key; unsigned r, c, w0; int list; };      // list: 0 walker, 1 near, 2 bulk
+// out: one topological order of all tasks (what lgp_chaint_schedule publishes); chain / bulk: the two lists the workers take
+// from, each a subsequence of `out`
+static void chain_build(size_t n, std::vector<uint2> &out, std::vector<uint2> *chain = nullptr, std::vector<uint2> *bulk = nullptr) {
+  struct Item { long key; unsigned r, c, w0; bool on_chain; };
   out.clear();
   const int npanels = (int)((n + LGP_NB - 1) / LGP_NB);
   for (int k = 0; k < npanels; ++k) {
     const int kb = (int)((n - (size_t)LGP_NB * k) < (size_t)LGP_NB ? (n - (size_t)LGP_NB * k) : (size_t)LGP_NB), nq = kb / 128, R64 = 2 * nq;
     std::vector<Item> items;
     for (int j = 0; j < nq; ++j) {
-      const long base = (1024L * j) * 32;
-      items.push_back({base, 0u, 0u, CH_TYPE_P | (unsigned)j << 8 | (unsigned)k << 24, 0});
-      for (int r = 2 * j + 4; r < R64; ++r) {
-        const int list = r / 2 == j + 2 ? 1 : 2;           // the rows of the block after next
-        items.push_back({base + 1, (unsigned)r, 0u, CH_TYPE_S | (unsigned)j << 8 | (unsigned)k << 24, list});
+      items.push_back({(1024L * j) * 32, 0u, 0u, CH_TYPE_P | (unsigned)j << 8 | (unsigned)k << 24, true});
+      for (int r = 2 * j + 2; r < R64; ++r) {
+        const int d = r / 2 - j - 1;
+        const bool look = d == 0;                        // the rows of the next diagonal block
+        const long base = (1024L * j) * 32;
+        items.push_back({base + 1, (unsigned)r, 0u, CH_TYPE_S | (unsigned)j << 8 | (unsigned)k << 24, look});
         for (int c = 2 * j + 2; c <= r; ++c)
-          items.push_back({base + 2 + (c - 2 * j - 2), (unsigned)r, (unsigned)c, CH_TYPE_G | (unsigned)j << 8 | (unsigned)c << 16 | (unsigned)k << 24, list});
+          items.push_back({base + 2 + (c - 2 * j - 2), (unsigned)r, (unsigned)c, CH_TYPE_G | (unsigned)j << 8 | (unsigned)c << 16 | (unsigned)k << 24,
+                           look && c / 2 == j + 1});
       }
     }
     std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
@@ -328,15 +311,14 @@ static void chain_build(size_t n, std::vector<uint2> &out, std::vector<uint2> *c
       return a.c < b.c;
     });
     for (const Item &it : items) {
-      out.push_back(make_uint2(it.w0 | (it.list == 1 ? CH_ON_CHAIN : 0u), it.r));
-      if (it.list == 0 && walk) walk->push_back(make_uint2(3u | (it.w0 & ~255u), 0u));
-      if (it.list == 1 && chain) chain->push_back(make_uint2(it.w0, it.r));
-      if (it.list == 2 && bulk) bulk->push_back(make_uint2(it.w0, it.r));
+      out.push_back(make_uint2(it.w0 | (it.on_chain ? CH_ON_CHAIN : 0u), it.r));
+      if (it.on_chain && chain) chain->push_back(make_uint2(it.w0, it.r));
+      if (!it.on_chain && bulk) bulk->push_back(make_uint2(it.w0, it.r));
     }
   }
 }
 
-long lgp_chainw_schedule(size_t n, unsigned int *tasks, size_t capacity) {
+long lgp_chaint_schedule(size_t n, unsigned int *tasks, size_t capacity) {
   if (n == 0 || n % 128 != 0 || n > (size_t)LGP_NB * 255) {
     lgp_set_error("invalid argument: the chain schedule needs n a multiple of 128, at most %d", LGP_NB * 255);
     return LGP_EINVAL;
@@ -395,19 +377,19 @@ static bool chain_selftest(lgp_ctx *ctx) {
   return ok;
 }
 
-bool lgp_chainw_usable(lgp_ctx *ctx, size_t n, size_t ldl) {
+bool lgp_chaint_usable(lgp_ctx *ctx, size_t n, size_t ldl) {
   if (ctx->chain_mode == 0 && n >= 256 && n % 128 == 0 && ctx->stream2 != nullptr && ctx->stream3 != nullptr) {
     ctx->chain_mode = chain_selftest(ctx) ? 2 : 1;      // 2: checked and available, 1: off
   }
   return ctx->chain_mode == 2 && n >= 256 && n % 128 == 0 && n <= (size_t)LGP_NB * 255 && ldl < (1u << 20);
 }
 
-size_t lgp_chainw_state_bytes(size_t n) {
+size_t lgp_chaint_state_bytes(size_t n) {
   return ((size_t)LGP_CH_HEADER + (size_t)LGP_CH_PANEL * ((n + LGP_NB - 1) / LGP_NB)) * sizeof(unsigned);
 }
 
-int lgp_chainw_state(lgp_ctx *ctx, size_t n, unsigned **out) {
-  const size_t need = lgp_chainw_state_bytes(n);
+int lgp_chaint_state(lgp_ctx *ctx, size_t n, unsigned **out) {
+  const size_t need = lgp_chaint_state_bytes(n);
   if (ctx->chain_state_bytes < need) {
     // (the previous buffer, if any, is no longer in use: every factorisation joins its streams into ctx->stream, and the
     // caller's stream is synchronised by the blocking allocation)
@@ -421,92 +403,77 @@ int lgp_chainw_state(lgp_ctx *ctx, size_t n, unsigned **out) {
   return LGP_OK;
 }
 
-int lgp_chainw_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk, size_t row0) {
-  LGP_REQUIRE(lgp_chainw_usable(ctx, n, ldl), "matrix not covered by the chain kernel");
-  LGP_REQUIRE(ctx->chain_state != nullptr && ctx->chain_state_bytes >= lgp_chainw_state_bytes(n), "chain state not allocated");
+int lgp_chaint_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk, size_t row0) {
+  LGP_REQUIRE(lgp_chaint_usable(ctx, n, ldl), "matrix not covered by the chain kernel");
+  LGP_REQUIRE(ctx->chain_state != nullptr && ctx->chain_state_bytes >= lgp_chaint_state_bytes(n), "chain state not allocated");
   const uint2 *dtasks = nullptr;
   int ntasks = 0, nchain = 0;
   for (const auto &e : ctx->chain_sched)
-    if (e.key == ((unsigned long long)n | (1ull << 62))) {
+    if (e.key == (unsigned long long)n) {
       dtasks = static_cast<const uint2 *>(e.tasks);
       ntasks = e.ntasks;
       nchain = e.nchain;
     }
   if (dtasks == nullptr) {
-    std::vector<uint2> all, sched, bulk, walk;
-    chain_build(n, all, &sched, &bulk, &walk);
+    std::vector<uint2> all, sched, bulk;
+    chain_build(n, all, &sched, &bulk);
     nchain = (int)sched.size();
     sched.insert(sched.end(), bulk.begin(), bulk.end());
-    const int nlist = (int)sched.size();
-    // (the walker's steps follow the two lists, panel by panel with eight slots each: rows of the task trace only)
-    const size_t npan = (n + LGP_NB - 1) / LGP_NB;
-    sched.resize((size_t)nlist + 16 * npan, make_uint2(3u, 0u));
-    for (const uint2 &wk : walk) {
-      sched[(size_t)nlist + 8 * (wk.x >> 24) + ((wk.x >> 8) & 255u)] = wk;
-      sched[(size_t)nlist + 8 * npan + 8 * (wk.x >> 24) + ((wk.x >> 8) & 255u)] = make_uint2((wk.x & ~255u) | 4u, 0u);
-    }
     void *d = nullptr;
     LGP_HIP(hipMalloc(&d, sched.size() * sizeof(uint2)));
     // (blocking copy from pageable memory; once per matrix size and context)
     LGP_HIP(hipMemcpy(d, sched.data(), sched.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    ctx->chain_sched.push_back({(unsigned long long)n | (1ull << 62), d, nlist, nchain});
+    ctx->chain_sched.push_back({(unsigned long long)n, d, (int)sched.size(), nchain});
     dtasks = static_cast<const uint2 *>(d);
-    ntasks = nlist;
+    ntasks = (int)sched.size();
   }
-  const int ntrace = ntasks + 16 * (int)((n + LGP_NB - 1) / LGP_NB);      // (two trace rows per walker step)
   ChainArgs a;
   a.L = L; a.ldl = (long)ldl; a.n = (int)n; a.dblk = dblk; a.info = ctx->d_info;
   a.tasks = dtasks; a.ntasks = ntasks; a.nchain = nchain; a.state = static_cast<unsigned *>(ctx->chain_state);
   a.trace = nullptr;
   a.row0 = (long)row0;
   if (getenv("LGP_CHAIN_TRACE") != nullptr) {           // debugging aid: the last launch's task times, written out by lgp_ctx_destroy
-    if (ctx->chain_trace != nullptr && ctx->chain_trace_tasks < (size_t)ntrace) {
+    if (ctx->chain_trace != nullptr && ctx->chain_trace_tasks < (size_t)ntasks) {
       LGP_HIP(hipFree(ctx->chain_trace));
       ctx->chain_trace = nullptr;
     }
-    if (ctx->chain_trace == nullptr) LGP_HIP(hipMalloc(&ctx->chain_trace, (size_t)ntrace * 4 * sizeof(unsigned long long)));
-    ctx->chain_trace_tasks = (size_t)ntrace;
+    if (ctx->chain_trace == nullptr) LGP_HIP(hipMalloc(&ctx->chain_trace, (size_t)ntasks * 4 * sizeof(unsigned long long)));
+    ctx->chain_trace_tasks = (size_t)ntasks;
     ctx->chain_trace_sched = dtasks;
-    LGP_HIP(hipMemsetAsync(ctx->chain_trace, 0, (size_t)ntrace * 4 * sizeof(unsigned long long), stream));
+    LGP_HIP(hipMemsetAsync(ctx->chain_trace, 0, (size_t)ntasks * 4 * sizeof(unsigned long long), stream));
     a.trace = static_cast<unsigned long long *>(ctx->chain_trace);
   }
-  // workgroup 0 is the walker; of the workers (at least two: a task of one list may wait for a task of the other, which only
-  // a worker that holds no task of the first can run) the first `chainw` start on the near list
-  const int want = ctx->chain_workers < 3 ? 3 : ctx->chain_workers;
-  static const int samexcd_env = getenv("LGP_CHAIN_SAMEXCD") ? atoi(getenv("LGP_CHAIN_SAMEXCD")) : -1;
-  // near workers on the walker's XCD need workgroups 8, 16, 24: 25 resident workgroups at least
-  const bool samexcd = samexcd_env >= 0 ? samexcd_env != 0 : want >= 25;
-  const int workers = samexcd && want < 25 ? 25 : want;
+  // at least one worker beside the chain's own: tasks of the chain list wait for tasks of the bulk list (S(4, 1) for the tiles
+  // of step 0), which only a worker that is not holding a chain task can run
+  const int want = ctx->chain_workers < 2 ? 2 : ctx->chain_workers;
+  const int workers = ntasks < want ? (ntasks < 2 ? 2 : ntasks) : want;
   a.timeout = ctx->chain_timeout;
-  a.chainw = workers >= 6 ? 3 : 1;
-  a.samexcd = samexcd ? 1 : 0;
-  // two-workgroup mode (walker.inc, wk_tail; LGP_CHAIN_TAIL_WG=1, off by default): one more workgroup, on the walker's XCD when
-  // the launch has nine (workgroup i runs on XCD i mod 8).  Measured in round 4: correct, and NO faster -- 1.24 / 2.50 / 6.52 ms at
-  // N = 2048 / 4096 / 8192 against 1.27 / 2.50 / 6.50.  The first block of a square, whose rows nobody has to deliver, goes from 75 to
-  // 58 us; every other block waits ~27 us into the potf2 for the workers to bring the rows of block j + 1 up to date (their
-  // substitution against block j - 1, 19 us, and its tile updates, 9.5 us, start when THAT block is factored), after which solve and
-  // update still take their 31-41 us: the dependency that bounds the chain runs through the workers, not through the walker.
-  static const int tail_env = getenv("LGP_CHAIN_TAIL_WG") ? atoi(getenv("LGP_CHAIN_TAIL_WG")) : 0;
-  a.tailwg = 0;
-  a.scratch = nullptr;
-  int nblocks = workers;
-  if (tail_env != 0 && !samexcd) {
-    if (ctx->chain_scratch == nullptr) LGP_HIP(hipMalloc(&ctx->chain_scratch, (size_t)4 * 36 * 256 * sizeof(double)));
-    a.scratch = static_cast<double *>(ctx->chain_scratch);
-    nblocks = workers + 1;
-    a.tailwg = tail_env > 1 ? tail_env : (nblocks > 8 ? 8 : 1);
-    if (a.tailwg >= nblocks) a.tailwg = 1;
-  }
-  // dynamic LDS: the walker's buffers (walker.inc), and -- untouched -- what keeps other workgroups off a worker's CU (no
-  // trailing-update workgroup, 64 KB of LDS, fits beside 100 KB)
-  size_t hog = n <= ctx->chain_hog_max_n ? (size_t)ctx->chain_lds_kb * 1024 : 0;
-  if (hog < WK_LDS_BYTES) hog = WK_LDS_BYTES;
+  a.chainw = workers >= 4 ? 3 : 1;
+  static const bool samexcd = getenv("LGP_CHAIN_SAMEXCD") != nullptr;
+  a.samexcd = (samexcd && workers >= 17 && a.chainw == 3) ? 1 : 0;      // the chain offers three tasks at a time at most: S(2j+2), S(2j+3) / the three tiles of the next block
+  // dynamic LDS that is never touched: with it no trailing-update workgroup (64 KB of LDS) fits on a worker's CU
+  const size_t hog = n <= ctx->chain_hog_max_n ? (size_t)ctx->chain_lds_kb * 1024 : 0;
   if (!ctx->chain_attr_set) {      // per context (= per device; a context is used by one host thread at a time)
     LGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     ctx->chain_attr_set = true;
   }
-  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)nblocks), dim3(256), hog, stream, a);
+  hipLaunchKernelGGL(chain_kernel, dim3((unsigned)workers), dim3(256), hog, stream, a);
   LGP_LAUNCH_CHECK();
   return LGP_OK;
 }
 
+// ---- which chain kernel a context uses (LGP_CHAIN_IMPL=tasks|walker when the context is created; the task graph by default)
+long lgp_chainw_schedule(size_t n, unsigned int *tasks, size_t capacity);                                                            // chainw.hip
+bool lgp_chainw_usable(lgp_ctx *ctx, size_t n, size_t ldl);
+size_t lgp_chainw_state_bytes(size_t n);
+int lgp_chainw_state(lgp_ctx *ctx, size_t n, unsigned **out);
+int lgp_chainw_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk, size_t row0);
+
+extern "C" long lgp_chain_schedule(size_t n, unsigned int *tasks, size_t capacity) { return lgp_chaint_schedule(n, tasks, capacity); }
+extern "C" long lgp_chain_schedule_walker(size_t n, unsigned int *tasks, size_t capacity) { return lgp_chainw_schedule(n, tasks, capacity); }
+bool lgp_chain_usable(lgp_ctx *ctx, size_t n, size_t ldl) { return ctx->chain_impl ? lgp_chainw_usable(ctx, n, ldl) : lgp_chaint_usable(ctx, n, ldl); }
+size_t lgp_chain_state_bytes(size_t n) { return lgp_chaint_state_bytes(n) > lgp_chainw_state_bytes(n) ? lgp_chaint_state_bytes(n) : lgp_chainw_state_bytes(n); }
+int lgp_chain_state(lgp_ctx *ctx, size_t n, unsigned **out) { return ctx->chain_impl ? lgp_chainw_state(ctx, n, out) : lgp_chaint_state(ctx, n, out); }
+int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk, size_t row0) {
+  return ctx->chain_impl ? lgp_chainw_launch(ctx, stream, n, L, ldl, dblk, row0) : lgp_chaint_launch(ctx, stream, n, L, ldl, dblk, row0);
+}

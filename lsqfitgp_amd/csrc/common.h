@@ -49,6 +49,7 @@ struct lgp_ctx {
   // flag/counter words (LGP_CH_* layout)
   struct ChainSched { unsigned long long key; void *tasks; int ntasks, nchain; };
   std::vector<ChainSched> chain_sched;
+  int chain_impl = 0;                 // which chain kernel: 0 = the task graph of round 3 (chaint.hip), 1 = the walker (chainw.hip); env LGP_CHAIN_IMPL=tasks|walker
   void *chain_state = nullptr;
   void *chain_scratch = nullptr;      // hand-over buffers between the factor and the tail workgroup of the chain kernel (walker.inc)
   size_t chain_state_bytes = 0;

@@ -220,88 +220,6 @@ potf2_mfma_kernel(double *A, long lda, int nb, double *dblk, int *info, long row
 //     (redundantly: no hand-over inside the chain) and eliminates its own (at most two) tiles of block row s beside it;
 //     the eliminated tiles go to LDS; every wave updates its trailing tiles with A operands read from there.
 //   Two barriers per block step, 16 in all.
-constexpr int P4_ROWBUF = 8 * 4 * 64;   // block row s: tile of block column i, register r, lane  (doubles)
-
-template <int S>
-__device__ __forceinline__ void potf2m4_step(acc_t (&tA)[4], acc_t (&tB)[8], double (&rdn)[8], double *rowbuf, double *diagbuf, int w, int lane,
-                                             int n, int g, int nb, int *info, long row0) {
-  constexpr bool DIAG_IN_A = S <= 3;               // the diagonal tile (S, S) is tile S of block column S: column w = S or 7 - w = S
-  const int wd = DIAG_IN_A ? S : 7 - S;            // its owner
-  const bool hasA = S < w;                         // this wave owns a tile of block row S in its column A (right of the diagonal)
-  const bool hasB = S < 7 - w;                     // ... in its column B
-  // ---- 1. publish the diagonal tile
-  if (w == wd) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) diagbuf[r * 64 + lane] = DIAG_IN_A ? tA[S < 4 ? S : 0][r] : tB[S][r];
-  }
-  __syncthreads();
-  acc_t dt;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) dt[r] = diagbuf[r * 64 + lane];
-  LGP_P4STAMP(2 + 4 * S);
-  acc_t ta = hasA ? tA[S < 4 ? S : 0] : acc_t{0, 0, 0, 0};
-  acc_t tb = hasB ? tB[S] : acc_t{0, 0, 0, 0};
-  double dn = 1.0;
-  // ---- 2. the 16 pivots: diagonal tile copy + the wave's own tiles of the block row.  Lane crossing by VALU swaps and DPP
-  // (chain.h): per pivot  row broadcast of the pivot row -> its entry at the lane's own row index -> multiply -> fma.
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    double w0 = dt[r], w1 = ta[r], w2 = tb[r];
-    double dg = 1.0;
-    p4_pivot<0>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
-    p4_pivot<1>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
-    p4_pivot<2>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
-    p4_pivot<3>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
-    const bool badv = !(dg > 0.0) || (dg + dg == dg);
-    const unsigned long long badm = __builtin_amdgcn_ballot_w64(badv);
-    if (badm != 0 && w == wd) {
-      const int gb = (__builtin_ctzll(badm) >> 4);
-      if (n == 0 && g == 0 && 16 * S + 4 * r + gb < nb) atomicCAS(info, 0, (int)(row0 + 16 * S + 4 * r + gb + 1));
-    }
-    const double sclv = rsqrt_d(badv ? (double)NAN : dg);
-    w0 *= sclv; w1 *= sclv; w2 *= sclv;
-    dt[r] = w0; ta[r] = w1; tb[r] = w2;
-    // the finished rows of the wave's own tiles -> LDS (A operands of everybody's trailing updates)
-    if (hasA) rowbuf[(w * 4 + r) * 64 + lane] = w1;
-    if (hasB) rowbuf[((7 - w) * 4 + r) * 64 + lane] = w2;
-    if (r < 3) {
-      const double am = (n > 4 * r + 3) ? -w0 : 0.0;
-      dt = MmaD::run(am, w0, dt);
-      ta = MmaD::run(am, w1, ta);
-      tb = MmaD::run(am, w2, tb);
-    }
-  }
-  rdn[S] = rsqrt_d(dn);
-  if (w == wd) {
-    if (DIAG_IN_A) tA[S < 4 ? S : 0] = dt; else tB[S] = dt;
-  }
-  if (hasA) tA[S < 4 ? S : 0] = ta;
-  if (hasB) tB[S] = tb;
-  LGP_P4STAMP(3 + 4 * S);
-  __syncthreads();
-  LGP_P4STAMP(4 + 4 * S);
-  // ---- 3. trailing tiles of the wave's two block columns: t(j, i) -= U_sj^T U_si, the A operand from LDS
-#pragma unroll
-  for (int j = S + 1; j < 8; ++j) {
-    const bool doA = hasA && j <= w, doB = hasB && j <= 7 - w;      // wave-uniform
-    if (!(doA || doB)) continue;
-    double neg[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) neg[r] = -rowbuf[(j * 4 + r) * 64 + lane];
-    if (j < 4) {
-      if (doA) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tA[j < 4 ? j : 0] = MmaD::run(neg[r], ta[r], tA[j < 4 ? j : 0]);
-      }
-    }
-    if (doB) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tB[j] = MmaD::run(neg[r], tb[r], tB[j]);
-    }
-  }
-  LGP_P4STAMP(5 + 4 * S);
-}
-
 __global__ void __launch_bounds__(256) potf2_mfma4_kernel(double *A, long lda, int nb, double *dblk, int *info, long row0) {
   __shared__ double rowbuf[P4_ROWBUF];
   __shared__ double diagbuf[4 * 64];
