@@ -453,7 +453,7 @@ class _Isotropic(Kernel):
         deg = self._derivability()
         name = type(self).__name__
         if deg is None:
-            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, Bessel, GammaExp(gamma=2), Cauchy(alpha=2), CausalExpQuad(alpha=0), Taylor, Color, Pink, NNKernel, '
+            raise NotImplementedError(f'derivatives of {name}: no derivative core on the device (ExpQuad, Maternp, Matern, Bessel, GammaExp(gamma=2), Cauchy(alpha=2), CausalExpQuad(alpha=0), Taylor, Color, Pink, NNKernel, Zeta, '
                                       'Constant, Linear, Periodic, Cos, Sinc, Celerite, Harmonic, Wendland, Circular, Decaying, WienerIntegral, '
                                       'FracBrownian(H=1, K=1), StationaryFracBrownian(H=1) have one)')
         sides = []
@@ -952,6 +952,19 @@ class Zeta(_Stationary1D):
         new._coef_memo = {}
         return new
 
+    _kind = _lib.LGP_KERNEL_PSERIES                                         # (the derivative core; the values go through lgp_gram_pseries)
+
+    def _derivability(self):
+        return int(max(0, numpy.ceil(self._nu) - 1))                      # _kernels/_zeta.py:32-35
+
+    def _has_closed_form_diff(self, d):
+        return False
+
+    def _jet_pars(self):
+        if self._mode == _zeta.MODE_INTEGERS:
+            raise ValueError('Took 1 derivatives > limit 0 on argument of a kernel (Zeta).')
+        return int(self._mode) | int(self._uselog) << 4 | int(self._coef.size) << 8, tuple(float(v) for v in self._hpar4), tuple(float(v) for v in self._coef)
+
     def _table(self, ctx, dtype):
         key = (id(ctx), numpy.dtype(dtype).str)
         tab = self._coef_memo.get(key)
@@ -962,7 +975,7 @@ class Zeta(_Stationary1D):
 
     def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
         if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
-            raise NotImplementedError('derivatives of Zeta')
+            return _Isotropic.gram(self, xs, ys, ctx=ctx, out=out, deriv=deriv)      # -> `_gram_jet`: the expansion differentiated term by term
         xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
         n, m = xd.shape[1], yd.shape[1]
         if out is None:

@@ -304,6 +304,67 @@ __device__ __forceinline__ S jet_core(const JetArgs &g, const S &r2, const S &X,
     }
     return compose(a, f);
   }
+  if (k == LGP_KERNEL_PSERIES) {
+    // Zeta: the expansion that the value core sums (gram.hip, lsqfitgp_amd/_zeta.py), differentiated term by term in
+    // theta = 2 pi t, t the distance of |delta| to the nearest integer.  p & 15 = mode (0: sum_j c_j cos(j theta), 1: sum_n c_n
+    // theta^(2n) + theta^pw (A g + D)), p & 16 = with the logarithm; par = {A, pw, eps, D}; coef = the table, ntab = p >> 8.
+    const S ad = jabs(delta) + (sizeof(T) == 8 ? T(2.220446049250313e-16) : T(1.1920929e-07f));
+    const S xx = ad - floor(ad.val());
+    const S tt = jmin(xx, T(1) - xx);
+    const S th = tt * T(6.283185307179586476925286766559);
+    const double t = (double)th.val();
+    const int mode = g.p & 15, uselog = (g.p >> 4) & 1, ntab = g.p >> 8;
+    const double *tab = &g.coef[0][0];
+    double dv[5] = {0., 0., 0., 0., 0.};                             // d^m k / d theta^m
+    if (mode == 0) {
+      for (int j = ntab; j >= 1; --j) {
+        double sn, cs;
+        sincos((double)j * t, &sn, &cs);
+        const double c = tab[j - 1], j1 = (double)j, j2 = j1 * j1;
+        dv[0] += c * cs; dv[1] -= c * j1 * sn; dv[2] -= c * j2 * cs; dv[3] += c * j2 * j1 * sn; dv[4] += c * j2 * j2 * cs;
+      }
+    } else {
+      // the even power series: Horner per order on the falling factorials of 2n
+      for (int m = 0; m < 5; ++m) {
+        double acc = 0.;
+        for (int n = ntab - 1; n >= 0; --n) {
+          const int e = 2 * n - m;                                   // exponent of theta in the m-th derivative of theta^(2n)
+          if (e < 0) continue;
+          double ff = 1.;
+          for (int q = 0; q < m; ++q) ff *= (double)(2 * n - q);
+          acc += tab[n] * ff * (e == 0 ? 1. : pow(t, (double)e));
+        }
+        dv[m] = acc;
+      }
+      // the power term theta^pw (A g + D): g = 1; log theta (eps = 0); expm1(eps log theta) = theta^eps - 1
+      const double A = g.par[0], pw = g.par[1], eps = g.par[2], D = g.par[3];
+      auto addpow = [&](double coef, double ex) {                      // coef theta^ex and its derivatives
+        double ff = coef;
+        for (int m = 0; m < 5; ++m) {
+          const double e = ex - (double)m;
+          if (t > 0.) dv[m] += ff * pow(t, e);
+          else if (e == 0.) dv[m] += ff;                               // (theta = 0: positive powers vanish; negative ones only meet derivatives the process does not have)
+          ff *= e;
+        }
+      };
+      if (!uselog) addpow(A + D, pw);
+      else if (eps != 0.) { addpow(A, pw + eps); addpow(D - A, pw); }
+      else {
+        addpow(D, pw);
+        if (t > 0.) {                                                  // A theta^pw log theta: d^m = theta^(pw-m) (a_m log theta + b_m), a' = a (pw - m), b' = b (pw - m) + a
+          double am = A, bm = 0.;
+          const double lt = log(t);
+          for (int m = 0; m < 5; ++m) {
+            dv[m] += pow(t, pw - (double)m) * (am * lt + bm);
+            bm = bm * (pw - (double)m) + am;
+            am *= pw - (double)m;
+          }
+        }
+      }
+    }
+    const T f[5] = {T(dv[0]), T(dv[1]), T(dv[2] / 2.), T(dv[3] / 6.), T(dv[4] / 24.)};
+    return compose(th, f);
+  }
   if (k == LGP_KERNEL_PINK) {
     // k(x) = (Ci(a x) - Ci(x)) / L, a = 1 + dw, L = log1p(dw), x = |delta|; derivable once: Ci' = cos / x makes k' and k'' elementary
     // (their series in x below 1e-2, where the closed forms cancel); where x dw < sqrt(eps), cos(x (1 + dw / 2)) as the value core does
@@ -465,7 +526,7 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   const bool onevar = kernel == LGP_KERNEL_COS || kernel == LGP_KERNEL_PERIODIC || kernel == LGP_KERNEL_SINC || kernel == LGP_KERNEL_CELERITE ||
                       kernel == LGP_KERNEL_HARMONIC || kernel == LGP_KERNEL_WENDLAND || kernel == LGP_KERNEL_CIRCULAR || kernel == LGP_KERNEL_DECAYING ||
                       kernel == LGP_KERNEL_WIENERINTEGRAL || kernel == LGP_KERNEL_FRACBROWNIAN || kernel == LGP_KERNEL_STATIONARYFRACBROWNIAN ||
-                      kernel == LGP_KERNEL_TAYLOR || kernel == LGP_KERNEL_COLOR || kernel == LGP_KERNEL_PINK;
+                      kernel == LGP_KERNEL_TAYLOR || kernel == LGP_KERNEL_COLOR || kernel == LGP_KERNEL_PINK || kernel == LGP_KERNEL_PSERIES;
   const bool iso = kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY || kernel == LGP_KERNEL_MATERNP ||
                    kernel == LGP_KERNEL_CONSTANT || kernel == LGP_KERNEL_LINEAR || kernel == LGP_KERNEL_MATERN || kernel == LGP_KERNEL_BESSEL ||
                    kernel == LGP_KERNEL_CAUSALEXPQUAD || kernel == LGP_KERNEL_NNKERNEL;
@@ -485,6 +546,8 @@ int gram_jet_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.posabs = kernel == LGP_KERNEL_CAUSALEXPQUAD ? 1 : 0;           // input='posabs' (_Kernel/_isotropic.py:67-78)
   for (int i = 0; i < npar; ++i) g.par[i] = (double)hpar[i];
   for (int i = 0; i < ncoef; ++i) g.coef[i / 24][i % 24] = (double)hcoef[i];
+  LGP_REQUIRE(kernel != LGP_KERNEL_PSERIES || (npar == 4 && (p >> 8) <= 5 * 24 && ncoef >= (p >> 8) && ((p & 15) == 0 || (p & 15) == 1)),
+              "PSeries: p = mode | uselog << 4 | ntable << 8, {A, pw, eps, D}, the table as coefficients");
   LGP_REQUIRE(kernel != LGP_KERNEL_NNKERNEL || (npar == 1 && hpar[0] > T(0)), "NNKernel takes {sigma0^2}");
   if (kernel == LGP_KERNEL_PINK) {                       // hpar = {dw}: par = {dw, log1p(dw), sqrt(eps)} as the value core (_spectral.py:62-66)
     LGP_REQUIRE(npar == 1 && hpar[0] >= T(0) && hpar[0] < std::numeric_limits<T>::infinity(), "Pink takes {dw}, dw >= 0");

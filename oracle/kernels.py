@@ -713,7 +713,15 @@ def Zeta(*, nu=None, scale=None, loc=None, dim=None):
         if s > 1:
             return periodic_zeta_real(delta, s) / special.zeta(s, 1)
         return numpy.where(delta % 1, 0., 1.)
-    return Kernel(_stationary1d(core), scale=scale, loc=loc, dim=dim)
+    core_ = _stationary1d(core)
+    # ceil(nu) - 1 times derivable (_kernels/_zeta.py:32-35): the polylogarithm on the unit circle, its real part as the mean of the
+    # two conjugate values, as a function of the distance t to the nearest integer (symdiff.py differentiates polylog itself)
+    def sym(t):
+        sp = _sp()
+        sv = sp.Rational(float(s))
+        return (sp.polylog(sv, sp.exp(2 * sp.pi * sp.I * t)) + sp.polylog(sv, sp.exp(-2 * sp.pi * sp.I * t))) / (2 * sp.zeta(sv))
+    core_.symbolic = ('circ', sym) if nu > 1 else None
+    return Kernel(core_, scale=scale, loc=loc, dim=dim)
 
 
 def MA(*, w=None, norm=False, scale=None, loc=None, dim=None):

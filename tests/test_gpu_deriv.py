@@ -76,8 +76,10 @@ def test_what_is_not_available_says_so(lgp):
     x = np.linspace(0, 1, 5)
     with pytest.raises(ValueError):                                             # not derivable: the reference's error (_Kernel/_ops.py:85-90)
         lgp.GP(lgp.GammaExp(gamma=1.2)).addx(x, 'a', deriv=1).prior('a', raw=True)
-    with pytest.raises(NotImplementedError):                                     # derivable in the reference, no derivative core here yet
-        lgp.GP(lgp.Zeta(nu=2.5)).addx(x, 'a', deriv=1).prior('a', raw=True)
+    with pytest.raises(NotImplementedError):                                     # no derivable flag in the reference either (_basic.py:156): not built
+        lgp.GP(lgp.Gibbs()).addx(x, 'a', deriv=1).prior('a', raw=True)
+    with pytest.raises(ValueError):
+        lgp.GP(lgp.Zeta(nu=0.7)).addx(x, 'a', deriv=1).prior('a', raw=True)
     with pytest.raises(ValueError):                                             # ceil(nu) - 1 times derivable (_kernels/_matern.py:51-53)
         lgp.GP(lgp.Matern(nu=1.7)).addx(x, 'a', deriv=2).prior('a', raw=True)
     with pytest.raises(ValueError):
@@ -377,6 +379,38 @@ def test_pink_kernel_derivatives_vs_oracle(lgp, dw):
     assert abs(got[0, 0] - 1.1 * (1 + dw / 2) ** 2 / 1.2 ** 2) <= 1e-12 * got[0, 0]
     with pytest.raises(ValueError):
         kd.gram(x, y, deriv=(2, 0))
+
+
+@pytest.mark.parametrize('nu', [1.5, 2.4, 3., 3.0004, 5.2])
+def test_zeta_kernel_derivatives_vs_oracle(lgp, nu):
+    """ Zeta(nu) = Re Li_s(e^(2 pi i delta)) / zeta(s), s = 1 + 2 nu, ceil(nu) - 1 times derivable (_kernels/_zeta.py:32-70): the expansion the
+    value core sums, differentiated term by term in theta on the device -- the power series with its power / logarithmic term
+    (plain, at integer nu, next to one) and the Fourier series (s >= 10); the oracle differentiates the polylogarithm itself """
+    from scipy import special
+    rng = np.random.default_rng(int(100 * nu))
+    x = rng.uniform(-1.5, 1.5, 6); y = rng.uniform(-1.5, 1.5, 6)         # (the oracle's polylogarithms take a second each)
+    y[:3] = x[:3]
+    y[3] = x[3] + 1.3                                           # (a whole period apart -- the scale is 1.3 --: a coincidence too)
+    y[4] = x[4] + 0.65                                          # (the reflection point)
+    kd, ko = lgp.Zeta(nu=nu, scale=1.3) * 1.1, oracle.Zeta(nu=nu, scale=1.3) * 1.1
+    deg = int(np.ceil(nu) - 1)
+    orders = [(a, b) for a in range(min(deg, 2) + 1) for b in range(min(deg, 2) + 1) if a + b]
+    apart = np.abs(((x[:, None] - y[None, :]) / 1.3 + 0.5) % 1 - 0.5) > 1e-6
+    for a, b in orders:
+        got = kd.gram(x, y, deriv=(a, b)).to_host()
+        want = ko.diff(a, b)(x[:, None], y[None, :])
+        scale = max(np.abs(want).max(), 1e-3)
+        np.testing.assert_allclose(got[apart], want[apart], rtol=0, atol=2e-10 * scale, err_msg=f'nu={nu} {(a, b)}')
+    s = 1 + 2 * nu
+    got = kd.gram(x, y, deriv=(1, 1)).to_host()
+    exact = 1.1 * (2 * np.pi) ** 2 * special.zeta(s - 2, 1) / special.zeta(s, 1) / 1.3 ** 2       # sum_k (2 pi k)^2 k^-s
+    assert abs(got[0, 0] - exact) <= 1e-11 * exact and abs(got[3, 3] - exact) <= 1e-8 * exact
+    if deg >= 2:
+        got = kd.gram(x, y, deriv=(2, 2)).to_host()
+        exact = 1.1 * (2 * np.pi) ** 4 * special.zeta(s - 4, 1) / special.zeta(s, 1) / 1.3 ** 4
+        assert abs(got[1, 1] - exact) <= 1e-10 * exact
+    with pytest.raises(ValueError):
+        kd.gram(x, y, deriv=(deg + 1, 0))
 
 
 def test_nnkernel_derivatives_vs_oracle(lgp):
