@@ -271,14 +271,14 @@ def test_maternp_derivatives_along_named_fields_vs_oracle(lgp, p):
         kd.gram(x, y, deriv=((p + 1, 0, 0), (0, 0, 0)))             # derivable p times per side (_kernels/_matern.py:26-27)
 
 
-@pytest.mark.parametrize('nu', [1.2, 1.9, 2.3, 3.75, 7.1])
+@pytest.mark.parametrize('nu', [1.2, 2.3, 3.75])
 def test_matern_of_real_order_derivatives_vs_oracle(lgp, nu):
     """ Matern(nu), ceil(nu) - 1 times derivable (_kernels/_matern.py:51-76): the derivative core evaluates K of the orders nu - k on
     the device (csrc/bessel_k_dev.h) and uses the exact limits at coincident points; the oracle differentiates K_nu symbolically and
     evaluates in extended precision.  One- and three-dimensional points. """
     rng = np.random.default_rng(int(100 * nu))
-    x = rng.uniform(0.1, 3, 14); y = rng.uniform(0.1, 3, 11)
-    y[:4] = x[:4]
+    x = rng.uniform(0.1, 3, 10); y = rng.uniform(0.1, 3, 8)           # (the oracle evaluates K_nu in 120-400 digits)
+    y[:2] = x[:2]
     y[4] = x[4] + 1e-7; y[5] = x[5] - 3e-5                       # nearly coincident: large negative orders times small powers
     kd, ko = lgp.Matern(nu=nu, scale=1.3, loc=0.1) * 1.2, oracle.Matern(nu=nu, scale=1.3, loc=0.1) * 1.2
     deg = int(np.ceil(nu) - 1)
@@ -294,10 +294,10 @@ def test_matern_of_real_order_derivatives_vs_oracle(lgp, nu):
         kd.gram(x, y, deriv=(deg + 1, 0))
     # along named fields of three-dimensional points
     dt = [('a', float), ('b', float), ('c', float)]
-    X = np.empty(9, dt); Y = np.empty(7, dt)
+    X = np.empty(6, dt); Y = np.empty(5, dt)
     for f in 'abc':
-        X[f] = rng.uniform(0, 2, 9); Y[f] = rng.uniform(0, 2, 7)
-    Y[:3] = X[:3]
+        X[f] = rng.uniform(0, 2, 6); Y[f] = rng.uniform(0, 2, 5)
+    Y[:2] = X[:2]
     for sx, sy in [(('a', 1), ('b', 1)), (('c', 1), ('c', 1))] + ([(('b', 2), ('b', 2))] if deg >= 2 else []):
         ox = tuple((sx[1] if nm == sx[0] else 0) for nm in X.dtype.names)
         oy = tuple((sy[1] if nm == sy[0] else 0) for nm in X.dtype.names)
@@ -337,7 +337,7 @@ def test_bessel_kernel_derivatives_vs_oracle(lgp, nu):
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-11 * np.abs(want).max())
 
 
-@pytest.mark.parametrize('n', [4, 5, 6, 9])
+@pytest.mark.parametrize('n', [4, 5, 6])
 def test_color_kernel_derivatives_vs_oracle(lgp, n):
     """ Color(n) = (n - 1) Re E_n(-i |delta|), n // 2 - 1 times derivable (_kernels/_spectral.py:70-111): d^m/dx^m E_n(-i x) =
     i^m E_{n-m}(-i x), real and imaginary parts of the exponential integral of the lower orders on the device (series below x = 2,
@@ -388,7 +388,7 @@ def test_zeta_kernel_derivatives_vs_oracle(lgp, nu):
     (plain, at integer nu, next to one) and the Fourier series (s >= 10); the oracle differentiates the polylogarithm itself """
     from scipy import special
     rng = np.random.default_rng(int(100 * nu))
-    x = rng.uniform(-1.5, 1.5, 6); y = rng.uniform(-1.5, 1.5, 6)         # (the oracle's polylogarithms take a second each)
+    x = rng.uniform(-1.5, 1.5, 5); y = rng.uniform(-1.5, 1.5, 5)         # (the oracle's polylogarithms take a second each)
     y[:3] = x[:3]
     y[3] = x[3] + 1.3                                           # (a whole period apart -- the scale is 1.3 --: a coincidence too)
     y[4] = x[4] + 0.65                                          # (the reflection point)
