@@ -906,7 +906,12 @@ def main():
         except Exception as exc:
             out['default_path'] = {'error': repr(exc)}
         try:
-            out['small_n_latency'] = small_n_latency(ctx)
+            out['small_n_latency'] = sn = small_n_latency(ctx)
+            # (also as rows of the size sweep: the reference's own benchmark, through the host classes with default options)
+            for n in (10, 1000):
+                out['vs_N'].append({'workload': f'docs/userguide/optim.rst:88-159 predfromdata ExpQuad N={n} M=100 raw=True via the host classes, default options, wall clock best of 20',
+                                    'N': n, 'M': 100, 'ms_per_step': sn[f'N={n} default options ms'], 'ms_checks_off': sn[f'N={n} checkpos=False, checksym=False ms'],
+                                    'reference_published_ms': {'eager': sn['reference_published_ms'][f'N={n} eager'], 'jit': sn['reference_published_ms'][f'N={n} jit']}})
         except Exception as exc:
             out['small_n_latency'] = {'error': repr(exc)}
     out['cpu_baseline'] = None if args.no_cpu_baseline else cpu_baseline(cfg)
