@@ -777,23 +777,18 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
     if (have_u3) LGP_HIP(hipStreamWaitEvent(s1, E(EV_U3), 0));
     LGP_CHECK(lgp_gemm_launch<T>(ctx, s1, false, true, nb1, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
     // ---- sg: U2, the block column below that square; then s3 may touch it
-    static const bool u2_far = getenv("LGP_U2_STREAM") != nullptr && strcmp(getenv("LGP_U2_STREAM"), "far") == 0;
     LGP_HIP(hipStreamWaitEvent(sg, E(EV_SQ), 0));
     LGP_HIP(hipStreamWaitEvent(sg, E(EV_FAR), 0));
     const size_t rows_r = rows_t - nb1;
-    hipStream_t su2 = u2_far ? s3 : sg;
-    if (u2_far && have_u3) LGP_HIP(hipStreamWaitEvent(s3, E(EV_U3), 0));      // (the large update of the step before wrote this block column too)
     // (the last panels are bound by the chain: their updates leave room on every CU, see potrf_chain)
     static const long thin_env = getenv("LGP_THIN_LDS_KB") ? atol(getenv("LGP_THIN_LDS_KB")) : -1;
     ctx->gemm_thin_lds = thin_env >= 0 ? (size_t)thin_env * 1024 : (rows_t <= 6144 ? (size_t)70 * 1024 : (rows_t <= 12288 ? (size_t)20 * 1024 : 0));
     static const size_t u2_t128_min = getenv("LGP_U2_T128_MIN_ROWS") ? (size_t)atol(getenv("LGP_U2_T128_MIN_ROWS")) : (size_t)1 << 40;
     if (rows_r + nx > 0)
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, su2, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false,
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false,
                                    rows_r >= u2_t128_min ? 0 : 2));
-    if (!u2_far) {
-      LGP_HIP(hipEventRecord(E(EV_U2), sg));
-      LGP_HIP(hipStreamWaitEvent(s3, E(EV_U2), 0));
-    }
+    LGP_HIP(hipEventRecord(E(EV_U2), sg));
+    LGP_HIP(hipStreamWaitEvent(s3, E(EV_U2), 0));
     // ---- sg: U3, everything right of the next panel: the N^3/3 flops, one launch
     if (rows_r > 0) {
       const T *Pa = Pt + nb1 * ldl;                     // (rows_r + nx) x kb
@@ -908,24 +903,14 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
       // of the next in the late panels of N = 8192, where right-looking rows (every block followed by a K = 128 update of all
       // the remaining columns: 37 + 52 us per step against the chain's 68) fell 20 us further behind per block (~390 us).
       // (The early panels wait for the previous panel's updates instead: their far rows cannot start before U2.)
-      static const int far_rec = getenv("LGP_CHAIN_FAR_RECURSIVE") ? atoi(getenv("LGP_CHAIN_FAR_RECURSIVE")) : 0;
       for (size_t j = 0; j < nq; ++j) {
         const size_t j0 = j * LGP_DB;
-        if (j >= 1 && !far_rec) {
+        if (j >= 1) {
           LGP_HIP(wait_ge(sg, word(k, LGP_CH_READY) + (j - 1), (unsigned)(1 + 2 * nq - 2 * (j - 1) - 2)));
           LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_g, LGP_DB, j0, T(-1), Pg, ldl, P + j0 * ldl, ldl, T(1), Pg + j0, ldl, false, 2));
         }
         LGP_HIP(wait_ge(sg, word(k, LGP_CH_FLAGP) + j, 1));
         LGP_CHECK(subst(sg, Yk + j * (size_t)LGP_DBLK, Pg + j0, rows_g));
-        if (far_rec) {   // recursive order (as potrf_split): after block j the columns [c, c + s) get blocks [c - s, c), once the square's rows below block j are solved
-          const size_t c = j + 1, sbit = c & (~c + 1);
-          if (c < nq) {
-            const size_t ncol = (c + sbit <= nq ? sbit : nq - c) * LGP_DB, kk = sbit * LGP_DB;
-            LGP_HIP(wait_ge(sg, word(k, LGP_CH_READY) + j, (unsigned)(1 + 2 * nq - 2 * j - 2)));
-            LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_g, ncol, kk, T(-1), Pg + (c - sbit) * LGP_DB, ldl, P + (c * LGP_DB) * ldl + (c - sbit) * LGP_DB, ldl,
-                                         T(1), Pg + c * LGP_DB, ldl, false, far_rec == 1 ? 2 : 0));
-          }
-        }
       }
       LGP_HIP(hipStreamWriteValue32(sg, word(k, LGP_CH_GRP + g), 1, 0));
     }
