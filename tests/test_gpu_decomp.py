@@ -448,7 +448,7 @@ def driver_contexts(lgp):
     return launch, lgp.Context(0)
 
 
-@pytest.mark.parametrize('n,q', [(256, 0), (1152, 7), (2048, 0), (3200, 3)])
+@pytest.mark.parametrize('n,q', [(256, 0), (1152, 7), (2048, 0), (2432, 3)])
 def test_chain_kernel_against_launch_per_operation_driver(lgp, rng, driver_contexts, n, q):
     """ the two drivers of the blocked factorisation (csrc/potrf.hip: the chain kernel whose resident workers factor the
     diagonal squares, default up to N = 14336, and the launch-per-operation driver, LGP_CHAIN=0) on the same matrix: the

@@ -277,7 +277,7 @@ def test_matern_of_real_order_derivatives_vs_oracle(lgp, nu):
     the device (csrc/bessel_k_dev.h) and uses the exact limits at coincident points; the oracle differentiates K_nu symbolically and
     evaluates in extended precision.  One- and three-dimensional points. """
     rng = np.random.default_rng(int(100 * nu))
-    x = rng.uniform(0.1, 3, 10); y = rng.uniform(0.1, 3, 8)           # (the oracle evaluates K_nu in 120-400 digits)
+    x = rng.uniform(0.1, 3, 7); y = rng.uniform(0.1, 3, 6)            # (the oracle evaluates K_nu in 120-400 digits)
     y[:2] = x[:2]
     y[4] = x[4] + 1e-7; y[5] = x[5] - 3e-5                       # nearly coincident: large negative orders times small powers
     kd, ko = lgp.Matern(nu=nu, scale=1.3, loc=0.1) * 1.2, oracle.Matern(nu=nu, scale=1.3, loc=0.1) * 1.2
@@ -395,10 +395,11 @@ def test_zeta_kernel_derivatives_vs_oracle(lgp, nu):
     kd, ko = lgp.Zeta(nu=nu, scale=1.3) * 1.1, oracle.Zeta(nu=nu, scale=1.3) * 1.1
     deg = int(np.ceil(nu) - 1)
     orders = [(a, b) for a in range(min(deg, 2) + 1) for b in range(min(deg, 2) + 1) if a + b]
-    apart = np.abs(((x[:, None] - y[None, :]) / 1.3 + 0.5) % 1 - 0.5) > 1e-6
+    cols = [0, 3, 4]            # the oracle on three columns of y: a coincidence, the period, the reflection point -- and generic pairs in each
+    apart = (np.abs(((x[:, None] - y[None, :]) / 1.3 + 0.5) % 1 - 0.5) > 1e-6)[:, cols]
     for a, b in orders:
-        got = kd.gram(x, y, deriv=(a, b)).to_host()
-        want = ko.diff(a, b)(x[:, None], y[None, :])
+        got = kd.gram(x, y, deriv=(a, b)).to_host()[:, cols]
+        want = ko.diff(a, b)(x[:, None], y[None, cols])
         scale = max(np.abs(want).max(), 1e-3)
         np.testing.assert_allclose(got[apart], want[apart], rtol=0, atol=2e-10 * scale, err_msg=f'nu={nu} {(a, b)}')
     s = 1 + 2 * nu
