@@ -124,6 +124,43 @@ def solve_triangular_python(a, b, *, lower=False):
     return out.reshape(b.shape)
 
 
+def solve_batched(a, b, *, assume_a='gen', ctx=None, **kw):
+    """ ``a^-1 b`` batching matmul-like (``_decomp.py:330-347``): ``a`` (..., n, n), ``b`` (n,) or (..., n, k), the leading axes
+    broadcast against each other.  On the device only the case the reference itself uses (``assume_a='pos'``, symmetric positive
+    definite ``a``: tests/linalg/test_decomp.py:246,257): every distinct matrix of the batch is factored once, without
+    regularisation (`Chol` with eps = 0), and all the right-hand sides that go with it are solved in one call """
+    if assume_a not in ('pos', 'positive definite'):
+        raise NotImplementedError(f"solve_batched(assume_a={assume_a!r}): only positive definite matrices have a device solver (Cholesky)")
+    if kw.get('lower') or kw.get('transposed'):
+        raise NotImplementedError('solve_batched: lower= / transposed= are not supported')
+    a = numpy.asarray(a)
+    b = numpy.asarray(b)
+    if a.ndim < 2 or a.shape[-1] != a.shape[-2]:
+        raise ValueError(f'solve_batched: square matrices expected, found shape {a.shape}')
+    vec = b.ndim < 2
+    if vec:
+        b = b[:, None]
+    n = a.shape[-1]
+    if b.shape[-2] != n:
+        raise ValueError(f'solve_batched: right-hand side has {b.shape[-2]} rows, the matrices {n}')
+    batch = numpy.broadcast_shapes(a.shape[:-2], b.shape[:-2])
+    k = b.shape[-1]
+    dtype = _float_dtype(a, b)
+    bb = numpy.broadcast_to(b, batch + (n, k))
+    out = numpy.empty(batch + (n, k), dtype)
+    # the batch axes along which `a` really varies (size 1 in a, or missing: one factorisation serves the whole axis)
+    apad = a.reshape((1,) * (len(batch) - (a.ndim - 2)) + a.shape)
+    for idx in numpy.ndindex(*apad.shape[:-2]):
+        sel = tuple(slice(None) if apad.shape[ax] == 1 else i for ax, i in enumerate(idx))
+        rhs = bb[sel]                                         # (free axes ..., n, k)
+        free = rhs.shape[:-2]
+        flat = numpy.moveaxis(rhs.reshape((-1, n, k)), 1, 0).reshape(n, -1)          # n x (free * k)
+        dec = Chol(numpy.ascontiguousarray(apad[idx], dtype), epsrel=0, epsabs=0, ctx=ctx)
+        sol = numpy.asarray(dec.ginv_linear(numpy.ascontiguousarray(flat, dtype))).reshape(n, -1, k)
+        out[sel] = numpy.moveaxis(sol, 0, 1).reshape(free + (n, k))
+    return out[..., 0] if vec else out
+
+
 class Chol(Decomposition):
     """
     Cholesky decomposition. The matrix is regularized adding a small multiple

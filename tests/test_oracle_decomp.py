@@ -248,3 +248,18 @@ def test_solve_triangular_python(rng):
         util.assert_close_matrices(oracle.decomp.solve_triangular_python(a, b, lower=lower), linalg.solve_triangular(a, b, lower=lower), rtol=1e-13)
         v = rng.standard_normal(5)
         util.assert_close_matrices(oracle.decomp.solve_triangular_python(a, v, lower=lower), linalg.solve_triangular(a, v, lower=lower), rtol=1e-13)
+
+
+def test_solve_batched_arguments():
+    """ what `_linalg.solve_batched` refuses before it touches the device: the general (LU) solve, which has no device kernel, and
+    operands that do not fit (`_linalg/_decomp.py:330-347` passes everything to ``jlinalg.solve``) """
+    from lsqfitgp_amd import _linalg
+    a = np.eye(3)
+    with pytest.raises(NotImplementedError):
+        _linalg.solve_batched(a, np.ones(3))
+    with pytest.raises(NotImplementedError):
+        _linalg.solve_batched(a, np.ones(3), assume_a='sym')
+    with pytest.raises(ValueError):
+        _linalg.solve_batched(np.ones((3, 2)), np.ones(3), assume_a='pos')
+    with pytest.raises(ValueError):
+        _linalg.solve_batched(a, np.ones((4, 2)), assume_a='pos')
