@@ -533,7 +533,7 @@ class _Isotropic(Kernel):
             c = numpy.sqrt(2 * p + 1)
             factor = factor * (-1.) ** b * (c / scale) ** (a + b)
             return _lib.LGP_KERNEL_MATERNP_DIFF, p, (float((a + b) % 2),) + tuple(float(v) for v in coef), (('mul', factor),)
-        raise NotImplementedError('derivatives of the kernel are available in closed form for ExpQuad and Maternp only')
+        raise NotImplementedError('closed-form derivative cores exist for ExpQuad and Maternp (one-dimensional points); the other derivable kernels go through the truncated Taylor arithmetic of `lgp_gram_deriv`')
 
     def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
         """ device Gram matrix of two flat point sets; ``deriv=(dx, dy)``: of the kernel derived in x and in y (`_diff_call`) """
@@ -1797,7 +1797,7 @@ class BART(Kernel):
             alpha_a = numpy.asarray(alpha)
             beta_a = numpy.asarray(beta)
             if alpha_a.ndim or beta_a.ndim:
-                raise NotImplementedError('vectorised alpha/beta')
+                raise NotImplementedError('vectorised alpha/beta (see BART.correlation, which groups the pairs by parameters)')
             assert 0 <= alpha_a <= 1, 'alpha must be in [0, 1]'
             assert beta_a >= 0, 'beta must be in [0, inf)'
             d = numpy.arange(int(maxd) + 1)
@@ -1949,6 +1949,47 @@ class BART(Kernel):
         a2 = numpy.asarray(splitsafter_or_index2)
         for a in (a0, a1, a2):
             assert numpy.issubdtype(a.dtype, numpy.integer)
+        # alpha / beta / gamma (or pnt) with leading axes of their own (``_bart.py:373-401``: they broadcast against the leading axes
+        # of the counts): the device kernels take one set of parameters per launch, so the pairs are grouped by distinct parameters
+        if ((pnt is None and (numpy.ndim(alpha) or numpy.ndim(beta))) or (pnt is not None and numpy.ndim(pnt) > 1)
+                or (not isinstance(gamma, str) and numpy.ndim(gamma))):
+            if pnt is None:
+                al, be = numpy.asarray(alpha), numpy.asarray(beta)
+                plead = numpy.broadcast_shapes(al.shape, be.shape)
+                cols = [(numpy.broadcast_to(al, plead), al.dtype if al.ndim else None), (numpy.broadcast_to(be, plead), be.dtype if be.ndim else None)]
+            else:
+                pn = numpy.asarray(pnt)
+                plead = pn.shape[:-1]
+                cols = [(pn[..., i], pn.dtype) for i in range(pn.shape[-1])]
+            npar = len(cols)
+            glead = ()
+            if not isinstance(gamma, str):
+                ga = numpy.asarray(gamma)
+                glead = ga.shape
+                cols.append((ga, ga.dtype if ga.ndim else None))
+            b0, b1, b2 = numpy.broadcast_arrays(a0, a1, a2)
+            full = numpy.broadcast_shapes(b0.shape[:-1], plead, glead)
+            nvar = b0.shape[-1]
+            flat = [numpy.broadcast_to(b, full + (nvar,)).reshape(-1, nvar) for b in (b0, b1, b2)]
+            table = numpy.stack([numpy.broadcast_to(c, full).reshape(-1).astype(numpy.float64) for c, _ in cols], axis=1)
+            uniq, inv = numpy.unique(table, axis=0, return_inverse=True)
+            inv = inv.reshape(-1)
+            # (a parameter given as a scalar keeps its own type, Python scalars stay weak; array values carry the array's type)
+            typed = lambda v, dt, orig: orig if dt is None else dt.type(v)
+            out = None
+            for u, row in enumerate(uniq):
+                sel = inv == u
+                kw = dict(maxd=maxd, debug=debug, intercept=intercept, weights=weights, reset=reset, altinput=altinput)
+                if pnt is None:
+                    kw.update(alpha=typed(row[0], cols[0][1], alpha), beta=typed(row[1], cols[1][1], beta))
+                else:
+                    kw.update(alpha=alpha, beta=beta, pnt=numpy.array(row[:npar], cols[0][1]))
+                kw['gamma'] = gamma if isinstance(gamma, str) else typed(row[npar], cols[npar][1], gamma)
+                res = cls.correlation(flat[0][sel], flat[1][sel], flat[2][sel], **kw)
+                if out is None:
+                    out = numpy.empty(len(inv), res.dtype)
+                out[sel] = res
+            return out.reshape(full)
         assert numpy.all(a0 >= 0), 'splitting counts must be nonnegative'
         if altinput:
             assert numpy.all((0 <= a1) & (a1 <= a0)), 'splitting index must be in [0, n]'

@@ -272,6 +272,31 @@ def test_bart_correlation_classmethod(lgp, rng):
         lgp.BART.correlation(*sss, maxd=12)             # a slice deeper than 10 levels: use `reset`
 
 
+def test_bart_correlation_vectorised_parameters(lgp, rng):
+    """ alpha / beta / gamma / pnt with leading axes of their own, broadcast against the leading axes of the counts
+    (``_kernels/_bart.py:373-401``): the device groups the pairs by distinct parameters; the oracle broadcasts like the reference """
+    p = 4
+    sb, sbw, sa = rng.integers(0, 5, (3, 6, 1, p))
+    alpha = np.array([0.95, 0.7, 0.5])
+    beta = np.array([[2.], [0.7]]) * np.ones(3)                  # (2, 3)
+    c1 = lgp.BART.correlation(sb, sbw, sa, alpha=alpha, beta=2., maxd=2)
+    c2 = oracle.BART.correlation(sb, sbw, sa, alpha=alpha, beta=2., maxd=2)
+    assert c1.shape == c2.shape == (6, 3)
+    util.assert_allclose(c1, c2, rtol=1e-14, atol=4e-15)
+    sb2, sbw2, sa2 = rng.integers(0, 5, (3, 5, 1, 1, p))
+    gamma = np.array([0., 0.3, 1.])
+    c1 = lgp.BART.correlation(sb2, sbw2, sa2, alpha=alpha, beta=beta, gamma=gamma, maxd=3, reset=[1])
+    c2 = oracle.BART.correlation(sb2, sbw2, sa2, alpha=alpha, beta=beta, gamma=gamma, maxd=3, reset=[1])
+    assert c1.shape == c2.shape == (5, 2, 3)
+    util.assert_allclose(c1, c2, rtol=1e-14, atol=4e-15)
+    pnt = np.array([[0.9, 0.5, 0.2], [0.8, 0.1, 0.05]])
+    c1 = lgp.BART.correlation(sb[:, 0][:2], sbw[:, 0][:2], sa[:, 0][:2], pnt=pnt, gamma='auto')
+    c2 = oracle.BART.correlation(sb[:, 0][:2], sbw[:, 0][:2], sa[:, 0][:2], pnt=pnt, gamma='auto')
+    assert c1.shape == c2.shape == (2,)
+    util.assert_allclose(c1, c2, rtol=1e-14, atol=4e-15)
+    assert lgp.BART.correlation(sb, sbw, sa, alpha=alpha.astype('f'), beta=np.float32(2), maxd=1).dtype == np.float32
+
+
 def test_bart_corr_one_cases(lgp, rng):
     """ correlation = 1 when the points coincide, all weights vanish or there are no covariates (ref :105-133) """
     p = 4
