@@ -454,6 +454,20 @@ int lgp_posterior_solved_f64(lgp_ctx *ctx, size_t n, size_t m, const double *dL,
                              const double *dKxsxs, size_t ldk, double *dmean, double *dcov, size_t ldc, double *hmlnd);
 int lgp_posterior_solved_f32(lgp_ctx *ctx, size_t n, size_t m, const float *dL, size_t ldl, const float *dWt, size_t ldw,
                              const float *dKxsxs, size_t ldk, float *dmean, float *dcov, size_t ldc, float *hmlnd);
+/* GP.pred(fromdata=True, raw=True) (_GP/_compute.py:138-305) for the plain question -- one isotropic kernel, n points conditioned on,
+ * m predicted, diagonal noise -- from HOST buffers to HOST results in one call (uploads, Kxxs^T into the carried rows, the fused
+ * Gram build + factorisation of lgp_gram_chol_factor_rhs, the posterior of lgp_posterior_solved, one download).
+ * hpts: HOST d x (n + m), row f = coordinate f of the n data points followed by the m prediction points.  hy: HOST n.
+ * hnoise: HOST n (diagonal of the data covariance) or NULL.
+ * dP: DEVICE d x (n + m), receives the points.  dL: DEVICE (n + nx) x n with leading dimension ldl, nx >= m + 1 (whole 128-row tiles
+ * are fastest): on exit the factor L, and below it rows n .. n + m = (L^-1 [Kxxs | y])^T.  ddblk: lgp_chol_dblk_size(n).
+ * dwork: DEVICE m m + m + 2 + n doubles.  hout: HOST m m + m + 2 doubles: the posterior covariance (m x m), the posterior mean (m),
+ * minus_log_normal_density(y) (_decomp.py:484-488), and one scratch value.  heps_out: the jitter that was added (_decomp.py:393).
+ * Returns 0, info > 0 (first non-positive pivot) or an error.  Synchronises. */
+int lgp_predict_isotropic_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d, const double *hpts, size_t n, size_t m,
+                              int has_loc, double loc, int has_scale, double scale, int nops, const int *hops_code, const double *hops_val,
+                              const double *hy, const double *hnoise, double *dP, double *dL, size_t ldl, size_t nx, double *ddblk,
+                              double *dwork, double *hout, double *heps_out);
 /* minus_log_normal_density(r, value=True) (_decomp.py:466-488): 1/2 (n log 2pi + 2 sum log L_ii + |L^-1 r|^2).
  * dr (n) is overwritten with L^-1 r.  Synchronises. */
 int lgp_mlnd_value_f64(lgp_ctx *ctx, size_t n, const double *dL, size_t ldl, const double *ddblk,

@@ -1246,10 +1246,11 @@ class GP:
 
     def _pred_one_call(self, inkey, outkey, y, ycovblocks, givencov=None):
         """ The plain question -- one set of points conditioned on, one predicted, one isotropic kernel the fused entry point covers,
-        no checks that need the assembled blocks -- in THREE calls of the library instead of fifteen: the cross blocks straight into
-        the rows carried below the factor, ``lgp_gram_chol_factor_rhs`` (Gram build + regularisation + factorisation, Kxx never
-        materialised), ``lgp_posterior_solved``.  Same arithmetic as the general path with ``fuse_solve`` (the kernels are the
-        same); what it saves is host work: at N = 1000 the general path spends more time in Python than the GPU in kernels
+        no checks that need the assembled blocks -- in ONE call of the library instead of fifteen (``lgp_predict_isotropic``: the
+        cross blocks straight into the rows carried below the factor, the Gram build + regularisation + factorisation of
+        ``lgp_gram_chol_factor_rhs`` with Kxx never materialised, the posterior of ``lgp_posterior_solved``, one upload of the points
+        and one download of the results).  Same arithmetic as the general path with ``fuse_solve`` (the kernels are the
+        same); what it saves is host work and round trips: at N = 1000 the general path spends more time in Python than the GPU in kernels
         (the reference's own benchmark, ``docs/userguide/optim.rst:88-159``).  Returns None when the question is not of this kind. """
         if self._checkpositive or self._checksym or not self._fuse_solve or self._decomptype is not Chol or self._decompkw:
             return None
@@ -1298,37 +1299,29 @@ class GP:
         ctx = self.ctx
         lib = _lib.load()
         F = ctypes.c_double
-        P = DeviceArray.from_host(pts, ctx=ctx)                          # one upload: [x | xs], SoA
-        xd, xsd = P.block(0, d, 0, n), P.block(0, d, n, n + m)
+        # ONE call: the points, y and the noise go up, Kxxs^T lands in the rows carried below the factor, the fused Gram build +
+        # factorisation and the posterior run, covariance + mean + density come down together (lgp_predict_isotropic)
+        P = DeviceArray.empty((d, n + m), numpy.float64, ctx)
         nx = -(-(m + 1) // 128) * 128                                     # carried rows, padded to whole tiles
         L = DeviceArray.empty((n + nx, n), numpy.float64, ctx)
-        if nx > m + 1:
-            L.block(n + m + 1, n + nx, 0, n).fill_zero()
+        dblk = DeviceArray.empty((lib.lgp_chol_dblk_size(n),), numpy.float64, ctx)
+        work = DeviceArray.empty((m * m + m + 2 + n,), numpy.float64, ctx)
         nops, codes, vals = _kernels._ops_arrays(kernel._outops, F)
         npar, hpar = kernel._par_args(F)
-        kargs = (int(kernel._loc is not None), F(kernel._loc or 0), int(kernel._scale is not None), F(kernel._scale or 1), nops, codes, vals)
-        top = L.block(n, n + m, 0, n)
-        _lib.check(lib.lgp_gram_isotropic_f64(ctx.handle, kernel._kind, int(kernel._p), npar, hpar, d, xsd.ptr, xsd.ld, m, xd.ptr, xd.ld, n,
-                                              *kargs, 0, top.ptr, top.ld), 'lgp_gram_isotropic')       # Kxxs^T into the carried rows
-        L.block(n + m, n + m + 1, 0, n).assign(DeviceArray.from_host(numpy.asarray(y, float).reshape(1, n), ctx=ctx))
-        Kss = DeviceArray.empty((m, m), numpy.float64, ctx)
-        _lib.check(lib.lgp_gram_isotropic_f64(ctx.handle, kernel._kind, int(kernel._p), npar, hpar, d, xsd.ptr, xsd.ld, m, xsd.ptr, xsd.ld, m,
-                                              *kargs, 1, Kss.ptr, Kss.ld), 'lgp_gram_isotropic')
-        dblk = DeviceArray.empty((lib.lgp_chol_dblk_size(n),), numpy.float64, ctx)
-        nz = None if noise is None else DeviceArray.from_host(noise, ctx=ctx)
+        yh = numpy.ascontiguousarray(y, float).reshape(n)
+        nh = None if noise is None else numpy.ascontiguousarray(noise, float).reshape(n)
+        hout = numpy.empty(m * m + m + 2)
         eps = F()
-        info = _lib.check(lib.lgp_gram_chol_factor_rhs_f64(ctx.handle, kernel._kind, int(kernel._p), npar, hpar, d, xd.ptr, xd.ld, n, *kargs,
-                                                           F(0.), None if nz is None else nz.ptr, F(0.), F(0.), _lib.LGP_EPS_AUTO_REL,
-                                                           L.ptr, L.ld, nx, dblk.ptr, ctypes.byref(eps)), 'lgp_gram_chol_factor_rhs')
+        info = _lib.check(lib.lgp_predict_isotropic_f64(ctx.handle, kernel._kind, int(kernel._p), npar, hpar, d, pts.ctypes.data, n, m,
+                                                        int(kernel._loc is not None), F(kernel._loc or 0), int(kernel._scale is not None), F(kernel._scale or 1),
+                                                        nops, codes, vals, yh.ctypes.data, None if nh is None else nh.ctypes.data, P.ptr, L.ptr, L.ld, nx,
+                                                        dblk.ptr, work.ptr, hout.ctypes.data, ctypes.byref(eps)), 'lgp_predict_isotropic')
         if info != 0:
             raise numpy.linalg.LinAlgError('cholesky decomposition not finite, probably matrix not pos def numerically')
-        mean_d = DeviceArray.empty((m,), numpy.float64, ctx)
-        cov_d = DeviceArray.empty((m, m), numpy.float64, ctx)
-        Wt = L.block(n, n + m + 1, 0, n)
-        dens = F()
-        _lib.check(lib.lgp_posterior_solved_f64(ctx.handle, n, m, L.ptr, L.ld, Wt.ptr, Wt.ld, Kss.ptr, Kss.ld, mean_d.ptr, cov_d.ptr, cov_d.ld,
-                                                ctypes.byref(dens)), 'lgp_posterior_solved')
-        mean, cov = mean_d.to_host(), cov_d.to_host()
+        cov = hout[:m * m].reshape(m, m).copy()
+        mean = hout[m * m:m * m + m].copy()
+        dens = F(hout[m * m + m])
+        nz = None if nh is None else work.rows(m * m + m + 2, m * m + m + 2 + n)
         # the factorisation stays, as on the general path: a `marginal_likelihood` of the same data (with the same givencov) finds it,
         # with the density of y that came out of this solve; another question solves against it
         def matrix(kernel=kernel, xa=xa, nz=nz):

@@ -94,6 +94,8 @@ def _signatures():
         'lgp_chol_dblk_size': (c_size_t, [_S]),
         'lgp_profile_begin': (c_int, [c_void_p]),
         'lgp_profile_end': (c_int, [c_void_p, POINTER(c_size_t), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+        'lgp_predict_isotropic_f64': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_double), c_int, c_void_p, _S, _S, c_int, c_double, c_int, c_double,
+                                              c_int, POINTER(c_int), POINTER(c_double), c_void_p, c_void_p, _P, _P, _S, _S, _P, _P, c_void_p, POINTER(c_double)]),
         'lgp_comm_unique_id': (c_int, [c_void_p]),
         'lgp_comm_init': (c_int, [c_void_p, c_int, c_int, c_void_p]),
         'lgp_comm_init_host': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -647,6 +647,43 @@ int lgp_posterior_solved_f32(lgp_ctx *c, size_t n, size_t m, const float *L, siz
                              const float *K, size_t ldk, float *mean, float *cov, size_t ldc, float *hmlnd) {
   return posterior_solved_impl<float>(c, n, m, L, ldl, Wt, ldw, K, ldk, mean, cov, ldc, hmlnd);
 }
+// The plain question of GP.predfromdata -- one isotropic kernel, n data points, m prediction points, diagonal noise -- from host
+// buffers to host results in one call: two uploads, the cross blocks straight into the rows carried below the factor, the fused
+// Gram build + regularisation + factorisation, the posterior, ONE download.  The same kernels in the same order as the separate
+// entry points (lgp_gram_isotropic, lgp_gram_chol_factor_rhs, lgp_posterior_solved): what it saves is host round trips, which are
+// all that a problem of a thousand points costs (docs/userguide/optim.rst:88-159).
+int lgp_predict_isotropic_f64(lgp_ctx *c, int kernel, int p, int npar, const double *hpar, int d, const double *hpts, size_t n, size_t m,
+                              int has_loc, double loc, int has_scale, double scale, int nops, const int *hops_code, const double *hops_val,
+                              const double *hy, const double *hnoise, double *dP, double *dL, size_t ldl, size_t nx, double *ddblk, double *dwork,
+                              double *hout, double *heps_out) {
+  LGP_REQUIRE(c != nullptr && hpts != nullptr && hy != nullptr && dP != nullptr && dL != nullptr && ddblk != nullptr && dwork != nullptr && hout != nullptr,
+              "null pointer");
+  LGP_REQUIRE(n >= 1 && m >= 1 && d >= 1, "empty problem");
+  LGP_REQUIRE(nx >= m + 1 && ldl >= n, "the carried rows: nx >= m + 1, ldl >= n");
+  DeviceGuard dg(c->device);
+  hipStream_t st = c->stream;
+  const size_t np = n + m;
+  double *Wt = dL + n * ldl;                                    // (m + 1) x n: Kxxs^T, then y
+  double *dcov = dwork, *dmean = dwork + m * m, *dsc = dmean + m, *dnoise = dsc + 2;
+  LGP_HIP(hipMemcpyAsync(dP, hpts, (size_t)d * np * sizeof(double), hipMemcpyHostToDevice, st));
+  LGP_HIP(hipMemcpyAsync(Wt + m * ldl, hy, n * sizeof(double), hipMemcpyHostToDevice, st));
+  if (hnoise) LGP_HIP(hipMemcpyAsync(dnoise, hnoise, n * sizeof(double), hipMemcpyHostToDevice, st));
+  if (nx > m + 1) LGP_HIP(hipMemset2DAsync(Wt + (m + 1) * ldl, ldl * sizeof(double), 0, n * sizeof(double), nx - m - 1, st));
+  const double *dx = dP, *dxs = dP + n;                         // coordinate f of point i at dP[f * np + i]
+  LGP_CHECK(lgp_gram_isotropic_f64(c, kernel, p, npar, hpar, d, dxs, np, m, dx, np, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, 0, Wt, ldl));
+  LGP_CHECK(lgp_gram_isotropic_f64(c, kernel, p, npar, hpar, d, dxs, np, m, dxs, np, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, 1, dcov, m));
+  const int info = lgp_gram_chol_factor_rhs_f64(c, kernel, p, npar, hpar, d, dx, np, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, 0.0,
+                                                hnoise ? dnoise : nullptr, 0.0, 0.0, LGP_EPS_AUTO_REL, dL, ldl, nx, ddblk, heps_out);
+  if (info != 0) return info;                                   // an error (< 0) or the first bad pivot (> 0)
+  LGP_CHECK(posterior_solved_impl<double>(c, n, m, dL, ldl, Wt, ldl, dcov, m, dmean, dcov, m, nullptr));
+  LGP_CHECK(lgp_logdet_device<double>(c, st, n, dL, ldl, dsc));
+  LGP_CHECK(lgp_dot_strided_device<double>(c, st, n, Wt + m * ldl, 1, Wt + m * ldl, 1, dsc + 1));
+  LGP_HIP(hipMemcpyAsync(hout, dwork, (m * m + m + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+  LGP_HIP(hipStreamSynchronize(st));
+  double *h = hout + m * m + m;                                 // _decomp.py:484-488
+  h[0] = 0.5 * ((double)n * std::log(2 * M_PI) + 2.0 * h[0] + h[1]);
+  return LGP_OK;
+}
 int lgp_mlnd_value_f64(lgp_ctx *c, size_t n, const double *L, size_t ldl, const double *dblk, double *r, double *h) {
   return mlnd_impl<double>(c, n, L, ldl, dblk, r, h);
 }
