@@ -4,7 +4,7 @@ end=$(( $(date +%s) + ${1:-600} ))
 i=0
 while [ $(date +%s) -lt $end ]; do
   i=$((i+1))
-  if ! python -m pytest tests/test_gpu_dist.py -x -q -m gpu -k "4100-128-4 or 3300-256-5" > gpurun_out/hunt_last.log 2>&1; then
+  if ! python -m pytest tests/test_gpu_dist.py -x -q -m gpu -k "4100-128-4" > gpurun_out/hunt_last.log 2>&1; then
     cp gpurun_out/hunt_last.log gpurun_out/hunt_FAILED_$i.log
     echo "iteration $i FAILED" >> gpurun_out/hunt.log
     exit 0
