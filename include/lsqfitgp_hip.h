@@ -585,6 +585,19 @@ int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_t nx, doubl
  * numpy + gloo (tests/test_dist_gloo.py). */
 long lgp_chol_dist_plan(size_t n, size_t nb, size_t nx, size_t nranks, size_t slab, unsigned long long *pieces, size_t capacity,
                         size_t *nslots, size_t *slab_out);
+/* The SCHEDULE of that factorisation for one rank, without a device: lgp_chol_factor_dist_f64 itself runs with a tracer that
+ * writes every enqueue down instead of performing it -- event waits and records, kernel launches, copies and broadcasts, each
+ * with its stream and the operand ranges it was given.  20 int64 words per record (kind, stream, 18 arguments: layout in
+ * csrc/common.h, decoder and checker in tests/dist_trace.py), at most `capacity` records written to `rec` (may be NULL);
+ * returns their number (negative: error).  slab as in lgp_chol_dist_plan; flags: -1 = the library's defaults for `nranks`,
+ * else bit 0 = a rank's own pieces are broadcast from the communication stream behind an event (default with several ranks)
+ * instead of from the stream that packed them, bit 1 = squares go to the chain kernel where the library would use it, bit 2 =
+ * broadcasts are issued with one rank too.  The same records are written by a live call under LGP_DIST_TRACE=<path> (one file
+ * <path>.rank<r> per rank); LGP_DIST_JITTER=<seed> puts spin kernels of random length in front of randomly chosen enqueues.
+ * The CPU suite checks that every pair of conflicting accesses of the schedule is ordered by stream order and event edges, and
+ * that a simulator running it in any order those edges allow computes the factor (tests/test_dist_trace.py).  No reference
+ * counterpart. */
+long lgp_chol_dist_trace(size_t n, size_t nb, size_t nx, int rank, int nranks, size_t slab, int flags, long long *rec, size_t capacity);
 /* One horizontal slab of the staircase update above: rows [roff, roff + rows) below the diagonal of the first block column
  * of dC (which points at the slab's first row, as dA does; dB points at the panel row of that diagonal). */
 int lgp_update_nt_slab_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dA, size_t lda, const double *dB, size_t ldb,

@@ -111,10 +111,13 @@ class Task:
         return f'Task({self.index}, {self.stream}, {self.kind}, {self.piece}, waits={self.waits})'
 
 
-def factor_tasks(layout, plan=None, nx=0):
+def factor_tasks(layout, plan=None, nx=0, owner_comm=None):
     """
     What ``lgp_chol_factor_dist`` (``csrc/dist.hip``) enqueues on this rank, operation by operation, in the same order and
-    with the same event waits: a list of `Task`.  Streams: ``'s1'`` (squares), ``'s3'`` (rows below them), ``'sx'``
+    with the same event waits: a list of `Task`.  (A readable restatement: ``tests/test_dist_trace.py`` holds it to the records
+    that the C++ itself writes down, ``lgp_chol_dist_trace``.)  ``owner_comm``: ``'stream'`` -- a rank's own pieces are broadcast
+    from the communication stream behind an event (the library's default with several ranks), ``'order'`` -- from the stream
+    that packed them (one rank; ``LGP_DIST_OWNER_COMM``).  Streams: ``'s1'`` (squares), ``'s3'`` (rows below them), ``'sx'``
     (broadcasts), ``'sc'`` (bulk updates).  Kinds, for a piece ``(b, i, r0, r1)``:
 
         'U'      owner(b): rows of the piece of block column b -= P(b-1)[rows] P(b-1)[rows of block b]'  (i = 0: the square, on
@@ -125,10 +128,12 @@ def factor_tasks(layout, plan=None, nx=0):
         'PACK'   owner(b), i > 0: the rows copied into panel slot b % nslots (for the broadcast: the owner's own updates read the rows
                  where they lie, behind 'SOLVE')
         'BCAST'  every rank, i > 0: the piece broadcast from owner(b) (a collective: same order on every rank); the owner issues it
-                 on 's3' behind 'PACK', the others on 'sx' 
+                 on 'sx' behind the event of 'PACK' (or on 's3' right behind 'PACK': ``owner_comm='order'``), the others on 'sx' 
         'BULK'   every rank, i > 0: block columns ``extra`` (owned, >= b + 2) restricted to the rows of the piece
     """
     L, me = layout, layout.rank
+    if owner_comm is None:
+        owner_comm = 'order' if L.nranks <= 1 else 'stream'
     if plan is None:
         plan = dist_plan(L.n, L.nb, nx, L.nranks)
     pieces, nslots, _ = plan
@@ -187,8 +192,12 @@ def factor_tasks(layout, plan=None, nx=0):
                 rec['ready', b, i] = push('s3', 'PACK', p, slot_events(b))
         if i == 0:
             continue
-        # (the owner sends from the stream that packed, in its order: no event between the two; the others on the broadcast stream)
-        rec['recv', b, i] = push('s3', 'BCAST', p, []) if L.owner(b) == me else push('sx', 'BCAST', p, slot_events(b))
+        # (the owner: from the communication stream behind the pack's event, or from the stream that packed in its order with no
+        # event between the two; the others on the communication stream once the slot is free)
+        if L.owner(b) == me:
+            rec['recv', b, i] = push('s3', 'BCAST', p, []) if owner_comm == 'order' else push('sx', 'BCAST', p, [('ready', b, i)])
+        else:
+            rec['recv', b, i] = push('sx', 'BCAST', p, slot_events(b))
         if b + 1 < L.nblocks and L.owner(b + 1) == me:
             # U2: the rows of this piece below the square of the look-ahead column b + 1 = one piece of panel b + 1
             r2 = max(r0, min((b + 2) * L.nb, L.n))

@@ -5,12 +5,16 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <type_traits>
 #include <vector>
 #include "../../include/lsqfitgp_hip.h"
 
+struct lgp_tracer;
+
 struct lgp_ctx {
   int device = 0;
+  lgp_tracer *tracer = nullptr;       // schedule tracer / jitter of the sharded factorisation (dist.hip), normally absent
   hipStream_t stream = nullptr;       // main stream: all public entry points enqueue here
   hipStream_t stream2 = nullptr;      // look-ahead stream of the blocked factorisation
   hipStream_t stream3 = nullptr;      // far-row stream of the factorisation (rows below a panel's diagonal square)
@@ -79,6 +83,47 @@ struct lgp_ctx {
   size_t prof_used = 0;
 };
 
+// ---- schedule tracer of the sharded factorisation (dist.hip) ------------------------------------------------------------
+// What lgp_chol_factor_dist_f64 enqueues -- every event wait, event record, kernel launch, copy and broadcast with the stream it
+// goes to and the operand ranges it was given -- written down as it is enqueued (LGP_DIST_TRACE=<path>: one file per rank), or
+// instead of being enqueued (`dry`: lgp_chol_dist_trace, host only, no device), so that the CPU suite can check the schedule the
+// C++ really produces: every pair of conflicting accesses ordered by stream order + event edges, and the factor it computes when
+// a simulator runs it in any order those edges allow (tests/dist_trace.py).  `jitter` (LGP_DIST_JITTER=<seed>): a spin kernel of
+// random 0-300 us in front of randomly chosen enqueues, so that an edge missing from the schedule shows within tens of runs.
+constexpr int LGP_TR_FIELDS = 20;      // int64 words per record: kind, stream, 18 arguments
+enum {
+  LGP_TR_WAIT = 1,      // event
+  LGP_TR_RECORD = 2,    // event
+  LGP_TR_MARK = 3,      // what, b, i, r0, r1   (what: 0 lane, 1 comm, 2 bulk, 3 u1; context for the records that follow)
+  LGP_TR_GEMM = 10,     // m, n, k, spA, offA, lda, spB, offB, ldb, spC, offC, ldc, lower, cyc_nb, cyc_g1, roff, ta | tb << 1
+  LGP_TR_SUBST = 11,    // off(dblk workspace), jb, spX, offX, ldx, rows          X <- X L_jj^-T
+  LGP_TR_POTF2 = 12,    // spA, offA, lda, nb, off(dblk workspace)
+  LGP_TR_COPY2D = 13,   // spD, offD, ldd, spS, offS, lds, rows, cols
+  LGP_TR_BCAST = 14,    // sp, off, elements, root
+  LGP_TR_CHAINSQ = 15,  // spP, offP, ldl, kb, off(dblk workspace)               a square factored by the chain kernel
+  LGP_TR_TAIL = 16,     // n, spL, offL, ldl, off(dblk), nx, row0                 the trailing matrix handed to the chain driver (one rank)
+  LGP_TR_EXTRACT = 17,  // spL, offL, ldl, n, off(dblk workspace)
+  LGP_TR_SCALE = 18,    // rows, cols, spA, offA, lda
+  LGP_TR_MEMSET = 19,   // (the info word)
+};
+struct lgp_tracer {
+  bool dry = false, log = false;
+  unsigned long long jitter = 0;          // xorshift state, 0 = off
+  long long slab = -1;                    // dry runs: slab height (-1: the library's default)
+  int flags = -1;                         // dry runs: bit 0 owner sends through the communication stream, bit 1 chain kernel usable, bit 2 force comm
+  std::vector<long long> rec;
+  std::vector<const void *> streams, events;
+  const char *base[3] = {nullptr, nullptr, nullptr};      // spaces: 0 the rank's block columns, 1 the panel slots, 2 the diagonal-block workspaces
+  size_t bytes[3] = {0, 0, 0};
+};
+void lgp_tr_log(lgp_ctx *ctx, int kind, hipStream_t st, std::initializer_list<long long> args);
+void lgp_tr_ptr(lgp_ctx *ctx, const void *p, long long &space, long long &off);       // (offset in doubles)
+inline bool lgp_tr_dry(const lgp_ctx *ctx) { return ctx->tracer != nullptr && ctx->tracer->dry; }
+int lgp_tr_wait(lgp_ctx *ctx, hipStream_t st, hipEvent_t ev);        // hipStreamWaitEvent, logged / jittered / skipped as the tracer says
+int lgp_tr_record(lgp_ctx *ctx, hipEvent_t ev, hipStream_t st);      // hipEventRecord, likewise
+// a traced operation: logs it (with jitter in front) and says whether it is to be enqueued at all
+#define LGP_TRACED(ctx, kind, st, ...) ((ctx)->tracer == nullptr || (lgp_tr_log((ctx), (kind), (st), {__VA_ARGS__}), !(ctx)->tracer->dry))
+
 int lgp_prof_start(lgp_ctx *ctx, hipStream_t stream, double flops);
 int lgp_prof_stop(lgp_ctx *ctx, hipStream_t stream);
 
@@ -127,6 +172,7 @@ struct WsGuard {
 struct DeviceGuard {
   int prev = -1;
   explicit DeviceGuard(int dev) {
+    if (dev < 0) return;                // (a dry run of a schedule: no device, no runtime call)
     (void)hipGetDevice(&prev);
     if (prev != dev) (void)hipSetDevice(dev);
     else prev = -1;

@@ -581,6 +581,13 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   LGP_REQUIRE(ldc >= n, "ldc < n");
   LGP_REQUIRE(k == 0 || lda >= (ta ? m : k), "lda too small");
   LGP_REQUIRE(k == 0 || ldb >= (tb ? k : n), "ldb too small");
+  if (ctx->tracer != nullptr) {            // the sharded factorisation's schedule, written down (dist.hip); dry: nothing is launched
+    long long sa, oa, sb, ob, sc, oc;
+    lgp_tr_ptr(ctx, A, sa, oa); lgp_tr_ptr(ctx, B, sb, ob); lgp_tr_ptr(ctx, C, sc, oc);
+    if (!LGP_TRACED(ctx, LGP_TR_GEMM, stream, (long long)m, (long long)n, (long long)k, sa, oa, (long long)lda, sb, ob, (long long)ldb, sc, oc, (long long)ldc,
+                    lower ? 1 : 0, cyc_nb, cyc_g1, roff, (ta ? 1 : 0) | (tb ? 2 : 0)))
+      return LGP_OK;
+  }
   // Small outputs sit on the dependent chains of the panel factorisation and of the triangular solves: with
   // 128x128 tiles they would occupy a handful of CUs for 8+ K-steps of 4096 cycles each; 64x64 tiles quarter
   // the per-workgroup latency and spread the product over 4x more CUs.  In-place products (C aliasing an

@@ -499,6 +499,11 @@ __global__ void __launch_bounds__(256) scale_rows_kernel(T *L, long ldl, int n, 
 template <typename T>
 int lgp_potf2_launch(lgp_ctx *ctx, hipStream_t stream, T *A, size_t lda, int nb, T *dblk, size_t row0) {
   LGP_REQUIRE(nb >= 1 && nb <= LGP_DB, "diagonal block size must be in [1,128]");
+  if (ctx->tracer != nullptr) {
+    long long sa, oa, sw, ow;
+    lgp_tr_ptr(ctx, A, sa, oa); lgp_tr_ptr(ctx, dblk, sw, ow);
+    if (!LGP_TRACED(ctx, LGP_TR_POTF2, stream, sa, oa, (long long)lda, nb, ow)) return LGP_OK;
+  }
   // fp64: the four-wave matrix-core kernel of potf2m.hip (46 us alone against 60 us for the VALU kernel below; end to end
   // N = 4096 4.24 -> 3.69 ms, N = 8192 10.7 -> 9.7 ms, N = 16384 39.6 -> 37.4 ms, N = 32768 204 -> 200.7 ms).
   // ctx->potf2_mode (env LGP_POTF2): 0 / 2 = that kernel, 1 = VALU kernel, 3 = the one-wave matrix-core kernel, which needs a
@@ -997,6 +1002,21 @@ int lgp_potrf_chain_tail_f64(lgp_ctx *ctx, size_t n, double *L, size_t ldl, doub
 // (optional): event j = "block j of the square factored and the square's rows below it solved"; block j of these rows then
 // starts behind event j - 1 (update) and event j (substitution), i.e. the rows follow the square one block behind instead of
 // waiting for all of it.
+// X <- X L_jj^-T for `rows` rows (the matrix-core substitution), written down for the schedule tracer of dist.hip when there is one
+template <typename T>
+static int subst_right_traced(lgp_ctx *ctx, hipStream_t st, const T *w, size_t jb, T *X, size_t ldx, size_t rows) {
+  if (rows == 0) return LGP_OK;
+  if (ctx->tracer != nullptr) {
+    long long sw, ow, sx, ox;
+    lgp_tr_ptr(ctx, w, sw, ow); lgp_tr_ptr(ctx, X, sx, ox);
+    if (!LGP_TRACED(ctx, LGP_TR_SUBST, st, ow, (long long)jb, sx, ox, (long long)ldx, (long long)rows)) return LGP_OK;
+  }
+  hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((rows + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, st, w, (int)jb, X, (long)ldx,
+                     (long)rows);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+
 template <typename T>
 int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *Pfar, size_t ldl, const T *Psq, const T *Yk,
                       const hipEvent_t *blk_events) {
@@ -1008,13 +1028,11 @@ int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *P
   for (size_t j0 = 0; j0 < kb; j0 += LGP_DB, ++j) {
     const size_t jb = (kb - j0) < (size_t)LGP_DB ? (kb - j0) : (size_t)LGP_DB;
     if (j0 > 0 && !recursive) {
-      if (blk_events) LGP_HIP(hipStreamWaitEvent(st, blk_events[j - 1], 0));
+      if (blk_events) LGP_CHECK(lgp_tr_wait(ctx, st, blk_events[j - 1]));
       LGP_CHECK(lgp_gemm_launch<T>(ctx, st, false, true, rows, jb, j0, T(-1), Pfar, ldl, Psq + j0 * ldl, ldl, T(1), Pfar + j0, ldl, false, 2));
     }
-    if (blk_events) LGP_HIP(hipStreamWaitEvent(st, blk_events[j], 0));
-    hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((rows + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, st,
-                       Yk + (j0 / LGP_DB) * (size_t)LGP_DBLK, (int)jb, Pfar + j0, (long)ldl, (long)rows);
-    LGP_LAUNCH_CHECK();
+    if (blk_events) LGP_CHECK(lgp_tr_wait(ctx, st, blk_events[j]));
+    LGP_CHECK(subst_right_traced<T>(ctx, st, Yk + (j0 / LGP_DB) * (size_t)LGP_DBLK, jb, Pfar + j0, ldl, rows));
     if (recursive) {     // after block j the columns [c, c + s) get blocks [c - s, c), c = j + 1, s = its lowest set bit (behind event j: the square's rows of those blocks are final)
       const size_t c = j + 1, sbit = c & (~c + 1);
       if (c < nq) {
@@ -1036,13 +1054,21 @@ int lgp_square_factor_f64(lgp_ctx *ctx, hipStream_t st, size_t kb, double *P, si
                           const hipEvent_t *blk_events) {
   typedef double T;
   const size_t nq = (kb + LGP_DB - 1) / LGP_DB;
-  if (use_chain && kb >= 256 && lgp_chain_usable(ctx, kb, ldl)) {
-    unsigned *state = nullptr;
-    LGP_CHECK(lgp_chain_state(ctx, kb, &state));
-    LGP_HIP(hipMemsetAsync(state, 0, lgp_chain_state_bytes(kb), st));
-    LGP_CHECK(lgp_chain_launch(ctx, st, kb, P, ldl, Yk, row0));
+  if (use_chain && kb >= 256 && (lgp_tr_dry(ctx) || lgp_chain_usable(ctx, kb, ldl))) {
+    bool enqueue = true;
+    if (ctx->tracer != nullptr) {
+      long long sp, op, sw, ow;
+      lgp_tr_ptr(ctx, P, sp, op); lgp_tr_ptr(ctx, Yk, sw, ow);
+      enqueue = LGP_TRACED(ctx, LGP_TR_CHAINSQ, st, sp, op, (long long)ldl, (long long)kb, ow);
+    }
+    if (enqueue) {
+      unsigned *state = nullptr;
+      LGP_CHECK(lgp_chain_state(ctx, kb, &state));
+      LGP_HIP(hipMemsetAsync(state, 0, lgp_chain_state_bytes(kb), st));
+      LGP_CHECK(lgp_chain_launch(ctx, st, kb, P, ldl, Yk, row0));
+    }
     if (blk_events)
-      for (size_t j = 0; j < nq; ++j) LGP_HIP(hipEventRecord(blk_events[j], st));
+      for (size_t j = 0; j < nq; ++j) LGP_CHECK(lgp_tr_record(ctx, blk_events[j], st));
     return LGP_OK;
   }
   size_t j = 0;
@@ -1052,12 +1078,8 @@ int lgp_square_factor_f64(lgp_ctx *ctx, hipStream_t st, size_t kb, double *P, si
     LGP_CHECK(lgp_potf2_launch<T>(ctx, st, P + j0 * ldl + j0, ldl, (int)jb, w, row0 + j0));
     const size_t below = kb - (j0 + jb);
     T *X = P + (j0 + jb) * ldl + j0;
-    if (below > 0) {
-      hipLaunchKernelGGL((subst_right_mfma_kernel<T>), dim3((unsigned)((below + SUBSTM_ROWS - 1) / SUBSTM_ROWS)), dim3(256), 0, st, w, (int)jb, X,
-                         (long)ldl, (long)below);
-      LGP_LAUNCH_CHECK();
-    }
-    if (blk_events) LGP_HIP(hipEventRecord(blk_events[j], st));
+    LGP_CHECK(subst_right_traced<T>(ctx, st, w, jb, X, ldl, below));
+    if (blk_events) LGP_CHECK(lgp_tr_record(ctx, blk_events[j], st));
     if (below > 0) LGP_CHECK(lgp_gemm_launch<T>(ctx, st, false, true, below, below, jb, T(-1), X, ldl, X, ldl, T(1), P + (j0 + jb) * ldl + (j0 + jb), ldl, true));
   }
   return LGP_OK;

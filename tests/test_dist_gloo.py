@@ -144,7 +144,7 @@ def _check_factor(full, K, n):
         np.testing.assert_allclose(full[n:], linalg.solve_triangular(ref, K[n:].T, lower=True).T, rtol=1e-9, atol=1e-11)
 
 
-def simulate(world, n, nb, nx, slab, seed):
+def simulate(world, n, nb, nx, slab, seed, owner_comm=None):
     """ all ranks in one process; the next operation is drawn at random among those whose stream predecessors and event waits
     are complete (a broadcast: on every rank at once) """
     rng = np.random.default_rng(seed)
@@ -153,7 +153,7 @@ def simulate(world, n, nb, nx, slab, seed):
     ranks = []
     for r in range(world):
         L = Layout(n, nb, r, world)
-        tasks, nslots = factor_tasks(L, plan, nx)
+        tasks, nslots = factor_tasks(L, plan, nx, owner_comm)
         queues = {}
         for t in tasks:
             queues.setdefault(t.stream, []).append(t)
@@ -163,7 +163,8 @@ def simulate(world, n, nb, nx, slab, seed):
                           bcasts=[t.index for t in tasks if t.kind == 'BCAST'], bpos=0))
         for t in tasks:
             if t.kind == 'BCAST':
-                assert t.stream == ('s3' if L.owner(t.piece[0]) == r else 'sx')
+                in_order = owner_comm == 'order' or (owner_comm is None and world == 1)
+                assert t.stream == ('s3' if L.owner(t.piece[0]) == r and in_order else 'sx')
     # every rank issues the same broadcasts in the same order
     order = [[t.piece for t in rk['tasks'] if t.kind == 'BCAST'] for rk in ranks]
     assert all(o == order[0] for o in order)
@@ -219,7 +220,7 @@ def simulate(world, n, nb, nx, slab, seed):
 ])
 def test_schedule_simulated_with_random_interleaving(world, n, nb, nx, slab):
     for seed in range(6):
-        simulate(world, n, nb, nx, slab, seed)
+        simulate(world, n, nb, nx, slab, seed, ('order', 'stream')[seed % 2])
 
 
 def test_plan_properties():

@@ -207,6 +207,48 @@ def test_ranks_share_the_gpu(lgp, tmp_path, n, nb, world, carry, amp, slab, bcas
     util.assert_close_matrices(full, o._L, rtol=1e-11)
 
 
+@pytest.mark.parametrize('n,nb,world,slab,jitter', [(1100, 128, 4, 256, None), (1700, 256, 2, 256, 5)])
+def test_live_schedule_is_the_dry_schedule(lgp, tmp_path, n, nb, world, slab, jitter):
+    """ what the library enqueues on the device (LGP_DIST_TRACE) is, record for record, what its dry run writes down
+    (lgp_chol_dist_trace) -- the schedule that tests/test_dist_trace.py proves free of unordered conflicts on CPU; with
+    LGP_DIST_JITTER (spin kernels of random length in front of randomly chosen enqueues) the results stay right """
+    import os
+    import socket
+    import subprocess
+    import sys
+    from . import dist_trace as dt
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    m = 37
+    script = os.path.join(os.path.dirname(__file__), 'two_rank_worker.py')
+    env = dict(os.environ, LGP_TEST_CARRY='1', LGP_TEST_AMP='1', LGP_TEST_SENDRECV='1', LGP_DIST_SLAB=str(slab), LGP_DIST_TRACE=str(tmp_path / 'trace'),
+               LGP_CHAIN='0')                                      # (whether squares go to the chain kernel is a run-time question: off here, as in the dry run)
+    if jitter is not None:
+        env['LGP_DIST_JITTER'] = str(jitter)
+    procs = [subprocess.Popen([sys.executable, script, str(rank), str(world), str(port), str(n), str(nb), str(m), str(tmp_path)],
+                              cwd=os.path.dirname(os.path.dirname(__file__)), env=env) for rank in range(world)]
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    for rank in range(world):
+        live, status = dt.load_trace(str(tmp_path / f'trace.rank{rank}'))
+        assert status == 0
+        dry = dt.dry_trace(n, nb, 128, rank, world, slab, 1)
+        assert live.shape == dry.shape and np.array_equal(live, dry), f'rank {rank}: the live schedule differs from the dry run'
+    rng = np.random.default_rng(7)
+    x = rng.uniform(0, n / 16, n)
+    xs = rng.uniform(0, n / 16, m)
+    y = np.sin(x / 4) + 0.1 * rng.standard_normal(n)
+    o = oracle.Chol(oracle.ExpQuad()(x[:, None], x[None, :]) + 0.01 * np.eye(n))
+    mean_o = o.pinv_bilinear(oracle.ExpQuad()(x[:, None], xs[None, :]), y)
+    for rank in range(world):
+        r = np.load(tmp_path / f'rank{rank}.npz')
+        assert np.linalg.norm(r['mean'] - mean_o) <= 1e-8 * np.linalg.norm(mean_o)
+        for b in r['owned']:
+            c0 = int(b) * nb
+            util.assert_close_matrices(r[f'b{b}'], o._L[c0:, c0:c0 + r[f'b{b}'].shape[1]], rtol=1e-10)
+
+
 def _sharded_against_single_gpu(lgp, tmp_path, n, world, slab=None):
     """ the sharded factorisation of configuration C4's workload (block columns of 1024, `world` ranks sharing the GPU, panel
     pieces through the host-staged transport, [Kxxs | y] carried through the factorisation) against the single-GPU driver on the
