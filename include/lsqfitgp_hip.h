@@ -598,6 +598,14 @@ long lgp_chol_dist_plan(size_t n, size_t nb, size_t nx, size_t nranks, size_t sl
  * that a simulator running it in any order those edges allow computes the factor (tests/test_dist_trace.py).  No reference
  * counterpart. */
 long lgp_chol_dist_trace(size_t n, size_t nb, size_t nx, int rank, int nranks, size_t slab, int flags, long long *rec, size_t capacity);
+/* The last lgp_chol_factor_dist_f64 of this context measured from inside (for the multi-GPU line of bench.py: is a step bound
+ * by compute, by the links or by the chain of slabs?).  enable: 1 / 0 switch the measurement on / off for the calls that follow
+ * (pairs of timing events around the compute stream's waits for arriving pieces and around the packs: keep it off in timed
+ * runs), -1 leaves it as it is.  out (8 doubles, may be NULL): wall ms of the call; ms the compute stream was idle in front of a
+ * piece that had not arrived (or, for a panel of its own, was not solved); ms of packs; panel bytes its updates read from other
+ * ranks; panel bytes of its own; pieces; broadcast algorithm (0 none, 1 the transport's broadcast, 2 scatter + all-gather);
+ * 1 if own pieces were handed to the communication stream.  No reference counterpart. */
+int lgp_dist_stats(lgp_ctx *ctx, int enable, double *out);
 /* One horizontal slab of the staircase update above: rows [roff, roff + rows) below the diagonal of the first block column
  * of dC (which points at the slab's first row, as dA does; dB points at the panel row of that diagonal). */
 int lgp_update_nt_slab_f64(lgp_ctx *ctx, size_t rows, size_t cols, size_t k, const double *dA, size_t lda, const double *dB, size_t ldb,

@@ -140,6 +140,30 @@ class Context:
         rows = [tuple(int(v) for v in r) for r in buf[:cnt]]
         return rows[:ns.value], rows[ns.value:]
 
+    def bcast_check(self, nbytes=8 << 20, root=0):
+        """ one broadcast of ``nbytes`` of a known pattern from ``root`` with the current algorithm, checked on every rank:
+        None if this rank holds the pattern afterwards, else what went wrong (an exception's text, or 'wrong contents') """
+        import numpy
+        n = max(1, nbytes // 8)
+        pattern = (numpy.arange(n, dtype=numpy.float64) * 1.25 + 3.).reshape(1, n)
+        try:
+            buf = DeviceArray.from_host(pattern if self.rank == root else numpy.zeros((1, n)), ctx=self)
+            _lib.check(self._lib.lgp_bcast(self._handle, buf.ptr, n * 8, int(root)), 'lgp_bcast')
+            self.sync()
+            return None if numpy.array_equal(buf.to_host(), pattern) else 'wrong contents after the broadcast'
+        except Exception as exc:
+            return repr(exc)
+
+    def dist_stats(self, enable=None):
+        """ `lgp_dist_stats`: the last sharded factorisation measured from inside, as a dict; ``enable`` switches the measurement
+        on / off for the calls that follow """
+        out = (ctypes.c_double * 8)()
+        _lib.check(self._lib.lgp_dist_stats(self._handle, -1 if enable is None else int(bool(enable)), out), 'lgp_dist_stats')
+        keys = ('wall_ms', 'wait_ms', 'pack_ms', 'bytes_from_peers', 'bytes_own', 'pieces', 'bcast_algo', 'owner_via_comm_stream')
+        d = dict(zip(keys, (float(v) for v in out)))
+        d['bcast_algo'] = {0: None, 1: 'broadcast', 2: 'scatter + all-gather'}[int(d['bcast_algo'])]
+        return d
+
     def comm_info(self):
         """ (rank, number of ranks, transport) as the communicator reports them; transport 'none' | 'rccl' | 'host' """
         r, n, t = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

@@ -117,6 +117,7 @@ def _signatures():
         'lgp_colabssum_f64': (c_int, [c_void_p, _S, _S, _P, _S, _P]),
         'lgp_chol_factor_dist_f64': (c_int, [c_void_p, _S, _S, _S, _P, _S, _P, _P, _S, _S, _P, POINTER(c_int)]),
         'lgp_chol_dist_plan': (ctypes.c_long, [_S, _S, _S, _S, _S, _P, _S, POINTER(c_size_t), POINTER(c_size_t)]),
+        'lgp_dist_stats': (c_int, [c_void_p, c_int, _P]),
         'lgp_chol_dist_trace': (ctypes.c_long, [_S, _S, _S, c_int, c_int, _S, c_int, _P, _S]),
         'lgp_update_nt_slab_f64': (c_int, [c_void_p, _S, _S, _S, _P, _S, _P, _S, _P, _S, _S, _S, _S]),
         'lgp_max_f64': (c_int, [c_void_p, _S, _P, _P]),

@@ -11,9 +11,11 @@ Every collective is entered by all ranks in the same order (as with any communic
 answers.  No reference counterpart (the reference is single-process; SURVEY.md section 2, negative inventory).
 
 How the ranks find rank 0's port:
-* ``LGP_RDZV_PORT`` (set by ``bench.py``'s own launcher, which picks a free port before it starts the ranks), else
-* a file ``<tmp>/lgp_rdzv_<uid>_<parent pid>_<MASTER_PORT>`` that rank 0 writes after binding an ephemeral port: under
-  ``python -m torch.distributed.run`` MASTER_PORT itself belongs to the launcher's own store, so it only names the job.
+* ``LGP_RDZV_PORT`` (an explicit port: tests), else
+* a file ``<tmp>/lgp_rdzv_<uid>/<parent pid>_<MASTER_PORT>`` (directory 0700, file 0600, owner checked) that rank 0 writes after
+  binding an ephemeral port -- no port is chosen before it is bound: ``bench.py``'s own launcher and ``python -m
+  torch.distributed.run`` both work this way (MASTER_PORT only names the job; under torchrun it belongs to the launcher's store).
+The handshake carries a token shared by the ranks of one job (``LGP_RDZV_TOKEN`` from the launcher).
 """
 
 import json
@@ -60,9 +62,27 @@ def _recvmsg(sock):
 
 
 def _discovery_path():
+    """ the file through which rank 0 tells the ranks of its job where it listens: inside a directory that only this user can enter
+    (created 0700; refused if it belongs to somebody else or is open to others), so that no other local user can plant or replace it """
     job = os.environ.get('MASTER_PORT', '0')
     uid = os.getuid() if hasattr(os, 'getuid') else 0
-    return os.path.join(tempfile.gettempdir(), f'lgp_rdzv_{uid}_{os.getppid()}_{job}')
+    d = os.path.join(tempfile.gettempdir(), f'lgp_rdzv_{uid}')
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or (hasattr(os, 'getuid') and st.st_uid != uid) or (st.st_mode & 0o077):
+        raise PermissionError(f'rendezvous directory {d} is not a private directory of this user')
+    return os.path.join(d, f'{os.getppid()}_{job}')
+
+
+def _token():
+    """ 16 bytes that the ranks of one job share (LGP_RDZV_TOKEN from the launcher; under torchrun its run id) and a stranger does not """
+    import hashlib
+    secret = os.environ.get('LGP_RDZV_TOKEN') or os.environ.get('TORCHELASTIC_RUN_ID') or ''
+    return hashlib.sha256(('lgp-rdzv:' + secret).encode()).digest()[:16]
 
 
 class Rendezvous:
@@ -98,7 +118,7 @@ class Rendezvous:
         if not port:                       # publish the ephemeral port for the ranks that share our parent process
             self._path = _discovery_path()
             tmp = f'{self._path}.{os.getpid()}'
-            with open(tmp, 'w') as f:
+            with open(os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600), 'w') as f:
                 json.dump({'port': lst.getsockname()[1], 'world': self.world, 'pid': os.getpid()}, f)
             os.replace(tmp, self._path)
         deadline = time.monotonic() + self.timeout
@@ -111,12 +131,13 @@ class Rendezvous:
                 raise TimeoutError(f'rendezvous: ranks {missing} did not connect within {self.timeout:.0f} s') from None
             try:
                 conn.settimeout(10.)
-                hello = _recvexact(conn, len(_MAGIC) + 8)
-                r, w = struct.unpack('<ii', hello[len(_MAGIC):])
-                if bytes(hello[:len(_MAGIC)]) != _MAGIC or w != self.world or not 0 < r < self.world or r in self._peers:
+                hello = _recvexact(conn, len(_MAGIC) + 8 + 16)
+                r, w = struct.unpack('<ii', hello[len(_MAGIC):len(_MAGIC) + 8])
+                if (bytes(hello[:len(_MAGIC)]) != _MAGIC or bytes(hello[len(_MAGIC) + 8:]) != _token() or w != self.world or not 0 < r < self.world
+                        or r in self._peers):
                     conn.close()
                     continue
-                conn.sendall(_MAGIC)
+                conn.sendall(_MAGIC + _token())
             except (OSError, ConnectionError, struct.error):
                 conn.close()
                 continue
@@ -133,6 +154,8 @@ class Rendezvous:
             if p is None:
                 try:
                     with open(path) as f:
+                        if hasattr(os, 'getuid') and os.fstat(f.fileno()).st_uid != os.getuid():
+                            raise OSError('the discovery file belongs to another user')
                         d = json.load(f)
                     p = int(d['port']) if int(d.get('world', -1)) == self.world else None
                 except (OSError, ValueError, KeyError):
@@ -142,8 +165,8 @@ class Rendezvous:
                 try:
                     s.settimeout(10.)
                     s.connect((self.addr, p))
-                    s.sendall(_MAGIC + struct.pack('<ii', self.rank, self.world))
-                    if bytes(_recvexact(s, len(_MAGIC))) != _MAGIC:
+                    s.sendall(_MAGIC + struct.pack('<ii', self.rank, self.world) + _token())
+                    if bytes(_recvexact(s, len(_MAGIC) + 16)) != _MAGIC + _token():
                         raise ConnectionError('not a rendezvous of this job')
                     s.settimeout(None)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)

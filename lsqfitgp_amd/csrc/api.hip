@@ -248,6 +248,7 @@ int lgp_ctx_destroy(lgp_ctx *c) {
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->panel_events) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->dist_events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->dist_timing_events) (void)hipEventDestroy(e);
   if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
   for (hipStream_t s : c->far_streams)
     if (s != c->stream3) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
@@ -662,6 +663,11 @@ int lgp_predict_isotropic_f64(lgp_ctx *c, int kernel, int p, int npar, const dou
   LGP_REQUIRE(nx >= m + 1 && ldl >= n, "the carried rows: nx >= m + 1, ldl >= n");
   DeviceGuard dg(c->device);
   hipStream_t st = c->stream;
+  // the uploads below read the caller's pageable host buffers asynchronously: no path out of this function may leave them in flight
+  struct Drain {
+    hipStream_t s;
+    ~Drain() { (void)hipStreamSynchronize(s); }
+  } drain{st};
   const size_t np = n + m;
   double *Wt = dL + n * ldl;                                    // (m + 1) x n: Kxxs^T, then y
   double *dcov = dwork, *dmean = dwork + m * m, *dsc = dmean + m, *dnoise = dsc + 2;

@@ -29,6 +29,11 @@ struct lgp_ctx {
   size_t reserve_max_n = 0;                    // env LGP_RESERVE_MAX_N: largest matrix that reserves CUs (0: never, the default: measured slower)
   std::vector<hipEvent_t> panel_events;   // per 128-block of a panel: potf2 done, look-ahead rows solved, bulk done
   std::vector<hipEvent_t> dist_events;    // the events of the sharded factorisation's schedule (dist.hip), kept between calls: several hundred per call
+  // lgp_dist_stats: the last sharded factorisation measured from inside -- timing event pairs around the compute stream's waits for
+  // arriving pieces and around the packs -- off unless asked for (the timed steps of bench.py run without)
+  int dist_stats_on = 0;
+  std::vector<hipEvent_t> dist_timing_events;
+  double dist_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   int *d_info = nullptr;              // pivot info word (0 = ok, else 1-based index), device
   void *d_scratch = nullptr;          // small reductions (>= 64 KiB)

@@ -33,6 +33,7 @@
 // updates with panel b are through (free events of sc and of the look-ahead streams).
 #include "common.h"
 #include <algorithm>
+#include <chrono>
 
 template <typename T>
 int lgp_far_rows_impl(lgp_ctx *ctx, hipStream_t st, size_t rows, size_t kb, T *Pfar, size_t ldl, const T *Psq, const T *Yk,
@@ -273,6 +274,18 @@ extern "C" long lgp_chol_dist_trace(size_t n, size_t nb, size_t nx, int rank, in
   return (long)count;
 }
 
+// The last lgp_chol_factor_dist_f64 of this context measured from inside.  enable: 1 / 0 switch the measurement on / off for the
+// calls that follow (timing event pairs on the compute stream and around the packs: not for timed runs), -1 leaves it.
+// out (8 values, may be NULL): wall ms of the call, ms the compute stream waited for pieces, ms of packs, panel bytes read
+// from other ranks, panel bytes of its own, pieces, broadcast algorithm (0 none, 1 the transport's broadcast, 2 scatter +
+// all-gather), 1 if own pieces were sent from the communication stream.
+extern "C" int lgp_dist_stats(lgp_ctx *ctx, int enable, double *out) {
+  LGP_REQUIRE(ctx != nullptr, "null context");
+  if (enable >= 0) ctx->dist_stats_on = enable != 0;
+  if (out != nullptr) memcpy(out, ctx->dist_stats, sizeof ctx->dist_stats);
+  return LGP_OK;
+}
+
 // The plan of the sharded factorisation, for callers that allocate its panel slots and for the CPU restatement of the
 // schedule (tests/test_dist_gloo.py executes this very list over numpy + gloo).  Host only.
 extern "C" long lgp_chol_dist_plan(size_t n, size_t nb, size_t nx, size_t nranks, size_t slab, unsigned long long *pieces, size_t capacity,
@@ -366,6 +379,21 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   };
   EventPool pool(ctx->dist_events);
   pool.dry = dry;
+  // lgp_dist_stats: pairs of timing events (wait_pairs around the compute stream's waits for a piece, pack_pairs around the packs)
+  const bool stats = ctx->dist_stats_on != 0 && !dry;
+  std::vector<hipEvent_t> wait_pairs, pack_pairs;
+  size_t timing_used = 0;
+  double bytes_recv = 0, bytes_own = 0;
+  auto stamp = [&](hipStream_t st, std::vector<hipEvent_t> &into) {
+    if (timing_used == ctx->dist_timing_events.size()) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      ctx->dist_timing_events.push_back(e);
+    }
+    hipEvent_t e = ctx->dist_timing_events[timing_used++];
+    if (hipEventRecord(e, st) == hipSuccess) into.push_back(e);
+  };
+  const auto wall0 = std::chrono::steady_clock::now();
   if (tr != nullptr) {
     tr->base[0] = reinterpret_cast<const char *>(dLloc); tr->bytes[0] = rows_all * ldl * sizeof(double);
     tr->base[1] = reinterpret_cast<const char *>(dpanels); tr->bytes[1] = dpanels ? nslots * rows_all * ldp * sizeof(double) : 0;
@@ -490,9 +518,11 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
         lgp_tr_ptr(ctx, panel_rows(b, p.r0), sd, od); lgp_tr_ptr(ctx, C, ss, os);
         enqueue = LGP_TRACED(ctx, LGP_TR_COPY2D, st, sd, od, (long long)ldp, ss, os, (long long)ldl, (long long)(p.r1 - p.r0), (long long)kb);
       }
+      if (stats) stamp(st, pack_pairs);
       if (enqueue)
         LGP_HIP(hipMemcpy2DAsync(panel_rows(b, p.r0), ldp * sizeof(double), C, ldl * sizeof(double), kb * sizeof(double), p.r1 - p.r0,
                                  hipMemcpyDeviceToDevice, st));
+      if (stats) stamp(st, pack_pairs);
     }
     if (!owner_sends_in_order) LGP_CHECK(lgp_tr_record(ctx, ev_ready[b][p.i], st));
     return LGP_OK;
@@ -528,7 +558,10 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   auto bulk = [&](const Piece &p) -> int {
     const size_t b = p.b;
     if (tr != nullptr && tr->log) lgp_tr_log(ctx, LGP_TR_MARK, sc, {2, (long long)p.b, (long long)p.i, (long long)p.r0, (long long)p.r1});
+    if (stats) stamp(sc, wait_pairs);
     LGP_CHECK(lgp_tr_wait(ctx, sc, avail(b, p.i)));
+    if (stats) stamp(sc, wait_pairs);
+    (owner(b) == me ? bytes_own : bytes_recv) += (double)((p.r1 - p.r0) * width(b) * sizeof(double));
     size_t ldq = 0;
     (void)prow(b, p.r0, ldq);                              // the leading dimension of this panel's rows for this rank
     if (b + 1 < nblocks && owner(b + 1) == me) {
@@ -645,6 +678,25 @@ extern "C" int lgp_chol_factor_dist_f64(lgp_ctx *ctx, size_t n, size_t nb, size_
   (void)hipStreamSynchronize(sx);
   (void)hipStreamSynchronize(sc);
   tracer_scope.dump(failed);
+  if (stats) {
+    auto total = [](const std::vector<hipEvent_t> &v) {
+      double ms = 0;
+      for (size_t k = 0; k + 1 < v.size(); k += 2) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, v[k], v[k + 1]) == hipSuccess) ms += t;
+      }
+      return ms;
+    };
+    double *o = ctx->dist_stats;
+    o[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();      // the call, wall clock
+    o[1] = total(wait_pairs);           // the compute stream idle in front of a piece that had not arrived / was not solved yet
+    o[2] = total(pack_pairs);
+    o[3] = bytes_recv;                  // panel bytes this rank's updates read from other ranks
+    o[4] = bytes_own;
+    o[5] = (double)(wait_pairs.size() / 2);
+    o[6] = (G >= 3 && ctx->bcast_algo != 1 && (ctx->bcast_algo == 2 || ctx->comm != nullptr)) ? 2 : (G >= 2 ? 1 : 0);   // 2: scatter + all-gather (pieces >= bcast_min), 1: the transport's broadcast
+    o[7] = owner_sends_in_order ? 0 : 1;
+  }
   if (failed != LGP_OK) return failed;
   if (hinfo) *hinfo = info;
   return lgp_info_result(ctx, info) < 0 ? LGP_EHIP : LGP_OK;

@@ -463,6 +463,14 @@ def test_bench_gpus_2_launches_two_ranks():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['scaling'] == 'strong' and out['transport'] == 'host' and out['rccl_ranks'] is None
     assert out['config']['N'] == 8192 and out['steps'] == 1
+    # the sharded line's roofline: panel traffic against the links, per-rank phase times from inside the library (lgp_dist_stats)
+    roof = out['roofline']
+    assert roof['bound'] == 'xgmi' and roof['unit'] == 'GB/s' and roof['peak'] == 153. and out['bcast_algo'] == roof['bcast_algo'] == 'broadcast'
+    assert roof['bytes_from_peers_per_rank_per_step'] > 0.3 * 8192 * 8192 * 8 / 2 / 2 and len(roof['per_rank_ms']) == 2
+    for r in roof['per_rank_ms']:
+        assert r['factorisation_wall'] > 0 and 0 <= r['waiting_for_pieces'] <= r['factorisation_wall'] and r['pack'] > 0
+    assert roof['achieved'] is None or roof['frac'] == pytest.approx(roof['achieved'] / roof['peak'])
+    assert 'sharded_path_error' not in out
     assert out['replicas']['scaling'] == 'weak' and out['replicas']['value'] > 0
     assert 'torch' not in res.stderr.lower()
     # the sharded step computed the same log marginal likelihood as the single-GPU step of the same workload
@@ -473,3 +481,29 @@ def test_bench_gpus_2_launches_two_ranks():
     wl.step()
     lgp.Context.default().sync()
     assert abs(out['log_marginal_likelihood'] - wl.results['mll']) <= 1e-9 * abs(wl.results['mll'])
+
+
+def test_bench_gpus_3_tries_both_broadcasts_and_a_second_workload():
+    """ three ranks on the one GPU (host-staged transport): the sharded step is measured with the transport's broadcast first, then
+    with scatter + all-gather behind one checked broadcast, the better one is the line; a second workload rides as
+    `sharded_c3` (here a small one, named through the environment) """
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'LGP_RDZV_PORT', 'LGP_DEVICE')}
+    env.update(LGP_DIST_TRANSPORT='host', LGP_BENCH_STRONG_CONFIG='r4096')
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '3', '--config', 'c2', '--replica-config', 'r4096', '--steps', '1', '--warmup', '1',
+                          '--no-cpu-baseline', '--no-sweep'], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 3 and sorted(out['bcast_attempts_ms_per_step']) == ['plain', 'scatter'] and 'sharded_path_error' not in out
+    best = min(out['bcast_attempts_ms_per_step'], key=out['bcast_attempts_ms_per_step'].get)
+    assert out['bcast_algo'] == {'plain': 'broadcast', 'scatter': 'scatter + all-gather'}[best]
+    assert out['roofline']['links_used_per_gpu'] == (2 if best == 'scatter' else 1)
+    c3 = out['sharded_c3']
+    assert c3['config']['N'] == 4096 and c3['roofline']['bound'] == 'xgmi' and c3['value'] > 0
+
