@@ -50,11 +50,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
-    """ compile and link; returns the library path """
+def build_library(force=False, verbose=False, variant=None, defines=()):
+    """ compile and link; returns the library path.  ``variant`` / ``defines``: a second build of the same sources with other
+    compile-time switches (objects under csrc/build_<variant>, library liblsqfitgp_hip_<variant>.so), for same-box A/B runs """
     hipcc = _hipcc()
+    libpath = LIBPATH if variant is None else os.path.join(HERE, f'liblsqfitgp_hip_{variant}.so')
     headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith((".h", ".inc"))] + [os.path.join(HERE, "..", "include", "lsqfitgp_hip.h")]
-    objdir = os.path.join(CSRC, 'build')
+    objdir = os.path.join(CSRC, 'build' if variant is None else f'build_{variant}')
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
@@ -63,7 +65,7 @@ def build_library(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
         objs.append(obj)
         if force or _stale(obj, [srcpath] + headers):
-            cmd = [hipcc] + COMMON + extra + ['-c', srcpath, '-o', obj]
+            cmd = [hipcc] + COMMON + extra + [f'-D{d}' for d in defines] + ['-c', srcpath, '-o', obj]
             if verbose:
                 print(' '.join(cmd))
             procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -73,15 +75,20 @@ def build_library(force=False, verbose=False):
             raise RuntimeError('compilation failed: ' + ' '.join(cmd) + '\n' + out)
         if verbose and out.strip():
             print(out)
-    if force or _stale(LIBPATH, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIBPATH] + objs + ['-ldl']
+    if force or _stale(libpath, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', libpath] + objs + ['-ldl']
         if verbose:
             print(' '.join(cmd))
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if res.returncode != 0:
             raise RuntimeError('link failed: ' + ' '.join(cmd) + '\n' + res.stdout)
-    return LIBPATH
+    return libpath
 
 
 if __name__ == '__main__':
-    print(build_library(verbose=True))
+    import sys
+    # python -m lsqfitgp_amd._build [variant DEFINE[=VALUE] ...]
+    if len(sys.argv) > 1:
+        print(build_library(verbose=True, variant=sys.argv[1], defines=sys.argv[2:]))
+    else:
+        print(build_library(verbose=True))

@@ -188,7 +188,9 @@ _lib = None
 
 
 def library_path():
-    return _build.LIBPATH
+    """ the in-tree library; LGP_LIBRARY names another BUILD of it (same sources, other compile-time switches: the same-box A/B
+    comparisons of tools/ab_lib.sh), never another implementation """
+    return os.environ.get('LGP_LIBRARY') or _build.LIBPATH
 
 
 def load():

@@ -89,6 +89,63 @@ __device__ __forceinline__ void p4_pivot(int r, double &w0, double &w1, double &
   dn = (n == kk) ? d : dn;
 }
 
+// ---- the four pivots 4 r .. 4 r + 3 of a slab TOGETHER (round 5; -DLGP_P4_QUAD=0 compiles the pivot-by-pivot code above instead).
+// The 4 x 4 pivot block is read out of the diagonal tile once (10 values, uniform) and factored as U' D U in uniform arithmetic:
+// the six multipliers and four pivots of the quad are known after three reciprocals, none of which waits for a lane crossing.
+// The rows are then eliminated in the usual order -- row G of every tile as it is after the steps before it, broadcast to the
+// other lane groups through the LDS crossbar, times the lane group's own multiplier -- so the arithmetic on the rows is that of
+// Gaussian elimination (a first version applied the accumulated transformation T = inverse of the unit lower factor to the
+// original rows in one go: equal speed, but for smooth kernels with a small jitter the residual |L L' - A| of a block went
+// from 1e-15 to 1e-13, tools/p4_probe.hip).
+__device__ __forceinline__ double lgp_opaque(double v) {        // (keeps the compiler from sinking a uniform computation into the lanes that select it)
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+__device__ __forceinline__ void p4_quad(int r, double &w0, double &w1, double &w2, double &dg, double &dn, int n, int g) {
+  const int c0 = 4 * r;
+  // (row 0 of the quad is final as it stands: its broadcasts are asked for first, so that the crossbar's ~100 cycles pass beside the
+  // uniform arithmetic below and not behind it)
+  const int a0 = n * 4, a1 = (16 + n) * 4, a2 = (32 + n) * 4;
+  double x = MmaD::bpermute(a0, w0), y = MmaD::bpermute(a0, w1), z = MmaD::bpermute(a0, w2);
+  // the 4 x 4 pivot block, upper part: entry (G, G') of the slab's register r sits at lane 16 G + 4 r + G' of the diagonal tile
+  const double b00 = readlane_d(w0, c0), b01 = readlane_d(w0, c0 + 1), b02 = readlane_d(w0, c0 + 2), b03 = readlane_d(w0, c0 + 3);
+  const double b11 = readlane_d(w0, 16 + c0 + 1), b12 = readlane_d(w0, 16 + c0 + 2), b13 = readlane_d(w0, 16 + c0 + 3);
+  const double b22 = readlane_d(w0, 32 + c0 + 2), b23 = readlane_d(w0, 32 + c0 + 3);
+  const double b33 = readlane_d(w0, 48 + c0 + 3);
+  // U' D U of it (the multiplier m_kG = u_kG / d_k eliminates row G with pivot row k)
+  const double rc0 = rcp_chain(b00);
+  const double m01 = lgp_opaque(b01 * rc0), m02 = lgp_opaque(b02 * rc0), m03 = lgp_opaque(b03 * rc0);
+  const double d1 = __builtin_fma(-m01, b01, b11), c12 = __builtin_fma(-m01, b02, b12), c13 = __builtin_fma(-m01, b03, b13);
+  const double c22 = __builtin_fma(-m02, b02, b22), c23 = __builtin_fma(-m02, b03, b23), c33 = __builtin_fma(-m03, b03, b33);
+  const double rc1 = rcp_chain(d1);
+  const double m12 = lgp_opaque(c12 * rc1), m13 = lgp_opaque(c13 * rc1);
+  const double d2 = __builtin_fma(-m12, c12, c22), e23 = __builtin_fma(-m12, c13, c23), e33 = __builtin_fma(-m13, c13, c33);
+  const double rc2 = rcp_chain(d2);
+  const double m23 = lgp_opaque(e23 * rc2);
+  const double d3 = lgp_opaque(__builtin_fma(-m23, e23, e33));
+  const double d1o = lgp_opaque(d1), d2o = lgp_opaque(d2);
+  // the lane group's own multiplier in each of the three elimination steps (zero where a step leaves the row alone)
+  const bool g1 = g == 1, g2 = g == 2, g3 = g == 3;
+  double q0 = g1 ? m01 : 0.0; q0 = g2 ? m02 : q0; q0 = g3 ? m03 : q0;
+  double q1 = g2 ? m12 : 0.0; q1 = g3 ? m13 : q1;
+  const double q2 = g3 ? m23 : 0.0;
+  w0 = __builtin_fma(-q0, x, w0); w1 = __builtin_fma(-q0, y, w1); w2 = __builtin_fma(-q0, z, w2);
+  x = MmaD::bpermute(a1, w0); y = MmaD::bpermute(a1, w1); z = MmaD::bpermute(a1, w2);      // (lane swaps for the diagonal tile: 317 vs 305 cycles per pivot)
+  w0 = __builtin_fma(-q1, x, w0); w1 = __builtin_fma(-q1, y, w1); w2 = __builtin_fma(-q1, z, w2);
+  x = MmaD::bpermute(a2, w0); y = MmaD::bpermute(a2, w1); z = MmaD::bpermute(a2, w2);
+  w0 = __builtin_fma(-q2, x, w0); w1 = __builtin_fma(-q2, y, w1); w2 = __builtin_fma(-q2, z, w2);
+  double dsel = g1 ? d1o : b00; dsel = g2 ? d2o : dsel; dsel = g3 ? d3 : dsel;
+  dg = dsel;
+  const int nq = n & 3;
+  double dcol = nq == 1 ? d1o : b00; dcol = nq == 2 ? d2o : dcol; dcol = nq == 3 ? d3 : dcol;
+  dn = ((n >> 2) == r) ? dcol : dn;
+}
+
+#ifndef LGP_P4_QUAD
+#define LGP_P4_QUAD 1
+#endif
+
 // ---- the four-wave potf2 (potf2m.hip: the stand-alone kernel; chaint.hip: task P of the task-graph chain kernel)
 constexpr int P4_ROWBUF = 8 * 4 * 64;   // block row s: tile of block column i, register r, lane  (doubles)
 
@@ -109,8 +166,15 @@ __device__ __forceinline__ void potf2m4_step(acc_t (&tA)[4], acc_t (&tB)[8], dou
 #pragma unroll
   for (int r = 0; r < 4; ++r) dt[r] = diagbuf[r * 64 + lane];
   LGP_P4STAMP(2 + 4 * S);
+#if LGP_P4_QUAD
+  // (a wave that owns no tile of this block row in a column works on whatever that register holds: never stored, and cheaper than
+  // the zeroing selects, which the compiler rematerialised in front of every matrix-core instruction)
+  acc_t ta = tA[S < 4 ? S : 0];
+  acc_t tb = tB[S];
+#else
   acc_t ta = hasA ? tA[S < 4 ? S : 0] : acc_t{0, 0, 0, 0};
   acc_t tb = hasB ? tB[S] : acc_t{0, 0, 0, 0};
+#endif
   double dn = 1.0;
   // ---- 2. the 16 pivots: diagonal tile copy + the wave's own tiles of the block row.  Lane crossing by VALU swaps and DPP
   // (chain.h): per pivot  row broadcast of the pivot row -> its entry at the lane's own row index -> multiply -> fma.
@@ -118,10 +182,14 @@ __device__ __forceinline__ void potf2m4_step(acc_t (&tA)[4], acc_t (&tB)[8], dou
   for (int r = 0; r < 4; ++r) {
     double w0 = dt[r], w1 = ta[r], w2 = tb[r];
     double dg = 1.0;
+#if LGP_P4_QUAD
+    p4_quad(r, w0, w1, w2, dg, dn, n, g);
+#else
     p4_pivot<0>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
     p4_pivot<1>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
     p4_pivot<2>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
     p4_pivot<3>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
+#endif
     const bool badv = !(dg > 0.0) || (dg + dg == dg);
     const unsigned long long badm = __builtin_amdgcn_ballot_w64(badv);
     if (badm != 0 && w == wd) {

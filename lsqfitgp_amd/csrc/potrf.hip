@@ -964,22 +964,46 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     // column of 1024 is too few tiles per launch -- right-looking stays).  LGP_CHAIN_LEFT_MAX_N.
     static const size_t left_max_n = getenv("LGP_CHAIN_LEFT_MAX_N") ? (size_t)atol(getenv("LGP_CHAIN_LEFT_MAX_N")) : 8192;
     const bool right_looking = n > left_max_n;
+    // The only thing that waits for this update through its flag word is U1 of the NEXT panel, i.e. the square of block column k+2
+    // (everything else follows in s0's own order).  That square comes first, as a launch of its own with the flag right behind it:
+    // the next square then never waits for the bulk of an update that happens to take longer than a square's 0.53 ms (round 4's
+    // trace at N = 8192: hand-overs of 237 / 380 / 417 / 370 us in front of panels 2-5, where the update with all panels so far
+    // is 0.6-0.7 ms).  LGP_CHAIN_U3_SPLIT=0: one launch, flag behind all of it.
+    static const bool u3_split = !(getenv("LGP_CHAIN_U3_SPLIT") != nullptr && atoi(getenv("LGP_CHAIN_U3_SPLIT")) == 0);
+    const size_t nb2 = rows_r < NB ? rows_r : NB;       // width of panel k+2
+    bool flagged = false;
     if (rows_r > 0 && right_looking) {
       const T *Pa = Pt + nb1 * ldl;                     // (rows_r + nx) x kb
       T *Cc = L + (t0 + nb1) * ldl + (t0 + nb1);
-      const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0) + (double)nx * (double)rows_r;
+      size_t top = 0;
+      if (u3_split && rows_r + nx > nb2) {
+        LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, nb2, nb2, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 2));
+        LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U3), 1, 0));
+        flagged = true;
+        top = nb2;
+      }
+      const size_t mrows = rows_r + nx - top;
+      const double entries = 0.5 * (double)rows_r * ((double)rows_r + 1.0) + (double)nx * (double)rows_r - 0.5 * (double)top * ((double)top + 1.0);
       // (timed for bench.py when it is the 128-tile instantiation that profilers list as gemm_kernel<..., 128, 256, 1>)
-      const bool timed = ((rows_r + nx + 127) / 128) * ((rows_r + 127) / 128) > lgp_gemm_t64_trailing_max();   // lgp_gemm_launch's 128-tile criterion
+      const bool timed = ((mrows + 127) / 128) * ((rows_r + 127) / 128) > lgp_gemm_t64_trailing_max();   // lgp_gemm_launch's 128-tile criterion
       if (timed) LGP_CHECK(lgp_prof_start(ctx, s0, 2.0 * (double)kb * entries));
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, rows_r, kb, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 3));
+      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, mrows, rows_r, kb, T(-1), Pa + top * ldl, ldl, Pa, ldl, T(1), Cc + top * ldl, ldl, true, 3, 0, 0, (int)top));
       if (timed) LGP_CHECK(lgp_prof_stop(ctx, s0));
     } else if (rows_r > 0) {
-      const size_t t2 = t0 + nb1, nb2 = rows_r < NB ? rows_r : NB;
+      const size_t t2 = t0 + nb1;
       const T *Pa = L + t2 * ldl;                       // (rows_r + nx) x t0: every panel so far, the rows from square k+2 down
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, nb2, t0, T(-1), Pa, ldl, Pa, ldl, T(1), L + t2 * ldl + t2, ldl, true, 6));
+      T *Cc = L + t2 * ldl + t2;
+      if (u3_split && rows_r + nx > nb2) {
+        LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, nb2, nb2, t0, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 6));
+        LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U3), 1, 0));
+        flagged = true;
+        LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx - nb2, nb2, t0, T(-1), Pa + nb2 * ldl, ldl, Pa, ldl, T(1), Cc + nb2 * ldl, ldl, false, 6));
+      } else {
+        LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, nb2, t0, T(-1), Pa, ldl, Pa, ldl, T(1), Cc, ldl, true, 6));
+      }
     }
     ctx->gemm_thin_lds = 0;
-    LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U3), 1, 0));
+    if (!flagged) LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U3), 1, 0));
   }
   // the factor is complete on the caller's stream when the chain kernel has left and every row group is done
   LGP_HIP(hipStreamWaitEvent(s0, E(EV_SQ), 0));
