@@ -78,6 +78,79 @@ class Decomposition(abc.ABC):
         """ Minus log of a Normal density with covariance K, and derivatives
         (``_decomp.py:181-243``) """
 
+    @classmethod
+    def make_derivs(cls, K_fun, r_fun, primal, *, args=(), kw={}, vec=None, value=False, gradrev=False, gradfwd=False, fisher=False,
+                    fishvec=False):
+        """
+        Prepares the derivative arguments of `minus_log_normal_density` (``_decomp.py:588-652``: same signature, same returns
+        ``(K, r, out)`` with ``out`` holding ``dK_vjp`` / ``dr_vjp`` for ``gradrev`` and ``fishvec``, ``dK_jvp_vec`` /
+        ``dr_jvp_vec`` for ``fishvec``, ``dK`` (n, n, p) / ``dr`` (n, p) for ``gradfwd`` and ``fisher``).
+
+        The reference gets them from jax (``vjp`` / ``jvp`` / ``jacfwd`` of the traced functions).  Here ``K_fun(primal, *args,
+        **kw)`` and ``r_fun`` are evaluated ONCE on a `Dual` primal that carries the p unit tangents (forward mode through the
+        Python operators and numpy ufuncs the functions use, ``lsqfitgp_amd/_dual.py``); the Jacobians are formed from the
+        tangents, and the vector-Jacobian products are contractions with them -- with p hyperparameters and n^2 outputs that is
+        what reverse mode would compute as well.  Functions whose arithmetic `Dual` does not cover (a ``NotImplementedError`` /
+        ``TypeError`` / ``ValueError`` on the dual primal, or tangents that disagree with one directional central difference
+        because a dual number was turned into a float on the way) are differentiated by central differences with a step of
+        6e-6 max(1, |primal_k|): slower and good to ~1e-9 relative instead of to rounding.
+        """
+        from .._dual import Dual, split
+        primal = numpy.asarray(primal, float)
+        if primal.ndim != 1:
+            raise ValueError(f'primal must be a 1d array, found shape {primal.shape}')
+        p = primal.size
+        f = lambda fun: (lambda x: fun(x, *args, **kw))
+        K_fun, r_fun = f(K_fun), f(r_fun)
+
+        steps = 6e-6 * numpy.maximum(1., numpy.abs(primal))
+
+        def central(fun, direction):
+            return (numpy.asarray(fun(primal + steps * direction), float) - numpy.asarray(fun(primal - steps * direction), float)) / 2
+
+        def jacobian(fun):
+            """ value and Jacobian (value.shape + (p,)) """
+            try:
+                out = fun(Dual(primal, {k: numpy.eye(p)[k] for k in range(p)}))
+                val, tan = split(out)
+                val = numpy.asarray(val, float)
+                jac = numpy.zeros(val.shape + (p,))
+                for k, t in tan.items():
+                    jac[..., k] = numpy.broadcast_to(numpy.asarray(t, float), val.shape)
+                # arithmetic that turns a dual number into a float on the way (an assignment into a float array, ``float(x)``)
+                # loses its tangent without an error: one directional central difference says whether that happened
+                direction = numpy.random.default_rng(0).choice([-1., 1.], p)
+                fd = central(fun, direction)
+                if not numpy.allclose(jac @ (steps * direction), fd, rtol=1e-4, atol=1e-7 * max(1., float(numpy.max(numpy.abs(val), initial=0.))) * float(steps.max())):
+                    raise ValueError('the tangents of the dual evaluation disagree with a central difference')
+                return val, jac
+            except (NotImplementedError, TypeError, ValueError):
+                val = numpy.asarray(fun(primal), float)
+                jac = numpy.empty(val.shape + (p,))
+                for k in range(p):
+                    e = numpy.zeros(p)
+                    e[k] = 1.
+                    jac[..., k] = central(fun, e) / steps[k]
+                return val, jac
+
+        out = {}
+        if gradrev or fishvec or gradfwd or fisher:
+            K, dK = jacobian(K_fun)
+            r, dr = jacobian(r_fun)
+        else:
+            K, r = numpy.asarray(K_fun(primal), float), numpy.asarray(r_fun(primal), float)
+        if gradrev or fishvec:
+            out['dK_vjp'] = lambda x: numpy.einsum('ij,ijk->k', numpy.asarray(x), dK)
+            out['dr_vjp'] = lambda x: numpy.asarray(x) @ dr
+        if fishvec:
+            vec = numpy.asarray(vec, float)
+            out['dK_jvp_vec'] = dK @ vec
+            out['dr_jvp_vec'] = dr @ vec
+        if gradfwd or fisher:
+            out['dK'] = dK
+            out['dr'] = dr
+        return K, r, out
+
     @property
     def eps(self):
         """ The threshold below which eigenvalues are too small to be determined """

@@ -965,11 +965,13 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     static const size_t left_max_n = getenv("LGP_CHAIN_LEFT_MAX_N") ? (size_t)atol(getenv("LGP_CHAIN_LEFT_MAX_N")) : 8192;
     const bool right_looking = n > left_max_n;
     // The only thing that waits for this update through its flag word is U1 of the NEXT panel, i.e. the square of block column k+2
-    // (everything else follows in s0's own order).  That square comes first, as a launch of its own with the flag right behind it:
-    // the next square then never waits for the bulk of an update that happens to take longer than a square's 0.53 ms (round 4's
-    // trace at N = 8192: hand-overs of 237 / 380 / 417 / 370 us in front of panels 2-5, where the update with all panels so far
-    // is 0.6-0.7 ms).  LGP_CHAIN_U3_SPLIT=0: one launch, flag behind all of it.
-    static const bool u3_split = !(getenv("LGP_CHAIN_U3_SPLIT") != nullptr && atoi(getenv("LGP_CHAIN_U3_SPLIT")) == 0);
+    // (everything else follows in s0's own order).  LGP_CHAIN_U3_SPLIT=1 (round 5, off): that square first, as a launch of its own
+    // with the flag right behind it, so that the next square never waits for the bulk of an update.  Measured on one box: N = 8192
+    // 6.33-6.44 against 6.18-6.30 ms, N = 12288 16.1 against 14.9 (the rest of a right-looking update as a row slab loses its
+    // triangular tile map), N = 16384 equal.  The kernel trace says why it cannot help: in the middle panels of N = 8192 it is the
+    // rows below the square (16 dependent launches per panel, 2-3 times slower beside the update than alone: 733 us against the
+    // square's 530) that the next square waits for, not this flag (profiles/r05_chain_timeline_8192.txt).
+    static const bool u3_split = getenv("LGP_CHAIN_U3_SPLIT") != nullptr && atoi(getenv("LGP_CHAIN_U3_SPLIT")) != 0;
     const size_t nb2 = rows_r < NB ? rows_r : NB;       // width of panel k+2
     bool flagged = false;
     if (rows_r > 0 && right_looking) {

@@ -82,3 +82,53 @@ def test_zero_tangents_are_dropped():
 def test_unsupported_ufunc_is_refused():
     with pytest.raises(NotImplementedError):
         np.arccosh(Dual(2., {'a': 1.}))
+
+
+def test_make_derivs_forms_what_minus_log_normal_density_takes():
+    import numpy
+    """ `Decomposition.make_derivs` (reference: _linalg/_decomp.py:588-652 over jax): Jacobians from ONE evaluation on a dual primal,
+    against central differences; a function that turns a dual number into a float on the way (assignment into a float array) is
+    noticed and differentiated by central differences instead of returning a Jacobian that silently misses a term """
+    from lsqfitgp_amd._linalg._decomp import Decomposition
+    n = 6
+    rng = numpy.random.default_rng(3)
+    Q = numpy.linalg.qr(rng.standard_normal((n, n)))[0]
+    z = rng.standard_normal(n)
+
+    def K_fun(s, shift, scale=1.):
+        ev = shift + numpy.cos(s[0] + numpy.arange(n)) * numpy.exp(0.1 * s[1]) * scale
+        return (Q * ev) @ Q.T
+
+    def r_fun(s, shift, scale=1.):
+        return s[0] * z + numpy.sin(s[1]) * scale
+
+    def K_lossy(s, shift, scale=1.):
+        rot = numpy.eye(n)
+        rot[0, 0] = numpy.cos(s[0])             # (float(dual): the tangent is gone, no error)
+        return rot @ K_fun(s, shift, scale) @ rot.T
+
+    s = numpy.array([0.3, -0.7])
+    vec = numpy.array([1., 2.])
+
+    def fd(f, k, h=1e-6):
+        e = numpy.zeros(2)
+        e[k] = h
+        return (f(s + e, 1.5, scale=2.) - f(s - e, 1.5, scale=2.)) / (2 * h)
+
+    for Kf in (K_fun, K_lossy):
+        K, r, out = Decomposition.make_derivs(Kf, r_fun, s, args=(1.5,), kw=dict(scale=2.), vec=vec, gradrev=True, gradfwd=True, fisher=True, fishvec=True)
+        numpy.testing.assert_array_equal(K, Kf(s, 1.5, scale=2.))
+        numpy.testing.assert_array_equal(r, r_fun(s, 1.5, scale=2.))
+        assert out['dK'].shape == (n, n, 2) and out['dr'].shape == (n, 2)
+        for k in range(2):
+            numpy.testing.assert_allclose(out['dK'][..., k], fd(Kf, k), atol=2e-8)
+            numpy.testing.assert_allclose(out['dr'][..., k], fd(r_fun, k), atol=2e-8)
+        X = rng.standard_normal((n, n))
+        numpy.testing.assert_allclose(out['dK_vjp'](X), numpy.einsum('ij,ijk->k', X, out['dK']))
+        numpy.testing.assert_allclose(out['dr_vjp'](z), z @ out['dr'])
+        numpy.testing.assert_allclose(out['dK_jvp_vec'], out['dK'] @ vec)
+        numpy.testing.assert_allclose(out['dr_jvp_vec'], out['dr'] @ vec)
+    assert Decomposition.make_derivs(K_fun, r_fun, s, args=(1.5,))[2] == {}
+    with pytest.raises(ValueError):
+        Decomposition.make_derivs(K_fun, r_fun, s.reshape(1, 2), args=(1.5,))
+

@@ -36,6 +36,36 @@ class TestDeviceChol(DecompTestBase):
         assert isinstance(decomp, lsqfitgp_amd.Decomposition)
 
 
+    # the reference's derivative tests as it writes them, through `make_derivs` (tests/linalg/test_decomp.py:227-261); jax.jacrev /
+    # jacfwd of the likelihood are replaced by central differences of it, `_linalg.solve_batched` is the device one
+    def test_make_derivs_gradrev(self, likelihood, s, decomp, r, r_factory, K_factory):
+        _, _, kw = decomp.make_derivs(K_factory, r_factory, s, gradrev=True)
+        _, result, _, _, _ = decomp.minus_log_normal_density(r, gradrev=True, **kw)
+        util.assert_close_matrices(np.atleast_1d(result), np.atleast_1d(self._fd(likelihood, s)), rtol=1e-5, atol=1e-7)
+
+    def test_make_derivs_gradfwd(self, likelihood, s, decomp, r, r_factory, K_factory):
+        _, _, kw = decomp.make_derivs(K_factory, r_factory, s, gradfwd=True)
+        _, _, result, _, _ = decomp.minus_log_normal_density(r, gradfwd=True, **kw)
+        util.assert_close_matrices(np.atleast_1d(result), np.atleast_1d(self._fd(likelihood, s)), rtol=1e-5, atol=1e-7)
+
+    def test_make_derivs_fisher_and_fishvec(self, s, decomp, r, K, K_factory, r_factory, rng):
+        import lsqfitgp_amd
+        Kout, rout, kw = decomp.make_derivs(K_factory, r_factory, s, fisher=True)
+        np.testing.assert_array_equal(Kout, K)
+        np.testing.assert_array_equal(rout, r)
+        assert kw['dK'].shape == K.shape + s.shape and kw['dr'].shape == r.shape + s.shape
+        _, _, _, result, _ = decomp.minus_log_normal_density(r, fisher=True, **kw)
+        dK, dr = kw['dK'], kw['dr']
+        invK_dK = lsqfitgp_amd._linalg.solve_batched(K, np.moveaxis(dK, 2, 0), assume_a='pos')
+        expected = 1/2 * np.einsum('kij,qji->kq', invK_dK, invK_dK) + dr.T @ linalg.solve(K, dr, assume_a='pos')
+        util.assert_close_matrices(np.atleast_2d(result), expected, rtol=1e-9)
+        vec = rng.standard_normal(s.shape)
+        _, _, kw = decomp.make_derivs(K_factory, r_factory, s, fishvec=True, vec=vec)
+        assert sorted(kw) == ['dK_jvp_vec', 'dK_vjp', 'dr_jvp_vec', 'dr_vjp']
+        _, _, _, _, fv = decomp.minus_log_normal_density(r, fishvec=True, **kw)
+        util.assert_close_matrices(np.atleast_1d(fv), expected @ vec, rtol=1e-9)
+
+
 def randpd(rng, n, dtype=np.float64, cond_shift=0.5):
     Q = rng.standard_normal((n, n))
     return (Q @ Q.T / n + np.eye(n) * cond_shift).astype(dtype)
