@@ -262,8 +262,8 @@ def cpu_baseline(main_cfg):
     """ CPU baseline on this box's host cores: the C++ / OpenMP backend behind the
     library's C-ABI (`kind` "port": a restatement of the reference's path, not the reference), one warm-up + best of N, with
     all the CPUs this process may use and with one; beside it the numpy / scipy oracle (LAPACK potrf / trsm, what JAX-CPU lowers
-    to) with its BLAS threads capped to the same CPUs.  C2 at N = 8192, C3 at N = 8192 and ONCE at its full N = 32768, C5's
-    Gram rows with the numpy oracle.  About a minute in all. """
+    to) with its BLAS threads capped to the same CPUs.  C2 at N = 8192, C3 at N = 8192 and at its full N = 32768 (best of 3), C5's
+    Gram rows with the numpy oracle (256 of the 4096 rows timed, the full matrix extrapolated and labelled so).  About 80 s in all. """
     from threadpoolctl import threadpool_limits, threadpool_info
     from oracle import cpu as cpu_backend
     info = threadpool_info()
@@ -295,7 +295,7 @@ def cpu_baseline(main_cfg):
         out[name] = {'all_cores': best_backend(cfg, 8192, cpus, 5), 'one_core': best_backend(cfg, 4096, 1, 3),
                      'numpy_scipy_oracle_all_cores': best_oracle(cfg, 8192, cpus, 2)}
     try:
-        out['c3']['full_size_all_cores'] = best_backend(CONFIGS['c3'], CONFIGS['c3']['n'], cpus, 1)
+        out['c3']['full_size_all_cores'] = best_backend(CONFIGS['c3'], CONFIGS['c3']['n'], cpus, 3)
     except MemoryError as exc:
         out['c3']['full_size_all_cores'] = {'error': repr(exc)}
     try:        # C5: rows of the BART Gram matrix of the real workload by the numpy oracle + the f64 factorisation by the backend
@@ -312,7 +312,9 @@ def cpu_baseline(main_cfg):
         K = np.eye(4096) * 5 + 0.5
         t0 = time.perf_counter(); be.chol(K); tc = time.perf_counter() - t0
         out['c5'] = {'bart_gram_pairs_per_s': rows * 4096 / tg, 'bart_gram_rows_timed': rows, 'bart_gram_full_matrix_s_extrapolated': tg * 4096 / rows,
-                     'cholesky_4096_s': tc, 'threads': cpus, 'note': 'numpy oracle Gram rows (vectorised over pairs) + C++ backend Cholesky'}
+                     'cholesky_4096_s': tc, 'threads': cpus,
+                     'note': 'numpy oracle Gram rows (vectorised over pairs) + C++ backend Cholesky; the Gram time of the full 4096 x 4096 matrix is EXTRAPOLATED from '
+                             f'the {rows} rows timed (the pairs are independent: linear in the rows)'}
         assert blk.shape == (rows, 4096)
     except Exception as exc:
         out['c5'] = {'error': repr(exc)}
@@ -483,23 +485,26 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4          # wave64 vector instructions per n
 
 def bart_roofline(n, ms):
     """ the BART Gram kernel is bound by vector-ALU ISSUE, not by HBM (4 bytes written per pair = 0.17 TB/s): its roofline is
-    the wave64 VALU instruction rate.  Instructions per pair from the committed counter pass (profiles/r03_c5_bart_valu.json:
+    the wave64 VALU instruction rate.  Instructions per pair from the committed counter pass (profiles/rNN_c5_bart_valu.json, the newest:
     SQ_INSTS_VALU of one launch / pairs, p = 10 axes x 5 iterations of the depth-2 closed form, fp32 without contraction);
     achieved = that count x pairs of this launch / its duration measured live """
-    per_pair = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_c5_bart_valu.json')) as f:
-            d = json.load(f)
-        per_pair = d['SQ_INSTS_VALU'] / d['pairs']           # wave instructions per pair (each covers 64 pairs' worth of lanes)
-    except Exception:
-        pass
+    per_pair = source = None
+    for tag in ('r05', 'r04', 'r03'):                        # the newest committed counter pass (tools/pmc_bart.sh)
+        try:
+            with open(os.path.join(ROOT, 'profiles', f'{tag}_c5_bart_valu.json')) as f:
+                d = json.load(f)
+            per_pair = d['SQ_INSTS_VALU'] / d['pairs']       # wave instructions per pair (each covers 64 pairs' worth of lanes)
+            source = f'profiles/{tag}_c5_bart_valu.json'
+            break
+        except Exception:
+            continue
     out = {'kernel': 'gram_bart_kernel<float> (N x N)', 'ms': ms, 'gpairs_per_s': n * n / (ms * 1e-3) / 1e9,
            'hbm_written_GB_per_s': 4. * n * n / (ms * 1e-3) / 1e9,
            'note': 'bin indices uploaded once (kernel.prepare), output preallocated; includes the per-call upload of the per-axis constants'}
     if per_pair is not None:
         ach = per_pair * n * n / (ms * 1e-3) / 1e9
         out.update({'bound': 'valu', 'achieved': ach, 'peak': VALU_PEAK_GINSTR, 'unit': 'G wave-instructions/s', 'frac': ach / VALU_PEAK_GINSTR,
-                    'valu_lane_instructions_per_pair': per_pair * 64})
+                    'valu_lane_instructions_per_pair': per_pair * 64, 'instruction_count_source': source})
     return out
 
 
@@ -550,13 +555,15 @@ def pmc_traffic(config):
     """ HBM bytes per trailing-update launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE
     x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, collected in their own runs of this same
     command); counters cannot be read live from inside the process, so None when no committed pass matches """
-    path = next((q for q in (os.path.join(ROOT, 'profiles', f'{tag}_{config}_pmc_traffic.json') for tag in ('r04', 'r03', 'r02', 'r01')) if os.path.exists(q)), '')
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return d['hbm_read_bytes_per_launch_corrected'] + d['hbm_write_bytes_per_launch']
-    except Exception:
-        return None
+    for tag in ('r05', 'r04', 'r03', 'r02', 'r01'):          # the newest committed pass that holds numbers
+        path = os.path.join(ROOT, 'profiles', f'{tag}_{config}_pmc_traffic.json')
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            return d['hbm_read_bytes_per_launch_corrected'] + d['hbm_write_bytes_per_launch'], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def init_transport(ctx, rdzv, rank, world):
@@ -982,7 +989,8 @@ def main():
             'peak': FP64_MFMA_PEAK_TFLOPS,
             'unit': 'TFLOP/s',
             'frac': achieved / FP64_MFMA_PEAK_TFLOPS if achieved else None,
-            'traffic': pmc_traffic(args.config),
+            'traffic': pmc_traffic(args.config)[0],
+            'traffic_source': pmc_traffic(args.config)[1],       # (counters cannot be read from inside the process: a committed rocprofv3 --pmc pass of this command)
             'launches': int(launches.value),
             'avg_launch_ms': tot_ms.value / max(launches.value, 1),
             'avg_launch_gflop': tot_fl.value / max(launches.value, 1) / 1e9,

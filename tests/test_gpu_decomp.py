@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import oracle
+from scipy import linalg
 from . import util
 from .test_oracle_decomp import DecompTestBase
 

@@ -27,12 +27,21 @@ trace = one('stats/**/*kernel_trace.csv')
 tr = list(csv.DictReader(open(trace)))
 def is_nt(name):
     return 'gemm_kernel<double, false, true, 128' in name or 'gemm_kernelIdLb0ELb1ELi128' in name
-def is_trailing(name):   # the TAG = 1 instantiation (lgp_potrf_impl's trailing update)
+def is_trailing_128(name):   # the TAG = 1 instantiation (lgp_potrf_impl's trailing update)
     return 'gemm_kernel<double, false, true, 128, 256, 1>' in name or 'gemm_kernelIdLb0ELb1ELi128ELi256ELi1E' in name
+def is_small_path(name):     # configurations that never launch it (C2: N = 8192): their updates are the 64-tile NT instantiation, beside the chain kernel
+    return 'gemm_kernel<double, false, true, 64' in name or 'gemm_kernelIdLb0ELb1ELi64' in name or 'chain_kernel' in name
+is_trailing = is_trailing_128
 bench = json.loads(open(os.path.join(out, 'bench_stats.json')).read().strip().splitlines()[-1])
 n_launch = bench['roofline']['launches']
 nt = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in tr if is_trailing(r['Kernel_Name'])]
 summary = {'bench_line_under_rocprof': bench}
+matched = 'gemm_kernel<double, false, true, 128, 256, 1> (the trailing updates on 128-tiles)'
+if not nt:       # no 128-tile trailing update in this configuration: the counters below are those of its 64-tile updates + the chain kernel
+    is_trailing = is_small_path
+    matched = 'gemm_kernel<double, false, true, 64, ...> + chain_kernel (this configuration launches no 128-tile trailing update)'
+    nt = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in tr if is_trailing(r['Kernel_Name'])]
+summary['kernels_matched'] = matched
 if nt:
     summary['trailing_update_launches_in_trace'] = len(nt)      # warmup + timed steps
     summary['trailing_update_avg_ms_in_trace'] = sum(nt) / len(nt) / 1e6
@@ -67,6 +76,7 @@ alg = None
 res = {
     'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 1 step of bench.py %s); units KB; gfx950 '
             'correction: FETCH_SIZE x2 for wide coalesced reads (MI355X_MICROARCH.md HBM section)' % cfg,
+    'kernels_matched': matched,
     'trailing_update_launches_bench': launches,
     'trailing_update_launches_matched': len(tf),
     'fetch_size_kb_sum': sum(d[2] for d in tf),
@@ -78,8 +88,9 @@ if tf:
     res['hbm_read_bytes_per_launch_corrected'] = 2 * 1024 * res['fetch_size_kb_sum'] / len(tf)
     res['hbm_write_bytes_per_launch'] = 1024 * res['write_size_kb_sum'] / max(len(tw), 1)
     # algorithmic bytes of an average launch: read + write the lower triangle of C once, read the panel once
-    res['algorithmic_bytes_per_launch_avg'] = b1['roofline']['avg_launch_gflop'] * 1e9 / (2.0 * 1024) * 8 * 2
-    res['traffic_over_algorithmic'] = (res['hbm_read_bytes_per_launch_corrected'] + res['hbm_write_bytes_per_launch']) / res['algorithmic_bytes_per_launch_avg']
+    if b1['roofline']['avg_launch_gflop']:
+        res['algorithmic_bytes_per_launch_avg'] = b1['roofline']['avg_launch_gflop'] * 1e9 / (2.0 * 1024) * 8 * 2
+        res['traffic_over_algorithmic'] = (res['hbm_read_bytes_per_launch_corrected'] + res['hbm_write_bytes_per_launch']) / res['algorithmic_bytes_per_launch_avg']
 with open(os.path.join(dst, f'{tag}_{cfg}_pmc_traffic.json'), 'w') as f:
     json.dump(res, f, indent=1)
 print(json.dumps(res, indent=1))
@@ -93,7 +104,7 @@ try:
     nl = sum(1 for r in mtrace if is_trailing(r['Kernel_Name']))
     util = {
         'note': 'rocprofv3 --kernel-trace --pmc ' + ' '.join(names) + ' (1 step of bench.py %s), sums over the trailing-update launches (tag-1 gemm)' % cfg,
-        'launches': nl, 'duration_ms_sum': dur_ns / 1e6, **sums,
+        'kernels_matched': matched, 'launches': nl, 'duration_ms_sum': dur_ns / 1e6, **sums,
         # an fp64 16x16x4 MFMA occupies its SIMD for 64 cycles (tools/f64_rate_probe.hip); 1024 SIMDs; the counter sums all SEs/XCDs
         'mfma_pipe_busy_frac_from_insts': sums['SQ_INSTS_MFMA'] * 64 / (dur_ns * 1e-9 * 2.4e9 * 1024) if dur_ns else None,
         'mfma_busy_cycles_per_mfma_inst': sums['SQ_VALU_MFMA_BUSY_CYCLES'] / sums['SQ_INSTS_MFMA'] if sums['SQ_INSTS_MFMA'] else None,
