@@ -243,6 +243,7 @@ int lgp_ctx_destroy(lgp_ctx *c) {
   for (const auto &e : c->chain_sched) (void)hipFree(e.tasks);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
@@ -663,6 +664,17 @@ int lgp_predict_isotropic_f64(lgp_ctx *c, int kernel, int p, int npar, const dou
   LGP_REQUIRE(nx >= m + 1 && ldl >= n, "the carried rows: nx >= m + 1, ldl >= n");
   DeviceGuard dg(c->device);
   hipStream_t st = c->stream;
+  if (lgp_predict_small_fits(kernel, d, n, m)) {
+    // a small problem: one launch of one workgroup does all of it, inputs and results through mapped host memory (gram.hip)
+    int info = 0;
+    double *dnz = dwork + m * m + m + 2;
+    LGP_CHECK(lgp_predict_small_f64(c, kernel, p, npar, hpar, d, hpts, n, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, hy, hnoise, dP, dL, ldl,
+                                    nx, ddblk, dnz, hout, heps_out, &info));
+    if (info != 0) return info;
+    double *h = hout + m * m + m;                               // _decomp.py:484-488
+    h[0] = 0.5 * ((double)n * std::log(2 * M_PI) + 2.0 * h[0] + h[1]);
+    return LGP_OK;
+  }
   // the uploads below read the caller's pageable host buffers asynchronously: no path out of this function may leave them in flight
   struct Drain {
     hipStream_t s;

@@ -39,6 +39,7 @@ struct lgp_ctx {
   void *d_scratch = nullptr;          // small reductions (>= 64 KiB)
   size_t scratch_bytes = 0;
   void *h_pinned = nullptr;           // pinned host staging for scalar results (4 KiB)
+  void *h_small = nullptr;            // pinned, device-mapped staging of the one-launch small prediction (1 MiB, created on first use; gram.hip)
   void *comm = nullptr;               // ncclComm_t
   // alternative transport: collectives done by a caller-supplied host function on a staged copy (lgp_comm_init_host)
   int (*hostfn)(void *user, int op, void *hbuf, size_t count, int root) = nullptr;
@@ -244,6 +245,11 @@ template <typename T>
 int lgp_trsm_impl(lgp_ctx *ctx, hipStream_t stream, size_t n, const T *L, size_t ldl, const T *dblk, int trans, T *B, size_t ldb, size_t nrhs);
 
 int lgp_extract_dblk_public(lgp_ctx *ctx, hipStream_t stream, const double *L, size_t ldl, size_t n, double *dblk);   // potrf.hip
+// the whole prediction of a small problem in one launch (gram.hip); lgp_predict_isotropic_f64 takes it when it fits
+bool lgp_predict_small_fits(int kernel, int d, size_t n, size_t m);
+int lgp_predict_small_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d, const double *hpts, size_t n, size_t m, int has_loc, double loc,
+                          int has_scale, double scale, int nops, const int *hops_code, const double *hops_val, const double *hy, const double *hnoise,
+                          double *dP, double *dL, size_t ldl, size_t nx, double *ddblk, double *dnoise, double *hout, double *heps_out, int *info_out);
 
 // ---- reductions (elementwise.hip) -------------------------------------------------------------
 template <typename T>

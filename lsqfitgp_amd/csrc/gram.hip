@@ -1772,6 +1772,238 @@ extern "C" int lgp_gram_bart_jvp_f64(lgp_ctx *ctx, int p, const int32_t *dix, si
 }
 
 // ---- Gram build + Chol.__init__ in one call: the matrix K = kernel(x, x) + diag(noise) goes straight into the factor ----
+// ---- the whole prediction of a SMALL problem in one launch of one workgroup (round 5) --------------------------------------------
+// docs/userguide/optim.rst:88-159 times `predfromdata` at N = 10: there the general path's fifteen launches (two Gram kernels, the
+// fused build, scales, eps, a 34 us potf2 of a 10 x 10 block, substitutions, products, three copies) cost 0.25 ms of the 0.31.
+// For n <= 64, m <= 256, n (n + m + 2) <= 18000 doubles of LDS everything happens here: points transformed, K = kernel(x, x) +
+// noise built in full, s = pow2 scales (_decomp.py:356-361), K~ = K / s / s', Gershgorin bound and jitter (:349-354,245-255),
+// Cholesky of K~ + eps I (:388), [Kxxs | y] scaled and solved against it, mean = X' x_y, cov = Kxsxs - X' X (_compute.py:254-260),
+// log-determinant and |x_y|^2 (:484-488).  Inputs are read from, and the results written to, pinned host memory that the
+// device maps: no copy engine, one launch, one synchronisation.  The factor, L = s L~, and the solved rows go to the device
+// buffers the caller keeps for the questions that follow (Chol._adopt).
+struct SmallIO {
+  const double *hpts, *hy, *hnoise;     // mapped host memory: coordinate f of point i at hpts[f (n + m) + i]; noise may be null
+  double *hout;                         // mapped host memory: cov (m m), mean (m), sum log L_ii, |L^-1 y|^2, eps, eps min s^2, info
+  double *dP, *dL, *dnoise;             // device: the points, the factor with the carried rows below, the noise vector
+  long ldl;
+  int nx;
+};
+
+__global__ void __launch_bounds__(256) predict_small_kernel(const IsoArgs<double> g, const SmallIO io) {
+  typedef double T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int n = g.n, m = g.m, d = g.d, np = n + m, lda = n + 1, mw = m + 1;
+  T *pt = reinterpret_cast<T *>(smem_raw);           // [d][n + m] transformed coordinates
+  T *A = pt + (size_t)d * np;                        // [n][n + 1]
+  T *W = A + (size_t)n * lda;                        // [n][m + 1]: Kxxs | y, then X = L~^-1 of it
+  T *sinv = W + (size_t)n * mw;                      // [n] 1 / s_i
+  T *red = sinv + n;                                 // [256] reductions
+  __shared__ T sh_eps, sh_piv;
+  __shared__ int sh_bad;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < d * np; idx += 256) {
+    T v = io.hpts[idx];
+    io.dP[idx] = v;
+    if (g.has_loc) v = v - g.loc;
+    if (g.has_scale) v = v / g.scale;
+    pt[idx] = v;
+  }
+  const T k0 = g.ops.apply(iso_core<T>(g, T(0)));
+  for (int i = tid; i < n; i += 256) {
+    const T nz = io.hnoise ? io.hnoise[i] : T(0);
+    if (io.hnoise) io.dnoise[i] = nz;
+    sinv[i] = T(1) / pow2_scale<T>(k0 + nz);
+  }
+  if (tid == 0) sh_bad = 0;
+  __syncthreads();
+  auto pair = [&](int i, int j) {                    // kernel of points i and j (indices into the n + m points), output operations applied
+    T r2 = T(0);
+    for (int f = 0; f < d; ++f) {
+      const T df = pt[f * np + i] - pt[f * np + j];
+      r2 = (f == 0) ? df * df : r2 + df * df;
+    }
+    return g.ops.apply(iso_core<T>(g, r2));
+  };
+  for (int idx = tid; idx < n * n; idx += 256) {
+    const int i = idx / n, j = idx % n;
+    T v = pair(i, j);
+    if (i == j) v = v + (io.hnoise ? io.hnoise[i] : T(0));
+    A[i * lda + j] = v * sinv[j] * sinv[i];
+  }
+  for (int idx = tid; idx < n * mw; idx += 256) {
+    const int i = idx / mw, c = idx % mw;
+    const T v = c < m ? pair(i, n + c) : io.hy[i];
+    W[i * mw + c] = v * sinv[i];
+  }
+  __syncthreads();
+  // Gershgorin: max_i sum_j |K~_ij|, and min s^2
+  T mx = -INFINITY, mn = INFINITY;
+  int isnan_ = 0;
+  for (int i = tid; i < n; i += 256) {
+    T rs = T(0);
+    for (int j = 0; j < n; ++j) rs += fabs(A[i * lda + j]);
+    if (rs != rs) isnan_ = 1;
+    mx = rs > mx ? rs : mx;
+    const T si = T(1) / sinv[i], s2 = si * si;
+    mn = s2 < mn ? s2 : mn;
+  }
+  red[tid] = isnan_ ? T(NAN) : mx;
+  __syncthreads();
+  if (tid == 0) {
+    T v = -INFINITY;
+    bool bad = false;
+    for (int t = 0; t < 256 && t < n; ++t) { if (red[t] != red[t]) bad = true; v = red[t] > v ? red[t] : v; }
+    const T maxeig = bad ? T(NAN) : v;
+    sh_eps = T(n) * T(2.220446049250313e-16) * maxeig;      // epsrel = 'auto', epsabs = 0 (_decomp.py:245-255)
+  }
+  __syncthreads();
+  red[tid] = mn;
+  const T eps = sh_eps;
+  __syncthreads();
+  if (tid == 0) {
+    T v = INFINITY;
+    for (int t = 0; t < 256 && t < n; ++t) v = red[t] < v ? red[t] : v;
+    io.hout[(size_t)m * m + m + 2] = eps;
+    io.hout[(size_t)m * m + m + 3] = eps * v;               // eps min s^2 (:393)
+  }
+  for (int i = tid; i < n; i += 256) A[i * lda + i] += eps;
+  __syncthreads();
+  // right-looking Cholesky of the lower triangle, column by column
+  for (int k = 0; k < n; ++k) {
+    if (tid == 0) {
+      const T dk = A[k * lda + k];
+      if (!(dk > T(0)) || dk + dk == dk) { if (!sh_bad) sh_bad = k + 1; sh_piv = T(NAN); }
+      else sh_piv = sqrt(dk);
+    }
+    __syncthreads();
+    const T lk = sh_piv;
+    for (int i = k + tid; i < n; i += 256) A[i * lda + k] = (i == k) ? lk : A[i * lda + k] / lk;
+    __syncthreads();
+    const int rem = n - k - 1;
+    for (int idx = tid; idx < rem * rem; idx += 256) {
+      const int i = k + 1 + idx / rem, j = k + 1 + idx % rem;
+      if (j <= i) A[i * lda + j] -= A[i * lda + k] * A[j * lda + k];
+    }
+    __syncthreads();
+  }
+  // X = L~^-1 W, one column per thread
+  for (int c = tid; c < mw; c += 256) {
+    for (int i = 0; i < n; ++i) {
+      T acc = W[i * mw + c];
+      for (int j = 0; j < i; ++j) acc -= A[i * lda + j] * W[j * mw + c];
+      W[i * mw + c] = acc / A[i * lda + i];
+    }
+  }
+  __syncthreads();
+  // posterior: straight to the mapped host buffer
+  for (int idx = tid; idx < m * m; idx += 256) {
+    const int a = idx / m, b = idx % m;
+    T q = T(0);
+    for (int i = 0; i < n; ++i) q += W[i * mw + a] * W[i * mw + b];
+    io.hout[idx] = pair(n + a, n + b) - q;
+  }
+  for (int a = tid; a < m; a += 256) {
+    T q = T(0);
+    for (int i = 0; i < n; ++i) q += W[i * mw + a] * W[i * mw + m];
+    io.hout[(size_t)m * m + a] = q;
+  }
+  if (tid == 0) {
+    T ld = T(0), q = T(0);
+    for (int i = 0; i < n; ++i) { ld += log(A[i * lda + i] / sinv[i]); q += W[i * mw + m] * W[i * mw + m]; }
+    io.hout[(size_t)m * m + m] = ld;
+    io.hout[(size_t)m * m + m + 1] = q;
+    io.hout[(size_t)m * m + m + 4] = (T)sh_bad;
+  }
+  // the factor L = s L~ (zeros above the diagonal) and the solved rows, for the caller's later questions
+  for (int idx = tid; idx < n * n; idx += 256) {
+    const int i = idx / n, j = idx % n;
+    io.dL[(long)i * io.ldl + j] = j <= i ? A[i * lda + j] / sinv[i] : T(0);
+  }
+  for (int idx = tid; idx < io.nx * n; idx += 256) {
+    const int c = idx / n, i = idx % n;
+    io.dL[(long)(n + c) * io.ldl + i] = c < mw ? W[i * mw + c] : T(0);
+  }
+}
+
+// whether lgp_predict_isotropic takes this road, and the road itself (api.hip)
+bool lgp_predict_small_fits(int kernel, int d, size_t n, size_t m) {
+  static const bool off = getenv("LGP_PREDICT_SMALL") != nullptr && atoi(getenv("LGP_PREDICT_SMALL")) == 0;
+  const bool kind = kernel == LGP_KERNEL_EXPQUAD || kernel == LGP_KERNEL_MATERNP || kernel == LGP_KERNEL_GAMMAEXP || kernel == LGP_KERNEL_CAUCHY;
+  return !off && kind && n >= 1 && n <= 64 && m >= 1 && m <= 256 && d >= 1 && (size_t)d * (n + m) + n * (n + m + 3) + 256 <= 18000;
+}
+
+int lgp_predict_small_f64(lgp_ctx *ctx, int kernel, int p, int npar, const double *hpar, int d, const double *hpts, size_t n, size_t m, int has_loc, double loc,
+                          int has_scale, double scale, int nops, const int *hops_code, const double *hops_val, const double *hy, const double *hnoise,
+                          double *dP, double *dL, size_t ldl, size_t nx, double *ddblk, double *dnoise, double *hout, double *heps_out, int *info_out) {
+  typedef double T;
+  LGP_REQUIRE(lgp_predict_small_fits(kernel, d, n, m), "not a small problem");
+  LGP_REQUIRE(p >= 0 && p <= MAX_P && nops >= 0 && nops <= MAX_OPS, "bad kernel parameters");
+  LGP_REQUIRE(!has_scale || (scale > T(0) && scale < T(INFINITY)), "scale must be positive and finite");
+  LGP_REQUIRE(!has_loc || (loc > T(-INFINITY) && loc < T(INFINITY)), "loc must be finite");
+  DeviceGuard dg(ctx->device);
+  const size_t np = n + m, nin = (size_t)d * np + 2 * n, nout = m * m + m + 5;
+  if (ctx->h_small == nullptr) LGP_HIP(hipHostMalloc(&ctx->h_small, (size_t)1 << 20, hipHostMallocDefault));     // (18000 + 256^2 + ... doubles fit)
+  T *hin = static_cast<T *>(ctx->h_small), *hres = hin + ((nin + 63) / 64) * 64;
+  memcpy(hin, hpts, (size_t)d * np * sizeof(T));
+  memcpy(hin + (size_t)d * np, hy, n * sizeof(T));
+  if (hnoise) memcpy(hin + (size_t)d * np + n, hnoise, n * sizeof(T));
+  void *dev = nullptr;
+  LGP_HIP(hipHostGetDevicePointer(&dev, ctx->h_small, 0));
+  T *din = static_cast<T *>(dev), *dres = din + (hres - hin);
+  IsoArgs<T> g;
+  g.x = g.y = nullptr; g.out = nullptr; g.dsc = nullptr;
+  g.ldx = g.ldy = g.ldo = 0;
+  g.n = (int)n; g.m = (int)m; g.d = d;
+  g.kernel = kernel; g.p = p;
+  g.has_loc = has_loc; g.has_scale = has_scale; g.loc = loc; g.scale = scale;
+  for (int i = 0; i < MAX_P; ++i) g.coef[i] = T(0);
+  int pos = 0;
+  for (int k = p - 1; k >= 0; --k) g.coef[pos++] = (T)((double)(p - k) / ((double)(2 * p - k) * (double)(k + 1)));
+  g.twop1 = (T)(2 * p + 1);
+  g.posabs = 0; g.xy = 0;
+  g.table = nullptr; g.ntable = 0; g.fill = T(0);
+  g.cbase = 0; g.cyc_nb = 0; g.cyc_stride = 0; g.wloc = 0;
+  for (int f = 0; f < 8; ++f) g.dord[f] = 0;
+  g.par[0] = g.par[1] = g.par[2] = g.par[3] = T(0);
+  g.flag = 0;
+  if (kernel == LGP_KERNEL_GAMMAEXP) {
+    LGP_REQUIRE(npar == 2 && hpar != nullptr && hpar[0] > T(0) && hpar[0] <= T(2), "GammaExp takes {gamma, gamma/2}, gamma in (0, 2]");
+    g.par[0] = hpar[0]; g.par[1] = hpar[1]; g.flag = hpar[0] == T(2);
+  } else if (kernel == LGP_KERNEL_CAUCHY) {
+    LGP_REQUIRE(npar == 3 && hpar != nullptr && hpar[0] > T(0) && hpar[0] <= T(2) && hpar[1] > T(0), "Cauchy takes {alpha, beta, -beta/alpha}");
+    g.par[0] = hpar[0] / T(2); g.par[1] = hpar[1]; g.par[2] = hpar[2]; g.flag = hpar[0] == T(2);
+  } else {
+    LGP_REQUIRE(npar == 0, "this kernel takes no real parameters");
+  }
+  g.ops.n = nops;
+  for (int i = 0; i < MAX_OPS; ++i) { g.ops.code[i] = 0; g.ops.val[i] = T(0); }
+  for (int i = 0; i < nops; ++i) {
+    LGP_REQUIRE(hops_code[i] == LGP_OP_MUL || hops_code[i] == LGP_OP_ADD, "unknown output operation");
+    g.ops.code[i] = hops_code[i];
+    g.ops.val[i] = hops_val[i];
+  }
+  SmallIO io;
+  io.hpts = din; io.hy = din + (size_t)d * np; io.hnoise = hnoise ? din + (size_t)d * np + n : nullptr;
+  io.hout = dres;
+  io.dP = dP; io.dL = dL; io.dnoise = dnoise; io.ldl = (long)ldl; io.nx = (int)nx;
+  const size_t shmem = ((size_t)d * np + n * (n + 1) + n * (m + 1) + n + 256) * sizeof(T);
+  static bool attr_set = false;
+  if (!attr_set) {
+    LGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(predict_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(predict_small_kernel, dim3(1), dim3(256), shmem, ctx->stream, g, io);
+  LGP_LAUNCH_CHECK();
+  LGP_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(hout, hres, (m * m + m + 2) * sizeof(T));
+  if (heps_out) *heps_out = hres[m * m + m + 3];
+  *info_out = (int)hres[m * m + m + 4];
+  (void)nout;
+  // the images of the diagonal blocks that later solves read (D, D', 1 / diag): enqueued, not waited for
+  if (*info_out == 0) LGP_CHECK(lgp_extract_dblk_public(ctx, ctx->stream, dL, ldl, n, ddblk));
+  return LGP_OK;
+}
+
 template <typename T>
 int lgp_chol_from_prepared(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nrhs, T *ws, size_t ntr, T epsrel, T epsabs, int flags,
                            T *heps_out);   // potrf.hip
