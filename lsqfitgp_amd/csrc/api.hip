@@ -690,14 +690,30 @@ int lgp_predict_isotropic_f64(lgp_ctx *c, int kernel, int p, int npar, const dou
   const double *dx = dP, *dxs = dP + n;                         // coordinate f of point i at dP[f * np + i]
   LGP_CHECK(lgp_gram_isotropic_f64(c, kernel, p, npar, hpar, d, dxs, np, m, dx, np, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, 0, Wt, ldl));
   LGP_CHECK(lgp_gram_isotropic_f64(c, kernel, p, npar, hpar, d, dxs, np, m, dxs, np, m, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, 1, dcov, m));
-  const int info = lgp_gram_chol_factor_rhs_f64(c, kernel, p, npar, hpar, d, dx, np, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, 0.0,
-                                                hnoise ? dnoise : nullptr, 0.0, 0.0, LGP_EPS_AUTO_REL, dL, ldl, nx, ddblk, heps_out);
-  if (info != 0) return info;                                   // an error (< 0) or the first bad pivot (> 0)
+  // ONE synchronisation per prediction: the factorisation leaves its read-back (eps, the pivot verdict) and the diagonal-block
+  // images to this function -- the posterior needs neither, its solve rode through the factorisation
+  int fst;
+  {
+    struct Defer {
+      lgp_ctx *c;
+      explicit Defer(lgp_ctx *ctx) : c(ctx) { c->defer_finish = 1; }
+      ~Defer() { c->defer_finish = 0; }
+    } defer(c);
+    fst = lgp_gram_chol_factor_rhs_f64(c, kernel, p, npar, hpar, d, dx, np, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, 0.0,
+                                       hnoise ? dnoise : nullptr, 0.0, 0.0, LGP_EPS_AUTO_REL, dL, ldl, nx, ddblk, nullptr);
+  }
+  if (fst != 0) return fst;                                     // an error (< 0)
   LGP_CHECK(posterior_solved_impl<double>(c, n, m, dL, ldl, Wt, ldl, dcov, m, dmean, dcov, m, nullptr));
   LGP_CHECK(lgp_logdet_device<double>(c, st, n, dL, ldl, dsc));
   LGP_CHECK(lgp_dot_strided_device<double>(c, st, n, Wt + m * ldl, 1, Wt + m * ldl, 1, dsc + 1));
   LGP_HIP(hipMemcpyAsync(hout, dwork, (m * m + m + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
   LGP_HIP(hipStreamSynchronize(st));
+  const double *hp = static_cast<const double *>(c->h_pinned);
+  int info = 0;
+  memcpy(&info, hp + 64, sizeof(int));
+  if (heps_out) *heps_out = hp[33];
+  if (const int verdict = lgp_info_result(c, info); verdict != 0) return verdict;      // a stall (< 0) or the first bad pivot (> 0)
+  LGP_CHECK(lgp_extract_dblk_public(c, st, dL, ldl, n, ddblk));  // (for the solves of later questions: enqueued, not waited for)
   double *h = hout + m * m + m;                                 // _decomp.py:484-488
   h[0] = 0.5 * ((double)n * std::log(2 * M_PI) + 2.0 * h[0] + h[1]);
   return LGP_OK;

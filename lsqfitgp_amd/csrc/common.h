@@ -39,6 +39,8 @@ struct lgp_ctx {
   void *d_scratch = nullptr;          // small reductions (>= 64 KiB)
   size_t scratch_bytes = 0;
   void *h_pinned = nullptr;           // pinned host staging for scalar results (4 KiB)
+  int defer_finish = 0;               // lgp_chol_from_prepared leaves its read-back (eps, pivot verdict -> h_pinned + 32 / + 64 doubles), its synchronisation
+                                      // and the diagonal-block images to the caller (lgp_predict_isotropic: one synchronisation per prediction)
   void *h_small = nullptr;            // pinned, device-mapped staging of the one-launch small prediction (1 MiB, created on first use; gram.hip)
   void *comm = nullptr;               // ncclComm_t
   // alternative transport: collectives done by a caller-supplied host function on a staged copy (lgp_comm_init_host)

@@ -534,9 +534,11 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
   // split-K for few-tile, deep-K products (X^T X, X^T y over N rows): deterministic slab reduction
   g.nsplit = 1; g.kchunk = 0; g.Cpart = nullptr;
   const size_t tiles = (size_t)g.tm * g.tn;
-  if (!lower && tiles * 4 <= (size_t)ctx->cus && k >= 2048) {
+  // (from k = 512 on for the tiniest outputs: the X'X and X'y of a posterior over a thousand points were two 59 us launches of 2-4
+  // workgroups walking K = 1000 alone; in slabs of 128 they are ~15 us each, docs/userguide/optim.rst's N = 1000 benchmark)
+  if (!lower && tiles * 4 <= (size_t)ctx->cus && (k >= 2048 || (k >= 512 && tiles <= 4))) {
     size_t ns = (2 * (size_t)ctx->cus) / tiles;
-    const size_t maxs = (k + 255) / 256;
+    const size_t maxs = k >= 2048 ? (k + 255) / 256 : (k + 127) / 128;
     if (ns > maxs) ns = maxs;
     if (ns > 1) {
       size_t kc = (k + ns - 1) / ns;

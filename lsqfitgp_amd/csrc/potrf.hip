@@ -1275,6 +1275,13 @@ int lgp_chol_from_prepared(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, si
   const int nbx = (int)((n + 2047) / 2048);
   hipLaunchKernelGGL((scale_rows_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, st, L, (long)ldl, ni, nbx, s, nonunit);
   LGP_LAUNCH_CHECK();
+  if (ctx->defer_finish) {
+    // the caller reads eps and the pivot verdict when it synchronises for its own results, and has the diagonal-block images made
+    // after that (they are not on the way to a posterior whose solve rode through the factorisation)
+    LGP_HIP(hipMemcpyAsync(static_cast<double *>(ctx->h_pinned) + 32, stats, 3 * sizeof(T), hipMemcpyDeviceToHost, st));
+    LGP_HIP(hipMemcpyAsync(static_cast<double *>(ctx->h_pinned) + 64, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+    return LGP_OK;
+  }
   LGP_CHECK(lgp_extract_dblk<T>(ctx, st, L, ldl, n, dblk));
   T hstats[3];
   int info = 0;
