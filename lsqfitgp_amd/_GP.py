@@ -809,9 +809,11 @@ class GP:
                 return {}
             xf = x.x.reshape(-1)
             yf = xf if y is x else y.x.reshape(-1)
-            if x.deriv or y.deriv:
-                raise NotImplementedError('tangents of the hyperparameters of derivative observations')
-            _, tans = kernel.gram_tangents(xf, yf, ctx=self.ctx)
+            kw = {}
+            if x.deriv or y.deriv:            # (as in `_makecovblock`: per-field orders on both sides when either names its fields)
+                orders = lambda e, other: e.deriv if (isinstance(e.deriv, tuple) or not isinstance(other.deriv, tuple)) else (0,) * len(other.deriv)
+                kw = {'deriv': (orders(x, y), orders(y, x))}
+            _, tans = kernel.gram_tangents(xf, yf, ctx=self.ctx, **kw)
             return tans
         if isinstance(x, _LinTransf):
             return self._tangents_lintransf(xkey, ykey)

@@ -261,7 +261,7 @@ class _Composite(Kernel):
     Sum or product of two kernels (``_Kernel/_alg.py:32-82``: ``k1 + k2``, ``k1 * k2``): each operand is evaluated by its own
     Gram kernel on the same points and the matrices are combined entry by entry on the device (`lgp_axpby` / `lgp_mul`); scalar
     operations applied to the composite afterwards follow.  The hyperparameter tangents (`_dual`) combine by linearity and
-    by the product rule.  Derivative observations: of a sum only (the terms' derivatives add).
+    by the product rule.  Derivative observations: of a sum the terms' derivatives add, of a product Leibniz' rule (`_gram_derived`).
     """
 
     def __init__(self, op, a, b):
@@ -309,22 +309,92 @@ class _Composite(Kernel):
     def gram(self, xs, ys, *, ctx=None, out=None, deriv=(0, 0)):
         if isinstance(xs, _PointBundle) != isinstance(ys, _PointBundle):
             raise TypeError('prepared and plain points mixed')
-        kw = {}
         if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
-            if self._op != 'add':
-                raise NotImplementedError('derivative observations of a product of kernels')
-            if any(op == 'add' for op, _ in self._outops):
-                raise NotImplementedError('derivative observations of a sum of kernels plus a constant: add the constant to a term')
-            kw = dict(deriv=deriv)
-        return self._combine(self._a.gram(self._part(xs, 0), self._part(ys, 0), ctx=ctx, **kw),
-                             self._b.gram(self._part(xs, 1), self._part(ys, 1), ctx=ctx, **kw), out)
+            return self._gram_derived(xs, ys, ctx, out, deriv)
+        return self._combine(self._a.gram(self._part(xs, 0), self._part(ys, 0), ctx=ctx),
+                             self._b.gram(self._part(xs, 1), self._part(ys, 1), ctx=ctx), out)
+
+    def _derived_gram_tangents(self, xs, ys, ctx, deriv):
+        """ a derived block of a composite and its tangents: sums add; products by Leibniz over both sides, each term
+        (dA) o B + A o (dB); the composite's own scalar factors (which may carry tangents themselves) last """
+        ga = lambda d: self._a.gram_tangents(self._part(xs, 0), self._part(ys, 0), ctx=ctx, deriv=d)
+        gb = lambda d: self._b.gram_tangents(self._part(xs, 1), self._part(ys, 1), ctx=ctx, deriv=d)
+        K0, tans = None, {}
+
+        def acc(target, w, X, Y):          # target += w X o Y  (Y None: w X)
+            term = _dev_mul(w, X, Y) if Y is not None else _dev_axpby(w, X, 0., None)
+            return term if target is None else _dev_axpby(1., target, 1., term, target)
+        if self._op == 'add':
+            for K, dK in (ga(deriv), gb(deriv)):
+                K0 = acc(K0, 1., K, None)
+                for k, T in dK.items():
+                    tans[k] = acc(tans.get(k), 1., T, None)
+        else:
+            for wx, ax, bx in self._splits(deriv[0]):
+                for wy, ay, by in self._splits(deriv[1]):
+                    (A, dA), (B, dB) = ga((ax, ay)), gb((bx, by))
+                    w = float(wx * wy)
+                    K0 = acc(K0, w, A, B)
+                    for k, T in dA.items():
+                        tans[k] = acc(tans.get(k), w, T, B)
+                    for k, T in dB.items():
+                        tans[k] = acc(tans.get(k), w, A, T)
+        a = _dual.Dual(1.)
+        for (op, c), dc in zip(self._outops, self._doutops):
+            if op == 'mul':
+                a = a * _dual.Dual(float(c), dc)
+        K = _dev_axpby(a.value, K0, 0., None)
+        out = {}
+        for k in set(tans) | set(a.tangents):
+            da = float(a.tangents.get(k, 0.))
+            out[k] = _dev_axpby(a.value, tans[k], da, K0) if k in tans else _dev_axpby(da, K0, 0., None)
+        return K, out
+
+    @staticmethod
+    def _splits(spec):
+        """ the ways of sharing the derivative orders of one side between two factors: ``[(binomial weight, spec of a, spec of b)]`` """
+        import itertools
+        import math
+        if isinstance(spec, (int, numpy.integer)):
+            return [(math.comb(int(spec), k), k, int(spec) - k) for k in range(int(spec) + 1)]
+        orders = tuple(int(v) for v in spec)
+        res = []
+        for part in itertools.product(*(range(o + 1) for o in orders)):
+            res.append((math.prod(math.comb(o, k) for o, k in zip(orders, part)), tuple(part), tuple(o - k for o, k in zip(orders, part))))
+        return res
+
+    def _gram_derived(self, xs, ys, ctx, out, deriv):
+        """ derivative observations of a composite (``_Kernel/_ops.py:115-211`` differentiates whatever the algebra of
+        ``_Kernel/_alg.py:32-82`` built): of a sum the terms' derivatives add; of a product Leibniz' rule over the orders of
+        both sides, every term the product of two derived blocks of the factors; constants added to the composite drop out, its
+        scalar factors multiply the result """
+        ga = lambda d: self._a.gram(self._part(xs, 0), self._part(ys, 0), ctx=ctx, deriv=d)
+        gb = lambda d: self._b.gram(self._part(xs, 1), self._part(ys, 1), ctx=ctx, deriv=d)
+        if self._op == 'add':
+            A, B = ga(deriv), gb(deriv)
+            dt = numpy.result_type(A.dtype, B.dtype)
+            M = _dev_axpby(1., _dev_astype(A, dt), 1., _dev_astype(B, dt), out)
+        else:
+            M = None
+            for wx, ax, bx in self._splits(deriv[0]):
+                for wy, ay, by in self._splits(deriv[1]):
+                    A, B = ga((ax, ay)), gb((bx, by))
+                    dt = numpy.result_type(A.dtype, B.dtype)
+                    M = _dev_mul(float(wx * wy), _dev_astype(A, dt), _dev_astype(B, dt), *((0., None) if M is None else (1., M)), out=M)
+            if out is not None:
+                out.assign(M)
+                M = out
+        for op, c in self._outops:                     # (added constants: their derivative is zero)
+            if op == 'mul':
+                _dev_axpby(float(c), M, 0., None, M)
+        return M
 
     def pairs(self, xs, ys, *, ctx=None):
         return self._combine(self._a.pairs(xs, ys, ctx=ctx), self._b.pairs(xs, ys, ctx=ctx))
 
     def gram_tangents(self, xs, ys, *, ctx=None, **kw):
         if kw.get('deriv') and any(numpy.any(numpy.asarray(o) != 0) for o in kw['deriv']):
-            raise NotImplementedError('tangents of the hyperparameters of a derived kernel')
+            return self._derived_gram_tangents(xs, ys, ctx, kw['deriv'])
         A, dA = self._a.gram_tangents(xs, ys, ctx=ctx)
         B, dB = self._b.gram_tangents(xs, ys, ctx=ctx)
         dt = numpy.result_type(A.dtype, B.dtype)
@@ -590,7 +660,7 @@ class _Isotropic(Kernel):
         if not live:
             return K, {}
         if any(numpy.any(numpy.asarray(o) != 0) for o in deriv):
-            raise NotImplementedError('tangents of the hyperparameters of a derived kernel')
+            return K, self._derived_tangents(xs, ys, ctx, deriv, live)
         core = self._copy(_outops=(), _doutops=(), _dscale={})
         if self._dscale:
             C, dC = core.gram_dscale(xs, ys, ctx=ctx)
@@ -617,6 +687,45 @@ class _Isotropic(Kernel):
                     _lib.check(fs(C.ctx.handle, C.shape[0], C.shape[1], T.ptr, T.ld, F(db)), 'lgp_add_scalar')
             tangents[k] = T
         return K, tangents
+
+    def _derived_tangents(self, xs, ys, ctx, deriv, live):
+        """ tangents of a DERIVED block (derivative observations, ``_Kernel/_ops.py:115-211``) -- what ``jax.jacfwd`` of the
+        reference's factory gives through ``diff``.  The kernels are stationary functions of u = (x - y) / scale, so with orders
+        alpha on the x side, beta on the y side and q = |alpha| + |beta|,  K_ab = scale^-q (-1)^|beta| (d^(alpha+beta) f)(u)  and
+
+            dK_ab / dscale = -(1 / scale) [ q K_ab + sum_f (x_f - y_f) K_(alpha + e_f, beta) ]
+
+        -- one more derived block per field (the extra order goes to the side that has room: d/dx = -d/dy).  Scalar factors
+        multiply, added constants have dropped out of a derived block. """
+        xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)
+        da, db = self._orders(deriv[0], d), self._orders(deriv[1], d)
+        core = self._copy(_outops=(), _doutops=(), _dscale={})
+        C = core.gram(xs, ys, ctx=ctx, deriv=(da, db))
+        a = _dual.Dual(1.)
+        for (op, c), dc in zip(self._outops, self._doutops):
+            if op == 'mul':
+                a = a * _dual.Dual(float(c), dc)
+        dC = None
+        if self._dscale:
+            scale = float(self._scale)
+            q = sum(da) + sum(db)
+            xh, yh = xd.to_host().astype(float), (xd if yd is xd else yd).to_host().astype(float)
+            dC = _dev_axpby(-q / scale, C, 0., None)
+            for f in range(d):
+                sign = 1.
+                try:
+                    E = core.gram(xs, ys, ctx=ctx, deriv=(tuple(o + (g == f) for g, o in enumerate(da)), db))
+                except (NotImplementedError, ValueError):
+                    E = core.gram(xs, ys, ctx=ctx, deriv=(da, tuple(o + (g == f) for g, o in enumerate(db))))
+                    sign = -1.
+                D = DeviceArray.from_host((xh[f][:, None] - yh[f][None, :]).astype(dtype), ctx=ctx)
+                dC = _dev_mul(-sign / scale, D, E, 1., dC, out=dC)
+        tangents = {}
+        for k in live:
+            ds, dak = float(self._dscale.get(k, 0.)), float(a.tangents.get(k, 0.))
+            # T = (a ds) dC + da C
+            tangents[k] = _dev_axpby(a.value * ds, dC, dak, C) if dC is not None else _dev_axpby(dak, C, 0., None)
+        return tangents
 
     def pairs(self, xs, ys, *, ctx=None):
         xd, yd, dtype, ctx, d = self._prepare(xs, ys, ctx)

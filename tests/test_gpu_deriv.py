@@ -504,3 +504,60 @@ def test_posterior_with_derivative_data_of_a_periodic_process(lgp):
     for k in co:
         np.testing.assert_allclose(cd[k], co[k], rtol=0, atol=1e-8)
     assert np.max(np.abs(md['dg'] - (np.cos(xs) + np.cos(2 * xs)))) < 0.05         # it does predict the slope
+
+
+@pytest.mark.parametrize('a,b', [(1, 0), (1, 1), (2, 0), (2, 1), (2, 2)])
+def test_derivatives_of_products_and_sums_of_kernels(lgp, a, b):
+    """ `_Kernel/_ops.py:115-211` differentiates whatever `_Kernel/_alg.py:32-82` built.  Device: Leibniz' rule over derived blocks
+    of the factors (`_Composite._gram_derived`).  Checked two ways: against the same rule spelled out over the ORACLE's derived
+    blocks (closed forms / sympy), and -- independently of any product rule -- against central differences of the oracle's
+    composite kernel itself """
+    import math
+    rng = np.random.default_rng(7 + 10 * a + b)
+    x = rng.uniform(0.2, 3, 19)
+    y = rng.uniform(0.2, 3, 23)
+    f = lambda mod: (mod.ExpQuad(scale=1.3), mod.Cauchy(alpha=2, beta=2.5, scale=0.9), mod.Maternp(p=3, scale=1.7))
+    (e, c, mt), (eo, co, mo) = f(lgp), f(oracle)
+    X, Y = x[:, None], y[None, :]
+    # product of two, times a scalar, plus a constant (which must drop out)
+    got = (0.7 * (e * c) + 0.4).gram(x, y, deriv=(a, b)).to_host()
+    want = 0.7 * sum(math.comb(a, i) * math.comb(b, j) * eo.diff(i, j)(X, Y) * co.diff(a - i, b - j)(X, Y) for i in range(a + 1) for j in range(b + 1))
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-11 * scale)
+    # central differences of the composite's VALUES (oracle), order (a, b): no product rule involved
+    ko = 0.7 * (eo * co) + 0.4
+    h = 2e-3
+
+    def stencil(order):
+        return {0: [(0, 1.)], 1: [(-1, -0.5 / h), (1, 0.5 / h)], 2: [(-1, 1 / h ** 2), (0, -2 / h ** 2), (1, 1 / h ** 2)]}[order]
+    fd = sum(wa * wb * ko((x + ia * h)[:, None], (y + ib * h)[None, :]) for ia, wa in stencil(a) for ib, wb in stencil(b))
+    np.testing.assert_allclose(got, fd, rtol=0, atol=3e-5 * scale)
+    # a sum plus a constant, and a product with a sum inside
+    got = ((e + mt) + 0.3).gram(x, y, deriv=(a, b)).to_host()
+    want = eo.diff(a, b)(X, Y) + mo.diff(a, b)(X, Y)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-11 * np.abs(want).max())
+    got = (e * (c + mt)).gram(x, y, deriv=(a, b)).to_host()
+    want = sum(math.comb(a, i) * math.comb(b, j) * eo.diff(i, j)(X, Y) * (co.diff(a - i, b - j)(X, Y) + mo.diff(a - i, b - j)(X, Y))
+               for i in range(a + 1) for j in range(b + 1))
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-11 * np.abs(want).max())
+
+
+def test_posterior_with_derivative_data_of_a_product_process(lgp):
+    """ values and slopes of a process with a product kernel observed together (the oracle assembles the same blocks by Leibniz) """
+    rng = np.random.default_rng(11)
+    x = np.sort(rng.uniform(0, 6, 30))
+    xs = np.linspace(0.5, 5.5, 9)
+    gp = (lgp.GP(lgp.ExpQuad(scale=1.5) * lgp.Periodic(outerscale=2.), checkpos=False, checksym=False)
+          .addx(x, 'f').addx(x, 'df', deriv=1).addx(xs, 'fs').addx(xs, 'dfs', deriv=1))
+    fx, dfx = np.sin(x) * np.cos(x / 3), np.cos(x) * np.cos(x / 3) - np.sin(x) * np.sin(x / 3) / 3
+    z = np.zeros((30, 30))
+    noise = {('f', 'f'): 1e-4 * np.eye(30), ('df', 'df'): 1e-4 * np.eye(30), ('f', 'df'): z, ('df', 'f'): z}
+    m, c = gp.predfromdata({'f': fx, 'df': dfx}, ['fs', 'dfs'], noise, raw=True)
+    # the slope of the posterior mean of the values is the posterior mean of the slopes: central differences on shifted points
+    h = 1e-4
+    gp2 = (lgp.GP(lgp.ExpQuad(scale=1.5) * lgp.Periodic(outerscale=2.), checkpos=False, checksym=False)
+           .addx(x, 'f').addx(x, 'df', deriv=1).addx(xs + h, 'p').addx(xs - h, 'q'))
+    m2, _ = gp2.predfromdata({'f': fx, 'df': dfx}, ['p', 'q'], noise, raw=True)
+    np.testing.assert_allclose(m['dfs'], (m2['p'] - m2['q']) / (2 * h), rtol=0, atol=1e-6)
+    assert np.abs(m['fs'] - np.sin(xs) * np.cos(xs / 3)).max() < 0.05 and np.abs(m['dfs']).max() > 0.3
+
