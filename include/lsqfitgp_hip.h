@@ -546,9 +546,6 @@ int lgp_panel_factor_f64(lgp_ctx *ctx, size_t rows, size_t nb, double *dP, size_
  * check that every task comes after the tasks it waits for and that executing the list factors the matrix.  No
  * counterpart in the reference (LAPACK potrf inside jlinalg.cholesky, _linalg/_decomp.py:388, orders its own blocks). */
 long lgp_chain_schedule(size_t n, unsigned int *tasks, size_t capacity);
-/* The same for the alternative chain kernel (contexts created with LGP_CHAIN_IMPL=walker; csrc/chainw.hip: workgroup 0 walks down
- * the diagonal and keeps the block on chip -- its steps are type 0 here --, the others take types 1 and 2 from a near and a bulk list). */
-long lgp_chain_schedule_walker(size_t n, unsigned int *tasks, size_t capacity);
 /* The same update for ALL block columns a rank owns in a 1-D block-column-cyclic layout, in one launch: dC is the
  * rank's local storage from its first not yet finished block column on (rows x cols, local block q of width nb =
  * global block (q0 + q) * nranks + rank), dP the panel rows from the global row of C(0,0) on (rows x k).  Element (i, j)

@@ -21,10 +21,7 @@ UNITS = [
     # accumulators that alternate between MFMA and vector ops stay in VGPRs (no AGPR copies)
     ('potrf.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form=1']),
     ('potf2m.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form=1']),
-    # the chain kernel (walker + workers): a unit of its own (with the walker's phases inlined into one loop body ROCm 7.2's AGPR
-    # rewrite pass crashed on the spills of this unit; they are functions of their own now, csrc/walker.inc)
-    ('chainw.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form=1']),
-    # the chain kernel of round 3 (task graph): the default (chaint.hip says why)
+    # the chain kernel (task graph of resident workers)
     ('chaint.hip', ['-mllvm', '-amdgpu-mfma-vgpr-form=1']),
     ('elementwise.hip', []),
     ('dist.hip', []),

@@ -108,7 +108,6 @@ def _signatures():
         'lgp_allreduce_max_f64': (c_int, [c_void_p, _P, _S]),
         'lgp_panel_factor_f64': (c_int, [c_void_p, _S, _S, _P, _S, _P, _S]),
         'lgp_chain_schedule': (ctypes.c_long, [_S, _P, _S]),
-        'lgp_chain_schedule_walker': (ctypes.c_long, [_S, _P, _S]),
         'lgp_update_nt_cyclic_f64': (c_int, [c_void_p, _S, _S, _S, _P, _S, _P, _S, _S, _S]),
         'lgp_update_nt_f64': (c_int, [c_void_p, _S, _S, _S, _P, _S, _P, _S, _P, _S, c_int]),
         'lgp_get_info': (c_int, [c_void_p, POINTER(c_int)]),

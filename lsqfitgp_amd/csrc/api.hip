@@ -151,7 +151,6 @@ int lgp_ctx_create(int device, lgp_ctx **out) {
   c->cus = prop.multiProcessorCount;
   if (const char *m = getenv("LGP_POTF2")) c->potf2_mode = strcmp(m, "valu") == 0 ? 1 : (strcmp(m, "mfma") == 0 ? 2 : (strcmp(m, "mfma1") == 0 ? 3 : 0));
   if (const char *m = getenv("LGP_CHAIN")) c->chain_mode = strcmp(m, "0") == 0 ? 1 : 0;
-  if (const char *m = getenv("LGP_CHAIN_IMPL")) c->chain_impl = strcmp(m, "walker") == 0 ? 1 : 0;
   if (const char *m = getenv("LGP_CHAIN_MAX_N")) c->chain_max_n = (size_t)strtoull(m, nullptr, 10);
   if (const char *m = getenv("LGP_CHAIN_HOG_MAX_N")) c->chain_hog_max_n = (size_t)strtoull(m, nullptr, 10);
   if (const char *m = getenv("LGP_CHAIN_WORKERS")) {
@@ -239,7 +238,6 @@ int lgp_ctx_destroy(lgp_ctx *c) {
     (void)hipFree(c->chain_trace);
   }
   if (c->chain_state) (void)hipFree(c->chain_state);
-  if (c->chain_scratch) (void)hipFree(c->chain_scratch);
   for (const auto &e : c->chain_sched) (void)hipFree(e.tasks);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);

@@ -1,9 +1,8 @@
 // chaint.hip -- the chain kernel of round 3: the diagonal squares of all panels factored by resident worker workgroups as a task graph
 // (P: factor a diagonal block, S: substitution of 64 rows, G: update of a 64 x 64 tile).  Round 4 built a replacement whose first
-// workgroup keeps the diagonal block on chip (chainw.hip, walker.inc); measured side by side on one box it is 9 % SLOWER up to
-// N = 4096 (1.28 vs 1.17 ms at N = 2048, 2.57 vs 2.35 at 4096, 6.43 vs 6.23 at 8192; equal from 16384 on), so this kernel is
-// the default again and the walker an option (LGP_CHAIN_IMPL=walker).  Both obey the same flag words (common.h, LGP_CH_*) and
-// are driven by the same potrf_chain (potrf.hip).
+// workgroup keeps the diagonal block on chip; measured side by side on one box it was 9 % SLOWER up to N = 4096 (1.28 vs 1.17 ms
+// at N = 2048, 2.57 vs 2.35 at 4096, 6.43 vs 6.23 at 8192; equal from 16384 on).  It was retired in round 5: sources, host test
+// and trace tools under docs/history/walker.  Driven by potrf_chain (potrf.hip) through the flag words of common.h (LGP_CH_*).
 #include "potf2_dev.h"
 #include <algorithm>
 #include <cstdlib>
@@ -462,18 +461,12 @@ int lgp_chaint_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, siz
   return LGP_OK;
 }
 
-// ---- which chain kernel a context uses (LGP_CHAIN_IMPL=tasks|walker when the context is created; the task graph by default)
-long lgp_chainw_schedule(size_t n, unsigned int *tasks, size_t capacity);                                                            // chainw.hip
-bool lgp_chainw_usable(lgp_ctx *ctx, size_t n, size_t ldl);
-size_t lgp_chainw_state_bytes(size_t n);
-int lgp_chainw_state(lgp_ctx *ctx, size_t n, unsigned **out);
-int lgp_chainw_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk, size_t row0);
-
+// ---- the chain kernel of the library (round 4 had an alternative whose first workgroup kept the diagonal block on chip: slower,
+// kept under docs/history/walker)
 extern "C" long lgp_chain_schedule(size_t n, unsigned int *tasks, size_t capacity) { return lgp_chaint_schedule(n, tasks, capacity); }
-extern "C" long lgp_chain_schedule_walker(size_t n, unsigned int *tasks, size_t capacity) { return lgp_chainw_schedule(n, tasks, capacity); }
-bool lgp_chain_usable(lgp_ctx *ctx, size_t n, size_t ldl) { return ctx->chain_impl ? lgp_chainw_usable(ctx, n, ldl) : lgp_chaint_usable(ctx, n, ldl); }
-size_t lgp_chain_state_bytes(size_t n) { return lgp_chaint_state_bytes(n) > lgp_chainw_state_bytes(n) ? lgp_chaint_state_bytes(n) : lgp_chainw_state_bytes(n); }
-int lgp_chain_state(lgp_ctx *ctx, size_t n, unsigned **out) { return ctx->chain_impl ? lgp_chainw_state(ctx, n, out) : lgp_chaint_state(ctx, n, out); }
+bool lgp_chain_usable(lgp_ctx *ctx, size_t n, size_t ldl) { return lgp_chaint_usable(ctx, n, ldl); }
+size_t lgp_chain_state_bytes(size_t n) { return lgp_chaint_state_bytes(n); }
+int lgp_chain_state(lgp_ctx *ctx, size_t n, unsigned **out) { return lgp_chaint_state(ctx, n, out); }
 int lgp_chain_launch(lgp_ctx *ctx, hipStream_t stream, size_t n, double *L, size_t ldl, double *dblk, size_t row0) {
-  return ctx->chain_impl ? lgp_chainw_launch(ctx, stream, n, L, ldl, dblk, row0) : lgp_chaint_launch(ctx, stream, n, L, ldl, dblk, row0);
+  return lgp_chaint_launch(ctx, stream, n, L, ldl, dblk, row0);
 }

@@ -61,9 +61,7 @@ struct lgp_ctx {
   // flag/counter words (LGP_CH_* layout)
   struct ChainSched { unsigned long long key; void *tasks; int ntasks, nchain; };
   std::vector<ChainSched> chain_sched;
-  int chain_impl = 0;                 // which chain kernel: 0 = the task graph of round 3 (chaint.hip), 1 = the walker (chainw.hip); env LGP_CHAIN_IMPL=tasks|walker
   void *chain_state = nullptr;
-  void *chain_scratch = nullptr;      // hand-over buffers between the factor and the tail workgroup of the chain kernel (walker.inc)
   size_t chain_state_bytes = 0;
   void *chain_trace = nullptr;        // LGP_CHAIN_TRACE=<file>: per-task times of the last launch
   size_t chain_trace_tasks = 0;
@@ -233,8 +231,6 @@ constexpr int LGP_CH_READY = 8;   // [8] kernel -> stream: 1 (block j factored) 
 constexpr int LGP_CH_FLAGP = 16;  // [8]
 constexpr int LGP_CH_FLAGS = 32;  // [16][8] row unit r solved against block j
 constexpr int LGP_CH_CNT = 160;   // [16][16] steps applied to tile (r, c)
-constexpr int LGP_CH_STEP = 416;  // [8] factor workgroup -> tail workgroup: block rows of diagonal block j published (walker.inc)
-constexpr int LGP_CH_DREADY = 424; // [8] tail workgroup -> factor workgroup: diagonal block j, with the update of block j - 1, is in the hand-over buffer
 // info word written when the workers of the chain kernel gave up waiting (a stall, not a pivot): reported as an error
 constexpr int LGP_INFO_STALLED = 0x7fffffff;
 int lgp_info_result(lgp_ctx *ctx, int info);      // info, or LGP_EHIP with the error text set for LGP_INFO_STALLED (potrf.hip)

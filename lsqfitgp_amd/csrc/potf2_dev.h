@@ -1,4 +1,4 @@
-// potf2_dev.h -- device pieces shared by the diagonal-block kernels (potf2m.hip) and the chain kernel (chainw.hip).
+// potf2_dev.h -- device pieces shared by the diagonal-block kernels (potf2m.hip) and the chain kernel (chaint.hip).
 #pragma once
 #include "chain.h"
 

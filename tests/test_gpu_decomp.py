@@ -504,23 +504,6 @@ def test_chain_kernel_against_launch_per_operation_driver(lgp, rng, driver_conte
         util.assert_close_matrices(b.solved(), o.pinv_correlate(B), rtol=1e-10)
 
 
-@pytest.mark.parametrize('n,q', [(1152, 7), (2048, 0)])
-def test_walker_chain_kernel_against_the_default(lgp, rng, n, q):
-    """ the alternative chain kernel of round 4 (contexts created with LGP_CHAIN_IMPL=walker: workgroup 0 keeps the diagonal block
-    on chip, csrc/chainw.hip) against the default task-graph kernel (csrc/chaint.hip) and the oracle """
-    K = randpd(rng, n) * 3.0
-    B = rng.standard_normal((n, q)) if q else None
-    a = lgp.Chol(K, ctx=_context_with_env(lgp, LGP_CHAIN_IMPL='walker'), rhs=B)
-    b = lgp.Chol(K, rhs=B)
-    o = oracle.Chol(K)
-    La, Lb = a.factor().to_host(), b.factor().to_host()
-    assert a.eps == b.eps
-    util.assert_close_matrices(La, o._L, rtol=1e-13)
-    util.assert_close_matrices(Lb, La, rtol=1e-13)
-    if q:
-        util.assert_close_matrices(a.solved(), b.solved(), rtol=1e-10)
-
-
 def test_chain_kernel_reports_a_bad_pivot(lgp, rng):
     """ a matrix that is not positive definite: the worker that meets the pivot records it and the factorisation goes on to
     its end (no worker is left waiting); the host raises the reference's error (_linalg/_decomp.py:389-391) """
