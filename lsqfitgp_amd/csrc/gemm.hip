@@ -75,6 +75,7 @@ struct GemmArgs {
   int nsm, nsn;        // super-tile counts (0: direct mapping)
   int nbulk;           // super-tiles mapped XCD-wise (a multiple of 8); the rest is dealt out slot by slot
   int alignedA, alignedB;
+  int prio;            // wave priority (s_setprio) of the launch: 0 leaves it alone
   int nsplit, kchunk;  // split-K: blockIdx.y = K slice, partial tiles go to Cpart[slice] (dense m x n), reduced afterwards
   T *Cpart;
 #ifdef LGP_GEMM_TRACE
@@ -267,6 +268,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_kernel(const GemmArgs<T> g) 
   constexpr int IMG_A = TileA::IMG, IMG_B = TileB::IMG;
   __shared__ __attribute__((aligned(16))) T lds[2 * IMG_A + 2 * IMG_B];
 
+  if (g.prio) __builtin_amdgcn_s_setprio(3);
   int ti, tj;
   LGP_STAMP(0);
   if (!map_tile(g.tm, g.tn, g.nsm, g.nsn, g.nbulk, g.lower && g.roff == 0, ti, tj)) return;
@@ -505,6 +507,7 @@ static int gemm_launch_ts(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, si
   g.cyc_nb = cyc_nb;
   g.cyc_g1 = cyc_g1;
   g.roff = roff;
+  g.prio = ctx->gemm_prio;
   g.tm = (int)((m + TS - 1) / TS);
   g.tn = (int)((n + TS - 1) / TS);
   g.alignedA = ((reinterpret_cast<uintptr_t>(A) % 16) == 0 && (lda % VEC) == 0) ? 1 : 0;

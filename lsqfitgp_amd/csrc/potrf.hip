@@ -35,8 +35,8 @@ namespace {
 // restores ctx->gemm_thin_lds (the thinning of the factorisation's updates) on every way out of a driver
 struct ThinGuard {
   lgp_ctx *c;
-  explicit ThinGuard(lgp_ctx *ctx) : c(ctx) { c->gemm_thin_lds = 0; }
-  ~ThinGuard() { c->gemm_thin_lds = 0; }
+  explicit ThinGuard(lgp_ctx *ctx) : c(ctx) { c->gemm_thin_lds = 0; c->gemm_prio = 0; }
+  ~ThinGuard() { c->gemm_thin_lds = 0; c->gemm_prio = 0; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -713,6 +713,10 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
   LGP_HIP(hipStreamWaitEvent(s1, E(EV_START), 0));
   LGP_HIP(hipStreamWaitEvent(s3, E(EV_START), 0));
   if (sg != s0) LGP_HIP(hipStreamWaitEvent(sg, E(EV_START), 0));
+  // Round 5: the look-ahead's products (the square's, the rows below it, U1) run at wave priority 3 like the substitutions and the
+  // potf2 beside them: they finish sooner, and the large update they share the CUs with loses less to them -- C3 on one box
+  // 191.4-192.2 against 193.0-193.1 ms, the large updates at 0.805-0.809 of peak against 0.785-0.787.  LGP_SPLIT_PRIO=0: off.
+  static const bool split_prio = !(getenv("LGP_SPLIT_PRIO") != nullptr && atoi(getenv("LGP_SPLIT_PRIO")) == 0);
   bool have_u3 = false, have_far = false;
   for (size_t k0 = 0; k0 < n; k0 += NB) {
     if constexpr (std::is_same<T, double>::value) {
@@ -750,6 +754,7 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
         //  N = 20480 50.7 -> 50.3 ms; 2 = the same on 128-tiles where they fill the GPU: equal)
         static const int far_rec_env = getenv("LGP_FAR_RECURSIVE") ? atoi(getenv("LGP_FAR_RECURSIVE")) : 1;
         const int far_rec = kb % LGP_DB == 0 ? far_rec_env : 0;          // (a ragged last panel keeps the left-looking order)
+        ctx->gemm_prio = split_prio ? 3 : 0;
         if (j0 > 0 && !right_looking && !far_rec)
           LGP_CHECK(lgp_gemm_launch<T>(ctx, s3, false, true, far, jb, j0, T(-1), Pfar, ldl, P + j0 * ldl, ldl, T(1), Pfar + j0, ldl, false, 2));
         LGP_CHECK(subst(s3, w, jb, Pfar + j0, far));
@@ -767,6 +772,7 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
         }
       }
       if (wc > 0) LGP_CHECK(lgp_gemm_launch<T>(ctx, s1, false, true, below, wc, jb, T(-1), Xsq, ldl, Xsq, ldl, T(1), P + (j0 + jb) * ldl + (j0 + jb), ldl, true));
+      ctx->gemm_prio = 0;
     }
     LGP_HIP(hipEventRecord(E(EV_SQ), s1));
     have_far = far > 0;
@@ -780,7 +786,10 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
     // ---- s1: U1, the next panel's square (it has every earlier update once U3 of the previous step is done)
     LGP_HIP(hipStreamWaitEvent(s1, E(EV_FAR), 0));
     if (have_u3) LGP_HIP(hipStreamWaitEvent(s1, E(EV_U3), 0));
-    LGP_CHECK(lgp_gemm_launch<T>(ctx, s1, false, true, nb1, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
+    ctx->gemm_prio = split_prio ? 3 : 0;
+    const int u1st = lgp_gemm_launch<T>(ctx, s1, false, true, nb1, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true);
+    ctx->gemm_prio = 0;
+    LGP_CHECK(u1st);
     // ---- sg: U2, the block column below that square; then s3 may touch it
     LGP_HIP(hipStreamWaitEvent(sg, E(EV_SQ), 0));
     LGP_HIP(hipStreamWaitEvent(sg, E(EV_FAR), 0));
@@ -912,7 +921,13 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
         const size_t j0 = j * LGP_DB;
         if (j >= 1) {
           LGP_HIP(wait_ge(sg, word(k, LGP_CH_READY) + (j - 1), (unsigned)(1 + 2 * nq - 2 * (j - 1) - 2)));
-          LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_g, LGP_DB, j0, T(-1), Pg, ldl, P + j0 * ldl, ldl, T(1), Pg + j0, ldl, false, 2));
+          // (round 5: the chain-side products at wave priority 3, like the substitutions and the potf2: N = 8192 6.12-6.19 vs 6.18-6.33 ms,
+          //  12288 15.05 vs 15.15-15.20 on one box; LGP_FAR_PRIO=0 switches it off)
+          static const bool far_prio = !(getenv("LGP_FAR_PRIO") != nullptr && atoi(getenv("LGP_FAR_PRIO")) == 0);
+          ctx->gemm_prio = far_prio ? 3 : 0;
+          const int gst = lgp_gemm_launch<T>(ctx, sg, false, true, rows_g, LGP_DB, j0, T(-1), Pg, ldl, P + j0 * ldl, ldl, T(1), Pg + j0, ldl, false, 2);
+          ctx->gemm_prio = 0;
+          LGP_CHECK(gst);
         }
         LGP_HIP(wait_ge(sg, word(k, LGP_CH_FLAGP) + j, 1));
         LGP_CHECK(subst(sg, Yk + j * (size_t)LGP_DBLK, Pg + j0, rows_g));
@@ -932,7 +947,11 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
       hipStream_t sg = ctx->far_streams[0];
       for (int g = 1; g < ng; ++g) LGP_HIP(wait_ge(sg, word(k, LGP_CH_GRP + g), 1));      // (the rows of the next square may sit in any group)
       if (k >= 1) LGP_HIP(wait_ge(sg, word(k - 1, LGP_CH_U3), 1));
-      LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, nb1, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true));
+      static const bool u1_prio = !(getenv("LGP_FAR_PRIO") != nullptr && atoi(getenv("LGP_FAR_PRIO")) == 0);
+      ctx->gemm_prio = u1_prio ? 3 : 0;
+      const int ust = lgp_gemm_launch<T>(ctx, sg, false, true, nb1, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true);
+      ctx->gemm_prio = 0;
+      LGP_CHECK(ust);
       if (!(ctx->chain_test_stall && k == 0)) LGP_HIP(hipStreamWriteValue32(sg, word(k + 1, LGP_CH_U1), 1, 0));
     }
     // ---- s0: U2, the block column below that square
