@@ -4,6 +4,7 @@
 // at N = 2048, 2.57 vs 2.35 at 4096, 6.43 vs 6.23 at 8192; equal from 16384 on).  It was retired in round 5: sources, host test
 // and trace tools under docs/history/walker.  Driven by potrf_chain (potrf.hip) through the flag words of common.h (LGP_CH_*).
 #include "potf2_dev.h"
+#define P4_QUAD_ARG (LGP_P4_QUAD != 0)      // the workers have their CUs to themselves: the four pivots of a register together (potf2_dev.h)
 #include <algorithm>
 #include <cstdlib>
 

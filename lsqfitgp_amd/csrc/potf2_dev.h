@@ -102,12 +102,20 @@ __device__ __forceinline__ double lgp_opaque(double v) {        // (keeps the co
   return v;
 }
 
+// XBAR: the row broadcasts through the LDS crossbar (ds_bpermute: two instructions per broadcast); not XBAR: by lane swaps (eight).
+template <bool XBAR>
+__device__ __forceinline__ double p4_bcast(double v, int G, int addr) {
+  if constexpr (XBAR) return MmaD::bpermute(addr, v);
+  else return lgp_rowbcast(v, G);
+}
+
+template <bool XBAR>
 __device__ __forceinline__ void p4_quad(int r, double &w0, double &w1, double &w2, double &dg, double &dn, int n, int g) {
   const int c0 = 4 * r;
   // (row 0 of the quad is final as it stands: its broadcasts are asked for first, so that the crossbar's ~100 cycles pass beside the
   // uniform arithmetic below and not behind it)
   const int a0 = n * 4, a1 = (16 + n) * 4, a2 = (32 + n) * 4;
-  double x = MmaD::bpermute(a0, w0), y = MmaD::bpermute(a0, w1), z = MmaD::bpermute(a0, w2);
+  double x = p4_bcast<XBAR>(w0, 0, a0), y = p4_bcast<XBAR>(w1, 0, a0), z = p4_bcast<XBAR>(w2, 0, a0);
   // the 4 x 4 pivot block, upper part: entry (G, G') of the slab's register r sits at lane 16 G + 4 r + G' of the diagonal tile
   const double b00 = readlane_d(w0, c0), b01 = readlane_d(w0, c0 + 1), b02 = readlane_d(w0, c0 + 2), b03 = readlane_d(w0, c0 + 3);
   const double b11 = readlane_d(w0, 16 + c0 + 1), b12 = readlane_d(w0, 16 + c0 + 2), b13 = readlane_d(w0, 16 + c0 + 3);
@@ -131,9 +139,9 @@ __device__ __forceinline__ void p4_quad(int r, double &w0, double &w1, double &w
   double q1 = g2 ? m12 : 0.0; q1 = g3 ? m13 : q1;
   const double q2 = g3 ? m23 : 0.0;
   w0 = __builtin_fma(-q0, x, w0); w1 = __builtin_fma(-q0, y, w1); w2 = __builtin_fma(-q0, z, w2);
-  x = MmaD::bpermute(a1, w0); y = MmaD::bpermute(a1, w1); z = MmaD::bpermute(a1, w2);      // (lane swaps for the diagonal tile: 317 vs 305 cycles per pivot)
+  x = p4_bcast<XBAR>(w0, 1, a1); y = p4_bcast<XBAR>(w1, 1, a1); z = p4_bcast<XBAR>(w2, 1, a1);
   w0 = __builtin_fma(-q1, x, w0); w1 = __builtin_fma(-q1, y, w1); w2 = __builtin_fma(-q1, z, w2);
-  x = MmaD::bpermute(a2, w0); y = MmaD::bpermute(a2, w1); z = MmaD::bpermute(a2, w2);
+  x = p4_bcast<XBAR>(w0, 2, a2); y = p4_bcast<XBAR>(w1, 2, a2); z = p4_bcast<XBAR>(w2, 2, a2);
   w0 = __builtin_fma(-q2, x, w0); w1 = __builtin_fma(-q2, y, w1); w2 = __builtin_fma(-q2, z, w2);
   double dsel = g1 ? d1o : b00; dsel = g2 ? d2o : dsel; dsel = g3 ? d3 : dsel;
   dg = dsel;
@@ -145,11 +153,22 @@ __device__ __forceinline__ void p4_quad(int r, double &w0, double &w1, double &w
 #ifndef LGP_P4_QUAD
 #define LGP_P4_QUAD 1
 #endif
+#ifndef P4_XBAR
+#define P4_XBAR 1          // the quad's row broadcasts through the LDS crossbar (0: lane swaps -- 426 instead of 300 cycles per pivot alone,
+#endif                     // and no faster beside the large update: what costs there is the register file, not the crossbar)
 
 // ---- the four-wave potf2 (potf2m.hip: the stand-alone kernel; chaint.hip: task P of the task-graph chain kernel)
 constexpr int P4_ROWBUF = 8 * 4 * 64;   // block row s: tile of block column i, register r, lane  (doubles)
 
-template <int S>
+// QUAD: the four pivots of a register together (`p4_quad`) or one by one (`p4_pivot`).  The quad is the faster block alone (36.5
+// against 40.7 us) but needs 256 + 128 registers where the pivot-by-pivot code needs 236: beside the large update, whose waves hold
+// 2 x 224 of a SIMD's 512, a 236-register workgroup fits the slot of ONE retiring workgroup, a 384-register one has to find a CU
+// with BOTH slots free -- 650-730 us per block on average in the C3 step (10 ms at worst) against 186-192.  Measured on one box
+// (LGP_POTF2_INSITU=pivot), the C3 step is nevertheless FASTER with the quad everywhere: 187.1-187.4 against 187.9-188.0 ms.  With
+// the pivot-by-pivot blocks the look-ahead gets in at once, the stream of the large updates idles 0.6 instead of 3.5-4.7 ms
+// between them -- and the large updates take 150.8 instead of 146.0 ms, because the look-ahead's kernels then run beside them for
+// longer.  A look-ahead that is held back interferes less; the quad is the default everywhere.
+template <int S, bool QUAD>
 __device__ __forceinline__ void potf2m4_step(acc_t (&tA)[4], acc_t (&tB)[8], double (&rdn)[8], double *rowbuf, double *diagbuf, int w, int lane,
                                              int n, int g, int nb, int *info, long row0) {
   constexpr bool DIAG_IN_A = S <= 3;               // the diagonal tile (S, S) is tile S of block column S: column w = S or 7 - w = S
@@ -166,15 +185,10 @@ __device__ __forceinline__ void potf2m4_step(acc_t (&tA)[4], acc_t (&tB)[8], dou
 #pragma unroll
   for (int r = 0; r < 4; ++r) dt[r] = diagbuf[r * 64 + lane];
   LGP_P4STAMP(2 + 4 * S);
-#if LGP_P4_QUAD
-  // (a wave that owns no tile of this block row in a column works on whatever that register holds: never stored, and cheaper than
-  // the zeroing selects, which the compiler rematerialised in front of every matrix-core instruction)
-  acc_t ta = tA[S < 4 ? S : 0];
-  acc_t tb = tB[S];
-#else
-  acc_t ta = hasA ? tA[S < 4 ? S : 0] : acc_t{0, 0, 0, 0};
-  acc_t tb = hasB ? tB[S] : acc_t{0, 0, 0, 0};
-#endif
+  // (QUAD: a wave that owns no tile of this block row in a column works on whatever that register holds: never stored, and cheaper
+  // than the zeroing selects, which the compiler rematerialised in front of every matrix-core instruction)
+  acc_t ta = (QUAD || hasA) ? tA[S < 4 ? S : 0] : acc_t{0, 0, 0, 0};
+  acc_t tb = (QUAD || hasB) ? tB[S] : acc_t{0, 0, 0, 0};
   double dn = 1.0;
   // ---- 2. the 16 pivots: diagonal tile copy + the wave's own tiles of the block row.  Lane crossing by VALU swaps and DPP
   // (chain.h): per pivot  row broadcast of the pivot row -> its entry at the lane's own row index -> multiply -> fma.
@@ -182,14 +196,14 @@ __device__ __forceinline__ void potf2m4_step(acc_t (&tA)[4], acc_t (&tB)[8], dou
   for (int r = 0; r < 4; ++r) {
     double w0 = dt[r], w1 = ta[r], w2 = tb[r];
     double dg = 1.0;
-#if LGP_P4_QUAD
-    p4_quad(r, w0, w1, w2, dg, dn, n, g);
-#else
-    p4_pivot<0>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
-    p4_pivot<1>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
-    p4_pivot<2>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
-    p4_pivot<3>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
-#endif
+    if constexpr (QUAD) {
+      p4_quad<P4_XBAR != 0>(r, w0, w1, w2, dg, dn, n, g);
+    } else {
+      p4_pivot<0>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
+      p4_pivot<1>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
+      p4_pivot<2>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
+      p4_pivot<3>(r, w0, w1, w2, dg, dn, n, g, hasA, hasB);
+    }
     const bool badv = !(dg > 0.0) || (dg + dg == dg);
     const unsigned long long badm = __builtin_amdgcn_ballot_w64(badv);
     if (badm != 0 && w == wd) {

@@ -220,11 +220,14 @@ potf2_mfma_kernel(double *A, long lda, int nb, double *dblk, int *info, long row
 //     (redundantly: no hand-over inside the chain) and eliminates its own (at most two) tiles of block row s beside it;
 //     the eliminated tiles go to LDS; every wave updates its trailing tiles with A operands read from there.
 //   Two barriers per block step, 16 in all.
+template <bool QUAD>
 __global__ void __launch_bounds__(256) potf2_mfma4_kernel(double *A, long lda, int nb, double *dblk, int *info, long row0) {
   __shared__ double rowbuf[P4_ROWBUF];
   __shared__ double diagbuf[4 * 64];
   __builtin_amdgcn_s_setprio(LGP_CHAIN_PRIO);
+#define P4_QUAD_ARG QUAD
 #include "potf2m4_block.inc"
+#undef P4_QUAD_ARG
 }
 
 }  // namespace
@@ -232,7 +235,10 @@ __global__ void __launch_bounds__(256) potf2_mfma4_kernel(double *A, long lda, i
 int lgp_potf2_mfma_launch(lgp_ctx *ctx, hipStream_t stream, double *A, size_t lda, int nb, double *dblk, size_t row0) {
   LGP_REQUIRE(lda < (1u << 20), "leading dimension too large for the 32-bit offsets of the diagonal-block kernel");
   if (ctx->potf2_mode != 3) {
-    hipLaunchKernelGGL(potf2_mfma4_kernel, dim3(1), dim3(256), 0, stream, A, (long)lda, nb, dblk, ctx->d_info, (long)row0);
+    // (LGP_POTF2_INSITU=pivot: one by one beside large updates, see potf2m4_step -- and why the quad stays the default there too)
+    static const bool insitu_pivot = getenv("LGP_POTF2_INSITU") != nullptr && strcmp(getenv("LGP_POTF2_INSITU"), "pivot") == 0;
+    if (LGP_P4_QUAD && (ctx->potf2_small || !insitu_pivot)) hipLaunchKernelGGL(potf2_mfma4_kernel<true>, dim3(1), dim3(256), 0, stream, A, (long)lda, nb, dblk, ctx->d_info, (long)row0);
+    else hipLaunchKernelGGL(potf2_mfma4_kernel<false>, dim3(1), dim3(256), 0, stream, A, (long)lda, nb, dblk, ctx->d_info, (long)row0);
     LGP_LAUNCH_CHECK();
     return LGP_OK;
   }

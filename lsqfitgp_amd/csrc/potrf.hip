@@ -33,6 +33,12 @@ int lgp_info_result(lgp_ctx *ctx, int info) {
 namespace {
 
 // restores ctx->gemm_thin_lds (the thinning of the factorisation's updates) on every way out of a driver
+// one wave that leaves after `ticks` of the 100 MHz clock (LGP_LOOKAHEAD_DELAY)
+__global__ void lookahead_delay_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 struct ThinGuard {
   lgp_ctx *c;
   explicit ThinGuard(lgp_ctx *ctx) : c(ctx) { c->gemm_thin_lds = 0; c->gemm_prio = 0; }
@@ -790,6 +796,18 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
     const int u1st = lgp_gemm_launch<T>(ctx, s1, false, true, nb1, nb1, kb, T(-1), Pt, ldl, Pt, ldl, T(1), C1, ldl, true);
     ctx->gemm_prio = 0;
     LGP_CHECK(u1st);
+    // LGP_LOOKAHEAD_DELAY=<fraction> (experiment): the next square -- and with it the rows below it -- starts only that fraction of
+    // the large update's estimated duration (its flops at 65 TFLOP/s) later: one wave that sleeps on the chain stream.  A look-ahead
+    // that is held back interferes less with the large update (potf2_dev.h); held back too long it makes the update's stream wait.
+    static const double la_delay = getenv("LGP_LOOKAHEAD_DELAY") ? atof(getenv("LGP_LOOKAHEAD_DELAY")) : 0.0;
+    if (la_delay > 0 && rows_t > nb1) {
+      const double rr = (double)(rows_t - nb1);
+      const double us = la_delay * (2.0 * (double)kb * (0.5 * rr * rr + (double)nx * rr)) / 65e12 * 1e6;
+      if (us >= 50.) {
+        hipLaunchKernelGGL(lookahead_delay_kernel, dim3(1), dim3(64), 0, s1, (unsigned long long)(us * 100.));      // (100 MHz clock)
+        LGP_LAUNCH_CHECK();
+      }
+    }
     // ---- sg: U2, the block column below that square; then s3 may touch it
     LGP_HIP(hipStreamWaitEvent(sg, E(EV_SQ), 0));
     LGP_HIP(hipStreamWaitEvent(sg, E(EV_FAR), 0));
@@ -1134,6 +1152,7 @@ template <typename T>
 int lgp_potrf_impl(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t nx) {
   LGP_REQUIRE(ldl >= n, "ldl < n");
   static const bool v1 = getenv("LGP_POTRF") != nullptr && strcmp(getenv("LGP_POTRF"), "v1") == 0;
+  ctx->potf2_small = n <= 8192;         // (no large update beside the diagonal blocks: the four-pivot potf2, potf2_dev.h)
   if (v1 || ctx->stream3 == nullptr) return potrf_lookahead_v1<T>(ctx, n, L, ldl, dblk, nx);
   if constexpr (std::is_same<T, double>::value) {
     if (lgp_chain_usable(ctx, n, ldl) && n <= ctx->chain_max_n) return potrf_chain(ctx, n, L, ldl, dblk, nx, 0, false);

@@ -31,7 +31,7 @@ int main(int argc, char **argv) {
   for (int rep = 0; rep < 5; ++rep) {
     CK(hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice));
     CK(hipEventRecord(e0));
-    potf2_mfma4_kernel<<<1, 256>>>(dA, n, n, dW, dinfo, 0);
+    potf2_mfma4_kernel<(LGP_P4_QUAD != 0)><<<1, 256>>>(dA, n, n, dW, dinfo, 0);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("potf2_mfma4 alone: %.1f us\n", ms * 1e3);
@@ -49,13 +49,13 @@ int main(int argc, char **argv) {
   }
   printf("LGP_P4_QUAD=%d jitter %.1e info %d: max |L - ref| = %.3e (max |L| %.3e), max |L L' - A| = %.3e\n", LGP_P4_QUAD, jitter, info, dl, nl, res);
   CK(hipEventRecord(e0));
-  for (int i = 0; i < 50; ++i) potf2_mfma4_kernel<<<1, 256>>>(dA, n, n, dW, dinfo, 0);
+  for (int i = 0; i < 50; ++i) potf2_mfma4_kernel<(LGP_P4_QUAD != 0)><<<1, 256>>>(dA, n, n, dW, dinfo, 0);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("potf2_mfma4 x50 back-to-back: %.1f us each\n", ms * 1e3 / 50);
 #ifdef LGP_POTF2_TRACE
   CK(hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice));
-  potf2_mfma4_kernel<<<1, 256>>>(dA, n, n, dW, dinfo, 0);
+  potf2_mfma4_kernel<(LGP_P4_QUAD != 0)><<<1, 256>>>(dA, n, n, dW, dinfo, 0);
   CK(hipDeviceSynchronize());
   unsigned long long st[64];
   CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(lgp_p4_trace), sizeof(st)));
