@@ -57,6 +57,7 @@ struct lgp_ctx {
   int potf2_mode = 0;                 // diagonal-block kernel: 0 = auto, 1 = VALU, 2 = matrix cores (env LGP_POTF2=valu|mfma)
   int gemm_prio = 0;                  // wave priority of the next products (0: default; 3 for the latency-bound products on the chain's side, LGP_FAR_PRIO)
   size_t gemm_thin_lds = 0;           // bytes of untouched dynamic LDS added to NT gemm launches (set around the trailing updates)
+  int potf2_late = 0;                 // potrf_split: the panel in hand belongs to the end of a large factorisation (its updates run on 64-tiles)
   int potf2_small = 1;                // auto mode: the factorisation in progress is small enough for the matrix-core kernel
   // the dependent chain of the factorisation as one launch of resident workers (potf2m.hip): schedules per matrix size,
   // flag/counter words (LGP_CH_* layout)

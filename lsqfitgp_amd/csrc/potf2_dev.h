@@ -167,7 +167,8 @@ constexpr int P4_ROWBUF = 8 * 4 * 64;   // block row s: tile of block column i, 
 // (LGP_POTF2_INSITU=pivot), the C3 step is nevertheless FASTER with the quad everywhere: 187.1-187.4 against 187.9-188.0 ms.  With
 // the pivot-by-pivot blocks the look-ahead gets in at once, the stream of the large updates idles 0.6 instead of 3.5-4.7 ms
 // between them -- and the large updates take 150.8 instead of 146.0 ms, because the look-ahead's kernels then run beside them for
-// longer.  A look-ahead that is held back interferes less; the quad is the default everywhere.
+// longer.  A look-ahead that is held back interferes less: the quad is the default beside the large (128-tile) updates; beside the
+// 64-tile updates of the last panels, where the step waits for the look-ahead, the pivot-by-pivot kernel is (potf2m.hip).
 template <int S, bool QUAD>
 __device__ __forceinline__ void potf2m4_step(acc_t (&tA)[4], acc_t (&tB)[8], double (&rdn)[8], double *rowbuf, double *diagbuf, int w, int lane,
                                              int n, int g, int nb, int *info, long row0) {

@@ -235,9 +235,12 @@ __global__ void __launch_bounds__(256) potf2_mfma4_kernel(double *A, long lda, i
 int lgp_potf2_mfma_launch(lgp_ctx *ctx, hipStream_t stream, double *A, size_t lda, int nb, double *dblk, size_t row0) {
   LGP_REQUIRE(lda < (1u << 20), "leading dimension too large for the 32-bit offsets of the diagonal-block kernel");
   if (ctx->potf2_mode != 3) {
-    // (LGP_POTF2_INSITU=pivot: one by one beside large updates, see potf2m4_step -- and why the quad stays the default there too)
-    static const bool insitu_pivot = getenv("LGP_POTF2_INSITU") != nullptr && strcmp(getenv("LGP_POTF2_INSITU"), "pivot") == 0;
-    if (LGP_P4_QUAD && (ctx->potf2_small || !insitu_pivot)) hipLaunchKernelGGL(potf2_mfma4_kernel<true>, dim3(1), dim3(256), 0, stream, A, (long)lda, nb, dblk, ctx->d_info, (long)row0);
+    // Which pivot scheme beside the updates of a large factorisation (potf2m4_step says why): the quad beside the 128-tile updates,
+    // where it holds the look-ahead back; one by one beside the 64-tile updates of the end, where the look-ahead is what the step
+    // waits for (C3 191.6 vs 191.9 ms, N = 20480 51.0-51.1 vs 51.3-51.4 on one box).  LGP_POTF2_INSITU=quad | pivot | late (default).
+    static const int insitu = getenv("LGP_POTF2_INSITU") == nullptr ? 2 : (strcmp(getenv("LGP_POTF2_INSITU"), "pivot") == 0 ? 1 : (strcmp(getenv("LGP_POTF2_INSITU"), "late") == 0 ? 2 : 0));
+    const bool pivot_now = !ctx->potf2_small && (insitu == 1 || (insitu == 2 && ctx->potf2_late));
+    if (LGP_P4_QUAD && !pivot_now) hipLaunchKernelGGL(potf2_mfma4_kernel<true>, dim3(1), dim3(256), 0, stream, A, (long)lda, nb, dblk, ctx->d_info, (long)row0);
     else hipLaunchKernelGGL(potf2_mfma4_kernel<false>, dim3(1), dim3(256), 0, stream, A, (long)lda, nb, dblk, ctx->d_info, (long)row0);
     LGP_LAUNCH_CHECK();
     return LGP_OK;

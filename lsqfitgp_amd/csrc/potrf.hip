@@ -741,6 +741,7 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
     T *P = L + k0 * ldl + k0;
     T *Yk = dblk + (k0 / LGP_DB) * (size_t)LGP_DBLK;
     const size_t far = n + nx - (k0 + kb);              // rows below the square, carried rows included
+    ctx->potf2_late = ((far + 127) / 128) * ((n - k0 - kb + 127) / 128) <= lgp_gemm_t64_trailing_max() ? 1 : 0;   // (this square runs beside a 64-tile update)
     T *Pfar = P + kb * ldl;
     // ---- the square on s1, the far rows one block behind on s3
     int bi = 0;

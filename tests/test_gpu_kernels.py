@@ -643,12 +643,15 @@ def test_sums_and_products_of_kernels(lgp, rng):
     # a GP on a sum of kernels: the prior covariance is the sum of the priors
     gp = lgp.GP(lgp.ExpQuad(scale=2.) + lgp.Cos() * 0.5, checkpos=False).addx(x, 'x')
     np.testing.assert_allclose(gp.prior('x', raw=True), (oracle.ExpQuad(scale=2.) + oracle.Cos() * 0.5)(x[:, None], x[None, :]), rtol=0, atol=1e-14)
-    # derivative observations pass through a sum, not through a product
+    # derivative observations pass through a sum term by term, through a product by Leibniz' rule (tests/test_gpu_deriv.py holds the
+    # latter to the oracle and to central differences)
     d1 = (lgp.ExpQuad(scale=2.) + lgp.ExpQuad(scale=0.5) * 3.).gram(x, y, deriv=(1, 1)).to_host()
     want = lgp.ExpQuad(scale=2.).gram(x, y, deriv=(1, 1)).to_host() + 3. * lgp.ExpQuad(scale=0.5).gram(x, y, deriv=(1, 1)).to_host()
     np.testing.assert_allclose(d1, want, rtol=0, atol=1e-14 * np.abs(want).max())
-    with pytest.raises(NotImplementedError):
-        (lgp.ExpQuad() * lgp.Cos()).gram(x, y, deriv=(1, 0))
+    e, c = lgp.ExpQuad(), lgp.Cos()
+    d2 = (e * c).gram(x, y, deriv=(1, 0)).to_host()
+    want = e.gram(x, y, deriv=(1, 0)).to_host() * c.gram(x, y).to_host() + e.gram(x, y).to_host() * c.gram(x, y, deriv=(1, 0)).to_host()
+    np.testing.assert_allclose(d2, want, rtol=0, atol=1e-14 * np.abs(want).max())
 
 
 def test_tangents_of_sums_and_products(lgp, rng):
