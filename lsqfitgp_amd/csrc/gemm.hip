@@ -607,6 +607,8 @@ int lgp_gemm_launch(lgp_ctx *ctx, hipStream_t stream, bool ta, bool tb, size_t m
   // they become ~100 short workgroups instead of 8 long ones (N = 4096: 90 -> 15 us per product)
   // tag & 4 (the left-looking block-column updates of the chain driver, K up to N): 64 x 64 tiles while 128-tiles would not fill the GPU
   static const size_t deep64 = getenv("LGP_GEMM_DEEP64") ? (size_t)atol(getenv("LGP_GEMM_DEEP64")) : 512;
+  static const bool force64 = getenv("LGP_GEMM_FORCE64") != nullptr;      // (measurements: every product that may on 64 x 64 tiles)
+  if (force64 && !aliased) return gemm_launch_ts<T, 64, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, 0, cyc_nb, cyc_g1, roff);
   if (!aliased && ((t128 <= t64big && k <= 2048) || (t128 <= 512 && k <= 256) || t128 <= 4 || ((tag & 4) && t128 <= deep64)))
     return gemm_launch_ts<T, 64, 256>(ctx, stream, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, 0, cyc_nb, cyc_g1, roff);
   // (a 512-thread variant, 4 x 2 waves of 32 x 64 at 4 waves per SIMD, was measured equal: 61.3 vs 61.7 TFLOP/s)
