@@ -13,6 +13,10 @@ starts = [i for i, r in enumerate(rows) if 'gram_reg_kernel' in r[2]]
 sel = rows[starts[-1]:]
 t0 = sel[0][0]
 big = [r for r in sel if '128, 256, 1' in r[2]]
+# (bench.py times the stand-alone Gram kernel after its steps: the step ends where those launches begin)
+after = [r[0] for r in sel if 'gram_iso_kernel' in r[2] and r[0] > big[-1][1]]
+if after:
+    sel = [r for r in sel if r[1] <= after[0]]
 q = big[0][3]
 onq = [r for r in sel if r[3] == q]
 print(f'step span {(max(r[1] for r in sel) - t0) / 1e3:.0f} us; queue {q} carries the large updates')
