@@ -90,6 +90,8 @@ class Workload:
         # fused Gram: lgp_gram_chol_factor_rhs writes tril((Kxx + ycov) / s / s') straight into the factor (K is never
         # materialised: one N x N allocation instead of two); LGP_BENCH_SEPARATE_GRAM=1 times the three-pass path instead
         self.fused_gram = self.fused and not os.environ.get('LGP_BENCH_SEPARATE_GRAM')
+        # the prediction never multiplies by the full factor: no stores of zeros above its diagonal (LGP_FACTOR_LOWER_ONLY)
+        self.lower_only = 0 if os.environ.get('LGP_BENCH_FULL_FACTOR') else _lib.LGP_FACTOR_LOWER_ONLY
         self.K = None if self.fused_gram else DA.empty((n, n), ctx=ctx)           # Kxx + ycov
         # fused: the factor with m + 1 extra rows [Kxxs | y]^T that the factorisation turns into (L^-1 [Kxxs | y])^T
         # (m + 1 padded with zero rows to whole 128-row tiles, so that the extra tiles take the kernels' aligned fast path)
@@ -138,7 +140,7 @@ class Workload:
         eps = ctypes.c_double()
         if self.fused_gram:
             info = ck(lib.lgp_gram_chol_factor_rhs_f64(ctx.handle, self.kind, self.p, 0, None, self.cfg['d'], self.x.ptr, self.x.ld, n, 0, 0., 1, 1., 0, None, None,
-                                                       self.noise, None, 0., 0., self._lib.LGP_EPS_AUTO_REL, self.L.ptr, self.L.ld, self.nx, self.dblk.ptr,
+                                                       self.noise, None, 0., 0., self._lib.LGP_EPS_AUTO_REL | self.lower_only, self.L.ptr, self.L.ld, self.nx, self.dblk.ptr,
                                                        ctypes.byref(eps)), 'gram_chol_factor_rhs')
         elif self.fused:
             info = ck(lib.lgp_chol_factor_rhs_f64(ctx.handle, n, self.K.ptr, self.K.ld, 0., 0., self._lib.LGP_EPS_AUTO_REL,

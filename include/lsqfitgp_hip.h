@@ -365,6 +365,10 @@ int lgp_allclose_f32(lgp_ctx *ctx, size_t rows, size_t cols, const float *dA, si
 
 #define LGP_EPS_AUTO_REL 1   /* epsrel='auto' -> n * finfo.eps   (_decomp.py:248-249) */
 #define LGP_EPS_AUTO_ABS 2   /* epsabs='auto' -> finfo.eps       (_decomp.py:250-251) */
+#define LGP_FACTOR_LOWER_ONLY 4 /* lgp_gram_chol_factor_rhs_* only: the entries of dL above the diagonal are left UNSPECIFIED outside the
+                                 * 128 x 128 diagonal blocks (no stores of zeros: half of the Gram kernel's traffic).  Every entry point of this
+                                 * library that takes a factor reads its lower triangle and the diagonal blocks only; lgp_zero_upper_* fills the
+                                 * zeros in afterwards for a consumer that multiplies by the full matrix (Decomposition.correlate). */
 
 /* Chol.__init__: s = diag_scale_pow2(K) (:356-361); Kt = K/s/s[:,None]; eps = epsrel*max_i sum_j|Kt_ij| + epsabs
  * (:245-255,349-354); Kt_ii += eps; Lt = cholesky(Kt) lower; L = Lt*s[:,None]; eps_out = eps*min(s^2).
@@ -448,6 +452,9 @@ int lgp_gram_chol_factor_rhs_f32(lgp_ctx *ctx, int kernel, int p, int npar, cons
                                  int nops, const int *hops_code, const float *hops_val,
                                  float noise, const float *dnoise, float epsrel, float epsabs, int eps_flags,
                                  float *dL, size_t ldl, size_t nrhs, float *ddblk, float *heps_out);
+/* The zeros above the diagonal of a factor made with LGP_FACTOR_LOWER_ONLY (dL: n x n).  Asynchronous on the context's stream. */
+int lgp_zero_upper_f64(lgp_ctx *ctx, size_t n, double *dL, size_t ldl);
+int lgp_zero_upper_f32(lgp_ctx *ctx, size_t n, float *dL, size_t ldl);
 /* lgp_posterior for right-hand sides solved that way: dWt = (m+1) x n, rows 0..m-1 = (L^-1 Kxxs)^T, row m = (L^-1 y)^T
  * (typically dL + n * ldl); same outputs as lgp_posterior. */
 int lgp_posterior_solved_f64(lgp_ctx *ctx, size_t n, size_t m, const double *dL, size_t ldl, const double *dWt, size_t ldw,
@@ -460,7 +467,8 @@ int lgp_posterior_solved_f32(lgp_ctx *ctx, size_t n, size_t m, const float *dL, 
  * hpts: HOST d x (n + m), row f = coordinate f of the n data points followed by the m prediction points.  hy: HOST n.
  * hnoise: HOST n (diagonal of the data covariance) or NULL.
  * dP: DEVICE d x (n + m), receives the points.  dL: DEVICE (n + nx) x n with leading dimension ldl, nx >= m + 1 (whole 128-row tiles
- * are fastest): on exit the factor L, and below it rows n .. n + m = (L^-1 [Kxxs | y])^T.  ddblk: lgp_chol_dblk_size(n).
+ * are fastest): on exit the factor L (as with LGP_FACTOR_LOWER_ONLY: nothing is promised above its diagonal), and below it rows
+ * n .. n + m = (L^-1 [Kxxs | y])^T.  ddblk: lgp_chol_dblk_size(n).
  * dwork: DEVICE m m + m + 2 + n doubles.  hout: HOST m m + m + 2 doubles: the posterior covariance (m x m), the posterior mean (m),
  * minus_log_normal_density(y) (_decomp.py:484-488), and one scratch value.  heps_out: the jitter that was added (_decomp.py:393).
  * Returns 0, info > 0 (first non-positive pivot) or an error.  Synchronises. */

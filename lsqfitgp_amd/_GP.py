@@ -1331,7 +1331,7 @@ class GP:
             if nz is not None:
                 _lib.check(lib.lgp_add_diag_f64(ctx.handle, n, K.ptr, K.ld, nz.ptr, F(0.)), 'lgp_add_diag')
             return K
-        solver = Chol._adopt(L.block(0, n, 0, n), dblk, eps.value, solved=L.block(n, n + m + 1, 0, n), matrix=matrix)
+        solver = Chol._adopt(L.block(0, n, 0, n), dblk, eps.value, solved=L.block(n, n + m + 1, 0, n), matrix=matrix, lower_only=True)
         ymean = numpy.asarray(y)
         solver._solved_key = ((outkey,), ymean.dtype.str, ymean.tobytes())
         solver._density_memo = (numpy.array(ymean, copy=True), numpy.float64(dens.value))

@@ -63,6 +63,7 @@ LGP_OP_MUL = 0
 LGP_OP_ADD = 1
 LGP_EPS_AUTO_REL = 1
 LGP_EPS_AUTO_ABS = 2
+LGP_FACTOR_LOWER_ONLY = 4
 LGP_COMM_ID_BYTES = 128
 
 _P = c_void_p          # device pointer
@@ -168,6 +169,7 @@ def _signatures():
             'lgp_gram_chol_factor_rhs_' + suf: (c_int, [c_void_p, c_int, c_int, c_int, POINTER(F), c_int, _P, _S, _S, c_int, F, c_int, F,
                                                        c_int, POINTER(c_int), POINTER(F), F, _P, F, F, c_int, _P, _S, _S, _P, POINTER(F)]),
             'lgp_potrf_' + suf: (c_int, [c_void_p, _S, _P, _S, _P]),
+            'lgp_zero_upper_' + suf: (c_int, [c_void_p, _S, _P, _S]),
             'lgp_trsm_' + suf: (c_int, [c_void_p, _S, _P, _S, _P, c_int, _P, _S, _S]),
             'lgp_gemm_' + suf: (c_int, [c_void_p, c_int, c_int, _S, _S, _S, F, _P, _S, _P, _S, F, _P, _S]),
             'lgp_colsumsq_' + suf: (c_int, [c_void_p, _S, _S, _P, _S, _P]),

@@ -303,11 +303,13 @@ class Chol(Decomposition):
         self._eps = self._dtype.type(eps.value)                        # :393
 
     @classmethod
-    def _adopt(cls, L, dblk, eps, *, solved=None, matrix=None):
+    def _adopt(cls, L, dblk, eps, *, solved=None, matrix=None, lower_only=False):
         """ a decomposition around a factor that the library has already computed (the fused Gram + factorisation entry point never
         materialises K): ``L`` (n, n) device block, ``dblk`` its diagonal-block workspace, ``solved`` (q, n) the rows carried
-        through the factorisation, ``matrix`` a callable that builds K on the device if somebody asks for it """
+        through the factorisation, ``matrix`` a callable that builds K on the device if somebody asks for it; ``lower_only``: the
+        factor was made with ``LGP_FACTOR_LOWER_ONLY`` (no zeros above its diagonal: `_full_factor` writes them on first use) """
         self = cls.__new__(cls)
+        self._upper_unset = bool(lower_only)
         self._K = None
         self._K_builder = matrix
         self._ctx = L.ctx
@@ -394,9 +396,18 @@ class Chol(Decomposition):
             self._K = self._K_builder()
         return self._K
 
+    def _full_factor(self):
+        """ L as a full matrix: the solves and the density read the lower triangle and the diagonal blocks only, a product with L
+        (``correlate``) or a download reads the zeros above the diagonal as well """
+        if getattr(self, '_upper_unset', False):
+            f, _ = _lib.fn('lgp_zero_upper', self._dtype)
+            _lib.check(f(self._ctx.handle, self.n, self._L.ptr, self._L.ld), 'lgp_zero_upper')
+            self._upper_unset = False
+        return self._L
+
     def factor(self):
         """ the lower factor L (device resident); not part of the reference API """
-        return self._L
+        return self._full_factor()
 
     def ginv_linear(self, X, *, device=False):
         # = K⁻¹X = L'⁻¹(L⁻¹X)                                  (:398-403)
@@ -424,7 +435,7 @@ class Chol(Decomposition):
 
     def pinv_bilinear_robj(self, A, r):
         # = A'K⁻¹r with r an array of objects                  (:411-415)
-        Lh = self._L.to_host()
+        Lh = self._full_factor().to_host()
         invLr = solve_triangular_python(Lh, numpy.asarray(r), lower=True)
         invLA, avec = self._rhs(A, copy=True)
         self._trsm(invLA, 0)
@@ -456,12 +467,12 @@ class Chol(Decomposition):
     def correlate(self, x, *, device=False):
         # = Lx                                                   (:429-431)
         X, vec = self._rhs(x, copy=False)
-        return self._out(self._gemm(False, False, self._L, X), vec, device)
+        return self._out(self._gemm(False, False, self._full_factor(), X), vec, device)
 
     def back_correlate(self, X, *, device=False):
         # = L'X                                                  (:433-435)
         Xd, vec = self._rhs(X, copy=False)
-        return self._out(self._gemm(True, False, self._L, Xd), vec, device)
+        return self._out(self._gemm(True, False, self._full_factor(), Xd), vec, device)
 
     def pinv_correlate(self, x, *, device=False):
         # = L⁻¹x                                                 (:437-439)

@@ -698,7 +698,7 @@ int lgp_predict_isotropic_f64(lgp_ctx *c, int kernel, int p, int npar, const dou
       ~Defer() { c->defer_finish = 0; }
     } defer(c);
     fst = lgp_gram_chol_factor_rhs_f64(c, kernel, p, npar, hpar, d, dx, np, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, 0.0,
-                                       hnoise ? dnoise : nullptr, 0.0, 0.0, LGP_EPS_AUTO_REL, dL, ldl, nx, ddblk, nullptr);
+                                       hnoise ? dnoise : nullptr, 0.0, 0.0, LGP_EPS_AUTO_REL | LGP_FACTOR_LOWER_ONLY, dL, ldl, nx, ddblk, nullptr);
   }
   if (fst != 0) return fst;                                     // an error (< 0)
   LGP_CHECK(posterior_solved_impl<double>(c, n, m, dL, ldl, Wt, ldl, dcov, m, dmean, dcov, m, nullptr));

@@ -66,6 +66,7 @@ struct IsoArgs {
   int ntable;
   T fill;
   int dord[8];     // ExpQuadDiff: total derivative order (x side + y side) along each of the first 8 fields
+  int lower_only;  // fused kernel: leave the entries above the diagonal outside the tiles that straddle it unwritten
   OutOps<T> ops;
 };
 
@@ -626,6 +627,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.posabs = posabs ? 1 : 0;
   g.xy = kernel == LGP_KERNEL_LINEAR ? 2 : ((kernel >= LGP_KERNEL_WIENER && kernel <= LGP_KERNEL_WIENERINTEGRAL) || kernel == LGP_KERNEL_TAYLOR ? 1 : (kernel == LGP_KERNEL_GIBBS ? 3 : 0));
   for (int f = 0; f < 8; ++f) g.dord[f] = 0;
+  g.lower_only = 0;
   if (kernel == LGP_KERNEL_EXPQUAD_DIFF) {
     if (npar == 0) g.dord[0] = p;
     for (int f = 0; f < npar; ++f) {
@@ -863,6 +865,7 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
   const int tid = threadIdx.x;
   const T k0 = g.ops.apply(iso_core_t<T, CORE>(g, T(0)));     // the kernel on its diagonal: r2 = 0 exactly, as for the pairs (i, i)
   const bool below = !COLS && col0 + GT_COLS - 1 < row0;   // every entry strictly below the diagonal: sums along the rows as well
+  const bool zeros = below && !g.lower_only;               // ... and the zeros of the mirror image
   constexpr int TPR = GR_ROWS / W, RPR = GT_THREADS / TPR;     // zero rounds: threads per mirrored row, rows per round
   const bool zfull = ((g.ldo % W) == 0) && ((reinterpret_cast<uintptr_t>(g.out) % 16) == 0);
   auto zero_round = [&](int zr) {
@@ -954,7 +957,7 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
       if (j < cend) acc[e] += fabs(v);
       res[e] = (j <= i) ? v : T(0);
     }
-    if (below) zero_round(r);
+    if (zeros) zero_round(r);
     if (below) {
       // sum along the row over this tile's columns: lanes, then the four waves in fixed order
       T rs = T(0);
@@ -976,7 +979,7 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
         if (col0 + c0 + e < cend) po[e] = res[e];
     }
   }
-  if (below)
+  if (zeros)
     for (int zr = rmax; zr < GR_ROWS; ++zr) zero_round(zr);      // (ragged last tile row: the rounds its loop did not reach)
 #pragma unroll
   for (int e = 0; e < W; ++e)
@@ -991,7 +994,8 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
 template <typename T>
 int gram_reg_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, int d, const T *dx, size_t ldx, size_t n, int has_loc, T loc,
                     int has_scale, T scale, int nops, const int *hops_code, const T *hops_val, T noise, const T *dnoise, T *dL, size_t ldl, T *dsvec,
-                    T *dpart, T *drpart, size_t *ntr_out, bool cols = false, size_t c0 = 0, size_t w = 0, size_t cyc_nb = 0, size_t cyc_stride = 0) {
+                    T *dpart, T *drpart, size_t *ntr_out, bool cols = false, size_t c0 = 0, size_t w = 0, size_t cyc_nb = 0, size_t cyc_stride = 0,
+                    bool lower_only = false) {
   LGP_REQUIRE(ctx != nullptr && dx != nullptr && dL != nullptr && dsvec != nullptr && dpart != nullptr && (cols || drpart != nullptr), "null pointer");
   LGP_REQUIRE(!cols || (w >= 1 && c0 < n && (cyc_nb || c0 + w <= n)), "column range outside the matrix");
   LGP_REQUIRE(!cols || cyc_nb == 0 || (cyc_nb % (GT_THREADS * VecOf<T>::W) == 0 && cyc_stride >= cyc_nb), "block width: a multiple of the tile width");
@@ -1017,6 +1021,7 @@ int gram_reg_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
   g.table = nullptr; g.ntable = 0; g.fill = T(0);
   g.cbase = 0; g.cyc_nb = 0; g.cyc_stride = 0; g.wloc = 0;
   for (int f = 0; f < 8; ++f) g.dord[f] = 0;
+  g.lower_only = lower_only ? 1 : 0;
   g.par[0] = g.par[1] = g.par[2] = T(0);
   g.flag = 0;
   if (kernel == LGP_KERNEL_GAMMAEXP) {
@@ -1964,6 +1969,7 @@ int lgp_predict_small_f64(lgp_ctx *ctx, int kernel, int p, int npar, const doubl
   g.table = nullptr; g.ntable = 0; g.fill = T(0);
   g.cbase = 0; g.cyc_nb = 0; g.cyc_stride = 0; g.wloc = 0;
   for (int f = 0; f < 8; ++f) g.dord[f] = 0;
+  g.lower_only = 0;
   g.par[0] = g.par[1] = g.par[2] = g.par[3] = T(0);
   g.flag = 0;
   if (kernel == LGP_KERNEL_GAMMAEXP) {
@@ -2024,7 +2030,7 @@ static int gram_chol_impl(lgp_ctx *ctx, int kernel, int p, int npar, const T *hp
   WsGuard ws_guard(ctx, ctx->stream, ws);      // (the calls below end with a stream synchronisation: nothing is using it by then)
   size_t got = 0;
   int st = gram_reg_launch<T>(ctx, kernel, p, npar, hpar, d, dx, ldx, n, has_loc, loc, has_scale, scale, nops, hops_code, hops_val, noise, dnoise, dL,
-                              ldl, ws, ws + 2 * n + 16, ws + 2 * n + 16 + ntr * n, &got);
+                              ldl, ws, ws + 2 * n + 16, ws + 2 * n + 16 + ntr * n, &got, false, 0, 0, 0, 0, (flags & LGP_FACTOR_LOWER_ONLY) != 0);
   if (st == LGP_OK) st = lgp_chol_from_prepared<T>(ctx, n, dL, ldl, ddblk, nrhs, ws, ntr + ntc_r, epsrel, epsabs, flags, heps_out);
   return st;
 }

@@ -493,6 +493,15 @@ __global__ void __launch_bounds__(256) scale_rows_kernel(T *L, long ldl, int n, 
   for (int j = jbeg + threadIdx.x; j < jbeg + 2048 && j <= i && j < n; j += 256) L[(long)i * ldl + j] *= s[i];
 }
 
+// the zeros above the diagonal of a factor made with LGP_FACTOR_LOWER_ONLY (one workgroup per 2048-column segment of a row)
+template <typename T>
+__global__ void __launch_bounds__(256) zero_upper_kernel(T *L, long ldl, int n, int nbx) {
+  const int i = blockIdx.x / nbx;
+  const int jbeg = (blockIdx.x % nbx) * 2048;
+  for (int j = jbeg + threadIdx.x; j < jbeg + 2048 && j < n; j += 256)
+    if (j > i) L[(long)i * ldl + j] = T(0);
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -815,7 +824,8 @@ static int potrf_split(lgp_ctx *ctx, size_t n, T *L, size_t ldl, T *dblk, size_t
     const size_t rows_r = rows_t - nb1;
     // (the last panels are bound by the chain: their updates leave room on every CU, see potrf_chain)
     static const long thin_env = getenv("LGP_THIN_LDS_KB") ? atol(getenv("LGP_THIN_LDS_KB")) : -1;
-    ctx->gemm_thin_lds = thin_env >= 0 ? (size_t)thin_env * 1024 : (rows_t <= 6144 ? (size_t)70 * 1024 : (rows_t <= 12288 ? (size_t)20 * 1024 : 0));
+    static const size_t thin_small = (size_t)(getenv("LGP_THIN_SMALL_KB") ? atol(getenv("LGP_THIN_SMALL_KB")) : 20) * 1024;      // (70 until round 5)
+    ctx->gemm_thin_lds = thin_env >= 0 ? (size_t)thin_env * 1024 : (rows_t <= 6144 ? thin_small : (rows_t <= 12288 ? (size_t)20 * 1024 : 0));
     static const size_t u2_t128_min = getenv("LGP_U2_T128_MIN_ROWS") ? (size_t)atol(getenv("LGP_U2_T128_MIN_ROWS")) : (size_t)1 << 40;
     if (rows_r + nx > 0)
       LGP_CHECK(lgp_gemm_launch<T>(ctx, sg, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false,
@@ -936,6 +946,9 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
       // of the next in the late panels of N = 8192, where right-looking rows (every block followed by a K = 128 update of all
       // the remaining columns: 37 + 52 us per step against the chain's 68) fell 20 us further behind per block (~390 us).
       // (The early panels wait for the previous panel's updates instead: their far rows cannot start before U2.)
+      // (Round 5 tried ONE resident launch per panel whose waves poll those words themselves, docs/history/far_resident: never
+      // faster -- N = 8192 6.39 against 6.11-6.25 ms, 12288 16.0 against 14.9 -- because what bounds these sizes is the update stream,
+      // busy without a gap, and the resident workgroups take CUs and L2 bandwidth from it for as long as they live.)
       for (size_t j = 0; j < nq; ++j) {
         const size_t j0 = j * LGP_DB;
         if (j >= 1) {
@@ -977,11 +990,15 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     for (int g = 0; g < ng; ++g) LGP_HIP(wait_ge(s0, word(k, LGP_CH_GRP + g), 1));
     const size_t rows_r = rows_t - nb1;
     // The updates with this panel leave room on every CU when the chain is what bounds the rest of the factorisation: untouched
-    // dynamic LDS thins their workgroups out (one 64-tile workgroup per CU below 6144 remaining rows, three below 12288), so
-    // that the far-row kernels of the next panel are dispatched at once and not squeezed (N = 4096 2.58 -> 2.48 ms, N = 8192
-    // 6.92 -> 6.55 ms; thinning the large updates of N = 16384 as well: 30.4 -> 31.4 ms, so they are left alone).
+    // dynamic LDS thins their workgroups out (three 64-tile workgroups per CU below 12288 remaining rows), so that the far-row
+    // kernels of the next panel are dispatched at once and not squeezed (N = 4096 2.58 -> 2.48 ms, N = 8192 6.92 -> 6.55 ms;
+    // thinning the large updates of N = 16384 as well: 30.4 -> 31.4 ms, so they are left alone).  Until round 5 it was ONE
+    // workgroup per CU below 6144 rows; since the chain-side products run at wave priority 3 that costs the updates -- whose
+    // stream is busy without a gap at N = 8192 -- more than it gives the rows: N = 8192 5.97-6.00 against 6.11-6.25 ms, 12288
+    // 14.52 against 14.85 on one box (LGP_THIN_SMALL_KB=70 is the old setting).
     static const long thin_env = getenv("LGP_THIN_LDS_KB") ? atol(getenv("LGP_THIN_LDS_KB")) : -1;
-    ctx->gemm_thin_lds = thin_env >= 0 ? (size_t)thin_env * 1024 : (rows_t <= 6144 ? (size_t)70 * 1024 : (rows_t <= 12288 ? (size_t)20 * 1024 : 0));
+    static const size_t thin_small = (size_t)(getenv("LGP_THIN_SMALL_KB") ? atol(getenv("LGP_THIN_SMALL_KB")) : 20) * 1024;      // (70 until round 5)
+    ctx->gemm_thin_lds = thin_env >= 0 ? (size_t)thin_env * 1024 : (rows_t <= 6144 ? thin_small : (rows_t <= 12288 ? (size_t)20 * 1024 : 0));
     // (U2 in blocks of 128 columns with a count in u2[k] behind each, so that step j of the rows below the next square waits for
     // block j only: measured worse, N = 8192 6.35 -> 7.2 ms -- eight 128-column products take 440 us where the one launch takes 290)
     // small matrices: U2 behind U1 (side by side U1 takes 130 us instead of 45 and the next square waits for it; N = 4096 2.44 ->
@@ -1341,6 +1358,19 @@ extern "C" int lgp_chol_factor_rhs_f32(lgp_ctx *ctx, size_t n, const float *dK, 
                                        float *dL, size_t ldl, size_t nrhs, float *ddblk, float *heps_out) {
   return chol_factor_impl<float>(ctx, n, dK, ldk, epsrel, epsabs, eps_flags, dL, ldl, ddblk, heps_out, nrhs);
 }
+
+template <typename T>
+static int zero_upper_entry(lgp_ctx *ctx, size_t n, T *L, size_t ldl) {
+  LGP_REQUIRE(ctx != nullptr && L != nullptr, "null pointer");
+  LGP_REQUIRE(n >= 1 && n < (1u << 30) && ldl >= n, "bad dimensions");
+  DeviceGuard dg(ctx->device);
+  const int nbx = (int)((n + 2047) / 2048);
+  hipLaunchKernelGGL((zero_upper_kernel<T>), dim3((unsigned)((size_t)nbx * n)), dim3(256), 0, ctx->stream, L, (long)ldl, (int)n, nbx);
+  LGP_LAUNCH_CHECK();
+  return LGP_OK;
+}
+extern "C" int lgp_zero_upper_f64(lgp_ctx *ctx, size_t n, double *dL, size_t ldl) { return zero_upper_entry<double>(ctx, n, dL, ldl); }
+extern "C" int lgp_zero_upper_f32(lgp_ctx *ctx, size_t n, float *dL, size_t ldl) { return zero_upper_entry<float>(ctx, n, dL, ldl); }
 
 extern "C" size_t lgp_chol_dblk_size(size_t n) { return ((n + LGP_DB - 1) / LGP_DB) * (size_t)LGP_DBLK; }
 

@@ -462,6 +462,57 @@ def test_fused_gram_factor(lgp, rng, dtype, n, d, q):
             util.assert_close_matrices(L1[n:n + q], L0[n:n + q], rtol=1e-9 if f64 else 2e-2)
 
 
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('n,d,q', [(1, 1, 0), (130, 1, 3), (1025, 2, 101), (2600, 3, 7), (4200, 1, 1)])
+def test_fused_gram_factor_lower_only(lgp, rng, dtype, n, d, q):
+    """ LGP_FACTOR_LOWER_ONLY: the fused entry point leaves the entries above the diagonal alone (no stores of zeros).  The storage
+    is filled with NaN first: the factor below the diagonal, the carried solve, eps and a later pair of triangular solves are
+    bit for bit those of the call without the flag -- nothing the library does reads above the diagonal outside the diagonal
+    blocks -- and lgp_zero_upper writes the zeros a product with the full matrix needs (Chol._full_factor) """
+    from lsqfitgp_amd import _lib
+    lib = _lib.load()
+    ctx = lgp.Context.default()
+    f64 = dtype == np.float64
+    suf, F = ('f64', ctypes.c_double) if f64 else ('f32', ctypes.c_float)
+    x = rng.uniform(0, max(n, 16) / 16, (d, n)).astype(dtype)
+    xd = lgp.DeviceArray.from_host(x)
+    B = rng.standard_normal((q, n)).astype(dtype)
+    R = rng.standard_normal((n, 3)).astype(dtype)
+    nx = -(-q // 128) * 128 if q else 0
+    outs = []
+    for flag in (0, _lib.LGP_FACTOR_LOWER_ONLY):
+        L = lgp.DeviceArray.from_host(np.full((n + nx, n), np.nan, dtype))
+        if nx:
+            L.block(n, n + nx, 0, n).fill_zero()
+        if q:
+            L.block(n, n + q, 0, n).assign(lgp.DeviceArray.from_host(B))
+        dblk = lgp.DeviceArray.empty((lib.lgp_chol_dblk_size(n),), dtype)
+        eps = F()
+        st = getattr(lib, 'lgp_gram_chol_factor_rhs_' + suf)(ctx.handle, _lib.LGP_KERNEL_EXPQUAD, 0, 0, None, d, xd.ptr, xd.ld, n, 0, F(0), 1, F(0.7),
+                                                              0, None, None, F(0.01), None, F(0), F(0), _lib.LGP_EPS_AUTO_REL | flag, L.ptr, L.ld,
+                                                              nx, dblk.ptr, ctypes.byref(eps))
+        assert _lib.check(st) == 0
+        Rd = lgp.DeviceArray.from_host(R)
+        for trans in (0, 1):
+            _lib.check(getattr(lib, 'lgp_trsm_' + suf)(ctx.handle, n, L.ptr, L.ld, dblk.ptr, trans, Rd.ptr, Rd.ld, 3))
+        Lh = L.to_host()
+        if flag:
+            _lib.check(getattr(lib, 'lgp_zero_upper_' + suf)(ctx.handle, n, L.ptr, L.ld))
+            assert np.all(np.triu(L.to_host()[:n], 1) == 0)
+            np.testing.assert_array_equal(np.tril(L.to_host()[:n]), np.tril(Lh[:n]))
+        else:
+            assert np.all(np.triu(Lh[:n], 1) == 0)
+        outs.append((eps.value, Lh, Rd.to_host()))
+    (e0, L0, R0), (e1, L1, R1) = outs
+    assert e0 == e1
+    np.testing.assert_array_equal(np.tril(L1[:n]), np.tril(L0[:n]))
+    np.testing.assert_array_equal(L1[n:], L0[n:])
+    np.testing.assert_array_equal(R1, R0)
+    assert np.all(np.isfinite(R1))
+    if n > 1024:
+        assert np.isnan(L1[0, n - 1])       # (the flag did something)
+
+
 @pytest.fixture(scope='module')
 def driver_contexts(lgp):
     """ two contexts on the same GPU: the launch-per-operation driver of the factorisation (LGP_CHAIN=0 when the context is
