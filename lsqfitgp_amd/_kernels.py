@@ -1895,6 +1895,26 @@ class BART(Kernel):
         self._splits = self._check_splits(splits, indices)
         self._indices = bool(indices)
         self._dpnt_ab = None
+        self._vector = None
+        if ((pnt is None and (numpy.ndim(alpha) or numpy.ndim(beta))) or (pnt is not None and numpy.ndim(pnt) > 1)
+                or (not isinstance(gamma, str) and numpy.ndim(gamma))):
+            # alpha / beta / gamma / pnt with leading axes of their own: in the reference they broadcast against the shape of the
+            # kernel's output (_bart.py:301-303 "fully vectorized", :373-401).  The device kernels take one set of parameters per
+            # launch: the pairs are grouped by distinct parameters (`correlation`), a scalar-parameter kernel per group
+            if self._dalpha or self._dbeta:
+                raise NotImplementedError('tangents of vectorised alpha / beta')
+            first = lambda v: v if not numpy.ndim(v) else numpy.asarray(v).reshape(-1)[0]
+            if numpy.size(alpha) == 0 or numpy.size(beta) == 0 or (pnt is not None and numpy.size(pnt) == 0):
+                raise ValueError('empty parameter array')
+            self._vector = dict(alpha=alpha, beta=beta, gamma=gamma, maxd=maxd, pnt=None if pnt is None else numpy.asarray(pnt),
+                                intercept=intercept, weights=weights, reset=reset)
+            # the scalar-parameter kernel of the first parameter set: argument checks, float type, index conversion
+            proto = BART(alpha=first(alpha), beta=first(beta), maxd=maxd, gamma=gamma if isinstance(gamma, str) else first(gamma), splits=splits,
+                         pnt=None if pnt is None else numpy.asarray(pnt).reshape(-1, numpy.shape(pnt)[-1])[0], intercept=intercept, weights=weights,
+                         reset=reset, indices=indices)
+            for name in ('_flt', '_pnt', '_gamma0', '_weights', '_brackets', '_deep'):
+                setattr(self, name, getattr(proto, name))
+            return
         # splitting probabilities, _bart.py:373-384
         if pnt is None:
             assert maxd == int(maxd) and maxd >= 0, maxd
@@ -1905,8 +1925,6 @@ class BART(Kernel):
             ft = numpy.result_type(*fl) if fl else numpy.dtype(numpy.float64)
             alpha_a = numpy.asarray(alpha)
             beta_a = numpy.asarray(beta)
-            if alpha_a.ndim or beta_a.ndim:
-                raise NotImplementedError('vectorised alpha/beta (see BART.correlation, which groups the pairs by parameters)')
             assert 0 <= alpha_a <= 1, 'alpha must be in [0, 1]'
             assert beta_a >= 0, 'beta must be in [0, inf)'
             d = numpy.arange(int(maxd) + 1)
@@ -1915,8 +1933,6 @@ class BART(Kernel):
             self._dpnt_ab = (1 / (1 + d).astype(ft) ** beta_a.astype(ft), -pnt * numpy.log((1 + d).astype(ft)))
         else:
             pnt = numpy.asarray(pnt)
-            if pnt.ndim != 1:
-                raise NotImplementedError('vectorised pnt')
         p = len(self._splits[0])
         if weights is None:
             weights = numpy.ones(p, pnt.dtype)                      # :387-390
@@ -1931,8 +1947,6 @@ class BART(Kernel):
             gamma = self._gamma(p, pnt)
         gamma_weak = isinstance(gamma, (bool, int, float)) and not isinstance(gamma, numpy.generic)
         gamma = numpy.asarray(gamma)
-        if gamma.ndim:
-            raise NotImplementedError('vectorised gamma')
         assert 0 <= gamma <= 1, 'gamma must be in [0, 1]'
         assert numpy.all((0 <= pnt) & (pnt <= 1)), 'pnt must be in [0, 1]'
         assert numpy.all(weights >= 0), 'weights must be in [0, inf)'
@@ -2213,8 +2227,37 @@ class BART(Kernel):
         ctx = ctx or Context.default()
         return DevicePoints('indices', DeviceArray.from_host(self._to_indices(xs), ctx=ctx), self._flt, ctx)
 
+    def _host_indices(self, xs):
+        return xs.array.to_host() if isinstance(xs, DevicePoints) else self._to_indices(xs)
+
+    def _vector_eval(self, ix, iy, shape, ctx, out=None):
+        """ vectorised parameters: `correlation` on the bin indices (it groups the pairs by distinct parameters and runs the scalar
+        kernels on the device), the parameters' leading axes broadcast against `shape` like in the reference, where they meet
+        the shape of the kernel's output (numpy rules: trailing axes first) """
+        v = self._vector
+        nsp = numpy.asarray(self._splits[0]).reshape((1,) * (ix.ndim - 1) + (-1,))
+        res = self.correlation(nsp, ix, iy, alpha=v['alpha'], beta=v['beta'], gamma=v['gamma'], maxd=v['maxd'], pnt=v['pnt'],
+                               intercept=v['intercept'], weights=v['weights'], reset=v['reset'], altinput=True)
+        res = numpy.asarray(res)
+        if res.shape != tuple(shape):
+            raise NotImplementedError(f'vectorised parameters broadcast the kernel output to {res.shape}: only parameter shapes that '
+                                      f'broadcast INTO the output shape {tuple(shape)} are evaluated here')
+        for op, c in self._outops:
+            res = res * res.dtype.type(c) if op == 'mul' else res + res.dtype.type(c)
+        dev = DeviceArray.from_host(numpy.ascontiguousarray(res, self._flt), ctx=ctx)
+        if out is None:
+            return dev
+        assert out.shape == dev.shape and out.dtype == dev.dtype
+        out.assign(dev)
+        return out
+
     def gram(self, xs, ys, *, ctx=None, out=None):
         ctx = ctx or Context.default()
+        if self._vector is not None:
+            ix, iy = self._host_indices(xs), self._host_indices(ys)
+            if ix.shape[1] != len(self._splits[0]) or iy.shape[1] != len(self._splits[0]):
+                raise ValueError(f'splitting grid is for {len(self._splits[0])} dimensions, found {ix.shape[1]}')
+            return self._vector_eval(ix[:, None, :], iy[None, :, :], (ix.shape[0], iy.shape[0]), ctx, out)
         same = ys is xs
         ixd = self._device_indices(xs, ctx)
         iyd = ixd if same else self._device_indices(ys, ctx)
@@ -2239,6 +2282,8 @@ class BART(Kernel):
         BART hyperparameters of ``bayestree.bart`` (``bayestree/_bart.py:187-205``), computed in the same pass as K.
         """
         ctx = ctx or Context.default()
+        if self._vector is not None:
+            raise NotImplementedError('tangents of a BART kernel with vectorised parameters')
         if dpnt is None:
             if self._dpnt_ab is None:
                 raise ValueError('the kernel was built from `pnt`: pass the derivatives of pnt explicitly')
@@ -2319,4 +2364,7 @@ class BART(Kernel):
         return self._run('lgp_pairs_bart', ctx, p, ixd, iyd, n, n, None if npair is not None else self._splits[0], npair, out, n)
 
     def pairs(self, xs, ys, *, ctx=None):
+        if self._vector is not None:
+            ix, iy = self._host_indices(xs), self._host_indices(ys)
+            return self._vector_eval(ix, iy, (ix.shape[0],), ctx or Context.default())
         return self._pairs_indices(self._to_indices(xs), self._to_indices(ys), ctx=ctx)

@@ -297,6 +297,48 @@ def test_bart_correlation_vectorised_parameters(lgp, rng):
     assert lgp.BART.correlation(sb, sbw, sa, alpha=alpha.astype('f'), beta=np.float32(2), maxd=1).dtype == np.float32
 
 
+def test_bart_kernel_object_with_vectorised_parameters(lgp, rng):
+    """ alpha / beta / gamma / pnt as arrays on the kernel OBJECT: in the reference they broadcast against the shape of the kernel's
+    output (``_kernels/_bart.py:301-303``: "fully vectorized", :373-401), trailing axes first -- one parameter per column of a Gram
+    matrix, or per row with a trailing unit axis.  Checked against the scalar-parameter kernels column by column / row by row, and
+    against the oracle's kernel object where it broadcasts the same way """
+    n, m, p = 9, 7, 4
+    X = rng.integers(0, 6, (n + m, p)).astype(float)
+    splits = lgp.BART.splits_from_coord(X)
+    x, y = _struct(X[:n]), _struct(X[n:])
+    alpha = rng.uniform(0.3, 0.95, m)
+    k = lgp.BART(splits=splits, alpha=alpha, beta=1.5, maxd=2)
+    G = k.gram(x, y).to_host()
+    assert G.shape == (n, m) and G.dtype == np.float64
+    for j in range(m):
+        ref = lgp.BART(splits=splits, alpha=alpha[j], beta=1.5, maxd=2).gram(x, y).to_host()
+        np.testing.assert_array_equal(G[:, j], ref[:, j])
+    R = oracle.BART(splits=splits, alpha=alpha, beta=1.5, maxd=2)(x[:, None], y[None, :])
+    util.assert_allclose(G, R, rtol=1e-14, atol=4e-15)
+    # one beta per row, one gamma per column, through a product with a constant and with reset
+    beta = rng.uniform(0.5, 3., (n, 1))
+    gamma = rng.uniform(0., 1., m)
+    k = 3. * lgp.BART(splits=splits, alpha=0.9, beta=beta, gamma=gamma, maxd=4, reset=[2])
+    G = k.gram(x, y).to_host()
+    for i in range(0, n, 4):
+        for j in range(0, m, 3):
+            ref = (3. * lgp.BART(splits=splits, alpha=0.9, beta=beta[i, 0], gamma=gamma[j], maxd=4, reset=[2])).gram(x, y).to_host()
+            assert G[i, j] == ref[i, j]
+    # pnt with a leading axis; element-wise evaluation (`pairs`): one parameter set per pair
+    pnt = np.stack([np.array([0.9, 0.5, 0.2]) * f for f in rng.uniform(0.5, 1., n)])
+    k = lgp.BART(splits=splits, pnt=pnt, gamma='auto')
+    v = k.pairs(x, _struct(X[n - 2:2 * n - 2])).to_host()
+    for i in range(n):
+        ref = lgp.BART(splits=splits, pnt=pnt[i], gamma='auto').pairs(x[i:i + 1], _struct(X[n - 2 + i:n - 1 + i])).to_host()
+        assert v[i] == ref[0]
+    # float32 parameters give a float32 kernel; a parameter shape that would ADD axes to the output is refused, so are tangents
+    assert lgp.BART(splits=splits, alpha=alpha.astype('f'), beta=np.float32(2)).gram(x, y).dtype == np.float32
+    with pytest.raises(NotImplementedError):
+        lgp.BART(splits=splits, alpha=np.full((2, 1, 1), 0.9)).gram(x, y)
+    with pytest.raises(NotImplementedError):
+        lgp.BART(splits=splits, alpha=alpha).gram_jvp(x, y)
+
+
 def test_bart_corr_one_cases(lgp, rng):
     """ correlation = 1 when the points coincide, all weights vanish or there are no covariates (ref :105-133) """
     p = 4
