@@ -884,7 +884,7 @@ class GP:
         mats = self._assembletangents(inkeys, tkeys, dtype)
         sizes = [self._elements[k].size for k in inkeys]
         n = sum(sizes)
-        offs = dict(zip(inkeys, numpy.pad(numpy.cumsum(sizes), (1, 0))[:-1]))
+        offs = dict(zip(inkeys, numpy.concatenate(([0], numpy.cumsum(sizes)))[:-1]))
         owned = set()
         for (row, col), db in dgc.items():
             for key, v in db.items():
@@ -1007,7 +1007,7 @@ class GP:
     def _slices(self, keylist):
         """ ``_elements.py:819-826`` """
         sizes = [self._elements[key].size for key in keylist]
-        stops = numpy.pad(numpy.cumsum(sizes), (1, 0))
+        stops = numpy.concatenate(([0], numpy.cumsum(sizes)))        # (numpy.pad costs 10 us)
         return [slice(stops[i - 1], stops[i]) for i in range(1, len(stops))]
 
     # ---- compute (``_GP/_compute.py``) ---------------------------------------------

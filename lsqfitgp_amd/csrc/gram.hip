@@ -1806,9 +1806,14 @@ __global__ void __launch_bounds__(256) predict_small_kernel(const IsoArgs<double
   __shared__ T sh_eps, sh_piv;
   __shared__ int sh_bad;
   const int tid = threadIdx.x;
+  // Several workgroups: each repeats the small factorisation in its own LDS (a dependent chain a single workgroup is alone with
+  // anyway) and takes its share of the m x m posterior covariance -- 10^4 kernel evaluations at m = 100, which one workgroup
+  // needed 40 of the kernel's 63 us for (N = 10).  Workgroup 0 writes everything else.
+  const bool first = blockIdx.x == 0;
+  const int nwg = gridDim.x;
   for (int idx = tid; idx < d * np; idx += 256) {
     T v = io.hpts[idx];
-    io.dP[idx] = v;
+    if (first) io.dP[idx] = v;
     if (g.has_loc) v = v - g.loc;
     if (g.has_scale) v = v / g.scale;
     pt[idx] = v;
@@ -1816,7 +1821,7 @@ __global__ void __launch_bounds__(256) predict_small_kernel(const IsoArgs<double
   const T k0 = g.ops.apply(iso_core<T>(g, T(0)));
   for (int i = tid; i < n; i += 256) {
     const T nz = io.hnoise ? io.hnoise[i] : T(0);
-    if (io.hnoise) io.dnoise[i] = nz;
+    if (io.hnoise && first) io.dnoise[i] = nz;
     sinv[i] = T(1) / pow2_scale<T>(k0 + nz);
   }
   if (tid == 0) sh_bad = 0;
@@ -1865,7 +1870,7 @@ __global__ void __launch_bounds__(256) predict_small_kernel(const IsoArgs<double
   red[tid] = mn;
   const T eps = sh_eps;
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && first) {
     T v = INFINITY;
     for (int t = 0; t < 256 && t < n; ++t) v = red[t] < v ? red[t] : v;
     io.hout[(size_t)m * m + m + 2] = eps;
@@ -1901,12 +1906,13 @@ __global__ void __launch_bounds__(256) predict_small_kernel(const IsoArgs<double
   }
   __syncthreads();
   // posterior: straight to the mapped host buffer
-  for (int idx = tid; idx < m * m; idx += 256) {
+  for (int idx = blockIdx.x * 256 + tid; idx < m * m; idx += 256 * nwg) {
     const int a = idx / m, b = idx % m;
     T q = T(0);
     for (int i = 0; i < n; ++i) q += W[i * mw + a] * W[i * mw + b];
     io.hout[idx] = pair(n + a, n + b) - q;
   }
+  if (!first) return;
   for (int a = tid; a < m; a += 256) {
     T q = T(0);
     for (int i = 0; i < n; ++i) q += W[i * mw + a] * W[i * mw + m];
@@ -1998,7 +2004,11 @@ int lgp_predict_small_f64(lgp_ctx *ctx, int kernel, int p, int npar, const doubl
     LGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(predict_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(predict_small_kernel, dim3(1), dim3(256), shmem, ctx->stream, g, io);
+  // one workgroup per 1024 entries of the posterior covariance, at most 16 (LGP_PREDICT_SMALL_WGS)
+  static const int wgs_env = getenv("LGP_PREDICT_SMALL_WGS") ? atoi(getenv("LGP_PREDICT_SMALL_WGS")) : 0;
+  size_t nwg = wgs_env > 0 ? (size_t)wgs_env : (m * m + 1023) / 1024;
+  nwg = nwg < 1 ? 1 : (nwg > 16 ? 16 : nwg);
+  hipLaunchKernelGGL(predict_small_kernel, dim3((unsigned)nwg), dim3(256), shmem, ctx->stream, g, io);
   LGP_LAUNCH_CHECK();
   LGP_HIP(hipStreamSynchronize(ctx->stream));
   memcpy(hout, hres, (m * m + m + 2) * sizeof(T));
