@@ -74,6 +74,70 @@ template <typename T> struct VecOf;
 template <> struct VecOf<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int W = 2; };
 template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int W = 4; };
 
+// ---- exp(-x) and sqrt for the two cores that fill the large Gram matrices (ExpQuad, Maternp), fp64.  The library versions spend a
+// third of their instructions on cases these callers cannot reach (the square root scales its argument against subnormals and
+// checks for zero / infinity; the exponential handles both signs and overflow) and on copying the polynomial's coefficients from
+// registers every time (v_fmac needs its addend in the destination): 19 + 32 instructions per entry, of ~117 in the fused Gram
+// kernel's loop.  Here: 10 + 23, the coefficients in scalar registers (a table in constant memory, read once per wave).
+__constant__ double LGP_EXP_TAYLOR[12] = {     // 1/13! .. 1/2!, highest first (|r| <= ln 2 / 2: truncation 4e-18)
+    1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07, 2.7557319223985893e-06, 2.48015873015873e-05,
+    0.0001984126984126984, 0.001388888888888889, 0.008333333333333333, 0.041666666666666664, 0.16666666666666666, 0.5};
+
+// exp(-x) for 0 <= x <= 1000 or NaN (the callers clamp)
+template <typename T>
+__device__ __forceinline__ T lgp_exp_neg_raw(T x) { return exp(-x); }
+template <>
+__device__ __forceinline__ double lgp_exp_neg_raw<double>(double x) {
+  const double n = __builtin_rint(x * -1.4426950408889634);        // rint(-x log2 e) <= 0
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, -x);    // -x - n ln 2, ln 2 in two pieces (n ln2_hi is exact)
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = LGP_EXP_TAYLOR[0];
+#pragma unroll
+  for (int k = 1; k < 12; ++k) {
+    // (three-address form with the coefficient in scalar registers: left to itself the compiler keeps the table in vector
+    //  registers and copies each coefficient into the destination of a v_fmac, one v_mov_b64 per step)
+    const double c = LGP_EXP_TAYLOR[k];
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(r), "s"(c));
+  }
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+// exp(-x) for x >= 0 (+inf gives 0: beyond 745.2 the result is zero; the comparison keeps a NaN)
+template <typename T>
+__device__ __forceinline__ T lgp_exp_neg(T x) { return exp(-x); }
+template <>
+__device__ __forceinline__ double lgp_exp_neg<double>(double x) { return lgp_exp_neg_raw<double>(!(x > 800.0) ? x : 800.0); }
+
+// sqrt(a) for a > 0 in the normal range, not infinite (NaN stays NaN): the callers add 1e-30 and clamp
+template <typename T>
+__device__ __forceinline__ T lgp_sqrt_pos(T a) { return sqrt(a); }
+template <>
+__device__ __forceinline__ double lgp_sqrt_pos<double>(double a) {
+  const double y = __builtin_amdgcn_rsq(a);                        // ~23 bits
+  double g = a * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, a);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, a);
+  return __builtin_fma(d, h, g);
+}
+// x = sqrt(a), a > 0, limited to 800 (exp(-x) is zero from 745.2 on, whatever polynomial multiplies it; keeps a NaN), and exp(-x)
+template <typename T>
+__device__ __forceinline__ T lgp_sqrt_exp(T a, T *e) {
+  const T x = sqrt(a);
+  *e = exp(-x);
+  return x;
+}
+template <>
+__device__ __forceinline__ double lgp_sqrt_exp<double>(double a, double *e) {
+  const double x = lgp_sqrt_pos<double>(!(a > 640000.0) ? a : 640000.0);
+  *e = lgp_exp_neg_raw<double>(x);
+  return x;
+}
+
 template <typename T>
 __device__ __forceinline__ T matern_real_of(const IsoArgs<T> &g, T r2, T *xdk) {
   if (g.flag) { *xdk = T(0); return r2 == T(0) ? T(1) : T(0); }          // nu = 0: _matern.py:74 "the correct limit is white"
@@ -165,21 +229,22 @@ __device__ __forceinline__ T special_core_mxdk(const IsoArgs<T> &g, T r2) {
 template <typename T, bool NU = false>
 __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0), T d1 = T(0)) {
   if (g.kernel == LGP_KERNEL_EXPQUAD) {
-    return exp(T(-0.5) * r2);
+    return lgp_exp_neg<T>(T(0.5) * r2);
   } else if (g.kernel == LGP_KERNEL_EXPQUAD_DIFF) {
     // mixed derivative of exp(-|u|^2 / 2), u = x - y field by field: along field f, a_f times in x and b_f times in y, it is
     // prod_f (-1)^{a_f} He_{a_f + b_f}(u_f) exp(-|u|^2 / 2) (probabilists' Hermite polynomials; the signs and the 1 / scale^order
     // of the chain rule are an output operation of the caller).  d0 arrives as the product of the Hermite factors (iso_aux).
     // What jax's elementwise_grad of the core gives for _Kernel/_ops.py:115-211 (`diff`) on ExpQuad, _kernels/_basic.py:75.
-    return d0 * exp(T(-0.5) * r2);
+    return d0 * lgp_exp_neg<T>(T(0.5) * r2);
   } else if (g.kernel == LGP_KERNEL_MATERNP_DIFF) {
     // derivative of total order q of K(u) = exp(-t) P_p(t), t = sqrt((2p+1) u^2 + 1e-30), in one dimension (d0 = u):
     // K^(q)(u) = (c sign u)^q exp(-t) Q_q(t), Q_0 = P_p, Q_{q+1} = Q_q' - Q_q; the coefficients of Q_q (degree g.p, ascending)
     // come from the host, c^q and the chain-rule factors are an output operation of the caller; flag: q odd
-    const T t = sqrt(g.twop1 * r2 + T(1e-30));
+    T et;
+    const T t = lgp_sqrt_exp<T>(g.twop1 * r2 + T(1e-30), &et);
     T poly = g.coef[g.p];
     for (int k = g.p - 1; k >= 0; --k) poly = poly * t + g.coef[k];
-    const T v = exp(-t) * poly;
+    const T v = et * poly;
     return g.flag ? (d0 > T(0) ? v : (d0 < T(0) ? -v : T(0))) : v;
   } else if (g.kernel == LGP_KERNEL_WENDLAND) {          // _kernels/_wendland.py:32-84: (1 - r)_+^(nu + k) poly(r), r < 1
     const T r = sqrt(r2);
@@ -274,10 +339,11 @@ __device__ __forceinline__ T iso_core(const IsoArgs<T> &g, T r2, T d0 = T(0), T 
     return pow(T(1) + power / g.par[1], g.par[2]);
   } else {
     T r2s = g.twop1 * r2;
-    T x = sqrt(r2s + T(1e-30));
+    T e;
+    const T x = lgp_sqrt_exp<T>(r2s + T(1e-30), &e);
     T poly = T(1);
     for (int k = 0; k < g.p; ++k) poly = T(1) + poly * g.coef[k] * T(2) * x;
-    return exp(-x) * poly;
+    return e * poly;
   }
 }
 
@@ -319,15 +385,16 @@ constexpr int CORE_GENERIC = 0, CORE_EXPQUAD = 1, CORE_MATERN1 = 2, CORE_MATERN2
 template <typename T, int CORE>
 __device__ __forceinline__ T iso_core_t(const IsoArgs<T> &g, T r2, T d0 = T(0), T d1 = T(0)) {
   if constexpr (CORE == CORE_EXPQUAD) {
-    return exp(T(-0.5) * r2);
+    return lgp_exp_neg<T>(T(0.5) * r2);
   } else if constexpr (CORE == CORE_MATERN1 || CORE == CORE_MATERN2 || CORE == CORE_MATERN3) {
     constexpr int P = CORE == CORE_MATERN1 ? 1 : (CORE == CORE_MATERN2 ? 2 : 3);
     const T r2s = T(2 * P + 1) * r2;
-    const T x = sqrt(r2s + T(1e-30));
+    T e;
+    const T x = lgp_sqrt_exp<T>(r2s + T(1e-30), &e);
     T poly = T(1);
 #pragma unroll
     for (int k = 0; k < P; ++k) poly = T(1) + poly * g.coef[k] * T(2) * x;      // (the same operations in the same order as iso_core)
-    return exp(-x) * poly;
+    return e * poly;
   } else if constexpr (CORE == CORE_MATERNNU) {
     T unused;
     return matern_real_of<T>(g, r2, &unused);
@@ -353,7 +420,7 @@ template <typename T>
 __device__ __forceinline__ T iso_core_dscale(const IsoArgs<T> &g, T r2, T &dk) {
   const T inv_s = g.has_scale ? T(1) / g.scale : T(1);
   if (g.kernel == LGP_KERNEL_EXPQUAD) {                  // k = exp(-r2/2): dk/dscale = k r2 / scale
-    const T k = exp(T(-0.5) * r2);
+    const T k = lgp_exp_neg<T>(T(0.5) * r2);
     dk = k * r2 * inv_s;
     return k;
   } else if (g.kernel == LGP_KERNEL_GAMMAEXP) {          // k = exp(-r2^(gamma/2)): dk/dscale = k gamma r2^(gamma/2) / scale
@@ -369,14 +436,14 @@ __device__ __forceinline__ T iso_core_dscale(const IsoArgs<T> &g, T r2, T &dk) {
     return k;
   } else {                                               // Maternp: k = exp(-x) poly(x), x = sqrt((2p+1) r2 + 1e-30); dx/dscale = -r2s / (x scale)
     const T r2s = g.twop1 * r2;
-    const T x = sqrt(r2s + T(1e-30));
+    T e;
+    const T x = lgp_sqrt_exp<T>(r2s + T(1e-30), &e);
     T poly = T(1), dpoly = T(0);
     for (int k = 0; k < g.p; ++k) {
       const T c2 = g.coef[k] * T(2);
       dpoly = dpoly * c2 * x + poly * c2;                // d/dx of (1 + poly c 2 x)
       poly = T(1) + poly * c2 * x;
     }
-    const T e = exp(-x);
     dk = e * (poly - dpoly) * r2s / x * inv_s;           // -(dk/dx) r2s / (x scale)
     return e * poly;
   }
