@@ -73,7 +73,8 @@ struct lgp_ctx {
                                       // factorisation and the workers' CUs are worth more to it (N = 32768: 186 ms split driver, 204 ms chain;
                                       // N = 16384: 30.2-30.5 ms here against 28.9-29.3 for the split driver with a chain tail of 8192 rows, N = 14336 equal)
   size_t chain_hog_max_n = 8192;      // ... and largest matrix for which the workers keep other workgroups off their CUs
-  int chain_workers = 16;             // resident worker workgroups = CUs taken from the trailing update (env LGP_CHAIN_WORKERS)
+  int chain_workers = 24;             // resident worker workgroups = CUs taken from the trailing update (env LGP_CHAIN_WORKERS); 16 until round 5:
+                                      // same box N = 2048 1.15 -> 1.09 ms, 4096 2.31 -> 2.22, 8192 5.89 -> 5.78, 12288 14.4 -> 14.25, 14336 and C3 equal; 32 equal, 48 worse
   int chain_lds_kb = 100;             // untouched dynamic LDS per worker that keeps other workgroups off its CU (env LGP_CHAIN_LDS_KB)
   unsigned long long chain_timeout = 1000000000ull;   // wall_clock64 ticks (100 MHz) a worker waits for one input: 10 s (env LGP_CHAIN_TIMEOUT_MS)
   bool chain_attr_set = false;        // the chain kernel's dynamic-LDS limit has been raised on this context's device
