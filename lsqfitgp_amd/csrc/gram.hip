@@ -598,6 +598,8 @@ __global__ void __launch_bounds__(GT_THREADS) gram_iso_kernel(const IsoArgs<T> g
   } else {
     // (measured instead: the transpose staged through LDS so that neighbouring lanes write one row -- slower, 2.6 against 2.2 ms at
     // N = 32768: what the mirrored half costs is HBM write locality, 32-entry runs 256 KB apart, not the coalescing of a store)
+    // (round 5: taller tiles, so that a mirrored row receives 128 or 512 consecutive entries from one workgroup instead of 32: 2.50 and
+    //  2.73 ms against 2.15 -- slower again; with the lean exp / sqrt the full grid takes 1.95-2.2 ms, so the symmetric form no longer gains)
     for (int rb = 0; rb < rmax; rb += MR) {
       T keep[MR][W];
       const int cnt = (rmax - rb) < MR ? (rmax - rb) : MR;
