@@ -109,6 +109,9 @@ __device__ __forceinline__ T lgp_exp_neg(T x) { return exp(-x); }
 template <>
 __device__ __forceinline__ double lgp_exp_neg<double>(double x) { return lgp_exp_neg_raw<double>(!(x > 800.0) ? x : 800.0); }
 
+#ifndef LGP_SQRT_TWO_CORRECTIONS
+#define LGP_SQRT_TWO_CORRECTIONS 0
+#endif
 // sqrt(a) for a > 0 in the normal range, not infinite (NaN stays NaN): the callers add 1e-30 and clamp
 template <typename T>
 __device__ __forceinline__ T lgp_sqrt_pos(T a) { return sqrt(a); }
@@ -120,9 +123,11 @@ __device__ __forceinline__ double lgp_sqrt_pos<double>(double a) {
   g = __builtin_fma(g, r, g);
   h = __builtin_fma(h, r, h);
   double d = __builtin_fma(-g, g, a);
+#if LGP_SQRT_TWO_CORRECTIONS
   g = __builtin_fma(d, h, g);
   d = __builtin_fma(-g, g, a);
-  return __builtin_fma(d, h, g);
+#endif
+  return __builtin_fma(d, h, g);               // (one residual correction: g is good to 2^-45 before it; the library's second one only decides the last rounding)
 }
 // x = sqrt(a), a > 0, limited to 800 (exp(-x) is zero from 745.2 on, whatever polynomial multiplies it; keeps a NaN), and exp(-x)
 template <typename T>
@@ -825,6 +830,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
     // ... and where it pays: the mirrored half is written in runs of 16 entries 8 N bytes apart, which HBM takes at ~3.9 TB/s
     // against 5.3-5.6 TB/s for whole tile rows.  ExpQuad, write-bound on the full grid (1.5-1.6 ms at N = 32768), would lose
     // (2.2 ms); the cores with more arithmetic per entry gain (Matern-5/2 3-D: 2.4 -> 2.2 ms); fp32 runs would be 64 bytes
+    // (round 5, lean exp / sqrt: Matern-5/2 3-D of a point set with itself 2.20-2.21 ms on the full grid, 2.02-2.07 as one triangle, same box)
     static const bool nosym = getenv("LGP_GRAM_FULL") != nullptr, allsym = getenv("LGP_GRAM_HALF") != nullptr;
     const bool sym = symmetric && !nosym && dx == dy && n == m && ldx == ldy && n >= (size_t)GT_COLS &&
                      kernel != LGP_KERNEL_EXPQUAD_DIFF && kernel != LGP_KERNEL_MATERNP_DIFF &&
