@@ -879,6 +879,7 @@ int gram_iso_launch(lgp_ctx *ctx, int kernel, int p, int npar, const T *hpar, in
 // matrix are the Gershgorin row sums, and the partial sums of the n / 128 tile rows are added in a fixed order afterwards
 // (deterministic, no atomics).  The upper triangle is evaluated only for those sums.
 constexpr int GR_ROWS = 128;
+constexpr int GR_BATCH = GT_THREADS / 32;      // rows whose sums along the row are formed together (gram_reg_kernel)
 
 template <typename T>
 __device__ __forceinline__ T pow2_scale(T d) {      // _decomp.py:356-361
@@ -905,7 +906,8 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
   T *sv = su + d * GR_ROWS;                            // [d][GT_COLS]
   T *sinv = sv + d * GT_COLS;                          // [GR_ROWS] 1 / s_i of the rows;  then [GR_ROWS] their noise
   T *snz = sinv + GR_ROWS;
-  T *srow = snz + GR_ROWS;                             // [4][GR_ROWS] per-wave sums along the rows (tiles below the diagonal)
+  T *srow = snz + GR_ROWS;                             // [GR_ROWS] sums along the rows (tiles below the diagonal)
+  T *sbat = srow + GR_ROWS;                            // [GR_BATCH][32] partial sums of a batch of rows (within the 4 GR_ROWS entries the sums own)
   const int n = g.n;
   // Only the tiles that reach the diagonal or lie below it are in the grid (numbered consecutively: row group G of RPB tile rows
   // has G + 1 tiles per row).  The entries above the diagonal of the factor's storage are zero: a tile entirely below the
@@ -1004,6 +1006,10 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
   }
   const bool colfull = (col0 + c0 + W <= cend) && ((g.ldo % W) == 0) && ((reinterpret_cast<uintptr_t>(g.out) % 16) == 0) && (!COLS || (g.cbase % W) == 0);
   const int rmax = (n - row0) < GR_ROWS ? (n - row0) : GR_ROWS;
+  // INTERIOR (workgroup-uniform): a whole tile strictly below the diagonal with every column in range and aligned stores -- no entry
+  // is on the diagonal, above it or outside the matrix, so the selects of the general body go
+  auto rows = [&](auto interior_c) {
+  constexpr bool INTERIOR = decltype(interior_c)::value;
   for (int r = 0; r < rmax; ++r) {
     const int i = row0 + r;
     const T rinv = sinv[r];
@@ -1027,23 +1033,34 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
         }
       }
       T v = g.ops.apply(iso_core_t<T, CORE>(g, r2));
-      if (i == j) v = v + cnz[e];                       // Kxx + ycov (_compute.py:85), noise on the diagonal
+      if (!INTERIOR && i == j) v = v + cnz[e];          // Kxx + ycov (_compute.py:85), noise on the diagonal
       v = v * cinv[e] * rinv;                           // K / s / s[:, None] (:385): exact, s is a power of two
-      if (j < cend) acc[e] += fabs(v);
-      res[e] = (j <= i) ? v : T(0);
+      if (INTERIOR || j < cend) acc[e] += fabs(v);
+      res[e] = (INTERIOR || j <= i) ? v : T(0);
     }
     if (zeros) zero_round(r);
     if (below) {
-      // sum along the row over this tile's columns: lanes, then the four waves in fixed order
+      // sum along the row over this tile's columns, in a fixed order (round 5): three exchanges among eight neighbouring lanes, the 32
+      // partial sums of a row parked in LDS, and once per eight rows 32 threads per row finish them with five exchanges -- ~11
+      // instructions per row and thread instead of the ~30 of a 64-lane exchange tree (12 ds_bpermute) per row
       T rs = T(0);
 #pragma unroll
-      for (int e = 0; e < W; ++e) rs += (col0 + c0 + e < n) ? fabs(res[e]) : T(0);
+      for (int e = 0; e < W; ++e) rs += (INTERIOR || col0 + c0 + e < n) ? fabs(res[e]) : T(0);
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) rs += __shfl_xor(rs, off, 64);
-      if ((tid & 63) == 0) srow[(tid >> 6) * GR_ROWS + r] = rs;
+      for (int off = 1; off <= 4; off <<= 1) rs += __shfl_xor(rs, off, 64);
+      if ((tid & 7) == 0) sbat[(r & (GR_BATCH - 1)) * 32 + (tid >> 3)] = rs;
+      if ((r & (GR_BATCH - 1)) == GR_BATCH - 1 || r == rmax - 1) {
+        __syncthreads();
+        const int q = tid >> 5, seg = tid & 31, rq = (r & ~(GR_BATCH - 1)) + q;      // GT_THREADS / 32 = GR_BATCH rows
+        T v = sbat[q * 32 + seg];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (seg == 0 && rq <= r) srow[rq] = v;
+        __syncthreads();
+      }
     }
     T *po = g.out + (long)i * g.ldo + lcol0 + c0;
-    if (colfull) {
+    if (INTERIOR || colfull) {
       vec_t v;
 #pragma unroll
       for (int e = 0; e < W; ++e) v[e] = res[e];
@@ -1054,6 +1071,10 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
         if (col0 + c0 + e < cend) po[e] = res[e];
     }
   }
+  };
+  const bool interior = below && row0 + GR_ROWS <= n && col0 + GT_COLS <= cend && ((g.ldo % W) == 0) && ((reinterpret_cast<uintptr_t>(g.out) % 16) == 0);
+  if (interior) rows(std::true_type{});
+  else rows(std::false_type{});
   if (zeros)
     for (int zr = rmax; zr < GR_ROWS; ++zr) zero_round(zr);      // (ragged last tile row: the rounds its loop did not reach)
 #pragma unroll
@@ -1062,7 +1083,7 @@ __global__ void __launch_bounds__(GT_THREADS) gram_reg_kernel(const IsoArgs<T> g
   if (below) {
     __syncthreads();
     for (int r = tid; r < rmax; r += GT_THREADS)
-      rpart[(long)tc * n + row0 + r] = ((srow[r] + srow[GR_ROWS + r]) + srow[2 * GR_ROWS + r]) + srow[3 * GR_ROWS + r];
+      rpart[(long)tc * n + row0 + r] = srow[r];
   }
 }
 

@@ -1,12 +1,9 @@
 #!/bin/bash
-# fused Gram + regularisation kernel at C3 under rocprofv3 --stats, repeated: tools/gram_reg_order.sh
-# (round 3: the LGP_GRAM_REG_ORDER switches this script was written for -- tile rows from both ends, no zero fill, no row sums --
-#  are gone from the kernel; what they measured is in DESIGN.md section 4)
+# the fused Gram + regularisation kernel inside bench.py (C3 and C2) under rocprofv3 --kernel-trace --stats:  bash tools/gram_reg_time.sh
 export TMPDIR=/tmp
-for o in ${ORDERS:-0 1 0 1}; do
-  export LGP_GRAM_REG_ORDER=$o
-  out=gpurun_out/greg_$o
-  rm -rf $out
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > $out.json 2> $out.log
-  echo "order $o: $(grep -h gram_reg_kernel $out/*/*kernel_stats.csv | head -n 1 | cut -c1-200)"
+for cfg in c3 c2; do
+  out=gpurun_out/greg_$cfg; rm -rf $out; mkdir -p $out
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > $out/bench.json 2> $out/log.txt || exit 1
+  f=$(find $out -name '*kernel_stats.csv' | head -1)
+  test -n "$f" && echo "$cfg: $(grep -h gram_reg_kernel $f | head -n 1 | sed 's/.*)",//' | cut -d, -f1-3)  (calls, total ns, average ns)"
 done
