@@ -335,7 +335,7 @@ def cpu_baseline(main_cfg):
 
 def size_sweep(ctx, main_cfg):
     """ "vs N" part of BASELINE.json's metric: the same step at smaller sizes and on configuration C2, 1 warmup + 3 timed
-    steps each (a fraction of a second in all); not part of `value` """
+    steps each (6 up to N = 16384; a fraction of a second in all); not part of `value` """
     out = []
     cases = [dict(CONFIGS['c2'])]
     if main_cfg['n'] < CONFIGS['c4']['n']:
@@ -350,16 +350,19 @@ def size_sweep(ctx, main_cfg):
         wl = Workload(c, ctx)
         wl.step()
         ctx.sync()
-        reps = 3 if c['n'] <= 32768 else 2
+        reps = (6 if c['n'] <= 16384 else 3) if c['n'] <= 32768 else 2
         evs = [[ctx.event() for _ in range(4)] for _ in range(reps)]
         t0 = time.perf_counter()
         for k in range(reps):
             wl.step(evs[k])
         ctx.sync()
         dt = (time.perf_counter() - t0) / reps
-        ph = np.array([[ctx.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in evs]).mean(axis=0)
+        phs = np.array([[ctx.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in evs])
+        ph = phs.mean(axis=0)
         out.append({'workload': c['name'], 'N': c['n'], 'ms_per_step': dt * 1e3, 'value': flops_fit_predict(c['n'], c['m']) / dt / 1e12,
-                    'cholesky_ms': float(ph[1]), 'cholesky_tflops': (c['n'] ** 3 / 3) / (ph[1] * 1e-3) / 1e12})
+                    'cholesky_ms': float(ph[1]), 'cholesky_tflops': (c['n'] ** 3 / 3) / (ph[1] * 1e-3) / 1e12,
+                    'cholesky_min_ms': float(phs[:, 1].min()), 'timed_steps': reps,
+                    'cholesky_phase': 'fused Gram build of Kxx + regularisation + factorisation with the carried solve, HIP events, mean (and min) over the timed steps'})
         del wl
     try:
         out.append(c5_step(ctx, steps=3, warmup=1))
