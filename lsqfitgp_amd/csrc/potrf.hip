@@ -1017,7 +1017,10 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     // leave the GPU idle; left-looking the work beside each square is 33-39 GFLOP for panels 0-3: N = 8192 6.45-6.55 -> 6.30 ms
     // (N = 4096 equal; N = 12288 14.9 -> 16.0, N = 16384 29.8 -> 34.6 ms: there the updates bound the factorisation, and a block
     // column of 1024 is too few tiles per launch -- right-looking stays).  LGP_CHAIN_LEFT_MAX_N.
-    static const size_t left_max_n = getenv("LGP_CHAIN_LEFT_MAX_N") ? (size_t)atol(getenv("LGP_CHAIN_LEFT_MAX_N")) : 8192;
+    // (round 5, with the updates thinned less and 24 workers: left-looking now wins up to N = 12288 -- same box, left against right:
+    //  9216 7.28-7.39 / 7.69-7.72 ms, 10240 9.15-9.20 / 9.54-9.62, 11264 11.5-11.7 / 11.9-12.2, 12288 14.31-14.33 / 14.47-14.49;
+    //  13312 17.8 / 17.4, 14336 21.8 / 21.0: right-looking from there on)
+    static const size_t left_max_n = getenv("LGP_CHAIN_LEFT_MAX_N") ? (size_t)atol(getenv("LGP_CHAIN_LEFT_MAX_N")) : 12288;
     const bool right_looking = n > left_max_n;
     // The only thing that waits for this update through its flag word is U1 of the NEXT panel, i.e. the square of block column k+2
     // (everything else follows in s0's own order).  LGP_CHAIN_U3_SPLIT=1 (round 5, off): that square first, as a launch of its own
