@@ -1008,7 +1008,7 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     if (rows_r + nx > 0)
       LGP_CHECK(lgp_gemm_launch<T>(ctx, s0, false, true, rows_r + nx, nb1, kb, T(-1), Pt + nb1 * ldl, ldl, Pt, ldl, T(1), C1 + nb1 * ldl, ldl, false, 2));
     LGP_HIP(hipStreamWriteValue32(s0, word(k, LGP_CH_U2), 1, 0));
-    // ---- s0: the bulk of the flops.  Up to N = 8192 LEFT-looking with a look-ahead of one block column: block column k+2 (its
+    // ---- s0: the bulk of the flops.  Up to N = 12288 (8192 until round 5) LEFT-looking with a look-ahead of one block column: block column k+2 (its
     // square and everything below) receives the update of ALL panels 0 .. k in one product, K = 1024 (k + 1), while the chain
     // kernel factors the square of panel k+1 (whose block column got the same treatment one panel earlier, and panel k's share
     // from U1 / U2).  Right-looking (everything right of block column k+1 updated with panel k alone) front-loads the work: at
