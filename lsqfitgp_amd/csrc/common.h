@@ -69,7 +69,8 @@ struct lgp_ctx {
   size_t chain_trace_tasks = 0;
   const void *chain_trace_sched = nullptr;
   int chain_mode = 0;                 // 0 = not yet checked, 1 = off (env LGP_CHAIN=0, or the self-test failed), 2 = available
-  size_t chain_max_n = 14336;         // largest matrix factored this way (env LGP_CHAIN_MAX_N); beyond, the trailing update bounds the
+  size_t chain_max_n = 12288;         // largest matrix factored this way (env LGP_CHAIN_MAX_N; 14336 until round 5: N = 14336 20.3-20.6 ms through the split driver
+                                      // with its chain tail against 20.75-20.84 here, 13312 17.13-17.25 against 17.30); beyond, the trailing update bounds the
                                       // factorisation and the workers' CUs are worth more to it (N = 32768: 186 ms split driver, 204 ms chain;
                                       // N = 16384: 30.2-30.5 ms here against 28.9-29.3 for the split driver with a chain tail of 8192 rows, N = 14336 equal)
   size_t chain_hog_max_n = 8192;      // ... and largest matrix for which the workers keep other workgroups off their CUs

@@ -516,7 +516,7 @@ def test_fused_gram_factor_lower_only(lgp, rng, dtype, n, d, q):
 @pytest.fixture(scope='module')
 def driver_contexts(lgp):
     """ two contexts on the same GPU: the launch-per-operation driver of the factorisation (LGP_CHAIN=0 when the context is
-    created) and the default (chain kernel up to N = 14336) """
+    created) and the default (chain kernel up to N = 12288) """
     import os
     old = os.environ.get('LGP_CHAIN')
     os.environ['LGP_CHAIN'] = '0'
@@ -533,7 +533,7 @@ def driver_contexts(lgp):
 @pytest.mark.parametrize('n,q', [(256, 0), (1152, 7), (2048, 0), (2432, 3)])
 def test_chain_kernel_against_launch_per_operation_driver(lgp, rng, driver_contexts, n, q):
     """ the two drivers of the blocked factorisation (csrc/potrf.hip: the chain kernel whose resident workers factor the
-    diagonal squares, default up to N = 14336, and the launch-per-operation driver, LGP_CHAIN=0) on the same matrix: the
+    diagonal squares, default up to N = 12288, and the launch-per-operation driver, LGP_CHAIN=0) on the same matrix: the
     same factor to rounding (the order of the additions differs), both satisfying L L^T = K + eps, and the same carried
     solve.  LAPACK potrf in the reference (_linalg/_decomp.py:388) is the third opinion (the oracle). """
     K = randpd(rng, n) * 37.0
