@@ -1,4 +1,4 @@
-"""Maternp(2) 3-D Gram of a point set with itself, N = 32768: python tools/bench_gram_sym.py   (LGP_GRAM_HALF_MATERN=1: one triangle + mirror)"""
+"""Maternp(2) 3-D Gram of a point set with itself, N = 32768: python tools/bench_gram_sym.py   (default: one triangle + mirror; LGP_GRAM_FULL=1: the full grid)"""
 import sys
 sys.path.insert(0, '.')
 import numpy as np
