@@ -90,9 +90,10 @@ class Workload:
         # fused Gram: lgp_gram_chol_factor_rhs writes tril((Kxx + ycov) / s / s') straight into the factor (K is never
         # materialised: one N x N allocation instead of two); LGP_BENCH_SEPARATE_GRAM=1 times the three-pass path instead
         self.fused_gram = self.fused and not os.environ.get('LGP_BENCH_SEPARATE_GRAM')
-        # the timed step leaves a complete factor behind (zeros above the diagonal, like the reference's jnp.linalg.cholesky), although the
-        # prediction never reads them; LGP_BENCH_LOWER_ONLY=1 passes LGP_FACTOR_LOWER_ONLY as GP.pred's one-call path does (-0.1 ms at C3)
-        self.lower_only = _lib.LGP_FACTOR_LOWER_ONLY if os.environ.get('LGP_BENCH_LOWER_ONLY') else 0
+        # like GP.pred's one-call path (_GP.py, _pred_one_call): LGP_FACTOR_LOWER_ONLY -- the prediction reads the factor's lower triangle
+        # only, so the Gram kernel stores no zeros above the diagonal (lgp_zero_upper writes them for a consumer that wants the full
+        # matrix).  LGP_BENCH_FULL_FACTOR=1 times the step with the zeros stored: +0.46 ms at C3 (fused Gram kernel 1.62 against 1.16 ms)
+        self.lower_only = 0 if os.environ.get('LGP_BENCH_FULL_FACTOR') else _lib.LGP_FACTOR_LOWER_ONLY
         self.K = None if self.fused_gram else DA.empty((n, n), ctx=ctx)           # Kxx + ycov
         # fused: the factor with m + 1 extra rows [Kxxs | y]^T that the factorisation turns into (L^-1 [Kxxs | y])^T
         # (m + 1 padded with zero rows to whole 128-row tiles, so that the extra tiles take the kernels' aligned fast path)

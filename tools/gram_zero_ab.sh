@@ -3,9 +3,8 @@
 #   bash tools/gram_zero_ab.sh   -> gpurun_out/gram_zero_ab.txt (kernel durations from rocprofv3 --kernel-trace --stats)
 export TMPDIR=/tmp
 out=gpurun_out/gram_zero_ab; rm -rf $out; mkdir -p $out
-export LGP_BENCH_LOWER_ONLY=1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/lower -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > $out/lower.json 2> $out/lower.log || exit 1
-unset LGP_BENCH_LOWER_ONLY
+export LGP_BENCH_FULL_FACTOR=1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/full -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep > $out/full.json 2> $out/full.log || exit 1
 for v in lower full; do
   f=$(find $out/$v -name '*kernel_stats.csv' | head -1)
