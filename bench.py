@@ -985,7 +985,10 @@ def main():
         'vs_baseline': None,
         'dtype': 'f64',
         'data': 'synthetic',
-        'config': {'workload': cfg['name'], 'N': n, 'M': m, 'd': cfg['d'], 'parallelism': 'single GPU'},
+        'config': {'workload': cfg['name'], 'N': n, 'M': m, 'd': cfg['d'], 'parallelism': 'single GPU',
+                   'factor': ('complete: zeros stored above the diagonal (LGP_BENCH_FULL_FACTOR=1)' if os.environ.get('LGP_BENCH_FULL_FACTOR') else
+                              'lower triangle only, as GP.pred does (LGP_FACTOR_LOWER_ONLY: the prediction never reads above the diagonal; '
+                              'LGP_BENCH_FULL_FACTOR=1 stores the zeros too, +0.46 ms at C3)')},
         'phases_ms': {'gram (cross blocks; Kxx is built inside the decomposition call)': float(phases[0]), 'gram + regularisation + decomposition': float(phases[1]), 'solves+likelihood': float(phases[2])},
         'cholesky_tflops': (n ** 3 / 3) / (phases[1] * 1e-3) / 1e12,
         'log_marginal_likelihood': wl.results.get('mll'),
