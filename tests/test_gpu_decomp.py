@@ -555,6 +555,31 @@ def test_chain_kernel_against_launch_per_operation_driver(lgp, rng, driver_conte
         util.assert_close_matrices(b.solved(), o.pinv_correlate(B), rtol=1e-10)
 
 
+@pytest.mark.parametrize('n,q', [(9216, 5), (12288, 0)])
+def test_chain_driver_left_looking_above_8192(lgp, rng, driver_contexts, n, q):
+    """ the sizes the chain driver took over in round 5 with LEFT-looking updates (potrf_chain, LGP_CHAIN_LEFT_MAX_N = 12288; right-looking
+    above 8192 before): the same factor and carried solve as the launch-per-operation driver to rounding, repeatably (two runs bit for
+    bit), and a solve that satisfies K x = b to the accuracy the conditioning allows """
+    x = np.sort(rng.uniform(0, n / 16, n))
+    K = np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2) + 0.01 * np.eye(n)
+    B = rng.standard_normal((n, q)) if q else None
+    ctx_launch, ctx_chain = driver_contexts
+    a = lgp.Chol(K, ctx=ctx_launch, rhs=B)
+    b = lgp.Chol(K, ctx=ctx_chain, rhs=B)
+    c = lgp.Chol(K, ctx=ctx_chain, rhs=B)
+    La, Lb, Lc = a.factor().to_host(), b.factor().to_host(), c.factor().to_host()
+    assert a.eps == b.eps
+    np.testing.assert_array_equal(Lb, Lc)
+    assert np.max(np.abs(Lb - La)) <= 1e-12 * np.max(np.abs(La))
+    assert np.all(np.triu(Lb, 1) == 0)
+    if q:
+        util.assert_close_matrices(b.solved(), a.solved(), rtol=1e-9)
+    r = rng.standard_normal(n)
+    sol = b.ginv_linear(r)
+    res = K @ sol + b.eps * sol - r
+    assert np.linalg.norm(res) <= 1e-9 * np.linalg.norm(r)
+
+
 def test_chain_kernel_reports_a_bad_pivot(lgp, rng):
     """ a matrix that is not positive definite: the worker that meets the pivot records it and the factorisation goes on to
     its end (no worker is left waiting); the host raises the reference's error (_linalg/_decomp.py:389-391) """
