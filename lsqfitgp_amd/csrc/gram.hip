@@ -398,7 +398,8 @@ __device__ __forceinline__ T iso_core_t(const IsoArgs<T> &g, T r2, T d0 = T(0), 
     const T x = lgp_sqrt_exp<T>(r2s + T(1e-30), &e);
     T poly = T(1);
 #pragma unroll
-    for (int k = 0; k < P; ++k) poly = T(1) + poly * g.coef[k] * T(2) * x;      // (the same operations in the same order as iso_core)
+    for (int k = 0; k < P; ++k) poly = T(1) + poly * (g.coef[k] * T(2)) * x;    // (bit for bit iso_core's poly * coef * 2 * x: doubling is exact, and
+                                                                                 //  the doubled coefficient is uniform -- one multiplication less per step and entry)
     return e * poly;
   } else if constexpr (CORE == CORE_MATERNNU) {
     T unused;
