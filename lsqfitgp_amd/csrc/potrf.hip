@@ -990,7 +990,7 @@ static int potrf_chain(lgp_ctx *ctx, size_t n, double *L, size_t ldl, double *db
     for (int g = 0; g < ng; ++g) LGP_HIP(wait_ge(s0, word(k, LGP_CH_GRP + g), 1));
     const size_t rows_r = rows_t - nb1;
     // The updates with this panel leave room on every CU when the chain is what bounds the rest of the factorisation: untouched
-    // dynamic LDS thins their workgroups out (three 64-tile workgroups per CU below 12288 remaining rows), so that the far-row
+    // dynamic LDS thins their workgroups out (two 64-tile workgroups per CU below 12288 remaining rows: 36.9 + 20 KB each of 160), so that the far-row
     // kernels of the next panel are dispatched at once and not squeezed (N = 4096 2.58 -> 2.48 ms, N = 8192 6.92 -> 6.55 ms;
     // thinning the large updates of N = 16384 as well: 30.4 -> 31.4 ms, so they are left alone).  Until round 5 it was ONE
     // workgroup per CU below 6144 rows; since the chain-side products run at wave priority 3 that costs the updates -- whose
